@@ -1,0 +1,241 @@
+/*
+ * set_hip.h — C ABI of libset_hip.so: the EditNet / DCNet per-timestep decode path of
+ * show-edit-tell as hand-written HIP kernels for MI355X (gfx950).
+ *
+ * The reference (fawazsammani/show-edit-tell) has no FFI: its boundary for this path is the
+ * Python nn.Module surface.  Each entry point below replaces the PyTorch ops
+ * behind one of those module calls; the reference file:line it replaces is cited on each.  The
+ * Python host side (show-edit-tell_amd/*.py) binds these with ctypes and keeps the reference's
+ * class names, constructor signatures, attribute names and state_dict keys.
+ *
+ * Conventions
+ *   - all tensors fp32 row-major contiguous unless a leading stride is given; ids/lengths int64
+ *   - weights are PyTorch (out,in) row-major and are used IN PLACE (no repacking)
+ *   - every pointer is a DEVICE pointer unless named host_*; nothing is allocated or freed here:
+ *     the caller supplies a workspace sized by the matching *_workspace_bytes() query
+ *   - all work is enqueued on `stream` (a hipStream_t); functions never synchronise
+ *   - return value: SET_OK or an error code; nothing throws across the ABI
+ *   - re-entrant per (workspace, stream) pair; no global mutable state
+ *   - alignment: base pointers 16-byte aligned, leading strides and K multiples of 4 floats;
+ *     every contraction length (D, A, F, 2D, ...) must be a multiple of 32 (SET_ERR_UNSUPPORTED)
+ */
+#ifndef SET_HIP_H
+#define SET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SET_OK 0
+#define SET_ERR_ARG 1          /* null pointer / non-positive size / misaligned */
+#define SET_ERR_UNSUPPORTED 2  /* dimension not supported by the kernels (see alignment rules) */
+#define SET_ERR_HIP 3          /* a HIP runtime call failed: see set_last_hip_error() */
+#define SET_ERR_WORKSPACE 4    /* workspace too small */
+
+#define SET_ACT_NONE 0
+#define SET_ACT_RELU 1
+#define SET_ACT_TANH 2
+#define SET_ACT_SIGMOID 3
+
+int set_abi_version(void);
+const char* set_error_string(int code);
+/* last hipError_t seen by this thread inside the library (0 = none) and its text */
+int set_last_hip_error(void);
+const char* set_last_hip_error_string(void);
+/* device the library was compiled for ("gfx950") */
+const char* set_target_arch(void);
+
+/* ------------------------------------------------------------------------------------------
+ * EditNet (reference editnet.py:449-548 `DecoderC`, editnet_rl.py:455-549)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct SetEditNetDims {
+    int B;      /* batch rows held by the workspace                                    */
+    int T;      /* padded previous-caption length (18 in the reference data, 20 in BASELINE) */
+    int R;      /* regions per image (36; up to 100 for adaptive features)              */
+    int F;      /* image_features_dim (2048)                                            */
+    int D;      /* decoder_dim == emb_dim == caption_features_dim (1024)                */
+    int A;      /* attention_dim (512)                                                  */
+    int V;      /* vocabulary size                                                      */
+    int maxT;   /* XE: max decode length (predictions.shape[1]); greedy: max_len + 1    */
+    int adaptive; /* 1: adaptive-features visual attention (editnet_adaptive.py:438-457) */
+} SetEditNetDims;
+
+/* state_dict tensors of DecoderC, device pointers, used in place */
+typedef struct SetEditNetWeights {
+    const float* embed;                     /* embed.embedding.weight (V,D)                         */
+    const float *enc_x2h_w, *enc_x2h_b;     /* caption_encoder.lstm_encoder_cell.x2h (4D,D)         */
+    const float *enc_h2h_w, *enc_h2h_b;     /* caption_encoder.lstm_encoder_cell.h2h (4D,D)         */
+    const float *enc_aff_w, *enc_aff_b;     /* caption_encoder.affine_hn (D,D)                      */
+    const float *ca_feat_w, *ca_feat_b;     /* caption_attention.cap_features_att (A,D)             */
+    const float *ca_dec_w, *ca_dec_b;       /* caption_attention.cap_decoder_att (A,D)              */
+    const float *ca_full_w, *ca_full_b;     /* caption_attention.cap_full_att (1,A)                 */
+    const float *ca_gate_w, *ca_gate_b;     /* caption_attention.context_gate (D,3D)                */
+    const float *ca_sc_w, *ca_sc_b;         /* caption_attention.sc_affine (D,D)                    */
+    const float *ca_tc_w, *ca_tc_b;         /* caption_attention.tc_affine (D,2D)                   */
+    const float *va_emb_w, *va_emb_b;       /* visual_attention.att_embed.0 (D,F)                   */
+    const float *va_feat_w, *va_feat_b;     /* visual_attention.features_att (A,D)                  */
+    const float *va_dec_w, *va_dec_b;       /* visual_attention.decoder_att (A,D)                   */
+    const float *va_full_w, *va_full_b;     /* visual_attention.full_att (1,A)                      */
+    const float *al_wih, *al_whh;           /* attention_lstm.weight_ih (4D,3D+F), weight_hh (4D,D) */
+    const float *al_bih, *al_bhh;           /* attention_lstm.bias_ih / bias_hh (4D)                */
+    const float *cl_x2h_w, *cl_x2h_b;       /* copy_lstm.x2h (4D,2D+F)                              */
+    const float *cl_h2h_w, *cl_h2h_b;       /* copy_lstm.h2h (4D,D)                                 */
+    const float *cl_cnew_w, *cl_cnew_b;     /* copy_lstm.gate_cnew (D,D)                            */
+    const float *cl_cmem_w, *cl_cmem_b;     /* copy_lstm.gate_cmem (D,D)                            */
+    const float *fc_w, *fc_b;               /* fc (V,D)                                             */
+} SetEditNetWeights;
+
+size_t set_editnet_workspace_bytes(const SetEditNetDims* d);
+
+/* Per-sequence prologue.  Replaces, for one batch: caption_encoder(prev, prevlen)
+ * (editnet.py:319-348, called at :501), image_mean = X.mean(1) (:503), init_hidden_state (:494-495)
+ * and — eval mode only — the loop-invariant projections that the reference recomputes every
+ * timestep: features_att(att_embed(X)) (:441-442), cap_features_att(H) (:370) and the
+ * final_hidden / image_mean columns of the attention_lstm input product (:527-532).
+ * `image_mean` may be NULL (computed here) or a (B,F) tensor (adaptive variant, editnet_adaptive.py:501).
+ * `prev` (B,T) int64, `prevlen` (B) int64, `X` (B,R,F).  Leaves the recurrent state zeroed. */
+int set_editnet_begin(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X,
+                      const float* image_mean, const int64_t* prev, const int64_t* prevlen,
+                      void* ws, size_t ws_bytes, void* stream);
+
+/* One decode timestep for rows [0,bt): embed -> attention_lstm -> caption_attention ->
+ * visual_attention -> select -> copy_lstm -> fc  (editnet.py:513-546, editnet_rl.py:505-513),
+ * eval mode.  `tokens` (bt) int64 device ids, or NULL to feed the token the previous
+ * set_editnet_greedy_pick produced (its fused embedding gather).  `X` is the same (B,R,F) feature
+ * tensor given to set_editnet_begin.  `logits` (bt,V) with leading stride ld_logits. */
+int set_editnet_step(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X,
+                     const int64_t* tokens, int64_t tokens_stride, int bt, float* logits,
+                     int64_t ld_logits, void* ws, size_t ws_bytes, void* stream);
+
+/* Greedy epilogue of one free-running step (editnet_rl.py:514-543): log_softmax, argmax (first
+ * index on ties), <end> -> 0, `unfinished` latch, seq[:,t] / seqLogprobs[:,t] stores; suppressed
+ * once every row has finished (the reference's `break`, :546), and the next step's embedding
+ * relu(E[it]) (editnet.py:300-304) gathered into the workspace.  seq (B,max_len) int64,
+ * seq_logp (B,max_len) fp32, both pre-zeroed by the caller; call with t = 0,1,2,... in order. */
+int set_editnet_greedy_pick(const SetEditNetWeights* w, const SetEditNetDims* d, const float* logits,
+                            int64_t ld_logits, int t, int64_t end_idx, int64_t* seq, float* seq_logp,
+                            int max_len, void* ws, size_t ws_bytes, void* stream);
+
+/* Whole free-running greedy decode (editnet_rl.py:485-549 with sample_max=True): prologue +
+ * (max_len+1) timesteps, no host synchronisation (the reference syncs every step at :546).
+ * Outputs seq (B,max_len) int64 and seq_logp (B,max_len) fp32 (overwritten). */
+int set_editnet_greedy(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X,
+                       const float* image_mean, const int64_t* prev, const int64_t* prevlen,
+                       int64_t start_idx, int64_t end_idx, int max_len, int64_t* seq,
+                       float* seq_logp, void* ws, size_t ws_bytes, void* stream);
+
+/* Teacher-forced XE forward (editnet.py:479-548, eval mode, use_ss=False) on a batch already
+ * sorted by decreasing caption length.  caps (B,Lc) int64 sorted; host_decode_lengths[B] on the
+ * HOST, non-increasing; predictions (B,maxT,V) is fully overwritten (zeros where not decoded). */
+int set_editnet_xe_forward(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X,
+                           const float* image_mean, const int64_t* caps, int64_t caps_stride,
+                           const int* host_decode_lengths, const int64_t* prev,
+                           const int64_t* prevlen, float* predictions, void* ws, size_t ws_bytes,
+                           void* stream);
+
+/* Debug / module-API accessor: device pointer of a named workspace tensor (NULL if unknown).
+ * names: "H" (B,T,D) "M" (B,T,D) "final_hidden" (B,D) "mask" (B,T) "att1" (B,R,A) "att1_c" (B,T,A)
+ * "image_mean" (B,F) "h1" "c1" "h2" "c2" "emb" "ctx_cap" "attend_cap" "sel" (B,D) "attend_img" (B,F)
+ * "alpha_c" (B,T) "alpha" (B,R) "logits" (B,V) "it" (B) int64 "unfinished" (B) int32 */
+void* set_editnet_ws_tensor(const SetEditNetDims* d, void* ws, const char* name);
+
+/* ------------------------------------------------------------------------------------------
+ * DCNet (reference dcnet.py:273-350 `DAE`, dcnet_rl.py:256-346) — text only, no image features
+ * ------------------------------------------------------------------------------------------ */
+typedef struct SetDcnetDims {
+    int B, T;
+    int D;      /* decoder_dim (1024)                       */
+    int A;      /* attention_dim (512)                      */
+    int C;      /* caption_features_dim (512); encoder output is 2C */
+    int E;      /* emb_dim (1024)                           */
+    int V;
+    int maxT;
+} SetDcnetDims;
+
+typedef struct SetDcnetWeights {
+    const float* embed;                          /* embed.embedding.weight (V,E)                  */
+    const float *enc_wih_f, *enc_whh_f, *enc_bih_f, *enc_bhh_f;   /* lstm_encoder.*_l0          */
+    const float *enc_wih_b, *enc_whh_b, *enc_bih_b, *enc_bhh_b;   /* lstm_encoder.*_l0_reverse  */
+    const float *enc_cat_w, *enc_cat_b;          /* caption_encoder.concat (2C,2C)                */
+    const float *ca_feat_w, *ca_feat_b;          /* caption_attention.cap_features_att (A,2C)     */
+    const float *ca_dec_w, *ca_dec_b;            /* caption_attention.cap_decoder_att (A,D)       */
+    const float *ca_full_w, *ca_full_b;          /* caption_attention.cap_full_att (1,A)          */
+    const float *al_wih, *al_whh, *al_bih, *al_bhh;   /* attention_lstm (4D,3E),(4D,D)            */
+    const float *ll_wih, *ll_whh, *ll_bih, *ll_bhh;   /* language_lstm (4D,2E),(4D,D)             */
+    const float *fc_w, *fc_b;                    /* fc (V,D)                                      */
+} SetDcnetWeights;
+
+size_t set_dcnet_workspace_bytes(const SetDcnetDims* d);
+/* caption_encoder (dcnet.py:220-243) + hoisted cap_features_att(enc) (dcnet.py:261) + zero state */
+int set_dcnet_begin(const SetDcnetWeights* w, const SetDcnetDims* d, const int64_t* prev,
+                    const int64_t* prevlen, void* ws, size_t ws_bytes, void* stream);
+/* one timestep (dcnet.py:336-347 / dcnet_rl.py:306-312), eval mode */
+int set_dcnet_step(const SetDcnetWeights* w, const SetDcnetDims* d, const int64_t* tokens,
+                   int64_t tokens_stride, int bt, float* logits, int64_t ld_logits, void* ws,
+                   size_t ws_bytes, void* stream);
+int set_dcnet_greedy(const SetDcnetWeights* w, const SetDcnetDims* d, const int64_t* prev,
+                     const int64_t* prevlen, int64_t start_idx, int64_t end_idx, int max_len,
+                     int64_t* seq, float* seq_logp, void* ws, size_t ws_bytes, void* stream);
+int set_dcnet_xe_forward(const SetDcnetWeights* w, const SetDcnetDims* d, const int64_t* caps,
+                         int64_t caps_stride, const int* host_decode_lengths, const int64_t* prev,
+                         const int64_t* prevlen, float* predictions, void* ws, size_t ws_bytes,
+                         void* stream);
+/* names: "enc" (B,T,2C) "final_hidden" (B,2C) "mask" (B,T) "att1_c" (B,T,A) "h1" "c1" "h2" "c2"
+ * "emb" "attend_cap" (B,2C) "alpha_c" (B,T) "logits" (B,V) "it" "unfinished" */
+void* set_dcnet_ws_tensor(const SetDcnetDims* d, void* ws, const char* name);
+
+/* ------------------------------------------------------------------------------------------
+ * Operator-level entry points (the sub-module `forward`s the reference's beam search calls
+ * directly, editnet.py:645-653 / eval_full.py:133-149)
+ * ------------------------------------------------------------------------------------------ */
+/* y = act(x W^T + bias): nn.Linear (+ ReLU/tanh/sigmoid).  x (M,K) ldx, w (N,K) ldw, y (M,N) ldy */
+size_t set_linear_workspace_bytes(int M, int N, int K);
+int set_linear_f32(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
+                   float* y, int64_t ldy, int M, int N, int K, int act, void* ws, size_t ws_bytes,
+                   void* stream);
+/* EmbeddingC.forward (editnet.py:300-304), eval: out[i] = relu(table[ids[i]]) */
+int set_embed_relu_f32(const float* table, const int64_t* ids, int64_t ids_stride, float* out,
+                       int64_t ldo, int n, int D, int V, void* stream);
+/* nn.LSTMCell / LSTMCellC (editnet.py:226-244): gates = x Wih^T + bih + h Whh^T + bhh, order i,f,g,o */
+size_t set_lstm_cell_workspace_bytes(int M, int D, int Kx);
+int set_lstm_cell_f32(const float* x, int64_t ldx, int Kx, const float* h, const float* c,
+                      const float* w_ih, int64_t ld_wih, const float* w_hh, const float* b_ih,
+                      const float* b_hh, float* h_out, float* c_out, int M, int D, void* ws,
+                      size_t ws_bytes, void* stream);
+/* CaptionAttentionC.forward (editnet.py:364-381); att1_c may be NULL (computed into ws).
+ * Outputs gated (M,D), alpha_c (M,T).  Also serves DCNet's CaptionAttention (dcnet.py:254-270)
+ * when gate weights are NULL: then `gated` receives the plain context (M,Dh). */
+size_t set_caption_attention_workspace_bytes(int M, int T, int D, int A);
+int set_caption_attention_f32(const SetEditNetWeights* w, const float* H, const float* att1_c,
+                              const float* h1, const float* word, const float* mask, float* gated,
+                              float* alpha_c, int M, int T, int D, int A, void* ws, size_t ws_bytes,
+                              void* stream);
+/* VisualAttentionC.forward (editnet.py:439-447); att1 may be NULL (att_embed + features_att are
+ * then recomputed exactly as the reference does every call).  adaptive != 0 selects the masked
+ * variant (editnet_adaptive.py:438-457).  ctx (M,F). */
+size_t set_visual_attention_workspace_bytes(int M, int R, int F, int D, int A);
+int set_visual_attention_f32(const SetEditNetWeights* w, const float* X, const float* att1,
+                             const float* h1, float* ctx, float* alpha, int M, int R, int F, int D,
+                             int A, int adaptive, void* ws, size_t ws_bytes, void* stream);
+/* SelectC.forward hard mode (editnet.py:403-421): sel = M[b,j*] * (a + (1-a)), j* = argmax alpha_c */
+int set_select_f32(const float* Mem, const float* alpha_c, float* sel, int M, int T, int D,
+                   void* stream);
+/* CopyLSTMCellC.forward (editnet.py:265-285); x (M,2D+F) */
+size_t set_copy_lstm_workspace_bytes(int M, int D, int Kx);
+int set_copy_lstm_f32(const SetEditNetWeights* w, const float* x, int64_t ldx, int Kx,
+                      const float* h2, const float* c2, const float* c_memory, float* h_out,
+                      float* c_out, int M, int D, void* ws, size_t ws_bytes, void* stream);
+/* CaptionEncoderC.forward (editnet.py:319-348): outputs padded to T (caller slices to max len).
+ * H, Mem (B,T,D) ; final_hidden (B,D) ; mask (B,T) */
+size_t set_caption_encoder_workspace_bytes(int B, int T, int D);
+int set_caption_encoder_f32(const SetEditNetWeights* w, const int64_t* seq, const int64_t* seq_len,
+                            float* H, float* Mem, float* final_hidden, float* mask, int B, int T,
+                            int D, int V, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SET_HIP_H */

@@ -1,0 +1,277 @@
+// Additive-attention kernels of the decode step (one workgroup of 4 waves per sample):
+//   caption attention  (CaptionAttentionC editnet.py:370-376 + SelectC :409-420 ; DCNet dcnet.py:261-268)
+//   visual attention   (VisualAttentionC  editnet.py:443-446 ; adaptive editnet_adaptive.py:449-456)
+// Both are HBM/L2 streaming kernels: the loop-invariant projection att1 (hoisted to the prologue
+// in eval mode) is read once per step, scored against the per-step decoder projection att2,
+// soft-maxed inside one wavefront with 64-lane shuffles, and the context is accumulated over
+// raw rows with one float4 column per thread (every feature element is read exactly once, so
+// nothing is staged through LDS: LDS only holds the <=R attention weights).
+#include "set_common.h"
+
+namespace set {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 ld4a(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+constexpr int ATT_MAX_ROWS = 256;   // T (caption) / R (regions) upper bound held in LDS
+
+// softmax over sc[0..n) in place (wave 0 of the block), also returns the first arg-max.
+// masked entries were filled with -1e10 by the caller (masked_fill, editnet.py:374).
+__device__ __forceinline__ void block_softmax(float* sc, int n, int tid, int* argmax_out) {
+    if (tid < 64) {
+        float m = -INFINITY;
+        for (int i = tid; i < n; i += 64) m = fmaxf(m, sc[i]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int i = tid; i < n; i += 64) { const float e = expf(sc[i] - m); sc[i] = e; s += e; }
+        s = wave_sum(s);
+        float best = -1.f; int bi = 0x7fffffff;
+        for (int i = tid; i < n; i += 64) {
+            const float a = sc[i] / s;
+            sc[i] = a;
+            if (a > best) { best = a; bi = i; }        // ascending i per lane: keeps the first max
+        }
+        if (argmax_out) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ob = __shfl_xor(best, o);
+                const int oi = __shfl_xor(bi, o);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if (tid == 0) *argmax_out = bi;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// caption attention + hard selection.  grid = M samples, 256 threads.
+//   e_t   = w_full . tanh(att1_c[b,t,:] + att2_c[b,:] + dec_bias) + b_full ; masked -> -1e10
+//   alpha = softmax_t(e) ; ctx = sum_t alpha_t H[b,t,:]
+//   sel   = Mem[b,j*,:] * (alpha_j* + (1 - alpha_j*)),  j* = first argmax_t alpha     (Mem may be NULL)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) caption_attention_k(const float* att1_c, Slabs att2_c, const float* dec_bias,
+                                                           const float* w_full, const float* b_full,
+                                                           const float* mask, const float* H, const float* Mem,
+                                                           float* ctx, float* sel, float* alpha_out, int T, int Dh,
+                                                           int A) {
+    __shared__ float sc[ATT_MAX_ROWS];
+    __shared__ int s_arg;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // per-lane slice of att2_c + bias and w_full: a = lane*4 + 256*q
+    const int nq = (A + 255) / 256;
+    f32x4 a2[2], wf[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        a2[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        wf[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int a = lane * 4 + 256 * q;
+        if (q < nq && a < A) {
+            f32x4 v = ld4a(att2_c.p + (long long)b * att2_c.ld + a);
+            for (int i = 1; i < att2_c.n; ++i) v += ld4a(att2_c.p + (long long)i * att2_c.stride + (long long)b * att2_c.ld + a);
+            a2[q] = v + ld4a(dec_bias + a);
+            wf[q] = ld4a(w_full + a);
+        }
+    }
+    const float bf = b_full[0];
+    for (int t = wave; t < T; t += 4) {
+        const float* row = att1_c + ((long long)b * T + t) * A;
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int a = lane * 4 + 256 * q;
+            if (q < nq && a < A) {
+                const f32x4 v = ld4a(row + a) + a2[q];
+                s += wf[q][0] * tanhf(v[0]) + wf[q][1] * tanhf(v[1]) + wf[q][2] * tanhf(v[2]) + wf[q][3] * tanhf(v[3]);
+            }
+        }
+        s = wave_sum(s);
+        if (lane == 0) sc[t] = (mask[(long long)b * T + t] == 0.f) ? -1e10f : (s + bf);
+    }
+    __syncthreads();
+    block_softmax(sc, T, tid, &s_arg);
+    __syncthreads();
+    if (alpha_out)
+        for (int t = tid; t < T; t += 256) alpha_out[(long long)b * T + t] = sc[t];
+    const int js = s_arg;
+    const float aj = sc[js];
+    const float wj = aj * 1.f + (1.f - aj);            // the reference's fp32 expression (editnet.py:417-418)
+    for (int d = tid * 4; d < Dh; d += 1024) {
+        const float* hp = H + (long long)b * T * Dh + d;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < T; ++t) acc += ld4a(hp + (long long)t * Dh) * sc[t];
+        *reinterpret_cast<f32x4*>(ctx + (long long)b * Dh + d) = acc;
+        if (Mem) {
+            const f32x4 m = ld4a(Mem + ((long long)b * T + js) * Dh + d);
+            *reinterpret_cast<f32x4*>(sel + (long long)b * Dh + d) = m * wj;
+        }
+    }
+}
+
+int caption_attention(const float* att1_c, Slabs att2_c, const float* dec_bias, const float* w_full,
+                      const float* b_full, const float* mask, const float* H, const float* Mem, float* ctx,
+                      float* sel, float* alpha_out, int M, int T, int Dh, int A, hipStream_t s) {
+    if (T > ATT_MAX_ROWS || A > 512 || (A & 3) || (Dh & 3)) return SET_ERR_UNSUPPORTED;
+    if (M <= 0) return SET_OK;
+    hipLaunchKernelGGL(caption_attention_k, dim3(M), dim3(256), 0, s, att1_c, att2_c, dec_bias, w_full, b_full, mask,
+                       H, Mem, ctx, sel, alpha_out, T, Dh, A);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// visual attention.  grid = (M samples, FS feature slices), 256 threads; every slice recomputes
+// the R scores (R*A MACs, att1 comes from L2 after the first slice) and owns F/FS output columns.
+//   e_r   = w_full . relu(att1[b,r,:] + att2[b,:] + dec_bias) + b_full     (ReLU, not tanh)
+//   rmask (adaptive only): e_r = -1e10 where rmask[b,r] == 0  (editnet_adaptive.py:453)
+//   alpha = softmax_r(e) ; ctx = sum_r alpha_r X[b,r,:]   (context over the RAW features)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) visual_attention_k(const float* att1, Slabs att2, const float* dec_bias,
+                                                          const float* w_full, const float* b_full, const float* X,
+                                                          const float* rmask, float* ctx, float* alpha_out, int R,
+                                                          int F, int A, int fcols) {
+    __shared__ float sc[ATT_MAX_ROWS];
+    const int b = blockIdx.x, fs = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nq = (A + 255) / 256;
+    f32x4 a2[2], wf[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        a2[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        wf[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int a = lane * 4 + 256 * q;
+        if (q < nq && a < A) {
+            f32x4 v = ld4a(att2.p + (long long)b * att2.ld + a);
+            for (int i = 1; i < att2.n; ++i) v += ld4a(att2.p + (long long)i * att2.stride + (long long)b * att2.ld + a);
+            a2[q] = v + ld4a(dec_bias + a);
+            wf[q] = ld4a(w_full + a);
+        }
+    }
+    const float bf = b_full[0];
+    for (int r = wave; r < R; r += 4) {
+        const float* row = att1 + ((long long)b * R + r) * A;
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int a = lane * 4 + 256 * q;
+            if (q < nq && a < A) {
+                const f32x4 v = ld4a(row + a) + a2[q];
+                s += wf[q][0] * fmaxf(v[0], 0.f) + wf[q][1] * fmaxf(v[1], 0.f) + wf[q][2] * fmaxf(v[2], 0.f) +
+                     wf[q][3] * fmaxf(v[3], 0.f);
+            }
+        }
+        s = wave_sum(s);
+        if (lane == 0) sc[r] = (rmask && rmask[(long long)b * R + r] == 0.f) ? -1e10f : (s + bf);
+    }
+    __syncthreads();
+    block_softmax(sc, R, tid, nullptr);
+    __syncthreads();
+    if (alpha_out && fs == 0)
+        for (int r = tid; r < R; r += 256) alpha_out[(long long)b * R + r] = sc[r];
+    const int f0 = fs * fcols;
+    for (int f = f0 + tid * 4; f < f0 + fcols && f < F; f += 1024) {
+        const float* xp = X + (long long)b * R * F + f;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int r = 0; r < R; ++r) acc += ld4a(xp + (long long)r * F) * sc[r];
+        *reinterpret_cast<f32x4*>(ctx + (long long)b * F + f) = acc;
+    }
+}
+
+int visual_attention(const float* att1, Slabs att2, const float* dec_bias, const float* w_full,
+                     const float* b_full, const float* X, const float* rmask, float* ctx, float* alpha_out, int M,
+                     int R, int F, int A, hipStream_t s) {
+    if (R > ATT_MAX_ROWS || A > 512 || (A & 3) || (F & 3)) return SET_ERR_UNSUPPORTED;
+    if (M <= 0) return SET_OK;
+    // enough workgroups to cover the chip: split the feature axis while slices stay >= 1024 columns
+    int fsn = 1;
+    while (M * fsn < 512 && F / (fsn * 2) >= 1024 && (F % (fsn * 2 * 4)) == 0) fsn *= 2;
+    const int fcols = F / fsn;
+    hipLaunchKernelGGL(visual_attention_k, dim3(M, fsn), dim3(256), 0, s, att1, att2, dec_bias, w_full, b_full, X,
+                       rmask, ctx, alpha_out, R, F, A, fcols);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// adaptive features: rmask[b,r] = 1 iff r < n_b and relu-embedded row fe[b,r,:] sums to non-zero,
+// where n_b = #rows of X[b] with non-zero sum (editnet_adaptive.py:440-449; pack_padded_sequence
+// keeps the FIRST n_b rows).  One wave per (b,r) row; n_b via a block-wide count.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) region_masks_k(const float* X, const float* fe, float* rmask, int R, int F,
+                                                      int D) {
+    __shared__ int nvalid;
+    __shared__ float fsum[ATT_MAX_ROWS];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) nvalid = 0;
+    __syncthreads();
+    for (int r = wave; r < R; r += 4) {
+        const float* xp = X + ((long long)b * R + r) * F;
+        float s = 0.f;
+        for (int f = lane * 4; f < F; f += 256) { const f32x4 v = ld4a(xp + f); s += (v[0] + v[1]) + (v[2] + v[3]); }
+        s = wave_sum(s);
+        const float* fp = fe + ((long long)b * R + r) * D;
+        float t = 0.f;
+        for (int d = lane * 4; d < D; d += 256) { const f32x4 v = ld4a(fp + d); t += (v[0] + v[1]) + (v[2] + v[3]); }
+        t = wave_sum(t);
+        if (lane == 0) {
+            if (s != 0.f) atomicAdd(&nvalid, 1);
+            fsum[r] = t;
+        }
+    }
+    __syncthreads();
+    for (int r = tid; r < R; r += 256) rmask[(long long)b * R + r] = (r < nvalid && fsum[r] != 0.f) ? 1.f : 0.f;
+}
+
+int region_masks(const float* X, const float* fe, float* rmask, int B, int R, int F, int D, hipStream_t s) {
+    if (R > ATT_MAX_ROWS || (F & 3) || (D & 3)) return SET_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(region_masks_k, dim3(B), dim3(256), 0, s, X, fe, rmask, R, F, D);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SelectC.forward, hard mode (editnet.py:409-420) as a stand-alone operator: one workgroup per row
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) select_rows_k(const float* Mem, const float* alpha, float* sel, int T, int D) {
+    __shared__ int s_arg;
+    __shared__ float s_val;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid < 64) {
+        float best = -INFINITY; int bi = 0x7fffffff;
+        for (int t = tid; t < T; t += 64) { const float a = alpha[(long long)b * T + t]; if (a > best) { best = a; bi = t; } }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (tid == 0) { s_arg = bi; s_val = best; }
+    }
+    __syncthreads();
+    const float aj = s_val;
+    const float wj = aj * 1.f + (1.f - aj);
+    for (int d = tid * 4; d < D; d += 1024) {
+        const f32x4 m = ld4a(Mem + ((long long)b * T + s_arg) * D + d);
+        *reinterpret_cast<f32x4*>(sel + (long long)b * D + d) = m * wj;
+    }
+}
+
+int select_rows(const float* Mem, const float* alpha, float* sel, int M, int T, int D, hipStream_t s) {
+    if (D & 3) return SET_ERR_UNSUPPORTED;
+    if (M <= 0) return SET_OK;
+    hipLaunchKernelGGL(select_rows_k, dim3(M), dim3(256), 0, s, Mem, alpha, sel, T, D);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+}  // namespace set

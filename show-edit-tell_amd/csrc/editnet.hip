@@ -1,0 +1,425 @@
+// Host-side sequencing of the EditNet decode path over the HIP kernels + the C ABI for it.
+// Everything is enqueued on the caller's stream; there is no host synchronisation anywhere
+// (the reference synchronises every timestep at editnet_rl.py:546 and :506).
+//
+// Per timestep (eval mode) the work is a chain of six grouped-GEMM launches separated by five
+// small pointwise / attention launches (dependencies of editnet.py:527-545):
+//   A  gates1 = [emb|h2|h1] x [Wih_emb|Wih_h2|Whh]      + copy-LSTM h2h(h2)          (needs prev state)
+//      -> LSTM pointwise (h1, c1)              [final_hidden / image_mean columns + biases hoisted: pre1]
+//   B  att2_c, att2, tc_affine, context_gate[word,h1], copy-LSTM x2h[:, h1]            (needs h1)
+//      -> caption attention + select, visual attention
+//   C  context_gate[ctx], sc_affine(ctx), gate_cmem(sel)                                (needs ctx, sel)
+//      -> context gating pointwise (attend_cap)
+//   D  copy-LSTM x2h[:, attend_cap | attend_img]                                        (needs both contexts)
+//      -> LSTM pointwise (c_new, o-gate)
+//   E  gate_cnew(c_new)  -> copy-gate pointwise (h2, c2)
+//   F  fc(h2)            -> greedy pick / predictions store
+#include <cstdlib>
+#include <cstring>
+#include "set_common.h"
+
+namespace set {
+
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+int gemm_target_wgs() {
+    static int v = env_int("SET_GEMM_TARGET_WGS", 512);
+    return v;
+}
+
+struct EditNetWs {
+    // per-sequence invariants (prologue)
+    float *H, *Mem, *final_hidden, *mask, *att1, *att1_c, *image_mean, *pre1, *rmask;
+    // recurrent state + per-step activations
+    float *h1, *c1, *h2, *c2, *emb, *ctx_cap, *attend_cap, *attend_img, *sel, *c_new, *ogate, *alpha_c, *alpha;
+    float* logits;
+    long long* it;
+    int *unfinished, *alive;
+    // split-K slabs, one region per GEMM of the step
+    float *sA0, *sA1, *sB0, *sB1, *sB2, *sB3, *sB4, *sC0, *sC1, *sC2, *sD0, *sE0, *sF0;
+    // prologue scratch
+    float *enc_h, *enc_c, *xg, *emb_seq, *fe, *s_enc, *s_aff, *s_pre;
+    size_t bytes;
+};
+
+static int check_dims(const SetEditNetDims* d) {
+    if (!d) return SET_ERR_ARG;
+    if (d->B <= 0 || d->T <= 0 || d->R <= 0 || d->F <= 0 || d->D <= 0 || d->A <= 0 || d->V <= 0 || d->maxT <= 0)
+        return SET_ERR_ARG;
+    if ((d->D % GEMM_BK) || (d->A % GEMM_BK) || (d->F % GEMM_BK)) return SET_ERR_UNSUPPORTED;
+    if (d->A > 512 || d->T > 256 || d->R > 256) return SET_ERR_UNSUPPORTED;
+    return SET_OK;
+}
+
+static EditNetWs carve(const SetEditNetDims* d, void* base) {
+    EditNetWs w;
+    Carver c(base);
+    const size_t B = d->B, T = d->T, R = d->R, F = d->F, D = d->D, A = d->A, V = d->V;
+    const size_t KS = GEMM_MAX_KSPLIT;
+    const size_t Vp = round_up(V, 64);
+    w.H = c.take<float>(B * T * D);
+    w.Mem = c.take<float>(B * T * D);
+    w.final_hidden = c.take<float>(B * D);
+    w.mask = c.take<float>(B * T);
+    w.att1 = c.take<float>(B * R * A);
+    w.att1_c = c.take<float>(B * T * A);
+    w.image_mean = c.take<float>(B * F);
+    w.pre1 = c.take<float>(B * 4 * D);
+    w.rmask = c.take<float>(B * R);
+    w.h1 = c.take<float>(B * D);
+    w.c1 = c.take<float>(B * D);
+    w.h2 = c.take<float>(B * D);
+    w.c2 = c.take<float>(B * D);
+    w.emb = c.take<float>(B * D);
+    w.ctx_cap = c.take<float>(B * D);
+    w.attend_cap = c.take<float>(B * D);
+    w.attend_img = c.take<float>(B * F);
+    w.sel = c.take<float>(B * D);
+    w.c_new = c.take<float>(B * D);
+    w.ogate = c.take<float>(B * D);
+    w.alpha_c = c.take<float>(B * T);
+    w.alpha = c.take<float>(B * R);
+    w.logits = c.take<float>(B * Vp);
+    w.it = c.take<long long>(B);
+    w.unfinished = c.take<int>(B);
+    w.alive = c.take<int>(d->maxT + 2);
+    w.sA0 = c.take<float>(KS * B * 4 * D);
+    w.sA1 = c.take<float>(KS * B * 4 * D);
+    w.sB0 = c.take<float>(KS * B * A);
+    w.sB1 = c.take<float>(KS * B * A);
+    w.sB2 = c.take<float>(KS * B * D);
+    w.sB3 = c.take<float>(KS * B * D);
+    w.sB4 = c.take<float>(KS * B * 4 * D);
+    w.sC0 = c.take<float>(KS * B * D);
+    w.sC1 = c.take<float>(KS * B * D);
+    w.sC2 = c.take<float>(KS * B * D);
+    w.sD0 = c.take<float>(KS * B * 4 * D);
+    w.sE0 = c.take<float>(KS * B * D);
+    w.sF0 = c.take<float>(KS * B * Vp);
+    w.enc_h = c.take<float>(B * D);
+    w.enc_c = c.take<float>(B * D);
+    w.xg = c.take<float>(B * T * 4 * D);
+    const size_t seq_rows = B * (T > (size_t)d->maxT ? T : (size_t)d->maxT);
+    w.emb_seq = c.take<float>(seq_rows * D);
+    w.fe = c.take<float>(B * R * D);
+    w.s_enc = c.take<float>(KS * B * 4 * D);
+    w.s_aff = c.take<float>(KS * B * D);
+    w.s_pre = c.take<float>(KS * B * 4 * D);
+    w.bytes = c.off;
+    return w;
+}
+
+// a GEMM problem whose output goes to a slab region sized for GEMM_MAX_KSPLIT slabs of (B,N)
+GemmProb slab_prob(float* slab, int M, int N, int Bmax) {
+    GemmProb p;
+    p.C = slab;
+    p.ldc = N;
+    p.slab_stride = (long long)Bmax * N;
+    p.M = M;
+    p.N = N;
+    return p;
+}
+// a GEMM problem that writes its (M,N) result in place with a fused bias/activation (no K split)
+GemmProb direct_prob(float* out, long long ldo, int M, int N, const float* bias, int act) {
+    GemmProb p;
+    p.C = out;
+    p.ldc = ldo;
+    p.slab_stride = 0;
+    p.M = M;
+    p.N = N;
+    p.bias = bias;
+    p.act = act;
+    p.max_ksplit = 1;
+    p.ksplit = 1;
+    return p;
+}
+
+// CaptionEncoderC.forward (editnet.py:319-348) without the length sort: rows advance while
+// t < len[b]; H / Mem rows beyond a caption's length stay zero; mask = (Mem.sum(2) != 0).
+int editnet_encoder(const SetEditNetWeights* w, const int64_t* seq, const int64_t* lens, float* H, float* Mem,
+                    float* final_hidden, float* mask, int B, int T, int D, int V, float* emb_seq, float* xg,
+                    float* enc_h, float* enc_c, float* s_enc, float* s_aff, hipStream_t st) {
+    const int tgt = gemm_target_wgs();
+    SET_TRY(embed_relu(w->embed, seq, 1, emb_seq, D, B * T, D, V, st));
+    {
+        GemmProb p = direct_prob(xg, 4 * D, B * T, 4 * D, w->enc_x2h_b, SET_ACT_NONE);
+        p.add(emb_seq, D, w->enc_x2h_w, D, D);
+        SET_TRY(gemm_group(&p, 1, st));
+    }
+    SET_TRY(zero_f32(H, (size_t)B * T * D, st));
+    SET_TRY(zero_f32(Mem, (size_t)B * T * D, st));
+    SET_TRY(zero_f32(enc_h, (size_t)B * D, st));
+    SET_TRY(zero_f32(enc_c, (size_t)B * D, st));
+    for (int t = 0; t < T; ++t) {
+        GemmProb p = slab_prob(s_enc, B, 4 * D, B);
+        p.add(enc_h, D, w->enc_h2h_w, D, D);
+        plan_ksplit(&p, 1, tgt);
+        if (t > 0) SET_TRY(gemm_group(&p, 1, st));            // h == 0 at t == 0: product is exactly zero
+        Slabs hh = slabs_of(p);
+        if (t == 0) hh.n = 0;
+        SET_TRY(encoder_pointwise(hh, xg, (long long)T * 4 * D, 4 * D, t, lens, 0, enc_h, enc_c, H, Mem,
+                                  (long long)T * D, D, 0, B, D, w->enc_h2h_b, st));
+    }
+    {
+        GemmProb p = slab_prob(s_aff, B, D, B);
+        p.add(enc_h, D, w->enc_aff_w, D, D);
+        plan_ksplit(&p, 1, tgt);
+        SET_TRY(gemm_group(&p, 1, st));
+        SET_TRY(reduce_bias_act(slabs_of(p), w->enc_aff_b, nullptr, final_hidden, D, B, D, SET_ACT_TANH, st));
+    }
+    SET_TRY(rowsum_mask(Mem, D, B * T, D, mask, st));
+    return SET_OK;
+}
+
+static int begin_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X, const float* image_mean,
+                      const int64_t* prev, const int64_t* prevlen, EditNetWs& ws, hipStream_t st) {
+    const int B = d->B, T = d->T, R = d->R, F = d->F, D = d->D, A = d->A;
+    const int tgt = gemm_target_wgs();
+    // ---- caption encoder (editnet.py:319-348)
+    SET_TRY(editnet_encoder(w, prev, prevlen, ws.H, ws.Mem, ws.final_hidden, ws.mask, B, T, D, d->V, ws.emb_seq, ws.xg,
+                            ws.enc_h, ws.enc_c, ws.s_enc, ws.s_aff, st));
+    // ---- hoisted, loop-invariant projections (eval mode)
+    {
+        GemmProb p = direct_prob(ws.att1_c, A, B * T, A, w->ca_feat_b, SET_ACT_NONE);     // editnet.py:370
+        p.add(ws.H, D, w->ca_feat_w, D, D);
+        SET_TRY(gemm_group(&p, 1, st));
+    }
+    {
+        GemmProb p = direct_prob(ws.fe, D, B * R, D, w->va_emb_b, SET_ACT_RELU);          // editnet.py:441
+        p.add(X, F, w->va_emb_w, F, F);
+        SET_TRY(gemm_group(&p, 1, st));
+        GemmProb q = direct_prob(ws.att1, A, B * R, A, w->va_feat_b, SET_ACT_NONE);       // editnet.py:442
+        q.add(ws.fe, D, w->va_feat_w, D, D);
+        SET_TRY(gemm_group(&q, 1, st));
+        if (d->adaptive) SET_TRY(region_masks(X, ws.fe, ws.rmask, B, R, F, D, st));
+    }
+    if (image_mean)
+        SET_HIP_TRY(hipMemcpyAsync(ws.image_mean, image_mean, sizeof(float) * B * F, hipMemcpyDeviceToDevice, st));
+    else
+        SET_TRY(mean_regions(X, ws.image_mean, B, R, F, st));                              // editnet.py:503
+    {
+        // attention_lstm input columns [D,2D) (final_hidden) and [3D,3D+F) (image_mean) + both biases
+        const long long ldw = 3LL * D + F;
+        GemmProb p = slab_prob(ws.s_pre, B, 4 * D, B);
+        p.add(ws.final_hidden, D, w->al_wih + D, ldw, D);
+        p.add(ws.image_mean, F, w->al_wih + 3 * D, ldw, F);
+        plan_ksplit(&p, 1, tgt);
+        SET_TRY(gemm_group(&p, 1, st));
+        SET_TRY(reduce_bias_act(slabs_of(p), w->al_bih, w->al_bhh, ws.pre1, 4 * D, B, 4 * D, SET_ACT_NONE, st));
+    }
+    SET_TRY(zero_f32(ws.h1, (size_t)B * D, st));
+    SET_TRY(zero_f32(ws.c1, (size_t)B * D, st));
+    SET_TRY(zero_f32(ws.h2, (size_t)B * D, st));
+    SET_TRY(zero_f32(ws.c2, (size_t)B * D, st));
+    return SET_OK;
+}
+
+// One timestep for rows [0,bt).  ws.emb must already hold relu(E[token]).  The vocabulary
+// projection is left as split-K slabs (`*logits_out`, bias NOT yet added) unless `dst` is given,
+// in which case (bt,V) logits with bias are written to dst (leading stride ld_dst).
+static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X, int bt, EditNetWs& ws, float* dst,
+                     long long ld_dst, Slabs* logits_out, hipStream_t st) {
+    const int B = d->B, T = d->T, R = d->R, F = d->F, D = d->D, A = d->A, V = d->V;
+    const int tgt = gemm_target_wgs();
+    const long long ld_ih = 3LL * D + F, ld_x2h = 2LL * D + F;
+    // ---- A
+    GemmProb a[2];
+    a[0] = slab_prob(ws.sA0, bt, 4 * D, B);
+    a[0].add(ws.emb, D, w->al_wih, ld_ih, D);
+    a[0].add(ws.h2, D, w->al_wih + 2 * D, ld_ih, D);
+    a[0].add(ws.h1, D, w->al_whh, D, D);
+    a[1] = slab_prob(ws.sA1, bt, 4 * D, B);
+    a[1].add(ws.h2, D, w->cl_h2h_w, D, D);
+    plan_ksplit(a, 2, tgt);
+    SET_TRY(gemm_group(a, 2, st));
+    const Slabs none{nullptr, 0, 0, 0};
+    SET_TRY(lstm_pointwise(slabs_of(a[0]), none, none, ws.pre1, 4 * D, nullptr, nullptr, ws.c1, ws.c1, ws.h1, nullptr,
+                           bt, D, st));
+    // ---- B
+    GemmProb b[5];
+    b[0] = slab_prob(ws.sB0, bt, A, B);
+    b[0].add(ws.h1, D, w->ca_dec_w, D, D);
+    b[1] = slab_prob(ws.sB1, bt, A, B);
+    b[1].add(ws.h1, D, w->va_dec_w, D, D);
+    b[2] = slab_prob(ws.sB2, bt, D, B);
+    b[2].add(ws.emb, D, w->ca_tc_w, 2 * D, D);
+    b[2].add(ws.h1, D, w->ca_tc_w + D, 2 * D, D);
+    b[3] = slab_prob(ws.sB3, bt, D, B);
+    b[3].add(ws.emb, D, w->ca_gate_w, 3 * D, D);
+    b[3].add(ws.h1, D, w->ca_gate_w + D, 3 * D, D);
+    b[4] = slab_prob(ws.sB4, bt, 4 * D, B);
+    b[4].add(ws.h1, D, w->cl_x2h_w, ld_x2h, D);
+    plan_ksplit(b, 5, tgt);
+    SET_TRY(gemm_group(b, 5, st));
+    SET_TRY(caption_attention(ws.att1_c, slabs_of(b[0]), w->ca_dec_b, w->ca_full_w, w->ca_full_b, ws.mask, ws.H, ws.Mem,
+                              ws.ctx_cap, ws.sel, ws.alpha_c, bt, T, D, A, st));
+    SET_TRY(visual_attention(ws.att1, slabs_of(b[1]), w->va_dec_b, w->va_full_w, w->va_full_b, X,
+                             d->adaptive ? ws.rmask : nullptr, ws.attend_img, ws.alpha, bt, R, F, A, st));
+    // ---- C
+    GemmProb c[3];
+    c[0] = slab_prob(ws.sC0, bt, D, B);
+    c[0].add(ws.ctx_cap, D, w->ca_gate_w + 2 * D, 3 * D, D);
+    c[1] = slab_prob(ws.sC1, bt, D, B);
+    c[1].add(ws.ctx_cap, D, w->ca_sc_w, D, D);
+    c[2] = slab_prob(ws.sC2, bt, D, B);
+    c[2].add(ws.sel, D, w->cl_cmem_w, D, D);
+    plan_ksplit(c, 3, tgt);
+    SET_TRY(gemm_group(c, 3, st));
+    SET_TRY(context_gate_pointwise(slabs_of(b[3]), slabs_of(c[0]), w->ca_gate_b, slabs_of(c[1]), w->ca_sc_b,
+                                   slabs_of(b[2]), w->ca_tc_b, ws.attend_cap, bt, D, st));
+    // ---- D
+    GemmProb dd = slab_prob(ws.sD0, bt, 4 * D, B);
+    dd.add(ws.attend_cap, D, w->cl_x2h_w + D, ld_x2h, D);
+    dd.add(ws.attend_img, F, w->cl_x2h_w + 2 * D, ld_x2h, F);
+    plan_ksplit(&dd, 1, tgt);
+    SET_TRY(gemm_group(&dd, 1, st));
+    SET_TRY(lstm_pointwise(slabs_of(a[1]), slabs_of(b[4]), slabs_of(dd), nullptr, 0, w->cl_x2h_b, w->cl_h2h_b, ws.c2,
+                           ws.c_new, nullptr, ws.ogate, bt, D, st));
+    // ---- E
+    GemmProb e = slab_prob(ws.sE0, bt, D, B);
+    e.add(ws.c_new, D, w->cl_cnew_w, D, D);
+    plan_ksplit(&e, 1, tgt);
+    SET_TRY(gemm_group(&e, 1, st));
+    SET_TRY(copy_gate_pointwise(slabs_of(e), w->cl_cnew_b, slabs_of(c[2]), w->cl_cmem_b, ws.c_new, ws.sel, ws.ogate,
+                                ws.c2, ws.h2, bt, D, st));
+    // ---- F
+    const long long Vp = (long long)round_up((size_t)V, 64);
+    GemmProb f = slab_prob(ws.sF0, bt, V, B);
+    f.ldc = Vp;
+    f.slab_stride = (long long)B * Vp;
+    f.add(ws.h2, D, w->fc_w, D, D);
+    plan_ksplit(&f, 1, tgt);
+    if (dst && f.ksplit == 1) {
+        f.C = dst; f.ldc = ld_dst; f.bias = w->fc_b; f.slab_stride = 0;
+        SET_TRY(gemm_group(&f, 1, st));
+    } else {
+        SET_TRY(gemm_group(&f, 1, st));
+        if (dst) SET_TRY(reduce_bias_act(slabs_of(f), w->fc_b, nullptr, dst, ld_dst, bt, V, SET_ACT_NONE, st));
+    }
+    if (logits_out) *logits_out = slabs_of(f);
+    return SET_OK;
+}
+
+}  // namespace set
+
+using namespace set;
+
+extern "C" {
+
+size_t set_editnet_workspace_bytes(const SetEditNetDims* d) {
+    if (check_dims(d) != SET_OK) return 0;
+    return carve(d, nullptr).bytes + 256;
+}
+
+static int prep(const SetEditNetDims* d, void* ws, size_t ws_bytes, EditNetWs* out) {
+    SET_TRY(check_dims(d));
+    if (!ws || !aligned16(ws)) return SET_ERR_ARG;
+    *out = carve(d, ws);
+    if (out->bytes > ws_bytes) return SET_ERR_WORKSPACE;
+    return SET_OK;
+}
+
+int set_editnet_begin(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X, const float* image_mean,
+                      const int64_t* prev, const int64_t* prevlen, void* ws, size_t ws_bytes, void* stream) {
+    if (!w || !X || !prev || !prevlen) return SET_ERR_ARG;
+    EditNetWs W;
+    SET_TRY(prep(d, ws, ws_bytes, &W));
+    return begin_impl(w, d, X, image_mean, prev, prevlen, W, (hipStream_t)stream);
+}
+
+
+int set_editnet_step(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X, const int64_t* tokens,
+                     int64_t tokens_stride, int bt, float* logits, int64_t ld_logits, void* ws, size_t ws_bytes,
+                     void* stream) {
+    if (!w || !X || !logits) return SET_ERR_ARG;
+    EditNetWs W;
+    SET_TRY(prep(d, ws, ws_bytes, &W));
+    if (bt <= 0 || bt > d->B || ld_logits < d->V) return SET_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (tokens) SET_TRY(embed_relu(w->embed, tokens, tokens_stride, W.emb, d->D, bt, d->D, d->V, st));
+    return step_impl(w, d, X, bt, W, logits, ld_logits, nullptr, st);
+}
+
+int set_editnet_greedy_pick(const SetEditNetWeights* w, const SetEditNetDims* d, const float* logits,
+                            int64_t ld_logits, int t, int64_t end_idx, int64_t* seq, float* seq_logp, int max_len,
+                            void* ws, size_t ws_bytes, void* stream) {
+    if (!w || !logits || !seq || !seq_logp || t < 0) return SET_ERR_ARG;
+    EditNetWs W;
+    SET_TRY(prep(d, ws, ws_bytes, &W));
+    if (t > d->maxT) return SET_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (t == 0) SET_TRY(set_tokens(W.it, 0, W.unfinished, W.alive, d->maxT + 2, d->B, st));
+    Slabs lg{logits, 0, ld_logits, 1};
+    return greedy_pick(lg, nullptr, d->V, t, max_len, end_idx, (long long*)seq, seq_logp, W.it, W.unfinished, W.alive,
+                       w->embed, W.emb, d->D, d->B, st);
+}
+
+int set_editnet_greedy(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X, const float* image_mean,
+                       const int64_t* prev, const int64_t* prevlen, int64_t start_idx, int64_t end_idx, int max_len,
+                       int64_t* seq, float* seq_logp, void* ws, size_t ws_bytes, void* stream) {
+    if (!w || !X || !prev || !prevlen || !seq || !seq_logp || max_len <= 0) return SET_ERR_ARG;
+    EditNetWs W;
+    SET_TRY(prep(d, ws, ws_bytes, &W));
+    if (max_len + 1 > d->maxT + 1 || start_idx < 0 || start_idx >= d->V) return SET_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int B = d->B;
+    SET_TRY(begin_impl(w, d, X, image_mean, prev, prevlen, W, st));
+    SET_HIP_TRY(hipMemsetAsync(seq, 0, sizeof(int64_t) * B * max_len, st));
+    SET_HIP_TRY(hipMemsetAsync(seq_logp, 0, sizeof(float) * B * max_len, st));
+    SET_TRY(set_tokens(W.it, start_idx, W.unfinished, W.alive, d->maxT + 2, B, st));
+    SET_TRY(embed_relu(w->embed, (const int64_t*)W.it, 1, W.emb, d->D, B, d->D, d->V, st));
+    // the reference runs max_len + 1 timesteps and discards the last one (editnet_rl.py:503,517-518)
+    for (int t = 0; t <= max_len; ++t) {
+        Slabs lg;
+        SET_TRY(step_impl(w, d, X, B, W, nullptr, 0, &lg, st));
+        if (t == max_len) break;
+        SET_TRY(greedy_pick(lg, w->fc_b, d->V, t, max_len, end_idx,
+                            (long long*)seq, seq_logp, W.it, W.unfinished, W.alive, w->embed, W.emb, d->D, B, st));
+    }
+    return SET_OK;
+}
+
+int set_editnet_xe_forward(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X,
+                           const float* image_mean, const int64_t* caps, int64_t caps_stride,
+                           const int* host_decode_lengths, const int64_t* prev, const int64_t* prevlen,
+                           float* predictions, void* ws, size_t ws_bytes, void* stream) {
+    if (!w || !X || !caps || !host_decode_lengths || !prev || !prevlen || !predictions) return SET_ERR_ARG;
+    EditNetWs W;
+    SET_TRY(prep(d, ws, ws_bytes, &W));
+    hipStream_t st = (hipStream_t)stream;
+    const int B = d->B, V = d->V, maxT = d->maxT;
+    for (int b = 0; b < B; ++b) {
+        if (host_decode_lengths[b] < 0 || host_decode_lengths[b] > maxT) return SET_ERR_ARG;
+        if (b && host_decode_lengths[b] > host_decode_lengths[b - 1]) return SET_ERR_ARG;   // sorted desc
+    }
+    if (caps_stride < maxT) return SET_ERR_ARG;
+    SET_TRY(begin_impl(w, d, X, image_mean, prev, prevlen, W, st));
+    SET_HIP_TRY(hipMemsetAsync(predictions, 0, sizeof(float) * (size_t)B * maxT * V, st));
+    for (int t = 0; t < maxT; ++t) {
+        int bt = 0;
+        while (bt < B && host_decode_lengths[bt] > t) ++bt;       // editnet.py:506
+        if (bt == 0) break;
+        SET_TRY(embed_relu(w->embed, caps + t, caps_stride, W.emb, d->D, bt, d->D, V, st));
+        SET_TRY(step_impl(w, d, X, bt, W, predictions + (size_t)t * V, (long long)maxT * V, nullptr, st));
+    }
+    return SET_OK;
+}
+
+void* set_editnet_ws_tensor(const SetEditNetDims* d, void* ws, const char* name) {
+    if (check_dims(d) != SET_OK || !ws || !name) return nullptr;
+    EditNetWs W = carve(d, ws);
+    struct { const char* n; void* p; } tab[] = {
+        {"H", W.H}, {"M", W.Mem}, {"final_hidden", W.final_hidden}, {"mask", W.mask}, {"att1", W.att1},
+        {"att1_c", W.att1_c}, {"image_mean", W.image_mean}, {"pre1", W.pre1}, {"rmask", W.rmask}, {"h1", W.h1},
+        {"c1", W.c1}, {"h2", W.h2}, {"c2", W.c2}, {"emb", W.emb}, {"ctx_cap", W.ctx_cap},
+        {"attend_cap", W.attend_cap}, {"attend_img", W.attend_img}, {"sel", W.sel}, {"c_new", W.c_new},
+        {"alpha_c", W.alpha_c}, {"alpha", W.alpha}, {"logits", W.logits}, {"it", W.it},
+        {"unfinished", W.unfinished}, {"alive", W.alive}};
+    for (auto& e : tab)
+        if (!strcmp(e.n, name)) return e.p;
+    return nullptr;
+}
+
+}  // extern "C"

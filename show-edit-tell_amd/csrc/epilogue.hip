@@ -1,0 +1,111 @@
+// Step epilogues on the vocabulary row (one workgroup per batch row, HBM/L2-bound reduction):
+//   greedy (editnet_rl.py:514-543, dcnet_rl.py:313-340): log_softmax, first arg-max, <end> -> 0,
+//   `unfinished` latch, seq / seqLogprobs stores, early-break emulation, and the NEXT step's
+//   embedding gather relu(E[it]) (editnet.py:300-304) fused in so the loop needs no extra launch.
+#include "set_common.h"
+
+namespace set {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float logit_at(const Slabs& s, const float* bias, long long row, int v) {
+    const float* p = s.p + row * s.ld + v;
+    float x = p[0];
+    for (int i = 1; i < s.n; ++i) x += p[(long long)i * s.stride];
+    return bias ? x + bias[v] : x;
+}
+
+// grid = B rows.  alive[t] counts rows still unfinished after step t (zeroed by the caller);
+// once alive[t-1] == 0 the reference has left its loop (`break`, editnet_rl.py:546) and nothing
+// more is written to seq / seq_logp.
+__global__ void __launch_bounds__(256) greedy_pick_k(Slabs logits, const float* bias, int V, int t, int max_len,
+                                                     long long end_idx, long long* seq, float* seq_logp,
+                                                     long long* it_buf, int* unfinished, int* alive,
+                                                     const float* table, float* emb_out, int D) {
+    __shared__ float s_val[4];
+    __shared__ int s_idx[4];
+    __shared__ float s_sum[4];
+    __shared__ long long s_tok;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // pass 1: max and its first index
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int v = tid; v < V; v += 256) {
+        const float x = logit_at(logits, bias, b, v);
+        if (x > best) { best = x; bi = v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { s_val[wave] = best; s_idx[wave] = bi; }
+    __syncthreads();
+    best = s_val[0]; bi = s_idx[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (s_val[w] > best || (s_val[w] == best && s_idx[w] < bi)) { best = s_val[w]; bi = s_idx[w]; }
+    // pass 2: sum exp(x - max)
+    float sum = 0.f;
+    for (int v = tid; v < V; v += 256) sum += expf(logit_at(logits, bias, b, v) - best);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) s_sum[wave] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        const float total = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+        const float logp = (best - best) - logf(total);         // log_softmax at the arg-max
+        long long it = bi;
+        if (it == end_idx) it = 0;
+        int unf = (t == 0) ? (it > 0) : (unfinished[b] && it > 0);
+        it = unf ? it : 0;
+        const bool broken = (t > 0) && (alive[t - 1] == 0);
+        if (t < max_len && !broken) {
+            seq[(long long)b * max_len + t] = it;
+            seq_logp[(long long)b * max_len + t] = logp;
+        }
+        unfinished[b] = unf;
+        if (unf) atomicAdd(&alive[t], 1);
+        it_buf[b] = it;
+        s_tok = it;
+    }
+    __syncthreads();
+    if (emb_out) {
+        const long long tok = s_tok;
+        for (int d = tid * 4; d < D; d += 1024) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(table + tok * D + d);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            *reinterpret_cast<f32x4*>(emb_out + (long long)b * D + d) = v;
+        }
+    }
+}
+
+int greedy_pick(Slabs logits, const float* bias, int V, int t, int max_len, long long end_idx, long long* seq,
+                float* seq_logp, long long* it, int* unfinished, int* alive, const float* table, float* emb_out,
+                int D, int B, hipStream_t s) {
+    if (B <= 0) return SET_OK;
+    if (D & 3) return SET_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(greedy_pick_k, dim3(B), dim3(256), 0, s, logits, bias, V, t, max_len, end_idx, seq, seq_logp,
+                       it, unfinished, alive, table, emb_out, D);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+// it[:] = value; unfinished[:] = 1; alive[0..n_alive) = 0
+__global__ void __launch_bounds__(256) set_tokens_k(long long* it, long long value, int* unfinished, int* alive,
+                                                    int n_alive, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) { it[i] = value; unfinished[i] = 1; }
+    if (i < n_alive) alive[i] = 0;
+}
+
+int set_tokens(long long* it, long long value, int* unfinished, int* alive, int n_alive, int B, hipStream_t s) {
+    const int n = B > n_alive ? B : n_alive;
+    hipLaunchKernelGGL(set_tokens_k, dim3(cdiv(n, 256)), dim3(256), 0, s, it, value, unfinished, alive, n_alive, B);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+}  // namespace set

@@ -1,0 +1,247 @@
+// Grouped skinny fp32 GEMM for the decode step:  C[M,N] = A[M,K] * W[N,K]^T  (nn.Linear layout).
+//
+// Why this shape: every contraction of the step (gate products of the two LSTM cells, the
+// attention projections, the context gate, the vocabulary projection) has M = the decode batch
+// (<= a few hundred rows) against a weight matrix that is streamed once.  fp32 in / fp32
+// accumulate is required by the 1e-4-logit / bit-exact-token target, so the math runs on
+// v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains, 157 TFLOP/s peak = 256 flop/clk/CU).
+//
+// Structure (one workgroup = 4 waves = one SIMD each):
+//   * tile BM x BN x 32; global -> registers (float4, whole 128-B rows) -> LDS with a 36-float
+//     row stride (conflict-free ds_write_b128 and ds_read_b128), two LDS buffers, one barrier
+//     per k-tile; the next k-tile's global loads are in flight during the MFMAs of this one.
+//   * K order inside an 8-wide block is permuted (lanes 0-31 take k0..3, lanes 32-63 k4..7) so one
+//     ds_read_b128 per operand row feeds four MFMAs; A and W use the same permutation.
+//   * several independent problems ride one launch (GemmLaunch holds up to 6 task descriptors)
+//     and each may be split along K into slabs (deterministic: slab s is written by exactly one
+//     workgroup; the consuming pointwise kernel adds the slabs in a fixed order).
+//   * K may be a concatenation of up to three (activation, weight-column-block) segments, so
+//     cat([emb, h2, h1]) x [W_ih[:, :D] | W_ih[:, 2D:3D] | W_hh] needs no copies of weights.
+#include "set_common.h"
+
+namespace set {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int LDS_STRIDE = 36;   // floats per staged row (32 + 4 pad): banks r*36 mod 64 distinct per lane group
+
+struct GemmTask {
+    const float* A[GEMM_MAX_SEG];
+    const float* W[GEMM_MAX_SEG];
+    long long lda[GEMM_MAX_SEG], ldw[GEMM_MAX_SEG];
+    int kt_end[GEMM_MAX_SEG];     // cumulative k-tiles at the end of each segment
+    float* C;
+    long long ldc, slab_stride;
+    const float* bias;
+    int M, N, act, nseg, ktiles, ksplit, tiles_m, tiles_n, wg_begin;
+};
+struct GemmLaunch {
+    GemmTask t[GEMM_MAX_TASKS];
+    int ntasks;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case SET_ACT_RELU: return v > 0.f ? v : 0.f;
+        case SET_ACT_TANH: return tanhf(v);
+        case SET_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        default: return v;
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
+    constexpr int LA = BM / 32, LW = BN / 32;            // float4 loads per thread per k-tile
+    static_assert(TM >= 1 && TN >= 1, "wave tile is a multiple of 32x32");
+    __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * LDS_STRIDE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+
+    // ---- which task / tile / k-slice is this workgroup
+    int ti = 0;
+#pragma unroll
+    for (int i = 1; i < GEMM_MAX_TASKS; ++i)
+        if (i < L.ntasks && (int)blockIdx.x >= L.t[i].wg_begin) ti = i;
+    const GemmTask& T = L.t[ti];
+    const int local = (int)blockIdx.x - T.wg_begin;
+    const int ks = local % T.ksplit;
+    const int tile = local / T.ksplit;
+    const int tn = tile % T.tiles_n, tm = tile / T.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kt0 = (int)(((long long)ks * T.ktiles) / T.ksplit);
+    const int kt1 = (int)(((long long)(ks + 1) * T.ktiles) / T.ksplit);
+
+    // ---- staging assignment: thread -> (row = tid/8 + 32*i, 16-byte column = tid%8)
+    const int srow = tid >> 3, scol = (tid & 7) * 4;
+    int arow[LA], wrow[LW];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) { int r = m0 + srow + 32 * i; arow[i] = r < T.M ? r : T.M - 1; }
+#pragma unroll
+    for (int i = 0; i < LW; ++i) { int r = n0 + srow + 32 * i; wrow[i] = r < T.N ? r : T.N - 1; }
+
+    f32x4 ra[LA], rw[LW];
+#define SET_GLOAD(KT)                                                                                   \
+    {                                                                                                   \
+        const int kt_ = (KT);                                                                           \
+        int s_ = 0, kbase_ = 0;                                                                         \
+        _Pragma("unroll") for (int i = 0; i < GEMM_MAX_SEG - 1; ++i)                                    \
+            if (i + 1 < T.nseg && kt_ >= T.kt_end[i]) { s_ = i + 1; kbase_ = T.kt_end[i]; }             \
+        const long long koff_ = (long long)(kt_ - kbase_) * GEMM_BK + scol;                             \
+        const float* Ab_ = T.A[0];                                                                      \
+        const float* Wb_ = T.W[0];                                                                      \
+        long long lda_ = T.lda[0], ldw_ = T.ldw[0];                                                     \
+        _Pragma("unroll") for (int i = 1; i < GEMM_MAX_SEG; ++i)                                        \
+            if (s_ == i) { Ab_ = T.A[i]; Wb_ = T.W[i]; lda_ = T.lda[i]; ldw_ = T.ldw[i]; }              \
+        _Pragma("unroll") for (int i = 0; i < LA; ++i)                                                  \
+            ra[i] = *reinterpret_cast<const f32x4*>(Ab_ + arow[i] * lda_ + koff_);                     \
+        _Pragma("unroll") for (int i = 0; i < LW; ++i)                                                  \
+            rw[i] = *reinterpret_cast<const f32x4*>(Wb_ + wrow[i] * ldw_ + koff_);                     \
+    }
+#define SET_LSTORE(BUF)                                                                                 \
+    {                                                                                                   \
+        float* sA_ = lds[(BUF)];                                                                        \
+        float* sW_ = lds[(BUF)] + BM * LDS_STRIDE;                                                      \
+        _Pragma("unroll") for (int i = 0; i < LA; ++i)                                                  \
+            *reinterpret_cast<f32x4*>(sA_ + (srow + 32 * i) * LDS_STRIDE + scol) = ra[i];              \
+        _Pragma("unroll") for (int i = 0; i < LW; ++i)                                                  \
+            *reinterpret_cast<f32x4*>(sW_ + (srow + 32 * i) * LDS_STRIDE + scol) = rw[i];              \
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int frow = lane & 31, fk = (lane >> 5) * 4;
+    int buf = 0;
+    if (kt0 < kt1) SET_GLOAD(kt0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        SET_LSTORE(buf);
+        __syncthreads();
+        if (kt + 1 < kt1) SET_GLOAD(kt + 1);
+        const float* sA = lds[buf] + (wm * TM * 32 + frow) * LDS_STRIDE + fk;
+        const float* sW = lds[buf] + BM * LDS_STRIDE + (wn * TN * 32 + frow) * LDS_STRIDE + fk;
+#pragma unroll
+        for (int kk = 0; kk < GEMM_BK / 8; ++kk) {
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(sA + i * 32 * LDS_STRIDE + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(sW + j * 32 * LDS_STRIDE + kk * 8);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        buf ^= 1;
+    }
+
+    // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* Cs = T.C + (long long)ks * T.slab_stride;
+    const bool fused = (T.ksplit == 1);
+    const int crow0 = m0 + wm * TM * 32 + 4 * (lane >> 5);
+    const int ccol0 = n0 + wn * TN * 32 + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = ccol0 + j * 32;
+        if (col >= T.N) continue;
+        const float bv = (fused && T.bias) ? T.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = crow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                if (row < T.M) {
+                    float v = acc[i][j][r];
+                    if (fused) v = apply_act(v + bv, T.act);
+                    Cs[(long long)row * T.ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+#undef SET_GLOAD
+#undef SET_LSTORE
+
+int gemm_tile_m(int M) { return M <= 32 ? 32 : (M <= 64 ? 64 : 128); }
+static int gemm_tile_n(int M) { return M <= 32 ? 128 : 64; }
+
+void plan_ksplit(GemmProb* probs, int n, int target_wgs) {
+    long long units = 0;
+    for (int i = 0; i < n; ++i) {
+        const int bm = gemm_tile_m(probs[i].M), bn = gemm_tile_n(probs[i].M);
+        units += (long long)cdiv(probs[i].M, bm) * cdiv(probs[i].N, bn) * probs[i].ktiles();
+    }
+    long long kper = (units + target_wgs - 1) / target_wgs;
+    if (kper < 4) kper = 4;
+    for (int i = 0; i < n; ++i) {
+        int ks = (int)((probs[i].ktiles() + kper - 1) / kper);
+        if (ks < 1) ks = 1;
+        if (ks > probs[i].max_ksplit) ks = probs[i].max_ksplit;
+        if (ks > probs[i].ktiles()) ks = probs[i].ktiles();
+        probs[i].ksplit = ks;
+    }
+}
+
+int gemm_group(const GemmProb* probs, int n, hipStream_t stream) {
+    if (n <= 0) return SET_OK;
+    if (n > GEMM_MAX_TASKS) return SET_ERR_ARG;
+    GemmLaunch L;
+    L.ntasks = n;
+    int wg = 0;
+    const int bm = gemm_tile_m(probs[0].M), bn = gemm_tile_n(probs[0].M);
+    for (int i = 0; i < n; ++i) {
+        const GemmProb& p = probs[i];
+        GemmTask& t = L.t[i];
+        if (p.M <= 0 || p.N <= 0 || p.nseg <= 0 || p.nseg > GEMM_MAX_SEG || !p.C) return SET_ERR_ARG;
+        if (gemm_tile_m(p.M) != bm) return SET_ERR_ARG;   // one tile shape per launch
+        int kt = 0;
+        for (int s = 0; s < GEMM_MAX_SEG; ++s) {
+            if (s < p.nseg) {
+                const GemmSeg& g = p.seg[s];
+                if (!g.A || !g.W || g.K <= 0) return SET_ERR_ARG;
+                if (g.K % GEMM_BK) return SET_ERR_UNSUPPORTED;
+                if (!aligned16(g.A) || !aligned16(g.W) || (g.lda & 3) || (g.ldw & 3)) return SET_ERR_ARG;
+                kt += g.K / GEMM_BK;
+                t.A[s] = g.A; t.W[s] = g.W; t.lda[s] = g.lda; t.ldw[s] = g.ldw;
+            } else {
+                t.A[s] = nullptr; t.W[s] = nullptr; t.lda[s] = 0; t.ldw[s] = 0;
+            }
+            t.kt_end[s] = kt;
+        }
+        t.C = p.C; t.ldc = p.ldc; t.slab_stride = p.slab_stride; t.bias = p.bias;
+        t.M = p.M; t.N = p.N; t.act = p.act; t.nseg = p.nseg; t.ktiles = kt;
+        t.ksplit = p.ksplit < 1 ? 1 : p.ksplit;
+        if (t.ksplit > kt) t.ksplit = kt;
+        if (t.ksplit > 1 && (p.act != SET_ACT_NONE)) return SET_ERR_ARG;
+        t.tiles_m = cdiv(p.M, bm); t.tiles_n = cdiv(p.N, bn);
+        t.wg_begin = wg;
+        wg += t.tiles_m * t.tiles_n * t.ksplit;
+    }
+    for (int i = n; i < GEMM_MAX_TASKS; ++i) { L.t[i] = L.t[0]; L.t[i].wg_begin = 0x7fffffff; }
+    dim3 grid(wg), block(256);
+    if (bm == 128)
+        hipLaunchKernelGGL((gemm_nt_f32<128, 64, 2, 2>), grid, block, 0, stream, L);
+    else if (bm == 64)
+        hipLaunchKernelGGL((gemm_nt_f32<64, 64, 2, 2>), grid, block, 0, stream, L);
+    else
+        hipLaunchKernelGGL((gemm_nt_f32<32, 128, 1, 4>), grid, block, 0, stream, L);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+}  // namespace set

@@ -1,0 +1,350 @@
+// Pointwise / reduction kernels of the decode step.  All are HBM/L2-bound streaming kernels:
+// one float4 of hidden units per thread, coalesced rows, slab partial sums of the split-K GEMMs
+// added in a fixed order (slab 0, 1, 2, ...) so results are run-to-run deterministic.
+#include "set_common.h"
+
+namespace set {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+thread_local int g_last_hip_error = 0;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// sum of the K-slabs of one GEMM output at (m, n..n+3)
+__device__ __forceinline__ f32x4 slab_sum4(const Slabs& s, long long m, int n) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (s.n <= 0) return v;
+    const float* p = s.p + m * s.ld + n;
+    v = ld4(p);
+    for (int i = 1; i < s.n; ++i) v += ld4(p + (long long)i * s.stride);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LSTM cell pointwise (nn.LSTMCell editnet.py:468,532 / LSTMCellC :235-242 / CopyLSTMCellC :274-280)
+//   gates[m, g*D + j] = g0 + g1 + g2 (slab sums) + pre + b0 + b1 ; order i, f, g, o
+//   c' = sig(f) c + sig(i) tanh(g);  h' = sig(o) tanh(c')     (h_out / ogate_out optional)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) lstm_pointwise_k(Slabs g0, Slabs g1, Slabs g2, const float* pre,
+                                                        long long ldpre, const float* b0, const float* b1,
+                                                        const float* c_in, float* c_out, float* h_out,
+                                                        float* ogate_out, int M, int D) {
+    const int per_row = D >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)M * per_row) return;
+    const long long m = idx / per_row;
+    const int j = (int)(idx - m * per_row) << 2;
+    f32x4 g[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = q * D + j;
+        f32x4 v = slab_sum4(g0, m, n);
+        v += slab_sum4(g1, m, n);
+        v += slab_sum4(g2, m, n);
+        if (pre) v += ld4(pre + m * ldpre + n);
+        if (b0) v += ld4(b0 + n);
+        if (b1) v += ld4(b1 + n);
+        g[q] = v;
+    }
+    const f32x4 c = ld4(c_in + m * D + j);
+    f32x4 cn, hn, og;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float ig = sigmoidf_(g[0][e]), fg = sigmoidf_(g[1][e]), gg = tanhf(g[2][e]);
+        og[e] = sigmoidf_(g[3][e]);
+        cn[e] = fg * c[e] + ig * gg;
+        hn[e] = og[e] * tanhf(cn[e]);
+    }
+    st4(c_out + m * D + j, cn);
+    if (h_out) st4(h_out + m * D + j, hn);
+    if (ogate_out) st4(ogate_out + m * D + j, og);
+}
+
+int lstm_pointwise(Slabs g0, Slabs g1, Slabs g2, const float* pre, long long ldpre, const float* b0,
+                   const float* b1, const float* c_in, float* c_out, float* h_out, float* ogate_out, int M,
+                   int D, hipStream_t s) {
+    if (D & 3) return SET_ERR_UNSUPPORTED;
+    const long long n = (long long)M * (D >> 2);
+    hipLaunchKernelGGL(lstm_pointwise_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g0, g1, g2, pre,
+                       ldpre, b0, b1, c_in, c_out, h_out, ogate_out, M, D);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// context gating (editnet.py:378-380):
+//   zt = sig(cg_a + cg_b + b_cg); out = zt*tanh(sc + b_sc) + (1-zt)*tanh(tc + b_tc)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) context_gate_k(Slabs cg_a, Slabs cg_b, const float* cg_bias, Slabs sc,
+                                                      const float* sc_bias, Slabs tc, const float* tc_bias,
+                                                      float* out, int M, int D) {
+    const int per_row = D >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)M * per_row) return;
+    const long long m = idx / per_row;
+    const int j = (int)(idx - m * per_row) << 2;
+    f32x4 z = slab_sum4(cg_a, m, j);
+    z += slab_sum4(cg_b, m, j);
+    z += ld4(cg_bias + j);
+    f32x4 s = slab_sum4(sc, m, j) + ld4(sc_bias + j);
+    f32x4 t = slab_sum4(tc, m, j) + ld4(tc_bias + j);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float zt = sigmoidf_(z[e]);
+        o[e] = zt * tanhf(s[e]) + (1.f - zt) * tanhf(t[e]);
+    }
+    st4(out + m * D + j, o);
+}
+
+int context_gate_pointwise(Slabs cg_a, Slabs cg_b, const float* cg_bias, Slabs sc, const float* sc_bias,
+                           Slabs tc, const float* tc_bias, float* out, int M, int D, hipStream_t s) {
+    if (D & 3) return SET_ERR_UNSUPPORTED;
+    const long long n = (long long)M * (D >> 2);
+    hipLaunchKernelGGL(context_gate_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cg_a, cg_b, cg_bias,
+                       sc, sc_bias, tc, tc_bias, out, M, D);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// copy gate (editnet.py:281-283):
+//   copy = sig(Wn c_new + bn + Wm sel + bm); c2' = copy*sel + (1-copy)*c_new; h2' = ogate*tanh(c2')
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) copy_gate_k(Slabs gn, const float* bn, Slabs gm, const float* bm,
+                                                   const float* c_new, const float* sel, const float* ogate,
+                                                   float* c_out, float* h_out, int M, int D) {
+    const int per_row = D >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)M * per_row) return;
+    const long long m = idx / per_row;
+    const int j = (int)(idx - m * per_row) << 2;
+    // reference order: (gate_cnew(c_new) + b) + (gate_cmem(c_memory) + b)
+    f32x4 a = slab_sum4(gn, m, j) + ld4(bn + j);
+    f32x4 b = slab_sum4(gm, m, j) + ld4(bm + j);
+    const f32x4 cn = ld4(c_new + m * D + j), sm = ld4(sel + m * D + j), og = ld4(ogate + m * D + j);
+    f32x4 co, ho;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float cg = sigmoidf_(a[e] + b[e]);
+        co[e] = cg * sm[e] + (1.f - cg) * cn[e];
+        ho[e] = og[e] * tanhf(co[e]);
+    }
+    st4(c_out + m * D + j, co);
+    st4(h_out + m * D + j, ho);
+}
+
+int copy_gate_pointwise(Slabs gn, const float* bn, Slabs gm, const float* bm, const float* c_new,
+                        const float* sel, const float* ogate, float* c_out, float* h_out, int M, int D,
+                        hipStream_t s) {
+    if (D & 3) return SET_ERR_UNSUPPORTED;
+    const long long n = (long long)M * (D >> 2);
+    hipLaunchKernelGGL(copy_gate_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gn, bn, gm, bm, c_new,
+                       sel, ogate, c_out, h_out, M, D);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// out[m, n] = act(sum_slabs + b0 + b1)        (N multiple of 4)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) reduce_bias_act_k(Slabs in, const float* b0, const float* b1, float* out,
+                                                         long long ldo, int M, int N, int act) {
+    const int per_row = N >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)M * per_row) return;
+    const long long m = idx / per_row;
+    const int j = (int)(idx - m * per_row) << 2;
+    f32x4 v = slab_sum4(in, m, j);
+    if (b0) v += ld4(b0 + j);
+    if (b1) v += ld4(b1 + j);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float x = v[e];
+        if (act == SET_ACT_RELU) x = x > 0.f ? x : 0.f;
+        else if (act == SET_ACT_TANH) x = tanhf(x);
+        else if (act == SET_ACT_SIGMOID) x = sigmoidf_(x);
+        v[e] = x;
+    }
+    st4(out + m * ldo + j, v);
+}
+
+// scalar variant for rows that are not 16-byte aligned (e.g. V = 9490 predictions)
+__global__ void __launch_bounds__(256) reduce_bias_act_scalar_k(Slabs in, const float* b0, const float* b1,
+                                                                float* out, long long ldo, int M, int N, int act) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)M * N) return;
+    const long long m = idx / N;
+    const int j = (int)(idx - m * N);
+    const float* p = in.p + m * in.ld + j;
+    float x = p[0];
+    for (int i = 1; i < in.n; ++i) x += p[(long long)i * in.stride];
+    if (b0) x += b0[j];
+    if (b1) x += b1[j];
+    if (act == SET_ACT_RELU) x = x > 0.f ? x : 0.f;
+    else if (act == SET_ACT_TANH) x = tanhf(x);
+    else if (act == SET_ACT_SIGMOID) x = sigmoidf_(x);
+    out[m * ldo + j] = x;
+}
+
+int reduce_bias_act(Slabs in, const float* b0, const float* b1, float* out, long long ldo, int M, int N, int act,
+                    hipStream_t s) {
+    if (M <= 0 || N <= 0) return SET_OK;
+    const bool vec = !(N & 3) && !(ldo & 3) && !(in.ld & 3) && !(in.stride & 3) && aligned16(out) && aligned16(in.p) &&
+                     (!b0 || aligned16(b0)) && (!b1 || aligned16(b1));
+    if (vec) {
+        const long long n = (long long)M * (N >> 2);
+        hipLaunchKernelGGL(reduce_bias_act_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, b0, b1, out, ldo,
+                           M, N, act);
+    } else {
+        const long long n = (long long)M * N;
+        hipLaunchKernelGGL(reduce_bias_act_scalar_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, b0, b1,
+                           out, ldo, M, N, act);
+    }
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// EmbeddingC.forward, eval (editnet.py:300-304): out[i] = relu(table[ids[i*stride]])
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) embed_relu_k(const float* table, const int64_t* ids, long long ids_stride,
+                                                    float* out, long long ldo, int n, int D, int V) {
+    const int per_row = D >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)n * per_row) return;
+    const long long i = idx / per_row;
+    const int j = (int)(idx - i * per_row) << 2;
+    long long id = ids[i * ids_stride];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);       // ids are validated by the caller; clamp = no OOB read
+    f32x4 v = ld4(table + id * D + j);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+    st4(out + i * ldo + j, v);
+}
+
+int embed_relu(const float* table, const int64_t* ids, long long ids_stride, float* out, long long ldo, int n,
+               int D, int V, hipStream_t s) {
+    if ((D & 3) || (ldo & 3)) return SET_ERR_UNSUPPORTED;
+    if (n <= 0) return SET_OK;
+    const long long t = (long long)n * (D >> 2);
+    hipLaunchKernelGGL(embed_relu_k, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, table, ids, ids_stride, out,
+                       ldo, n, D, V);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// image_mean = X.mean(1) (editnet.py:503): sequential sum over regions, then / R
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) mean_regions_k(const float* X, float* out, int B, int R, int F) {
+    const int per_row = F >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * per_row) return;
+    const long long b = idx / per_row;
+    const int j = (int)(idx - b * per_row) << 2;
+    const float* p = X + b * (long long)R * F + j;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < R; ++r) acc += ld4(p + (long long)r * F);
+    const float rr = (float)R;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = acc[e] / rr;
+    st4(out + b * F + j, acc);
+}
+
+int mean_regions(const float* X, float* out, int B, int R, int F, hipStream_t s) {
+    if (F & 3) return SET_ERR_UNSUPPORTED;
+    const long long t = (long long)B * (F >> 2);
+    hipLaunchKernelGGL(mean_regions_k, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, X, out, B, R, F);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// caption-encoder LSTM step (CaptionEncoderC editnet.py:333-338 ; nn.LSTM over a packed batch
+// dcnet.py:233).  The reference sorts by length and shrinks the batch prefix; per row that is:
+//   if t < len[b]:  (h,c) <- cell(x[b,pos], h, c);  H[b,pos] = h;  Mem[b,pos] = c
+// with pos = t (forward) or len[b]-1-t (reverse direction of the packed BiLSTM).
+// xg holds the hoisted input projection x W_x^T + b_x + b_h for every (b, position).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) encoder_pointwise_k(Slabs hh, const float* xg, long long ld_xg_row,
+                                                           long long ld_xg_t, int t, const int64_t* lens,
+                                                           int reverse, float* h, float* c, float* H, float* Mem,
+                                                           long long ld_out_b, long long ld_out_t, int out_col0,
+                                                           int B, int D, const float* b_extra) {
+    const int per_row = D >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * per_row) return;
+    const long long b = idx / per_row;
+    const int j = (int)(idx - b * per_row) << 2;
+    const int len = (int)lens[b];
+    if (t >= len) return;
+    const int pos = reverse ? (len - 1 - t) : t;
+    const float* xr = xg + b * ld_xg_row + (long long)pos * ld_xg_t;
+    f32x4 g[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        g[q] = slab_sum4(hh, b, q * D + j) + ld4(xr + q * D + j);
+        if (b_extra) g[q] += ld4(b_extra + q * D + j);
+    }
+    const f32x4 cp = ld4(c + b * D + j);
+    f32x4 cn, hn;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float ig = sigmoidf_(g[0][e]), fg = sigmoidf_(g[1][e]), gg = tanhf(g[2][e]), og = sigmoidf_(g[3][e]);
+        cn[e] = fg * cp[e] + ig * gg;
+        hn[e] = og * tanhf(cn[e]);
+    }
+    st4(c + b * D + j, cn);
+    st4(h + b * D + j, hn);
+    st4(H + b * ld_out_b + (long long)pos * ld_out_t + out_col0 + j, hn);
+    if (Mem) st4(Mem + b * ld_out_b + (long long)pos * ld_out_t + out_col0 + j, cn);
+}
+
+int encoder_pointwise(Slabs hh, const float* xg, long long ld_xg_row, long long ld_xg_t, int t,
+                      const int64_t* lens, int reverse, float* h, float* c, float* H, float* Mem,
+                      long long ld_out_b, long long ld_out_t, int out_col0, int B, int D, const float* b_extra,
+                      hipStream_t s) {
+    if (D & 3) return SET_ERR_UNSUPPORTED;
+    const long long n = (long long)B * (D >> 2);
+    hipLaunchKernelGGL(encoder_pointwise_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, hh, xg, ld_xg_row,
+                       ld_xg_t, t, lens, reverse, h, c, H, Mem, ld_out_b, ld_out_t, out_col0, B, D, b_extra);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// mask[row] = (sum_d x[row, d]) != 0   (editnet.py:340, dcnet.py:239): one wave per row
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) rowsum_mask_k(const float* x, long long ld_row, int rows, int D, float* mask) {
+    const int wave = (int)((blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    if (wave >= rows) return;
+    const float* p = x + (long long)wave * ld_row;
+    float s = 0.f;
+    for (int d = lane * 4; d < D; d += 256) {
+        f32x4 v = ld4(p + d);
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) mask[wave] = (s != 0.f) ? 1.f : 0.f;
+}
+
+int rowsum_mask(const float* x, long long ld_row, int rows, int D, float* mask, hipStream_t s) {
+    if (D & 3) return SET_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(rowsum_mask_k, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, s, x, ld_row, rows, D, mask);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+int zero_f32(float* p, size_t n, hipStream_t s) {
+    SET_HIP_TRY(hipMemsetAsync(p, 0, n * sizeof(float), s));
+    return SET_OK;
+}
+
+}  // namespace set

@@ -1,0 +1,143 @@
+// Internal helpers shared by the HIP translation units of libset_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/set_hip.h"
+
+namespace set {
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing: HIP failures are recorded per thread and surfaced as SET_ERR_HIP
+// ---------------------------------------------------------------------------------------------
+extern thread_local int g_last_hip_error;
+inline int hip_fail(hipError_t e) { g_last_hip_error = (int)e; return SET_ERR_HIP; }
+
+#define SET_HIP_TRY(expr)                                   \
+    do {                                                    \
+        hipError_t _e = (expr);                             \
+        if (_e != hipSuccess) return ::set::hip_fail(_e);   \
+    } while (0)
+#define SET_TRY(expr)                  \
+    do {                               \
+        int _rc = (expr);              \
+        if (_rc != SET_OK) return _rc; \
+    } while (0)
+#define SET_LAUNCH_CHECK() SET_HIP_TRY(hipGetLastError())
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// bump allocator over the caller-supplied workspace (256-byte granules)
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* p) : base(static_cast<char*>(p)) {}
+    template <typename T>
+    T* take(size_t n) {
+        T* r = reinterpret_cast<T*>(base + off);
+        off += round_up(n * sizeof(T), 256);
+        return r;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// grouped skinny GEMM  C[M,N] (+slabs) = A[M,K] * W[N,K]^T   (gemm_f32.hip)
+//   fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32; K may be the concatenation of up to
+//   three (A,W) column segments that live in different tensors (weights are used in place).
+// ---------------------------------------------------------------------------------------------
+constexpr int GEMM_BK = 32;
+constexpr int GEMM_MAX_SEG = 3;
+constexpr int GEMM_MAX_TASKS = 6;
+constexpr int GEMM_MAX_KSPLIT = 8;
+
+struct GemmSeg {
+    const float* A;   // (M, K) rows, leading stride lda
+    const float* W;   // (N, K) rows, leading stride ldw
+    long long lda, ldw;
+    int K;            // multiple of GEMM_BK
+};
+
+struct GemmProb {
+    GemmSeg seg[GEMM_MAX_SEG];
+    int nseg = 0;
+    float* C = nullptr;          // slab s at C + s*slab_stride; (M,N) rows with stride ldc
+    long long ldc = 0, slab_stride = 0;
+    const float* bias = nullptr; // fused only when ksplit == 1
+    int M = 0, N = 0;
+    int act = SET_ACT_NONE;      // fused only when ksplit == 1
+    int ksplit = 1;              // filled by plan_ksplit or by the caller
+    int max_ksplit = GEMM_MAX_KSPLIT;
+    void add(const float* A, long long lda, const float* W, long long ldw, int K) {
+        seg[nseg++] = GemmSeg{A, W, lda, ldw, K};
+    }
+    int ktiles() const { int k = 0; for (int i = 0; i < nseg; ++i) k += seg[i].K / GEMM_BK; return k; }
+};
+
+// choose per-problem ksplit so that the whole group launches about `target_wgs` workgroups of
+// similar length; problems with max_ksplit == 1 keep a fused bias/activation epilogue
+void plan_ksplit(GemmProb* probs, int n, int target_wgs);
+int gemm_group(const GemmProb* probs, int n, hipStream_t stream);
+int gemm_tile_m(int M);   // BM the launcher will pick for M rows
+
+// ---------------------------------------------------------------------------------------------
+// slab views consumed by the pointwise kernels: value(m,n) = sum_s p[s*stride + m*ld + n]
+// ---------------------------------------------------------------------------------------------
+struct Slabs {
+    const float* p;
+    long long stride;
+    long long ld;
+    int n;
+};
+inline Slabs slabs_of(const GemmProb& g) { return Slabs{g.C, g.slab_stride, g.ldc, g.ksplit}; }
+
+// editnet.hip (shared host helpers)
+int env_int(const char* name, int dflt);
+int gemm_target_wgs();
+GemmProb slab_prob(float* slab, int M, int N, int Bmax);
+GemmProb direct_prob(float* out, long long ldo, int M, int N, const float* bias, int act);
+int editnet_encoder(const SetEditNetWeights* w, const int64_t* seq, const int64_t* lens, float* H, float* Mem,
+                    float* final_hidden, float* mask, int B, int T, int D, int V, float* emb_seq, float* xg,
+                    float* enc_h, float* enc_c, float* s_enc, float* s_aff, hipStream_t st);
+
+// pointwise.hip
+int lstm_pointwise(Slabs g0, Slabs g1, Slabs g2, const float* pre, long long ldpre, const float* b0,
+                   const float* b1, const float* c_in, float* c_out, float* h_out, float* ogate_out,
+                   int M, int D, hipStream_t s);
+int context_gate_pointwise(Slabs cg_a, Slabs cg_b, const float* cg_bias, Slabs sc, const float* sc_bias,
+                           Slabs tc, const float* tc_bias, float* out, int M, int D, hipStream_t s);
+int copy_gate_pointwise(Slabs gn, const float* bn, Slabs gm, const float* bm, const float* c_new,
+                        const float* sel, const float* ogate, float* c_out, float* h_out, int M, int D,
+                        hipStream_t s);
+int reduce_bias_act(Slabs in, const float* b0, const float* b1, float* out, long long ldo, int M, int N,
+                    int act, hipStream_t s);
+int embed_relu(const float* table, const int64_t* ids, long long ids_stride, float* out, long long ldo,
+               int n, int D, int V, hipStream_t s);
+int mean_regions(const float* X, float* out, int B, int R, int F, hipStream_t s);
+int encoder_pointwise(Slabs hh, const float* xg, long long ld_xg_row, long long ld_xg_t, int t,
+                      const int64_t* lens, int reverse, float* h, float* c, float* H, float* Mem,
+                      long long ld_out_b, long long ld_out_t, int out_col0, int B, int D, const float* b_extra,
+                      hipStream_t s);
+int rowsum_mask(const float* x, long long ld_row, int rows, int D, float* mask, hipStream_t s);
+int zero_f32(float* p, size_t n, hipStream_t s);
+
+// attention.hip
+int caption_attention(const float* att1_c, Slabs att2_c, const float* dec_bias, const float* w_full,
+                      const float* b_full, const float* mask, const float* H, const float* Mem,
+                      float* ctx, float* sel, float* alpha_out, int M, int T, int Dh, int A,
+                      hipStream_t s);
+int visual_attention(const float* att1, Slabs att2, const float* dec_bias, const float* w_full,
+                     const float* b_full, const float* X, const float* rmask, float* ctx,
+                     float* alpha_out, int M, int R, int F, int A, hipStream_t s);
+int region_masks(const float* X, const float* fe, float* rmask, int B, int R, int F, int D, hipStream_t s);
+int select_rows(const float* Mem, const float* alpha, float* sel, int M, int T, int D, hipStream_t s);
+
+// epilogue.hip
+int greedy_pick(Slabs logits, const float* bias, int V, int t, int max_len, long long end_idx,
+                long long* seq, float* seq_logp, long long* it, int* unfinished, int* alive,
+                const float* table, float* emb_out, int D, int B, hipStream_t s);
+int set_tokens(long long* it, long long value, int* unfinished, int* alive, int n_alive, int B,
+               hipStream_t s);
+
+}  // namespace set

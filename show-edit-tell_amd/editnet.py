@@ -1,0 +1,397 @@
+"""EditNet on MI355X: the reference's `DecoderC` module surface over the HIP decode path.
+
+Mirrors `/root/reference/editnet.py:210-548`: same class names, constructor signatures,
+attribute names and `state_dict` keys, so checkpoints and the reference's train / evaluate
+loops (`editnet.py:551-740`) drop in.  The modules hold parameters in ordinary torch containers
+(nn.Linear / nn.LSTMCell / nn.Embedding); every `forward` runs hand-written gfx950 kernels
+through the C ABI in include/set_hip.h (csrc/libset_hip.so).  There is no PyTorch fallback:
+CPU tensors, non-fp32 parameters or a missing library raise.
+
+Scope of this file: eval-mode forward (teacher-forced XE loop and the per-operator calls used by
+beam search).  Train-mode (dropout / autograd) raises NotImplementedError until the backward
+kernels land.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import EditNetDims, EditNetWeights, EDITNET_WEIGHT_FIELDS, check, ptr, stream_of
+
+
+def _f32c(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+def _i64c(t):
+    return t if (t.dtype == torch.int64 and t.is_contiguous()) else t.long().contiguous()
+
+
+def _require_cuda(t, what):
+    if not t.is_cuda:
+        raise _lib.SetError("%s must live on the GPU: the decode path has no CPU fallback" % what)
+
+
+def _no_train(mod, what):
+    if mod.training:
+        raise NotImplementedError(
+            "%s: train mode (dropout + backward) is not built yet; call .eval()" % what)
+
+
+class LSTMCellC(nn.Module):
+    """reference editnet.py:210-244"""
+
+    def __init__(self, input_size, hidden_size):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.input_size = input_size
+        self.x2h = nn.Linear(input_size, 4 * hidden_size)
+        self.h2h = nn.Linear(hidden_size, 4 * hidden_size)
+        self.tanh = nn.Tanh()
+        self.init_parameters()
+
+    def init_parameters(self):
+        std = 1.0 / math.sqrt(self.hidden_size)
+        for p in self.parameters():
+            p.data.uniform_(-std, std)
+
+    def forward(self, x, states):
+        ht, ct = states
+        _require_cuda(x, "LSTMCellC input")
+        lib = _lib.load()
+        x, ht, ct = _f32c(x), _f32c(ht), _f32c(ct)
+        M, K, D = x.shape[0], x.shape[1], self.hidden_size
+        h_new, c_new = torch.empty_like(ht), torch.empty_like(ct)
+        ws = torch.empty(lib.set_lstm_cell_workspace_bytes(M, D, K), dtype=torch.uint8, device=x.device)
+        check(lib.set_lstm_cell_f32(ptr(x), K, K, ptr(ht), ptr(ct), ptr(self.x2h.weight), K, ptr(self.h2h.weight),
+                                    ptr(self.x2h.bias), ptr(self.h2h.bias), ptr(h_new), ptr(c_new), M, D, ptr(ws),
+                                    ws.numel(), stream_of(x.device)), "set_lstm_cell_f32")
+        return h_new, c_new
+
+
+class CopyLSTMCellC(nn.Module):
+    """reference editnet.py:247-285"""
+
+    def __init__(self, input_size, hidden_size):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.input_size = input_size
+        self.x2h = nn.Linear(input_size, 4 * hidden_size)
+        self.h2h = nn.Linear(hidden_size, 4 * hidden_size)
+        self.gate_cnew = nn.Linear(hidden_size, hidden_size)
+        self.gate_cmem = nn.Linear(hidden_size, hidden_size)
+        self.tanh = nn.Tanh()
+        self.init_parameters()
+
+    def init_parameters(self):
+        std = 1.0 / math.sqrt(self.hidden_size)
+        for p in self.parameters():
+            p.data.uniform_(-std, std)
+
+    def forward(self, x, states, c_memory):
+        ht, ct = states
+        _require_cuda(x, "CopyLSTMCellC input")
+        lib = _lib.load()
+        x, ht, ct, cm = _f32c(x), _f32c(ht), _f32c(ct), _f32c(c_memory)
+        M, K, D = x.shape[0], x.shape[1], self.hidden_size
+        w = EditNetWeights()
+        w.cl_x2h_w, w.cl_x2h_b = self.x2h.weight.data_ptr(), self.x2h.bias.data_ptr()
+        w.cl_h2h_w, w.cl_h2h_b = self.h2h.weight.data_ptr(), self.h2h.bias.data_ptr()
+        w.cl_cnew_w, w.cl_cnew_b = self.gate_cnew.weight.data_ptr(), self.gate_cnew.bias.data_ptr()
+        w.cl_cmem_w, w.cl_cmem_b = self.gate_cmem.weight.data_ptr(), self.gate_cmem.bias.data_ptr()
+        h_new, c_new = torch.empty_like(ht), torch.empty_like(ct)
+        ws = torch.empty(lib.set_copy_lstm_workspace_bytes(M, D, K), dtype=torch.uint8, device=x.device)
+        check(lib.set_copy_lstm_f32(C.byref(w), ptr(x), K, K, ptr(ht), ptr(ct), ptr(cm), ptr(h_new), ptr(c_new), M, D,
+                                    ptr(ws), ws.numel(), stream_of(x.device)), "set_copy_lstm_f32")
+        return h_new, c_new
+
+
+class EmbeddingC(nn.Module):
+    """reference editnet.py:288-304 (ReLU + Dropout(0.5) after the lookup; no padding_idx)"""
+
+    def __init__(self, word_map, emb_dim):
+        super().__init__()
+        self.emb_dim = emb_dim
+        self.word_map = word_map
+        self.embedding = nn.Embedding(len(word_map), self.emb_dim)
+        self.relu = nn.ReLU()
+        self.dropout = nn.Dropout(0.5)
+
+    def forward(self, x):
+        _no_train(self, "EmbeddingC")
+        _require_cuda(x, "token ids")
+        lib = _lib.load()
+        ids = _i64c(x)
+        n, D = ids.numel(), self.emb_dim
+        out = torch.empty(tuple(ids.shape) + (D,), dtype=torch.float32, device=ids.device)
+        check(lib.set_embed_relu_f32(ptr(self.embedding.weight), ptr(ids), 1, ptr(out), D, n, D,
+                                     self.embedding.num_embeddings, stream_of(ids.device)), "set_embed_relu_f32")
+        return out
+
+
+class CaptionEncoderC(nn.Module):
+    """reference editnet.py:307-348"""
+
+    def __init__(self, vocab_size, emb_dim, enc_hid_dim, embed):
+        super().__init__()
+        self.vocab_size = vocab_size
+        self.emb_dim = emb_dim
+        self.enc_hid_dim = enc_hid_dim
+        self.embed = embed
+        self.lstm_encoder_cell = LSTMCellC(emb_dim, enc_hid_dim)
+        self.affine_hn = nn.Linear(enc_hid_dim, enc_hid_dim)
+        self.tanh = nn.Tanh()
+
+    def forward(self, seq, seq_len):
+        _no_train(self, "CaptionEncoderC")
+        _require_cuda(seq, "previous captions")
+        lib = _lib.load()
+        seq, lens = _i64c(seq), _i64c(seq_len.reshape(-1))
+        B, T, D = seq.shape[0], seq.shape[1], self.enc_hid_dim
+        dev = seq.device
+        w = EditNetWeights()
+        cell = self.lstm_encoder_cell
+        w.embed = self.embed.embedding.weight.data_ptr()
+        w.enc_x2h_w, w.enc_x2h_b = cell.x2h.weight.data_ptr(), cell.x2h.bias.data_ptr()
+        w.enc_h2h_w, w.enc_h2h_b = cell.h2h.weight.data_ptr(), cell.h2h.bias.data_ptr()
+        w.enc_aff_w, w.enc_aff_b = self.affine_hn.weight.data_ptr(), self.affine_hn.bias.data_ptr()
+        H = torch.empty(B, T, D, dtype=torch.float32, device=dev)
+        M = torch.empty(B, T, D, dtype=torch.float32, device=dev)
+        fh = torch.empty(B, D, dtype=torch.float32, device=dev)
+        mask = torch.empty(B, T, dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.set_caption_encoder_workspace_bytes(B, T, D), dtype=torch.uint8, device=dev)
+        check(lib.set_caption_encoder_f32(C.byref(w), ptr(seq), ptr(lens), ptr(H), ptr(M), ptr(fh), ptr(mask), B, T, D,
+                                          self.vocab_size, ptr(ws), ws.numel(), stream_of(dev)),
+              "set_caption_encoder_f32")
+        tmax = int(lens.max().item())            # the reference pads to max(len) (editnet.py:327)
+        return H[:, :tmax], M[:, :tmax], fh, mask[:, :tmax]
+
+
+class CaptionAttentionC(nn.Module):
+    """reference editnet.py:351-381"""
+
+    def __init__(self, caption_features_dim, decoder_dim, attention_dim):
+        super().__init__()
+        self.cap_features_att = nn.Linear(caption_features_dim, attention_dim)
+        self.cap_decoder_att = nn.Linear(decoder_dim, attention_dim)
+        self.cap_full_att = nn.Linear(attention_dim, 1)
+        self.context_gate = nn.Linear((caption_features_dim * 2) + decoder_dim, caption_features_dim)
+        self.sc_affine = nn.Linear(caption_features_dim, caption_features_dim)
+        self.tc_affine = nn.Linear(decoder_dim * 2, caption_features_dim)
+        self.tanh = nn.Tanh()
+
+    def _weights(self):
+        w = EditNetWeights()
+        for f, m in (("ca_feat", self.cap_features_att), ("ca_dec", self.cap_decoder_att),
+                     ("ca_full", self.cap_full_att), ("ca_gate", self.context_gate), ("ca_sc", self.sc_affine),
+                     ("ca_tc", self.tc_affine)):
+            setattr(w, f + "_w", m.weight.data_ptr())
+            setattr(w, f + "_b", m.bias.data_ptr())
+        return w
+
+    def forward(self, caption_features, decoder_hidden, word, prev_caption_mask):
+        _require_cuda(caption_features, "caption features")
+        lib = _lib.load()
+        H, h1, word, mask = _f32c(caption_features), _f32c(decoder_hidden), _f32c(word), _f32c(prev_caption_mask)
+        M, T, D = H.shape
+        A = self.cap_decoder_att.out_features
+        w = self._weights()
+        gated = torch.empty(M, D, dtype=torch.float32, device=H.device)
+        alpha = torch.empty(M, T, dtype=torch.float32, device=H.device)
+        ws = torch.empty(lib.set_caption_attention_workspace_bytes(M, T, D, A), dtype=torch.uint8, device=H.device)
+        check(lib.set_caption_attention_f32(C.byref(w), ptr(H), None, ptr(h1), ptr(word), ptr(mask), ptr(gated),
+                                            ptr(alpha), M, T, D, A, ptr(ws), ws.numel(), stream_of(H.device)),
+              "set_caption_attention_f32")
+        return gated, alpha
+
+
+class SelectC(nn.Module):
+    """SCMA hard selection, reference editnet.py:383-421 (soft=False path)."""
+
+    def __init__(self, prev_caption_dim, decoder_dim):
+        super().__init__()
+
+    def forward(self, previous_encoded_m, sim_weights, soft=False):
+        if soft:
+            raise NotImplementedError("soft selection is never used by the reference (soft=False always)")
+        _require_cuda(previous_encoded_m, "encoder memory")
+        lib = _lib.load()
+        Mem, alpha = _f32c(previous_encoded_m), _f32c(sim_weights)
+        B, T, D = Mem.shape
+        sel = torch.empty(B, D, dtype=torch.float32, device=Mem.device)
+        check(lib.set_select_f32(ptr(Mem), ptr(alpha), ptr(sel), B, T, D, stream_of(Mem.device)), "set_select_f32")
+        return sel
+
+
+class VisualAttentionC(nn.Module):
+    """reference editnet.py:424-447"""
+
+    adaptive = 0
+
+    def __init__(self, image_features_dim, decoder_dim, attention_dim):
+        super().__init__()
+        self.att_embed = nn.Sequential(nn.Linear(image_features_dim, decoder_dim), nn.ReLU(), nn.Dropout(0.5))
+        self.features_att = nn.Linear(decoder_dim, attention_dim)
+        self.decoder_att = nn.Linear(decoder_dim, attention_dim)
+        self.full_att = nn.Linear(attention_dim, 1)
+        self.softmax = nn.Softmax(dim=1)
+
+    def _weights(self):
+        w = EditNetWeights()
+        for f, m in (("va_emb", self.att_embed[0]), ("va_feat", self.features_att), ("va_dec", self.decoder_att),
+                     ("va_full", self.full_att)):
+            setattr(w, f + "_w", m.weight.data_ptr())
+            setattr(w, f + "_b", m.bias.data_ptr())
+        return w
+
+    def forward(self, image_features, decoder_hidden):
+        _no_train(self, "VisualAttentionC")
+        _require_cuda(image_features, "image features")
+        lib = _lib.load()
+        X, h1 = _f32c(image_features), _f32c(decoder_hidden)
+        M, R, F = X.shape
+        D, A = self.decoder_att.in_features, self.decoder_att.out_features
+        w = self._weights()
+        ctx = torch.empty(M, F, dtype=torch.float32, device=X.device)
+        ws = torch.empty(lib.set_visual_attention_workspace_bytes(M, R, F, D, A), dtype=torch.uint8, device=X.device)
+        check(lib.set_visual_attention_f32(C.byref(w), ptr(X), None, ptr(h1), ptr(ctx), None, M, R, F, D, A,
+                                           self.adaptive, ptr(ws), ws.numel(), stream_of(X.device)),
+              "set_visual_attention_f32")
+        return ctx
+
+
+class _HipLSTMCell(nn.LSTMCell):
+    """nn.LSTMCell parameters (weight_ih, weight_hh, bias_ih, bias_hh) with a HIP forward."""
+
+    def forward(self, x, states=None):
+        _require_cuda(x, "LSTMCell input")
+        lib = _lib.load()
+        x = _f32c(x)
+        M, K, D = x.shape[0], x.shape[1], self.hidden_size
+        if states is None:
+            z = torch.zeros(M, D, dtype=torch.float32, device=x.device)
+            states = (z, z)
+        ht, ct = _f32c(states[0]), _f32c(states[1])
+        h_new, c_new = torch.empty_like(ht), torch.empty_like(ct)
+        ws = torch.empty(lib.set_lstm_cell_workspace_bytes(M, D, K), dtype=torch.uint8, device=x.device)
+        check(lib.set_lstm_cell_f32(ptr(x), K, K, ptr(ht), ptr(ct), ptr(self.weight_ih), K, ptr(self.weight_hh),
+                                    ptr(self.bias_ih), ptr(self.bias_hh), ptr(h_new), ptr(c_new), M, D, ptr(ws),
+                                    ws.numel(), stream_of(x.device)), "set_lstm_cell_f32")
+        return h_new, c_new
+
+
+class _HipLinear(nn.Linear):
+    """nn.Linear parameters with a HIP forward (fp32 MFMA GEMM)."""
+
+    def forward(self, x):
+        _require_cuda(x, "Linear input")
+        lib = _lib.load()
+        x = _f32c(x)
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.shape[-1])
+        M, K, N = x2.shape[0], x2.shape[1], self.out_features
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        ws = torch.empty(max(16, lib.set_linear_workspace_bytes(M, N, K)), dtype=torch.uint8, device=x.device)
+        check(lib.set_linear_f32(ptr(x2), K, ptr(self.weight), K, ptr(self.bias), ptr(y), N, M, N, K, 0, ptr(ws),
+                                 ws.numel(), stream_of(x.device)), "set_linear_f32")
+        return y.reshape(*lead, N)
+
+
+class DecoderC(nn.Module):
+    """reference editnet.py:449-548 — XE (teacher-forced) forward."""
+
+    _visual_attention_cls = VisualAttentionC
+    _adaptive = 0
+
+    def __init__(self, word_map, decoder_dim=1024, caption_features_dim=1024, emb_dim=1024, attention_dim=512,
+                 image_features_dim=2048):
+        super().__init__()
+        self.vocab_size = len(word_map)
+        self.dropout = nn.Dropout(0.5)
+        self.decoder_dim = decoder_dim
+        self.embed = EmbeddingC(word_map, emb_dim)
+        self.caption_encoder = CaptionEncoderC(len(word_map), emb_dim, caption_features_dim, self.embed)
+        self.caption_attention = CaptionAttentionC(caption_features_dim, decoder_dim, attention_dim)
+        self.visual_attention = self._visual_attention_cls(image_features_dim, decoder_dim, attention_dim)
+        self.select = SelectC(caption_features_dim, decoder_dim)
+        self.attention_lstm = _HipLSTMCell((emb_dim * 3) + image_features_dim, decoder_dim)
+        self.copy_lstm = CopyLSTMCellC((emb_dim * 2) + image_features_dim, decoder_dim)
+        self.tanh = nn.Tanh()
+        self.fc = _HipLinear(decoder_dim, self.vocab_size)
+        if not (decoder_dim == caption_features_dim == emb_dim):
+            raise ValueError("the reference's cat shapes force decoder_dim == caption_features_dim == emb_dim")
+        self._attention_dim = attention_dim
+        self._image_features_dim = image_features_dim
+        self._ws = None
+        self._ws_key = None
+
+    # ---- reference API ---------------------------------------------------------------------
+    def init_hidden_state(self, batch_size):
+        dev = self.fc.weight.device          # the parameters' device (the reference uses a module global)
+        h = torch.zeros(batch_size, self.decoder_dim, device=dev)
+        c = torch.zeros(batch_size, self.decoder_dim, device=dev)
+        return h, c
+
+    # ---- runtime plumbing ------------------------------------------------------------------
+    def _weights(self):
+        dev = self.fc.weight.device
+        params = dict(self.named_parameters())
+        return _lib.pack_weights(EditNetWeights, EDITNET_WEIGHT_FIELDS, params, dev)
+
+    def _dims(self, B, T, R, maxT):
+        return EditNetDims(B=B, T=T, R=R, F=self._image_features_dim, D=self.decoder_dim, A=self._attention_dim,
+                           V=self.vocab_size, maxT=maxT, adaptive=self._adaptive)
+
+    def _workspace(self, dims):
+        lib = _lib.load()
+        key = tuple(getattr(dims, f) for f, _ in EditNetDims._fields_) + (str(self.fc.weight.device),)
+        if self._ws_key != key:
+            n = lib.set_editnet_workspace_bytes(C.byref(dims))
+            if n == 0:
+                raise _lib.SetError("unsupported EditNet dims %r (contraction dims must be multiples of 32)" % (key,))
+            self._ws = torch.empty(n, dtype=torch.uint8, device=self.fc.weight.device)
+            self._ws_key = key
+        return self._ws
+
+    def ws_tensor(self, dims, name, shape, dtype=torch.float32):
+        """View of a named workspace tensor (debug / tests)."""
+        lib = _lib.load()
+        p = lib.set_editnet_ws_tensor(C.byref(dims), ptr(self._ws), name.encode())
+        if not p:
+            raise KeyError(name)
+        off = p - self._ws.data_ptr()
+        n = int(torch.tensor(shape).prod().item()) * torch.empty((), dtype=dtype).element_size()
+        return self._ws[off:off + n].view(dtype).view(*shape)
+
+    def forward(self, image_features, encoded_captions, caption_lengths, encoded_previous_captions,
+                previous_cap_length, use_ss=False, ss_prob=0.0, image_mean=None):
+        """Teacher-forced XE forward, reference editnet.py:479-548.  Returns
+        (predictions (B,max(decode_lengths),V), encoded_captions sorted, decode_lengths, sort_ind)."""
+        _no_train(self, "DecoderC.forward")
+        if use_ss and ss_prob > 0.0:
+            raise NotImplementedError("scheduled sampling is a train-mode feature (editnet.py:508-520)")
+        _require_cuda(image_features, "image features")
+        lib = _lib.load()
+        dev = image_features.device
+        batch_size = encoded_captions.size(0)
+        caption_lengths, sort_ind = caption_lengths.squeeze(1).sort(dim=0, descending=True)
+        X = _f32c(image_features[sort_ind])
+        encoded_captions = _i64c(encoded_captions[sort_ind])
+        prev = _i64c(encoded_previous_captions[sort_ind])
+        plen = _i64c(previous_cap_length[sort_ind].reshape(-1))
+        mean = None if image_mean is None else _f32c(image_mean[sort_ind])
+        decode_lengths = (caption_lengths - 1).tolist()
+        maxT = max(decode_lengths)
+        dims = self._dims(batch_size, prev.shape[1], X.shape[1], maxT)
+        ws = self._workspace(dims)
+        w = self._weights()
+        predictions = torch.empty(batch_size, maxT, self.vocab_size, dtype=torch.float32, device=dev)
+        dl = (C.c_int * batch_size)(*decode_lengths)
+        check(lib.set_editnet_xe_forward(C.byref(w), C.byref(dims), ptr(X), ptr(mean), ptr(encoded_captions),
+                                         encoded_captions.shape[1], dl, ptr(prev), ptr(plen), ptr(predictions),
+                                         ptr(ws), ws.numel(), stream_of(dev)), "set_editnet_xe_forward")
+        return predictions, encoded_captions, decode_lengths, sort_ind
