@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""Headline benchmark: EditNet decode-steps/sec at B=128 (36x2048 features, prev-caption len 20).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One bench "step" = one pass of the hot path over one batch: the free-running greedy decode of
+the reference's `editnet_rl.py:485-549` for a batch of 128 images — the per-sequence prologue
+(caption encoder + hoisted projections) plus 19 decode timesteps — entirely on the GPU through
+the C ABI (no host sync inside).  The metric counts decode timesteps:
+    value = n_gpus * K * 19 / wall_time          [decode-steps/sec, B=128 rows each]
+Inputs and weights are synthetic (seeded generator, random-init weights of the reference's
+architecture, V = 10 000) and are resident in HBM before the timed region.  Multi-GPU: the path
+shards by batch with replicated weights and no data-path collective: each rank
+decodes its own 128-image batch (weak scaling); timing is barrier / sync bracketed, max over ranks.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel = the fp32-MFMA grouped GEMM `gemm_nt_f32<128,64>` (six launches per
+                timestep); achieved = algorithmic FLOPs of its launches / their summed duration,
+                measured with HIP events on the launch stream in a second, identical, profiled pass
+                (`value` comes from the un-instrumented pass; both ms_per_step are reported)
+  kernels       the same event timing for every kernel family (ms per bench step)
+  cpu_baseline  the numpy oracle (oracle/editnet_np.py, a port of the reference's CPU path) timed
+                on this box's host cores for a bounded sample of the same workload
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B, R, F, T, V, D, A = 128, 36, 2048, 20, 10000, 1024, 512
+MAX_LEN = 18
+STEPS_PER_DECODE = MAX_LEN + 1          # editnet_rl.py:503 runs max_len + 1 timesteps
+PEAK_FP32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """Oracle (numpy port of the reference CPU path) on the host cores, bounded sample."""
+    import numpy as np
+    from oracle import editnet_np as EN
+    from show_edit_tell_amd import synth
+    sd = synth.editnet_state(14, V, D, A, F, emb_scale=3.0, fc_scale=8.0, gain=3.0)
+    P = EN.cast_params(sd)
+    X = synth.features(25, B, R, F)
+    prev, plen = synth.prev_captions(25, B, T, V, 5)
+    wm = synth.word_map(V)
+    EN.greedy_decode(P, wm["<start>"], wm["<end>"], prev[:8], plen[:8], X[:8])     # warm BLAS threads
+    n, t0 = 0, time.time()
+    while True:
+        EN.greedy_decode(P, wm["<start>"], wm["<end>"], prev, plen, X)
+        n += 1
+        el = time.time() - t0
+        if el > seconds_budget or n >= 10:
+            break
+    return dict(value=round(n * STEPS_PER_DECODE / el, 3), unit="decode-steps/sec", cores=os.cpu_count(),
+                kind="port", sample="%d full greedy decodes (prologue + 19 timesteps) of the B=128 workload, numpy fp32 "
+                "(OpenBLAS, all host threads), %.1f s" % (n, el))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the decode path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from show_edit_tell_amd import _lib, editnet_rl, synth
+    wm = synth.word_map(V)
+    dec = editnet_rl.DecoderC(wm, D, D, D, A, F)
+    sd = synth.editnet_state(14, V, D, A, F, emb_scale=3.0, fc_scale=8.0, gain=3.0)
+    sd["caption_encoder.embed.embedding.weight"] = sd["embed.embedding.weight"]
+    dec.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    dec = dec.to(dev).eval()
+    seed = 25 + rank
+    X = torch.from_numpy(synth.features(seed, B, R, F)).to(dev)
+    prev_np, plen_np = synth.prev_captions(seed, B, T, V, 5)
+    prev, plen = torch.from_numpy(prev_np).to(dev), torch.from_numpy(plen_np).to(dev)
+
+    def run(k):
+        out = None
+        for _ in range(k):
+            out = dec(wm, prev, plen, X, True, False)
+        return out
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        run(args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        seq, _ = run(args.steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+        prof = None
+        if rank == 0 and not args.no_profile:
+            lib = _lib.load()
+            lib.set_profile_enable(1)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            run(args.steps)
+            torch.cuda.synchronize(dev)
+            prof_elapsed = time.perf_counter() - t1
+            prof = _lib.profile_report()
+            lib.set_profile_enable(0)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    n_gpus = world
+    total_steps = n_gpus * args.steps * STEPS_PER_DECODE
+    line = {
+        "metric": "decode-steps/sec (B=128, 36x2048 feats, seqlen=20)",
+        "value": round(total_steps / elapsed, 2),
+        "unit": "decode-steps/sec",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "EditNet greedy decode (editnet_rl.py:485-549): prologue + 19 timesteps per bench step",
+                   "batch_per_gpu": B, "regions": R, "feat_dim": F, "prev_caption_len": T, "vocab": V,
+                   "decoder_dim": D, "attention_dim": A, "timesteps_per_bench_step": STEPS_PER_DECODE,
+                   "mode": "eval (loop-invariant projections hoisted)", "parallelism": "dp%d (no collective)" % n_gpus,
+                   "us_per_timestep_incl_prologue": round(1e6 * elapsed / (args.steps * STEPS_PER_DECODE), 2),
+                   "distinct_tokens_in_last_batch": int(torch.unique(seq).numel())},
+    }
+    if prof is not None:
+        by = {p["tag"]: p for p in prof}
+        g = by.get("gemm_nt_f32<128,64>")
+        if g and g["ms"] > 0:
+            tf = g["flops"] / (g["ms"] * 1e-3) / 1e12
+            line["roofline"] = {
+                "kernel": "gemm_nt_f32<128,64,2,2> (v_mfma_f32_32x32x2_f32)", "bound": "mfma",
+                "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "launches": g["launches"], "avg_us_per_launch": round(1e3 * g["ms"] / g["launches"], 2),
+                "algorithmic_gflop_per_launch": round(g["flops"] / g["launches"] / 1e9, 4),
+                "algorithmic_GBs": round(g["bytes"] / (g["ms"] * 1e-3) / 1e9, 1),
+                "timing": "HIP events on the launch stream, second identical pass (profiled ms_per_step %.3f)"
+                          % (1e3 * prof_elapsed / args.steps)}
+        line["kernels"] = {p["tag"]: {"launches_per_step": round(p["launches"] / args.steps, 2),
+                                      "ms_per_step": round(p["ms"] / args.steps, 4),
+                                      "GBs": round(p["bytes"] / max(p["ms"], 1e-9) / 1e6, 1),
+                                      "TFLOPs": round(p["flops"] / max(p["ms"], 1e-9) / 1e9, 2)} for p in prof}
+    if not args.no_cpu_baseline and n_gpus == 1:
+        line["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -49,6 +49,22 @@ const char* set_last_hip_error_string(void);
 const char* set_target_arch(void);
 
 /* ------------------------------------------------------------------------------------------
+ * Opt-in per-kernel timing (HIP events on the launch stream); used by bench.py.  Not part of the
+ * reference's surface.  set_profile_enable(1) clears previous records; set_profile_report
+ * synchronises the events and aggregates by kernel tag, returning the number of entries.
+ * flops / bytes are the ALGORITHMIC work of the recorded launches, not counters.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct SetProfileEntry {
+    char tag[32];
+    int launches;
+    double ms;
+    double flops;
+    double bytes;
+} SetProfileEntry;
+int set_profile_enable(int on);
+int set_profile_report(SetProfileEntry* out, int max_entries);
+
+/* ------------------------------------------------------------------------------------------
  * EditNet (reference editnet.py:449-548 `DecoderC`, editnet_rl.py:455-549)
  * ------------------------------------------------------------------------------------------ */
 typedef struct SetEditNetDims {
@@ -176,6 +192,10 @@ int set_dcnet_begin(const SetDcnetWeights* w, const SetDcnetDims* d, const int64
 int set_dcnet_step(const SetDcnetWeights* w, const SetDcnetDims* d, const int64_t* tokens,
                    int64_t tokens_stride, int bt, float* logits, int64_t ld_logits, void* ws,
                    size_t ws_bytes, void* stream);
+/* greedy epilogue of one free-running step (dcnet_rl.py:313-340); see set_editnet_greedy_pick */
+int set_dcnet_greedy_pick(const SetDcnetWeights* w, const SetDcnetDims* d, const float* logits,
+                          int64_t ld_logits, int t, int64_t end_idx, int64_t* seq, float* seq_logp,
+                          int max_len, void* ws, size_t ws_bytes, void* stream);
 int set_dcnet_greedy(const SetDcnetWeights* w, const SetDcnetDims* d, const int64_t* prev,
                      const int64_t* prevlen, int64_t start_idx, int64_t end_idx, int max_len,
                      int64_t* seq, float* seq_logp, void* ws, size_t ws_bytes, void* stream);
@@ -206,13 +226,14 @@ int set_lstm_cell_f32(const float* x, int64_t ldx, int Kx, const float* h, const
                       const float* b_hh, float* h_out, float* c_out, int M, int D, void* ws,
                       size_t ws_bytes, void* stream);
 /* CaptionAttentionC.forward (editnet.py:364-381); att1_c may be NULL (computed into ws).
- * Outputs gated (M,D), alpha_c (M,T).  Also serves DCNet's CaptionAttention (dcnet.py:254-270)
- * when gate weights are NULL: then `gated` receives the plain context (M,Dh). */
-size_t set_caption_attention_workspace_bytes(int M, int T, int D, int A);
+ * H (M,T,Dh) caption features, h1 (M,D) decoder state.  Outputs gated (M,Dh), alpha_c (M,T).
+ * Also serves DCNet's CaptionAttention (dcnet.py:254-270) when w->ca_gate_w is NULL: `gated`
+ * then receives the plain context (M,Dh) (Dh = 2C there; EditNet requires Dh == D). */
+size_t set_caption_attention_workspace_bytes(int M, int T, int Dh, int A);
 int set_caption_attention_f32(const SetEditNetWeights* w, const float* H, const float* att1_c,
                               const float* h1, const float* word, const float* mask, float* gated,
-                              float* alpha_c, int M, int T, int D, int A, void* ws, size_t ws_bytes,
-                              void* stream);
+                              float* alpha_c, int M, int T, int Dh, int D, int A, void* ws,
+                              size_t ws_bytes, void* stream);
 /* VisualAttentionC.forward (editnet.py:439-447); att1 may be NULL (att_embed + features_att are
  * then recomputed exactly as the reference does every call).  adaptive != 0 selects the masked
  * variant (editnet_adaptive.py:438-457).  ctx (M,F). */

@@ -77,6 +77,22 @@ class EditNetWeights(C.Structure):
     _fields_ = [(f, C.c_void_p) for f, _ in EDITNET_WEIGHT_FIELDS]
 
 
+class ProfileEntry(C.Structure):
+    _fields_ = [("tag", C.c_char * 32), ("launches", C.c_int), ("ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
+def profile_report(max_entries=64):
+    """[{tag, launches, ms, flops, bytes}] aggregated since set_profile_enable(1)."""
+    lib = load()
+    arr = (ProfileEntry * max_entries)()
+    n = lib.set_profile_report(arr, max_entries)
+    if n < 0:
+        check(-n, "set_profile_report")
+    return [dict(tag=arr[i].tag.decode(), launches=arr[i].launches, ms=arr[i].ms, flops=arr[i].flops,
+                 bytes=arr[i].bytes) for i in range(n)]
+
+
 class DcnetDims(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("B", "T", "D", "A", "C", "E", "V", "maxT")]
 
@@ -128,6 +144,8 @@ PROTOTYPES = {
     "set_last_hip_error": (_I, []),
     "set_last_hip_error_string": (C.c_char_p, []),
     "set_target_arch": (C.c_char_p, []),
+    "set_profile_enable": (_I, [_I]),
+    "set_profile_report": (_I, [_P, _I]),
     "set_editnet_workspace_bytes": (_Z, [C.POINTER(EditNetDims)]),
     "set_editnet_begin": (_I, [C.POINTER(EditNetWeights), C.POINTER(EditNetDims), _P, _P, _P, _P, _P, _Z, _P]),
     "set_editnet_step": (_I, [C.POINTER(EditNetWeights), C.POINTER(EditNetDims), _P, _P, _L, _I, _P, _L, _P, _Z, _P]),
@@ -153,8 +171,8 @@ PROTOTYPES = {
     "set_lstm_cell_workspace_bytes": (_Z, [_I, _I, _I]),
     "set_lstm_cell_f32": (_I, [_P, _L, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _I, _I, _P, _Z, _P]),
     "set_caption_attention_workspace_bytes": (_Z, [_I, _I, _I, _I]),
-    "set_caption_attention_f32": (_I, [C.POINTER(EditNetWeights), _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _Z,
-                                       _P]),
+    "set_caption_attention_f32": (_I, [C.POINTER(EditNetWeights), _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P,
+                                       _Z, _P]),
     "set_visual_attention_workspace_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "set_visual_attention_f32": (_I, [C.POINTER(EditNetWeights), _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _Z,
                                       _P]),
@@ -177,6 +195,9 @@ def load():
         raise SetError(
             "HIP library %s is missing: build it with `python -m show_edit_tell_amd.build` "
             "(there is no CPU fallback for the decode path)" % LIB_PATH)
+    # torch bundles its own HIP runtime (same SONAME as /opt/rocm's): import it FIRST so that this
+    # library binds to the runtime that owns torch's device pointers and streams.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         try:

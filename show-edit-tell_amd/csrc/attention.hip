@@ -123,6 +123,7 @@ int caption_attention(const float* att1_c, Slabs att2_c, const float* dec_bias, 
                       float* sel, float* alpha_out, int M, int T, int Dh, int A, hipStream_t s) {
     if (T > ATT_MAX_ROWS || A > 512 || (A & 3) || (Dh & 3)) return SET_ERR_UNSUPPORTED;
     if (M <= 0) return SET_OK;
+    ProfScope ps("caption_attention", s, 0.0, 4.0 * M * ((double)T * A + (double)T * Dh + 3.0 * Dh + att2_c.n * A));
     hipLaunchKernelGGL(caption_attention_k, dim3(M), dim3(256), 0, s, att1_c, att2_c, dec_bias, w_full, b_full, mask,
                        H, Mem, ctx, sel, alpha_out, T, Dh, A);
     SET_LAUNCH_CHECK();
@@ -196,6 +197,7 @@ int visual_attention(const float* att1, Slabs att2, const float* dec_bias, const
     int fsn = 1;
     while (M * fsn < 512 && F / (fsn * 2) >= 1024 && (F % (fsn * 2 * 4)) == 0) fsn *= 2;
     const int fcols = F / fsn;
+    ProfScope ps("visual_attention", s, 0.0, 4.0 * M * ((double)R * A + (double)R * F + F + att2.n * A));
     hipLaunchKernelGGL(visual_attention_k, dim3(M, fsn), dim3(256), 0, s, att1, att2, dec_bias, w_full, b_full, X,
                        rmask, ctx, alpha_out, R, F, A, fcols);
     SET_LAUNCH_CHECK();

@@ -1,0 +1,302 @@
+// Host-side sequencing of the DCNet (DAE) decode path + its C ABI.  Text-only denoising
+// auto-encoder (reference dcnet.py:273-350, dcnet_rl.py:256-346): BiLSTM caption encoder
+// (nn.LSTM on a packed batch), additive caption attention, two nn.LSTMCell updates, fc.
+// Four grouped-GEMM launches per timestep:
+//   A  gates1 = [emb|h2|h1] x [Wih_emb|Wih_h2|Whh] (+ hoisted final_hidden columns and biases)
+//      + language_lstm Whh(h2)                                   -> LSTM pointwise (h1, c1)
+//   B  att2_c = cap_decoder_att(h1), language_lstm Wih[:, :D](h1) -> caption attention (attend_cap)
+//   C  language_lstm Wih[:, D:](attend_cap)                       -> LSTM pointwise (h2, c2)
+//   D  fc(h2)
+#include <cstring>
+#include "set_common.h"
+
+namespace set {
+
+struct DcnetWs {
+    float *enc, *final_hidden, *mask, *att1_c, *pre1;
+    float *h1, *c1, *h2, *c2, *emb, *attend_cap, *alpha_c, *logits;
+    long long* it;
+    int *unfinished, *alive;
+    float *sA0, *sA1, *sB0, *sB1, *sC0, *sF0;
+    float *hf, *cf, *hb, *cb, *xg_f, *xg_b, *emb_seq, *s_ef, *s_eb, *s_cat, *s_pre;
+    size_t bytes;
+};
+
+static int check_dims(const SetDcnetDims* d) {
+    if (!d) return SET_ERR_ARG;
+    if (d->B <= 0 || d->T <= 0 || d->D <= 0 || d->A <= 0 || d->C <= 0 || d->E <= 0 || d->V <= 0 || d->maxT <= 0)
+        return SET_ERR_ARG;
+    if ((d->D % GEMM_BK) || (d->A % GEMM_BK) || (d->C % GEMM_BK) || (d->E % GEMM_BK)) return SET_ERR_UNSUPPORTED;
+    // attention_lstm input = [emb (E) | final_hidden (2C) | h2 (D)] must be 3E wide; language_lstm
+    // input = [h1 (D) | attend_cap (2C)] must be 2E wide (dcnet.py:286-287,336-345)
+    if (d->E + 2 * d->C + d->D != 3 * d->E || d->D + 2 * d->C != 2 * d->E) return SET_ERR_UNSUPPORTED;
+    if (d->A > 512 || d->T > 256) return SET_ERR_UNSUPPORTED;
+    return SET_OK;
+}
+
+static DcnetWs carve(const SetDcnetDims* d, void* base) {
+    DcnetWs w;
+    Carver c(base);
+    const size_t B = d->B, T = d->T, D = d->D, A = d->A, C = d->C, E = d->E, V = d->V, KS = GEMM_MAX_KSPLIT;
+    const size_t Vp = round_up(V, 64);
+    w.enc = c.take<float>(B * T * 2 * C);
+    w.final_hidden = c.take<float>(B * 2 * C);
+    w.mask = c.take<float>(B * T);
+    w.att1_c = c.take<float>(B * T * A);
+    w.pre1 = c.take<float>(B * 4 * D);
+    w.h1 = c.take<float>(B * D);
+    w.c1 = c.take<float>(B * D);
+    w.h2 = c.take<float>(B * D);
+    w.c2 = c.take<float>(B * D);
+    w.emb = c.take<float>(B * E);
+    w.attend_cap = c.take<float>(B * 2 * C);
+    w.alpha_c = c.take<float>(B * T);
+    w.logits = c.take<float>(B * Vp);
+    w.it = c.take<long long>(B);
+    w.unfinished = c.take<int>(B);
+    w.alive = c.take<int>(d->maxT + 2);
+    w.sA0 = c.take<float>(KS * B * 4 * D);
+    w.sA1 = c.take<float>(KS * B * 4 * D);
+    w.sB0 = c.take<float>(KS * B * A);
+    w.sB1 = c.take<float>(KS * B * 4 * D);
+    w.sC0 = c.take<float>(KS * B * 4 * D);
+    w.sF0 = c.take<float>(KS * B * Vp);
+    w.hf = c.take<float>(B * C);
+    w.cf = c.take<float>(B * C);
+    w.hb = c.take<float>(B * C);
+    w.cb = c.take<float>(B * C);
+    w.xg_f = c.take<float>(B * T * 4 * C);
+    w.xg_b = c.take<float>(B * T * 4 * C);
+    w.emb_seq = c.take<float>(B * T * E);
+    w.s_ef = c.take<float>(KS * B * 4 * C);
+    w.s_eb = c.take<float>(KS * B * 4 * C);
+    w.s_cat = c.take<float>(KS * B * 2 * C);
+    w.s_pre = c.take<float>(KS * B * 4 * D);
+    w.bytes = c.off;
+    return w;
+}
+
+static int begin_impl(const SetDcnetWeights* w, const SetDcnetDims* d, const int64_t* prev, const int64_t* prevlen,
+                      DcnetWs& ws, hipStream_t st) {
+    const int B = d->B, T = d->T, D = d->D, A = d->A, C = d->C, E = d->E;
+    const int tgt = gemm_target_wgs();
+    // ---- CaptionEncoder (dcnet.py:220-243): packed BiLSTM == per-row masked recurrences
+    SET_TRY(embed_relu(w->embed, prev, 1, ws.emb_seq, E, B * T, E, d->V, st));
+    {
+        GemmProb p[2];
+        p[0] = direct_prob(ws.xg_f, 4 * C, B * T, 4 * C, w->enc_bih_f, SET_ACT_NONE);
+        p[0].add(ws.emb_seq, E, w->enc_wih_f, E, E);
+        p[1] = direct_prob(ws.xg_b, 4 * C, B * T, 4 * C, w->enc_bih_b, SET_ACT_NONE);
+        p[1].add(ws.emb_seq, E, w->enc_wih_b, E, E);
+        SET_TRY(gemm_group(p, 2, st, "gemm:enc x2h"));
+    }
+    SET_TRY(zero_f32(ws.enc, (size_t)B * T * 2 * C, st));
+    SET_TRY(zero_f32(ws.hf, (size_t)B * C, st));
+    SET_TRY(zero_f32(ws.cf, (size_t)B * C, st));
+    SET_TRY(zero_f32(ws.hb, (size_t)B * C, st));
+    SET_TRY(zero_f32(ws.cb, (size_t)B * C, st));
+    for (int t = 0; t < T; ++t) {
+        GemmProb p[2];
+        p[0] = slab_prob(ws.s_ef, B, 4 * C, B);
+        p[0].add(ws.hf, C, w->enc_whh_f, C, C);
+        p[1] = slab_prob(ws.s_eb, B, 4 * C, B);
+        p[1].add(ws.hb, C, w->enc_whh_b, C, C);
+        plan_ksplit(p, 2, tgt);
+        if (t > 0) SET_TRY(gemm_group(p, 2, st, "gemm:enc h2h"));
+        Slabs f = slabs_of(p[0]), b = slabs_of(p[1]);
+        if (t == 0) { f.n = 0; b.n = 0; }
+        SET_TRY(encoder_pointwise(f, ws.xg_f, (long long)T * 4 * C, 4 * C, t, prevlen, 0, ws.hf, ws.cf, ws.enc, nullptr,
+                                  (long long)T * 2 * C, 2 * C, 0, B, C, w->enc_bhh_f, st));
+        SET_TRY(encoder_pointwise(b, ws.xg_b, (long long)T * 4 * C, 4 * C, t, prevlen, 1, ws.hb, ws.cb, ws.enc, nullptr,
+                                  (long long)T * 2 * C, 2 * C, C, B, C, w->enc_bhh_b, st));
+    }
+    {
+        GemmProb p = slab_prob(ws.s_cat, B, 2 * C, B);                 // tanh(concat([h_fwd, h_bwd])) dcnet.py:241-242
+        p.add(ws.hf, C, w->enc_cat_w, 2 * C, C);
+        p.add(ws.hb, C, w->enc_cat_w + C, 2 * C, C);
+        plan_ksplit(&p, 1, tgt);
+        SET_TRY(gemm_group(&p, 1, st));
+        SET_TRY(reduce_bias_act(slabs_of(p), w->enc_cat_b, nullptr, ws.final_hidden, 2 * C, B, 2 * C, SET_ACT_TANH, st));
+    }
+    SET_TRY(rowsum_mask(ws.enc, 2 * C, B * T, 2 * C, ws.mask, st));                    // dcnet.py:239
+    {
+        GemmProb p = direct_prob(ws.att1_c, A, B * T, A, w->ca_feat_b, SET_ACT_NONE);   // dcnet.py:261
+        p.add(ws.enc, 2 * C, w->ca_feat_w, 2 * C, 2 * C);
+        SET_TRY(gemm_group(&p, 1, st, "gemm:pro cap_features_att"));
+    }
+    {
+        GemmProb p = slab_prob(ws.s_pre, B, 4 * D, B);                 // final_hidden columns of attention_lstm
+        p.add(ws.final_hidden, 2 * C, w->al_wih + E, 3 * E, 2 * C);
+        plan_ksplit(&p, 1, tgt);
+        SET_TRY(gemm_group(&p, 1, st));
+        SET_TRY(reduce_bias_act(slabs_of(p), w->al_bih, w->al_bhh, ws.pre1, 4 * D, B, 4 * D, SET_ACT_NONE, st));
+    }
+    SET_TRY(zero_f32(ws.h1, (size_t)B * D, st));
+    SET_TRY(zero_f32(ws.c1, (size_t)B * D, st));
+    SET_TRY(zero_f32(ws.h2, (size_t)B * D, st));
+    SET_TRY(zero_f32(ws.c2, (size_t)B * D, st));
+    return SET_OK;
+}
+
+static int step_impl(const SetDcnetWeights* w, const SetDcnetDims* d, int bt, DcnetWs& ws, float* dst, long long ld_dst,
+                     Slabs* logits_out, hipStream_t st) {
+    const int B = d->B, T = d->T, D = d->D, A = d->A, C = d->C, E = d->E, V = d->V;
+    const int tgt = gemm_target_wgs();
+    const Slabs none{nullptr, 0, 0, 0};
+    GemmProb a[2];
+    a[0] = slab_prob(ws.sA0, bt, 4 * D, B);
+    a[0].add(ws.emb, E, w->al_wih, 3 * E, E);
+    a[0].add(ws.h2, D, w->al_wih + E + 2 * C, 3 * E, D);
+    a[0].add(ws.h1, D, w->al_whh, D, D);
+    a[1] = slab_prob(ws.sA1, bt, 4 * D, B);
+    a[1].add(ws.h2, D, w->ll_whh, D, D);
+    plan_ksplit(a, 2, tgt);
+    SET_TRY(gemm_group(a, 2, st, "gemm:A gates1+h2h"));
+    SET_TRY(lstm_pointwise(slabs_of(a[0]), none, none, ws.pre1, 4 * D, nullptr, nullptr, ws.c1, ws.c1, ws.h1, nullptr,
+                           bt, D, st));
+    GemmProb b[2];
+    b[0] = slab_prob(ws.sB0, bt, A, B);
+    b[0].add(ws.h1, D, w->ca_dec_w, D, D);
+    b[1] = slab_prob(ws.sB1, bt, 4 * D, B);
+    b[1].add(ws.h1, D, w->ll_wih, 2 * E, D);
+    plan_ksplit(b, 2, tgt);
+    SET_TRY(gemm_group(b, 2, st, "gemm:B att2_c,ll_h1"));
+    SET_TRY(caption_attention(ws.att1_c, slabs_of(b[0]), w->ca_dec_b, w->ca_full_w, w->ca_full_b, ws.mask, ws.enc,
+                              nullptr, ws.attend_cap, nullptr, ws.alpha_c, bt, T, 2 * C, A, st));
+    GemmProb c = slab_prob(ws.sC0, bt, 4 * D, B);
+    c.add(ws.attend_cap, 2 * C, w->ll_wih + D, 2 * E, 2 * C);
+    plan_ksplit(&c, 1, tgt);
+    SET_TRY(gemm_group(&c, 1, st, "gemm:C ll_ctx"));
+    SET_TRY(lstm_pointwise(slabs_of(a[1]), slabs_of(b[1]), slabs_of(c), nullptr, 0, w->ll_bih, w->ll_bhh, ws.c2, ws.c2,
+                           ws.h2, nullptr, bt, D, st));
+    const long long Vp = (long long)round_up((size_t)V, 64);
+    GemmProb f = slab_prob(ws.sF0, bt, V, B);
+    f.ldc = Vp;
+    f.slab_stride = (long long)B * Vp;
+    f.add(ws.h2, D, w->fc_w, D, D);
+    plan_ksplit(&f, 1, tgt);
+    if (dst && f.ksplit == 1) {
+        f.C = dst; f.ldc = ld_dst; f.bias = w->fc_b; f.slab_stride = 0;
+        SET_TRY(gemm_group(&f, 1, st, "gemm:F fc"));
+    } else {
+        SET_TRY(gemm_group(&f, 1, st, "gemm:F fc"));
+        if (dst) SET_TRY(reduce_bias_act(slabs_of(f), w->fc_b, nullptr, dst, ld_dst, bt, V, SET_ACT_NONE, st));
+    }
+    if (logits_out) *logits_out = slabs_of(f);
+    return SET_OK;
+}
+
+}  // namespace set
+
+using namespace set;
+
+extern "C" {
+
+size_t set_dcnet_workspace_bytes(const SetDcnetDims* d) {
+    if (check_dims(d) != SET_OK) return 0;
+    return carve(d, nullptr).bytes + 256;
+}
+
+static int prep(const SetDcnetDims* d, void* ws, size_t ws_bytes, DcnetWs* out) {
+    SET_TRY(check_dims(d));
+    if (!ws || !aligned16(ws)) return SET_ERR_ARG;
+    *out = carve(d, ws);
+    if (out->bytes > ws_bytes) return SET_ERR_WORKSPACE;
+    return SET_OK;
+}
+
+int set_dcnet_begin(const SetDcnetWeights* w, const SetDcnetDims* d, const int64_t* prev, const int64_t* prevlen,
+                    void* ws, size_t ws_bytes, void* stream) {
+    if (!w || !prev || !prevlen) return SET_ERR_ARG;
+    DcnetWs W;
+    SET_TRY(prep(d, ws, ws_bytes, &W));
+    return begin_impl(w, d, prev, prevlen, W, (hipStream_t)stream);
+}
+
+int set_dcnet_step(const SetDcnetWeights* w, const SetDcnetDims* d, const int64_t* tokens, int64_t tokens_stride,
+                   int bt, float* logits, int64_t ld_logits, void* ws, size_t ws_bytes, void* stream) {
+    if (!w || !logits) return SET_ERR_ARG;
+    DcnetWs W;
+    SET_TRY(prep(d, ws, ws_bytes, &W));
+    if (bt <= 0 || bt > d->B || ld_logits < d->V) return SET_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (tokens) SET_TRY(embed_relu(w->embed, tokens, tokens_stride, W.emb, d->E, bt, d->E, d->V, st));
+    return step_impl(w, d, bt, W, logits, ld_logits, nullptr, st);
+}
+
+int set_dcnet_greedy_pick(const SetDcnetWeights* w, const SetDcnetDims* d, const float* logits, int64_t ld_logits,
+                          int t, int64_t end_idx, int64_t* seq, float* seq_logp, int max_len, void* ws,
+                          size_t ws_bytes, void* stream) {
+    if (!w || !logits || !seq || !seq_logp || t < 0) return SET_ERR_ARG;
+    DcnetWs W;
+    SET_TRY(prep(d, ws, ws_bytes, &W));
+    if (t > d->maxT) return SET_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (t == 0) SET_TRY(set_tokens(W.it, 0, W.unfinished, W.alive, d->maxT + 2, d->B, st));
+    Slabs lg{logits, 0, ld_logits, 1};
+    return greedy_pick(lg, nullptr, d->V, t, max_len, end_idx, (long long*)seq, seq_logp, W.it, W.unfinished, W.alive,
+                       w->embed, W.emb, d->E, d->B, st);
+}
+
+int set_dcnet_greedy(const SetDcnetWeights* w, const SetDcnetDims* d, const int64_t* prev, const int64_t* prevlen,
+                     int64_t start_idx, int64_t end_idx, int max_len, int64_t* seq, float* seq_logp, void* ws,
+                     size_t ws_bytes, void* stream) {
+    if (!w || !prev || !prevlen || !seq || !seq_logp || max_len <= 0) return SET_ERR_ARG;
+    DcnetWs W;
+    SET_TRY(prep(d, ws, ws_bytes, &W));
+    if (max_len > d->maxT || start_idx < 0 || start_idx >= d->V) return SET_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int B = d->B;
+    SET_TRY(begin_impl(w, d, prev, prevlen, W, st));
+    SET_HIP_TRY(hipMemsetAsync(seq, 0, sizeof(int64_t) * B * max_len, st));
+    SET_HIP_TRY(hipMemsetAsync(seq_logp, 0, sizeof(float) * B * max_len, st));
+    SET_TRY(set_tokens(W.it, start_idx, W.unfinished, W.alive, d->maxT + 2, B, st));
+    SET_TRY(embed_relu(w->embed, (const int64_t*)W.it, 1, W.emb, d->E, B, d->E, d->V, st));
+    for (int t = 0; t <= max_len; ++t) {                                 // dcnet_rl.py:305,315-316
+        Slabs lg;
+        SET_TRY(step_impl(w, d, B, W, nullptr, 0, &lg, st));
+        if (t == max_len) break;
+        SET_TRY(greedy_pick(lg, w->fc_b, d->V, t, max_len, end_idx, (long long*)seq, seq_logp, W.it, W.unfinished,
+                            W.alive, w->embed, W.emb, d->E, B, st));
+    }
+    return SET_OK;
+}
+
+int set_dcnet_xe_forward(const SetDcnetWeights* w, const SetDcnetDims* d, const int64_t* caps, int64_t caps_stride,
+                         const int* host_decode_lengths, const int64_t* prev, const int64_t* prevlen,
+                         float* predictions, void* ws, size_t ws_bytes, void* stream) {
+    if (!w || !caps || !host_decode_lengths || !prev || !prevlen || !predictions) return SET_ERR_ARG;
+    DcnetWs W;
+    SET_TRY(prep(d, ws, ws_bytes, &W));
+    hipStream_t st = (hipStream_t)stream;
+    const int B = d->B, V = d->V, maxT = d->maxT;
+    for (int b = 0; b < B; ++b) {
+        if (host_decode_lengths[b] < 0 || host_decode_lengths[b] > maxT) return SET_ERR_ARG;
+        if (b && host_decode_lengths[b] > host_decode_lengths[b - 1]) return SET_ERR_ARG;
+    }
+    if (caps_stride < maxT) return SET_ERR_ARG;
+    SET_TRY(begin_impl(w, d, prev, prevlen, W, st));
+    SET_HIP_TRY(hipMemsetAsync(predictions, 0, sizeof(float) * (size_t)B * maxT * V, st));
+    for (int t = 0; t < maxT; ++t) {
+        int bt = 0;
+        while (bt < B && host_decode_lengths[bt] > t) ++bt;             // dcnet.py:334
+        if (bt == 0) break;
+        SET_TRY(embed_relu(w->embed, caps + t, caps_stride, W.emb, d->E, bt, d->E, V, st));
+        SET_TRY(step_impl(w, d, bt, W, predictions + (size_t)t * V, (long long)maxT * V, nullptr, st));
+    }
+    return SET_OK;
+}
+
+void* set_dcnet_ws_tensor(const SetDcnetDims* d, void* ws, const char* name) {
+    if (check_dims(d) != SET_OK || !ws || !name) return nullptr;
+    DcnetWs W = carve(d, ws);
+    struct { const char* n; void* p; } tab[] = {
+        {"enc", W.enc}, {"final_hidden", W.final_hidden}, {"mask", W.mask}, {"att1_c", W.att1_c}, {"pre1", W.pre1},
+        {"h1", W.h1}, {"c1", W.c1}, {"h2", W.h2}, {"c2", W.c2}, {"emb", W.emb}, {"attend_cap", W.attend_cap},
+        {"alpha_c", W.alpha_c}, {"logits", W.logits}, {"it", W.it}, {"unfinished", W.unfinished}, {"alive", W.alive}};
+    for (auto& e : tab)
+        if (!strcmp(e.n, name)) return e.p;
+    return nullptr;
+}
+
+}  // extern "C"

@@ -146,7 +146,7 @@ int editnet_encoder(const SetEditNetWeights* w, const int64_t* seq, const int64_
     {
         GemmProb p = direct_prob(xg, 4 * D, B * T, 4 * D, w->enc_x2h_b, SET_ACT_NONE);
         p.add(emb_seq, D, w->enc_x2h_w, D, D);
-        SET_TRY(gemm_group(&p, 1, st));
+        SET_TRY(gemm_group(&p, 1, st, "gemm:enc x2h"));
     }
     SET_TRY(zero_f32(H, (size_t)B * T * D, st));
     SET_TRY(zero_f32(Mem, (size_t)B * T * D, st));
@@ -156,7 +156,7 @@ int editnet_encoder(const SetEditNetWeights* w, const int64_t* seq, const int64_
         GemmProb p = slab_prob(s_enc, B, 4 * D, B);
         p.add(enc_h, D, w->enc_h2h_w, D, D);
         plan_ksplit(&p, 1, tgt);
-        if (t > 0) SET_TRY(gemm_group(&p, 1, st));            // h == 0 at t == 0: product is exactly zero
+        if (t > 0) SET_TRY(gemm_group(&p, 1, st, "gemm:enc h2h"));   // h == 0 at t == 0: product is exactly zero
         Slabs hh = slabs_of(p);
         if (t == 0) hh.n = 0;
         SET_TRY(encoder_pointwise(hh, xg, (long long)T * 4 * D, 4 * D, t, lens, 0, enc_h, enc_c, H, Mem,
@@ -189,10 +189,10 @@ static int begin_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const
     {
         GemmProb p = direct_prob(ws.fe, D, B * R, D, w->va_emb_b, SET_ACT_RELU);          // editnet.py:441
         p.add(X, F, w->va_emb_w, F, F);
-        SET_TRY(gemm_group(&p, 1, st));
+        SET_TRY(gemm_group(&p, 1, st, "gemm:pro att_embed"));
         GemmProb q = direct_prob(ws.att1, A, B * R, A, w->va_feat_b, SET_ACT_NONE);       // editnet.py:442
         q.add(ws.fe, D, w->va_feat_w, D, D);
-        SET_TRY(gemm_group(&q, 1, st));
+        SET_TRY(gemm_group(&q, 1, st, "gemm:pro features_att"));
         if (d->adaptive) SET_TRY(region_masks(X, ws.fe, ws.rmask, B, R, F, D, st));
     }
     if (image_mean)
@@ -233,7 +233,7 @@ static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const 
     a[1] = slab_prob(ws.sA1, bt, 4 * D, B);
     a[1].add(ws.h2, D, w->cl_h2h_w, D, D);
     plan_ksplit(a, 2, tgt);
-    SET_TRY(gemm_group(a, 2, st));
+    SET_TRY(gemm_group(a, 2, st, "gemm:A gates1+h2h"));
     const Slabs none{nullptr, 0, 0, 0};
     SET_TRY(lstm_pointwise(slabs_of(a[0]), none, none, ws.pre1, 4 * D, nullptr, nullptr, ws.c1, ws.c1, ws.h1, nullptr,
                            bt, D, st));
@@ -252,7 +252,7 @@ static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const 
     b[4] = slab_prob(ws.sB4, bt, 4 * D, B);
     b[4].add(ws.h1, D, w->cl_x2h_w, ld_x2h, D);
     plan_ksplit(b, 5, tgt);
-    SET_TRY(gemm_group(b, 5, st));
+    SET_TRY(gemm_group(b, 5, st, "gemm:B att2,tc,cg,x2h_h1"));
     SET_TRY(caption_attention(ws.att1_c, slabs_of(b[0]), w->ca_dec_b, w->ca_full_w, w->ca_full_b, ws.mask, ws.H, ws.Mem,
                               ws.ctx_cap, ws.sel, ws.alpha_c, bt, T, D, A, st));
     SET_TRY(visual_attention(ws.att1, slabs_of(b[1]), w->va_dec_b, w->va_full_w, w->va_full_b, X,
@@ -266,7 +266,7 @@ static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const 
     c[2] = slab_prob(ws.sC2, bt, D, B);
     c[2].add(ws.sel, D, w->cl_cmem_w, D, D);
     plan_ksplit(c, 3, tgt);
-    SET_TRY(gemm_group(c, 3, st));
+    SET_TRY(gemm_group(c, 3, st, "gemm:C cg_ctx,sc,cmem"));
     SET_TRY(context_gate_pointwise(slabs_of(b[3]), slabs_of(c[0]), w->ca_gate_b, slabs_of(c[1]), w->ca_sc_b,
                                    slabs_of(b[2]), w->ca_tc_b, ws.attend_cap, bt, D, st));
     // ---- D
@@ -274,14 +274,14 @@ static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const 
     dd.add(ws.attend_cap, D, w->cl_x2h_w + D, ld_x2h, D);
     dd.add(ws.attend_img, F, w->cl_x2h_w + 2 * D, ld_x2h, F);
     plan_ksplit(&dd, 1, tgt);
-    SET_TRY(gemm_group(&dd, 1, st));
+    SET_TRY(gemm_group(&dd, 1, st, "gemm:D x2h_ctx"));
     SET_TRY(lstm_pointwise(slabs_of(a[1]), slabs_of(b[4]), slabs_of(dd), nullptr, 0, w->cl_x2h_b, w->cl_h2h_b, ws.c2,
                            ws.c_new, nullptr, ws.ogate, bt, D, st));
     // ---- E
     GemmProb e = slab_prob(ws.sE0, bt, D, B);
     e.add(ws.c_new, D, w->cl_cnew_w, D, D);
     plan_ksplit(&e, 1, tgt);
-    SET_TRY(gemm_group(&e, 1, st));
+    SET_TRY(gemm_group(&e, 1, st, "gemm:E cnew"));
     SET_TRY(copy_gate_pointwise(slabs_of(e), w->cl_cnew_b, slabs_of(c[2]), w->cl_cmem_b, ws.c_new, ws.sel, ws.ogate,
                                 ws.c2, ws.h2, bt, D, st));
     // ---- F
@@ -293,9 +293,9 @@ static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const 
     plan_ksplit(&f, 1, tgt);
     if (dst && f.ksplit == 1) {
         f.C = dst; f.ldc = ld_dst; f.bias = w->fc_b; f.slab_stride = 0;
-        SET_TRY(gemm_group(&f, 1, st));
+        SET_TRY(gemm_group(&f, 1, st, "gemm:F fc"));
     } else {
-        SET_TRY(gemm_group(&f, 1, st));
+        SET_TRY(gemm_group(&f, 1, st, "gemm:F fc"));
         if (dst) SET_TRY(reduce_bias_act(slabs_of(f), w->fc_b, nullptr, dst, ld_dst, bt, V, SET_ACT_NONE, st));
     }
     if (logits_out) *logits_out = slabs_of(f);

@@ -87,6 +87,7 @@ int greedy_pick(Slabs logits, const float* bias, int V, int t, int max_len, long
                 int D, int B, hipStream_t s) {
     if (B <= 0) return SET_OK;
     if (D & 3) return SET_ERR_UNSUPPORTED;
+    ProfScope ps("greedy_pick", s, 0.0, 4.0 * B * (2.0 * V * logits.n + 2.0 * D));
     hipLaunchKernelGGL(greedy_pick_k, dim3(B), dim3(256), 0, s, logits, bias, V, t, max_len, end_idx, seq, seq_logp,
                        it, unfinished, alive, table, emb_out, D);
     SET_LAUNCH_CHECK();

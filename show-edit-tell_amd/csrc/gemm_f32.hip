@@ -197,7 +197,7 @@ void plan_ksplit(GemmProb* probs, int n, int target_wgs) {
     }
 }
 
-int gemm_group(const GemmProb* probs, int n, hipStream_t stream) {
+int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag) {
     if (n <= 0) return SET_OK;
     if (n > GEMM_MAX_TASKS) return SET_ERR_ARG;
     GemmLaunch L;
@@ -233,6 +233,16 @@ int gemm_group(const GemmProb* probs, int n, hipStream_t stream) {
         wg += t.tiles_m * t.tiles_n * t.ksplit;
     }
     for (int i = n; i < GEMM_MAX_TASKS; ++i) { L.t[i] = L.t[0]; L.t[i].wg_begin = 0x7fffffff; }
+    double flops = 0.0, bytes = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const GemmTask& t = L.t[i];
+        const double K = (double)t.ktiles * GEMM_BK;
+        flops += 2.0 * t.M * t.N * K;
+        bytes += 4.0 * ((double)t.M * K + (double)t.N * K + (double)t.M * t.N * t.ksplit);
+    }
+    const char* kname = bm == 128 ? "gemm_nt_f32<128,64>" : (bm == 64 ? "gemm_nt_f32<64,64>" : "gemm_nt_f32<32,128>");
+    ProfScope ps(kname, stream, flops, bytes);
+    ProfScope ps2(tag ? tag : "gemm:other", stream, flops, bytes);     // per-call-site breakdown (nested)
     dim3 grid(wg), block(256);
     if (bm == 128)
         hipLaunchKernelGGL((gemm_nt_f32<128, 64, 2, 2>), grid, block, 0, stream, L);

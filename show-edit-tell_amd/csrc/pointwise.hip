@@ -69,6 +69,7 @@ int lstm_pointwise(Slabs g0, Slabs g1, Slabs g2, const float* pre, long long ldp
                    int D, hipStream_t s) {
     if (D & 3) return SET_ERR_UNSUPPORTED;
     const long long n = (long long)M * (D >> 2);
+    ProfScope ps("lstm_pointwise", s, 0.0, 4.0 * M * D * (4.0 * (g0.n + g1.n + g2.n + (pre ? 1 : 0)) + 3.0));
     hipLaunchKernelGGL(lstm_pointwise_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g0, g1, g2, pre,
                        ldpre, b0, b1, c_in, c_out, h_out, ogate_out, M, D);
     SET_LAUNCH_CHECK();
@@ -105,6 +106,7 @@ int context_gate_pointwise(Slabs cg_a, Slabs cg_b, const float* cg_bias, Slabs s
                            Slabs tc, const float* tc_bias, float* out, int M, int D, hipStream_t s) {
     if (D & 3) return SET_ERR_UNSUPPORTED;
     const long long n = (long long)M * (D >> 2);
+    ProfScope ps("context_gate", s, 0.0, 4.0 * M * D * (cg_a.n + cg_b.n + sc.n + tc.n + 1.0));
     hipLaunchKernelGGL(context_gate_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cg_a, cg_b, cg_bias,
                        sc, sc_bias, tc, tc_bias, out, M, D);
     SET_LAUNCH_CHECK();
@@ -143,6 +145,7 @@ int copy_gate_pointwise(Slabs gn, const float* bn, Slabs gm, const float* bm, co
                         hipStream_t s) {
     if (D & 3) return SET_ERR_UNSUPPORTED;
     const long long n = (long long)M * (D >> 2);
+    ProfScope ps("copy_gate", s, 0.0, 4.0 * M * D * (gn.n + gm.n + 5.0));
     hipLaunchKernelGGL(copy_gate_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gn, bn, gm, bm, c_new,
                        sel, ogate, c_out, h_out, M, D);
     SET_LAUNCH_CHECK();
@@ -196,6 +199,7 @@ int reduce_bias_act(Slabs in, const float* b0, const float* b1, float* out, long
     if (M <= 0 || N <= 0) return SET_OK;
     const bool vec = !(N & 3) && !(ldo & 3) && !(in.ld & 3) && !(in.stride & 3) && aligned16(out) && aligned16(in.p) &&
                      (!b0 || aligned16(b0)) && (!b1 || aligned16(b1));
+    ProfScope ps("reduce_bias_act", s, 0.0, 4.0 * M * N * (in.n + 1.0));
     if (vec) {
         const long long n = (long long)M * (N >> 2);
         hipLaunchKernelGGL(reduce_bias_act_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, b0, b1, out, ldo,
@@ -232,6 +236,7 @@ int embed_relu(const float* table, const int64_t* ids, long long ids_stride, flo
     if ((D & 3) || (ldo & 3)) return SET_ERR_UNSUPPORTED;
     if (n <= 0) return SET_OK;
     const long long t = (long long)n * (D >> 2);
+    ProfScope ps("embed_relu", s, 0.0, 8.0 * n * D);
     hipLaunchKernelGGL(embed_relu_k, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, table, ids, ids_stride, out,
                        ldo, n, D, V);
     SET_LAUNCH_CHECK();
@@ -259,6 +264,7 @@ __global__ void __launch_bounds__(256) mean_regions_k(const float* X, float* out
 int mean_regions(const float* X, float* out, int B, int R, int F, hipStream_t s) {
     if (F & 3) return SET_ERR_UNSUPPORTED;
     const long long t = (long long)B * (F >> 2);
+    ProfScope ps("mean_regions", s, 0.0, 4.0 * B * F * (R + 1.0));
     hipLaunchKernelGGL(mean_regions_k, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, s, X, out, B, R, F);
     SET_LAUNCH_CHECK();
     return SET_OK;
@@ -311,6 +317,7 @@ int encoder_pointwise(Slabs hh, const float* xg, long long ld_xg_row, long long 
                       hipStream_t s) {
     if (D & 3) return SET_ERR_UNSUPPORTED;
     const long long n = (long long)B * (D >> 2);
+    ProfScope ps("encoder_pointwise", s, 0.0, 4.0 * B * D * (4.0 * hh.n + 4.0 + 5.0));
     hipLaunchKernelGGL(encoder_pointwise_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, hh, xg, ld_xg_row,
                        ld_xg_t, t, lens, reverse, h, c, H, Mem, ld_out_b, ld_out_t, out_col0, B, D, b_extra);
     SET_LAUNCH_CHECK();
@@ -337,6 +344,7 @@ __global__ void __launch_bounds__(256) rowsum_mask_k(const float* x, long long l
 
 int rowsum_mask(const float* x, long long ld_row, int rows, int D, float* mask, hipStream_t s) {
     if (D & 3) return SET_ERR_UNSUPPORTED;
+    ProfScope ps("rowsum_mask", s, 0.0, 4.0 * rows * D);
     hipLaunchKernelGGL(rowsum_mask_k, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, s, x, ld_row, rows, D, mask);
     SET_LAUNCH_CHECK();
     return SET_OK;

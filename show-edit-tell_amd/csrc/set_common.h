@@ -78,7 +78,7 @@ struct GemmProb {
 // choose per-problem ksplit so that the whole group launches about `target_wgs` workgroups of
 // similar length; problems with max_ksplit == 1 keep a fused bias/activation epilogue
 void plan_ksplit(GemmProb* probs, int n, int target_wgs);
-int gemm_group(const GemmProb* probs, int n, hipStream_t stream);
+int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag = nullptr);
 int gemm_tile_m(int M);   // BM the launcher will pick for M rows
 
 // ---------------------------------------------------------------------------------------------
@@ -91,6 +91,14 @@ struct Slabs {
     int n;
 };
 inline Slabs slabs_of(const GemmProb& g) { return Slabs{g.C, g.slab_stride, g.ldc, g.ksplit}; }
+
+// prof.hip: RAII timing scope around a kernel launch (no-op unless set_profile_enable(1))
+struct ProfScope {
+    int idx;
+    hipStream_t st;
+    ProfScope(const char* tag, hipStream_t s, double flops = 0.0, double bytes = 0.0);
+    ~ProfScope();
+};
 
 // editnet.hip (shared host helpers)
 int env_int(const char* name, int dflt);

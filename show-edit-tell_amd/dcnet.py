@@ -1,0 +1,190 @@
+"""DCNet (DAE) on MI355X: the reference's `DAE` module surface over the HIP decode path.
+
+Mirrors `/root/reference/dcnet.py:147-350`: `Embedding`, `CaptionEncoder`, `CaptionAttention`,
+`DAE` with the same constructor signatures, attribute names and `state_dict` keys.  DCNet is
+text-only (no image features, `dcnet.py:303`).  Eval-mode forward only for now.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import DcnetDims, DcnetWeights, DCNET_WEIGHT_FIELDS, EditNetWeights, check, ptr, stream_of
+from .editnet import _HipLinear, _HipLSTMCell, _f32c, _i64c, _no_train, _require_cuda
+
+
+class Embedding(nn.Module):
+    """reference dcnet.py:147-206 (the GloVe branch is dead code there: load_glove_embedding=False)"""
+
+    def __init__(self, word_map, emb_file, emb_dim, load_glove_embedding=False):
+        super().__init__()
+        if load_glove_embedding:
+            raise NotImplementedError("the reference hard-wires load_glove_embedding=False (dcnet.py:288)")
+        self.emb_dim = emb_dim
+        self.load_glove_embedding = load_glove_embedding
+        self.emb_file = emb_file
+        self.word_map = word_map
+        self.embedding = nn.Embedding(len(word_map), self.emb_dim)
+        self.relu = nn.ReLU()
+        self.dropout = nn.Dropout(0.5)
+
+    def forward(self, x):
+        _no_train(self, "Embedding")
+        _require_cuda(x, "token ids")
+        lib = _lib.load()
+        ids = _i64c(x)
+        n, D = ids.numel(), self.emb_dim
+        out = torch.empty(tuple(ids.shape) + (D,), dtype=torch.float32, device=ids.device)
+        check(lib.set_embed_relu_f32(ptr(self.embedding.weight), ptr(ids), 1, ptr(out), D, n, D,
+                                     self.embedding.num_embeddings, stream_of(ids.device)), "set_embed_relu_f32")
+        return out
+
+
+class CaptionEncoder(nn.Module):
+    """reference dcnet.py:209-243 — parameters live in an nn.LSTM container (same state_dict keys);
+    the forward runs through DAE's workspace (set_dcnet_begin)."""
+
+    def __init__(self, vocab_size, emb_dim, enc_hid_dim, concat_output_dim, embed):
+        super().__init__()
+        self.vocab_size = vocab_size
+        self.emb_dim = emb_dim
+        self.enc_hid_dim = enc_hid_dim
+        self.embed = embed
+        self.lstm_encoder = nn.LSTM(emb_dim, enc_hid_dim, batch_first=True, bidirectional=True)
+        self.concat = nn.Linear(enc_hid_dim * 2, concat_output_dim)
+        self._owner = None      # set by DAE (plain attribute, not a sub-module)
+
+    def forward(self, src, src_len):
+        _no_train(self, "CaptionEncoder")
+        if self._owner is None:
+            raise _lib.SetError("CaptionEncoder must be owned by a DAE (it runs through the DAE workspace)")
+        return self._owner()._encode(src, src_len)
+
+
+class CaptionAttention(nn.Module):
+    """reference dcnet.py:245-270"""
+
+    def __init__(self, caption_features_dim, decoder_dim, attention_dim):
+        super().__init__()
+        self.cap_features_att = nn.Linear(caption_features_dim * 2, attention_dim)
+        self.cap_decoder_att = nn.Linear(decoder_dim, attention_dim)
+        self.cap_full_att = nn.Linear(attention_dim, 1)
+
+    def forward(self, caption_features, decoder_hidden, prev_caption_mask):
+        _require_cuda(caption_features, "caption features")
+        lib = _lib.load()
+        H, h1, mask = _f32c(caption_features), _f32c(decoder_hidden), _f32c(prev_caption_mask)
+        M, T, Dh = H.shape
+        D, A = h1.shape[1], self.cap_decoder_att.out_features
+        w = EditNetWeights()          # gate weights stay NULL -> plain context (include/set_hip.h)
+        w.ca_feat_w, w.ca_feat_b = self.cap_features_att.weight.data_ptr(), self.cap_features_att.bias.data_ptr()
+        w.ca_dec_w, w.ca_dec_b = self.cap_decoder_att.weight.data_ptr(), self.cap_decoder_att.bias.data_ptr()
+        w.ca_full_w, w.ca_full_b = self.cap_full_att.weight.data_ptr(), self.cap_full_att.bias.data_ptr()
+        ctx = torch.empty(M, Dh, dtype=torch.float32, device=H.device)
+        ws = torch.empty(lib.set_caption_attention_workspace_bytes(M, T, max(Dh, D), A), dtype=torch.uint8,
+                         device=H.device)
+        check(lib.set_caption_attention_f32(C.byref(w), ptr(H), None, ptr(h1), None, ptr(mask), ptr(ctx), None, M, T,
+                                            Dh, D, A, ptr(ws), ws.numel(), stream_of(H.device)),
+              "set_caption_attention_f32")
+        return ctx
+
+
+class DAE(nn.Module):
+    """reference dcnet.py:273-350 — XE (teacher-forced) forward."""
+
+    def __init__(self, word_map, emb_file, decoder_dim=1024, attention_dim=512, caption_features_dim=512, emb_dim=1024):
+        super().__init__()
+        import weakref
+        self.vocab_size = len(word_map)
+        self.attention_lstm = _HipLSTMCell(emb_dim * 3, decoder_dim)
+        self.language_lstm = _HipLSTMCell(emb_dim * 2, decoder_dim)
+        self.embed = Embedding(word_map, emb_file, emb_dim, load_glove_embedding=False)
+        self.caption_encoder = CaptionEncoder(len(word_map), emb_dim, caption_features_dim, caption_features_dim * 2,
+                                              self.embed)
+        self.caption_encoder._owner = weakref.ref(self)
+        self.caption_attention = CaptionAttention(caption_features_dim, decoder_dim, attention_dim)
+        self.fc = _HipLinear(decoder_dim, len(word_map))
+        self.tanh = nn.Tanh()
+        self.decoder_dim = decoder_dim
+        self.dropout = nn.Dropout(0.5)
+        self._dims_cfg = (decoder_dim, attention_dim, caption_features_dim, emb_dim)
+        self._ws = None
+        self._ws_key = None
+
+    def init_hidden_state(self, batch_size):
+        dev = self.fc.weight.device
+        return (torch.zeros(batch_size, self.decoder_dim, device=dev),
+                torch.zeros(batch_size, self.decoder_dim, device=dev))
+
+    # ---- runtime plumbing
+    def _weights(self):
+        return _lib.pack_weights(DcnetWeights, DCNET_WEIGHT_FIELDS, dict(self.named_parameters()),
+                                 self.fc.weight.device)
+
+    def _dims(self, B, T, maxT):
+        D, A, Cc, E = self._dims_cfg
+        return DcnetDims(B=B, T=T, D=D, A=A, C=Cc, E=E, V=self.vocab_size, maxT=maxT)
+
+    def _workspace(self, dims):
+        lib = _lib.load()
+        key = tuple(getattr(dims, f) for f, _ in DcnetDims._fields_) + (str(self.fc.weight.device),)
+        if self._ws_key != key:
+            n = lib.set_dcnet_workspace_bytes(C.byref(dims))
+            if n == 0:
+                raise _lib.SetError("unsupported DCNet dims %r" % (key,))
+            self._ws = torch.empty(n, dtype=torch.uint8, device=self.fc.weight.device)
+            self._ws_key = key
+        return self._ws
+
+    def ws_tensor(self, dims, name, shape, dtype=torch.float32):
+        lib = _lib.load()
+        p = lib.set_dcnet_ws_tensor(C.byref(dims), ptr(self._ws), name.encode())
+        if not p:
+            raise KeyError(name)
+        off = p - self._ws.data_ptr()
+        n = int(torch.tensor(shape).prod().item()) * torch.empty((), dtype=dtype).element_size()
+        return self._ws[off:off + n].view(dtype).view(*shape)
+
+    def _encode(self, src, src_len):
+        """caption_encoder(src, src_len) -> (outputs (B,Tmax,2C), final_hidden (B,2C), mask (B,Tmax))"""
+        _require_cuda(src, "previous captions")
+        lib = _lib.load()
+        src, lens = _i64c(src), _i64c(src_len.reshape(-1))
+        B, T = src.shape
+        dims = self._dims(B, T, 19)
+        ws = self._workspace(dims)
+        w = self._weights()
+        check(lib.set_dcnet_begin(C.byref(w), C.byref(dims), ptr(src), ptr(lens), ptr(ws), ws.numel(),
+                                  stream_of(src.device)), "set_dcnet_begin")
+        Cc = self._dims_cfg[2]
+        tmax = int(lens.max().item())
+        enc = self.ws_tensor(dims, "enc", (B, T, 2 * Cc)).clone()
+        fh = self.ws_tensor(dims, "final_hidden", (B, 2 * Cc)).clone()
+        mask = self.ws_tensor(dims, "mask", (B, T)).clone()
+        return enc[:, :tmax], fh, mask[:, :tmax]
+
+    def forward(self, encoded_captions, caption_lengths, encoded_previous_captions, previous_cap_length):
+        """reference dcnet.py:303-350; returns (predictions, encoded_captions sorted, decode_lengths, sort_ind)."""
+        _no_train(self, "DAE.forward")
+        _require_cuda(encoded_captions, "captions")
+        lib = _lib.load()
+        dev = encoded_captions.device
+        batch_size = encoded_captions.size(0)
+        caption_lengths, sort_ind = caption_lengths.squeeze(1).sort(dim=0, descending=True)
+        encoded_captions = _i64c(encoded_captions[sort_ind])
+        prev = _i64c(encoded_previous_captions[sort_ind])
+        plen = _i64c(previous_cap_length[sort_ind].reshape(-1))
+        decode_lengths = (caption_lengths - 1).tolist()
+        maxT = max(decode_lengths)
+        dims = self._dims(batch_size, prev.shape[1], maxT)
+        ws = self._workspace(dims)
+        w = self._weights()
+        predictions = torch.empty(batch_size, maxT, self.vocab_size, dtype=torch.float32, device=dev)
+        dl = (C.c_int * batch_size)(*decode_lengths)
+        check(lib.set_dcnet_xe_forward(C.byref(w), C.byref(dims), ptr(encoded_captions), encoded_captions.shape[1], dl,
+                                       ptr(prev), ptr(plen), ptr(predictions), ptr(ws), ws.numel(), stream_of(dev)),
+              "set_dcnet_xe_forward")
+        return predictions, encoded_captions, decode_lengths, sort_ind

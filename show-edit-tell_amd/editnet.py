@@ -204,7 +204,7 @@ class CaptionAttentionC(nn.Module):
         alpha = torch.empty(M, T, dtype=torch.float32, device=H.device)
         ws = torch.empty(lib.set_caption_attention_workspace_bytes(M, T, D, A), dtype=torch.uint8, device=H.device)
         check(lib.set_caption_attention_f32(C.byref(w), ptr(H), None, ptr(h1), ptr(word), ptr(mask), ptr(gated),
-                                            ptr(alpha), M, T, D, A, ptr(ws), ws.numel(), stream_of(H.device)),
+                                            ptr(alpha), M, T, D, D, A, ptr(ws), ws.numel(), stream_of(H.device)),
               "set_caption_attention_f32")
         return gated, alpha
 

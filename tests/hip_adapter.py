@@ -27,3 +27,21 @@ def editnet_modules(name, dev="cuda:0"):
     xe = load_numpy_state(editnet.DecoderC(*args), d["sd"], dev)
     rl = load_numpy_state(editnet_rl.DecoderC(*args), d["sd"], dev)
     return d, xe, rl
+
+
+def dcnet_modules(name, dev="cuda:0"):
+    from show_edit_tell_amd import dcnet, dcnet_rl
+    d = cases.build_dcnet(name)
+    c = d["case"]
+    args = (d["wm"], None, c["D"], c["A"], c["C"], c["E"])
+    xe = load_numpy_state(dcnet.DAE(*args), d["sd"], dev)
+    rl = load_numpy_state(dcnet_rl.DAE(*args), d["sd"], dev)
+    return d, xe, rl
+
+
+def adaptive_module(name, dev="cuda:0"):
+    from show_edit_tell_amd import editnet_adaptive
+    d = cases.build_editnet(name)
+    c = d["case"]
+    args = (d["wm"], c["D"], c["D"], c["D"], c["A"], c["F"])
+    return d, load_numpy_state(editnet_adaptive.DecoderC(*args), d["sd"], dev)

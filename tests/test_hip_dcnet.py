@@ -1,0 +1,32 @@
+"""GPU parity: the HIP DCNet path against the reference's golden vectors (run with `pytest -m gpu`)."""
+import numpy as np
+import pytest
+import torch
+
+import parity
+from hip_adapter import dcnet_modules, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("name", ["dcnet_small", "dcnet_small_end", "dcnet_full_b4"])
+def test_dcnet_vs_golden(name):
+    d, xe, rl = dcnet_modules(name)
+    c, g = d["case"], parity.load(name)
+    prev, plen = to_dev(d["prev"]), to_dev(d["plen"])
+    with torch.no_grad():
+        enc, fh, mask = xe.caption_encoder(prev, plen)
+        parity.assert_close(_np(enc), g["enc_out"], parity.STATE_TOL, "dcnet encoder outputs")
+        parity.assert_close(_np(fh), g["enc_final"], parity.STATE_TOL, "dcnet final_hidden")
+        assert np.array_equal(_np(mask), g["enc_mask"])
+        ctx = xe.caption_attention(enc, to_dev(d["probe"]["h1"]), mask)
+        parity.assert_close(_np(ctx), g["op_ctx"], parity.STATE_TOL, "dcnet caption_attention")
+        pred, caps_s, dl, sort_ind = xe(to_dev(d["caps"]), to_dev(d["clen"]), prev, plen)
+        parity.check_xe(_np(pred), dl, _np(sort_ind), g, c["V"], small=c["D"] < 1024)
+        seq, logp = rl(d["wm"], prev, plen, True, False)
+    torch.cuda.synchronize()
+    parity.check_greedy(_np(seq), _np(logp), g)
