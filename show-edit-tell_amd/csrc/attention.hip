@@ -84,19 +84,37 @@ __global__ void __launch_bounds__(256) caption_attention_k(const float* att1_c, 
         }
     }
     const float bf = b_full[0];
-    for (int t = wave; t < T; t += 4) {
-        const float* row = att1_c + ((long long)b * T + t) * A;
-        float s = 0.f;
+    // each wave scores rows wave, wave+4, ...; RB rows are loaded before any is reduced so that their
+    // HBM/L2 round trips overlap (the reductions are 6-step cross-lane chains)
+    constexpr int RB = 5;
+    for (int t0 = wave; t0 < T; t0 += 4 * RB) {
+        f32x4 v[RB][2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int a = lane * 4 + 256 * q;
-            if (q < nq && a < A) {
-                const f32x4 v = ld4a(row + a) + a2[q];
-                s += wf[q][0] * tanhf(v[0]) + wf[q][1] * tanhf(v[1]) + wf[q][2] * tanhf(v[2]) + wf[q][3] * tanhf(v[3]);
+        for (int u = 0; u < RB; ++u) {
+            const int t = t0 + 4 * u;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int a = lane * 4 + 256 * q;
+                v[u][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (t < T && q < nq && a < A) v[u][q] = ld4a(att1_c + ((long long)b * T + t) * A + a);
             }
         }
-        s = wave_sum(s);
-        if (lane == 0) sc[t] = (mask[(long long)b * T + t] == 0.f) ? -1e10f : (s + bf);
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int t = t0 + 4 * u;
+            if (t >= T) break;
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int a = lane * 4 + 256 * q;
+                if (q < nq && a < A) {
+                    const f32x4 x = v[u][q] + a2[q];
+                    s += wf[q][0] * tanhf(x[0]) + wf[q][1] * tanhf(x[1]) + wf[q][2] * tanhf(x[2]) + wf[q][3] * tanhf(x[3]);
+                }
+            }
+            s = wave_sum(s);
+            if (lane == 0) sc[t] = (mask[(long long)b * T + t] == 0.f) ? -1e10f : (s + bf);
+        }
     }
     __syncthreads();
     block_softmax(sc, T, tid, &s_arg);
@@ -109,7 +127,15 @@ __global__ void __launch_bounds__(256) caption_attention_k(const float* att1_c, 
     for (int d = tid * 4; d < Dh; d += 1024) {
         const float* hp = H + (long long)b * T * Dh + d;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int t = 0; t < T; ++t) acc += ld4a(hp + (long long)t * Dh) * sc[t];
+        int t = 0;
+        for (; t + 8 <= T; t += 8) {                      // 8 rows in flight; accumulation stays in t order
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ld4a(hp + (long long)(t + u) * Dh);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u] * sc[t + u];
+        }
+        for (; t < T; ++t) acc += ld4a(hp + (long long)t * Dh) * sc[t];
         *reinterpret_cast<f32x4*>(ctx + (long long)b * Dh + d) = acc;
         if (Mem) {
             const f32x4 m = ld4a(Mem + ((long long)b * T + js) * Dh + d);
@@ -158,20 +184,36 @@ __global__ void __launch_bounds__(256) visual_attention_k(const float* att1, Sla
         }
     }
     const float bf = b_full[0];
-    for (int r = wave; r < R; r += 4) {
-        const float* row = att1 + ((long long)b * R + r) * A;
-        float s = 0.f;
+    constexpr int RB = 5;
+    for (int r0 = wave; r0 < R; r0 += 4 * RB) {
+        f32x4 v[RB][2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int a = lane * 4 + 256 * q;
-            if (q < nq && a < A) {
-                const f32x4 v = ld4a(row + a) + a2[q];
-                s += wf[q][0] * fmaxf(v[0], 0.f) + wf[q][1] * fmaxf(v[1], 0.f) + wf[q][2] * fmaxf(v[2], 0.f) +
-                     wf[q][3] * fmaxf(v[3], 0.f);
+        for (int u = 0; u < RB; ++u) {
+            const int r = r0 + 4 * u;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int a = lane * 4 + 256 * q;
+                v[u][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (r < R && q < nq && a < A) v[u][q] = ld4a(att1 + ((long long)b * R + r) * A + a);
             }
         }
-        s = wave_sum(s);
-        if (lane == 0) sc[r] = (rmask && rmask[(long long)b * R + r] == 0.f) ? -1e10f : (s + bf);
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int r = r0 + 4 * u;
+            if (r >= R) break;
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int a = lane * 4 + 256 * q;
+                if (q < nq && a < A) {
+                    const f32x4 x = v[u][q] + a2[q];
+                    s += wf[q][0] * fmaxf(x[0], 0.f) + wf[q][1] * fmaxf(x[1], 0.f) + wf[q][2] * fmaxf(x[2], 0.f) +
+                         wf[q][3] * fmaxf(x[3], 0.f);
+                }
+            }
+            s = wave_sum(s);
+            if (lane == 0) sc[r] = (rmask && rmask[(long long)b * R + r] == 0.f) ? -1e10f : (s + bf);
+        }
     }
     __syncthreads();
     block_softmax(sc, R, tid, nullptr);
@@ -182,8 +224,15 @@ __global__ void __launch_bounds__(256) visual_attention_k(const float* att1, Sla
     for (int f = f0 + tid * 4; f < f0 + fcols && f < F; f += 1024) {
         const float* xp = X + (long long)b * R * F + f;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int r = 0; r < R; ++r) acc += ld4a(xp + (long long)r * F) * sc[r];
+        int r = 0;
+        for (; r + 12 <= R; r += 12) {                    // 12 regions in flight; accumulation stays in r order
+            f32x4 v[12];
+#pragma unroll
+            for (int u = 0; u < 12; ++u) v[u] = ld4a(xp + (long long)(r + u) * F);
+#pragma unroll
+            for (int u = 0; u < 12; ++u) acc += v[u] * sc[r + u];
+        }
+        for (; r < R; ++r) acc += ld4a(xp + (long long)r * F) * sc[r];
         *reinterpret_cast<f32x4*>(ctx + (long long)b * F + f) = acc;
     }
 }

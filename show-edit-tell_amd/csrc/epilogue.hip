@@ -18,6 +18,11 @@ __device__ __forceinline__ float logit_at(const Slabs& s, const float* bias, lon
 // grid = B rows.  alive[t] counts rows still unfinished after step t (zeroed by the caller);
 // once alive[t-1] == 0 the reference has left its loop (`break`, editnet_rl.py:546) and nothing
 // more is written to seq / seq_logp.
+// REG = true: the row (<= 4*256*GP_MAXQ logits) is read ONCE as float4 (all K-slabs + bias summed
+// in registers), max / first-argmax and sum-exp are reduced from registers.
+constexpr int GP_MAXQ = 12;
+
+template <bool REG>
 __global__ void __launch_bounds__(256) greedy_pick_k(Slabs logits, const float* bias, int V, int t, int max_len,
                                                      long long end_idx, long long* seq, float* seq_logp,
                                                      long long* it_buf, int* unfinished, int* alive,
@@ -27,12 +32,57 @@ __global__ void __launch_bounds__(256) greedy_pick_k(Slabs logits, const float* 
     __shared__ float s_sum[4];
     __shared__ long long s_tok;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // pass 1: max and its first index
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int v = tid; v < V; v += 256) {
-        const float x = logit_at(logits, bias, b, v);
-        if (x > best) { best = x; bi = v; }
+    f32x4 x[GP_MAXQ];
+    if (REG) {
+        const float* row = logits.p + (long long)b * logits.ld;
+        // slab 0 (+ bias), then the remaining K-slabs in index order; GP_MAXQ independent float4 loads
+        // are in flight per pass
+        const bool bias4 = bias && !(V & 3) && ((reinterpret_cast<uintptr_t>(bias) & 15u) == 0);
+#pragma unroll
+        for (int q = 0; q < GP_MAXQ; ++q) {
+            const int v = (tid + 256 * q) * 4;
+            x[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (v < V) x[q] = *reinterpret_cast<const f32x4*>(row + v);
+        }
+        for (int i = 1; i < logits.n; ++i) {
+            f32x4 y[GP_MAXQ];
+#pragma unroll
+            for (int q = 0; q < GP_MAXQ; ++q) {
+                const int v = (tid + 256 * q) * 4;
+                y[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (v < V) y[q] = *reinterpret_cast<const f32x4*>(row + (long long)i * logits.stride + v);
+            }
+#pragma unroll
+            for (int q = 0; q < GP_MAXQ; ++q) x[q] += y[q];
+        }
+#pragma unroll
+        for (int q = 0; q < GP_MAXQ; ++q) {
+            const int v = (tid + 256 * q) * 4;
+            if (v < V) {
+                if (bias4) {
+                    x[q] += *reinterpret_cast<const f32x4*>(bias + v);
+                } else if (bias) {
+                    x[q][0] += bias[v];
+                    if (v + 1 < V) x[q][1] += bias[v + 1];
+                    if (v + 2 < V) x[q][2] += bias[v + 2];
+                    if (v + 3 < V) x[q][3] += bias[v + 3];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (v + e >= V) x[q][e] = -INFINITY;     // padding columns / rows past V
+        }
+#pragma unroll
+        for (int q = 0; q < GP_MAXQ; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (x[q][e] > best) { best = x[q][e]; bi = (tid + 256 * q) * 4 + e; }   // ascending index per thread
+    } else {
+        for (int v = tid; v < V; v += 256) {
+            const float xv = logit_at(logits, bias, b, v);
+            if (xv > best) { best = xv; bi = v; }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -46,9 +96,15 @@ __global__ void __launch_bounds__(256) greedy_pick_k(Slabs logits, const float* 
 #pragma unroll
     for (int w = 1; w < 4; ++w)
         if (s_val[w] > best || (s_val[w] == best && s_idx[w] < bi)) { best = s_val[w]; bi = s_idx[w]; }
-    // pass 2: sum exp(x - max)
     float sum = 0.f;
-    for (int v = tid; v < V; v += 256) sum += expf(logit_at(logits, bias, b, v) - best);
+    if (REG) {
+#pragma unroll
+        for (int q = 0; q < GP_MAXQ; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum += expf(x[q][e] - best);               // exp(-inf) == 0 for padding
+    } else {
+        for (int v = tid; v < V; v += 256) sum += expf(logit_at(logits, bias, b, v) - best);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     if (lane == 0) s_sum[wave] = sum;
@@ -88,8 +144,13 @@ int greedy_pick(Slabs logits, const float* bias, int V, int t, int max_len, long
     if (B <= 0) return SET_OK;
     if (D & 3) return SET_ERR_UNSUPPORTED;
     ProfScope ps("greedy_pick", s, 0.0, 4.0 * B * (2.0 * V * logits.n + 2.0 * D));
-    hipLaunchKernelGGL(greedy_pick_k, dim3(B), dim3(256), 0, s, logits, bias, V, t, max_len, end_idx, seq, seq_logp,
-                       it, unfinished, alive, table, emb_out, D);
+    const bool reg = V <= 4 * 256 * GP_MAXQ && !(logits.ld & 3) && !(logits.stride & 3) && aligned16(logits.p);
+    if (reg)
+        hipLaunchKernelGGL(greedy_pick_k<true>, dim3(B), dim3(256), 0, s, logits, bias, V, t, max_len, end_idx, seq,
+                           seq_logp, it, unfinished, alive, table, emb_out, D);
+    else
+        hipLaunchKernelGGL(greedy_pick_k<false>, dim3(B), dim3(256), 0, s, logits, bias, V, t, max_len, end_idx, seq,
+                           seq_logp, it, unfinished, alive, table, emb_out, D);
     SET_LAUNCH_CHECK();
     return SET_OK;
 }

@@ -23,6 +23,9 @@ namespace set {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// loads of A / W always target global memory: say so, or the compiler emits flat_load (which also
+// counts on lgkmcnt and would make every LDS wait drain the HBM loads)
+typedef const f32x4 __attribute__((address_space(1)))* gptr4;
 
 constexpr int LDS_STRIDE = 36;   // floats per staged row (32 + 4 pad): banks r*36 mod 64 distinct per lane group
 
@@ -84,32 +87,41 @@ __global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
 #pragma unroll
     for (int i = 0; i < LW; ++i) { int r = n0 + srow + 32 * i; wrow[i] = r < T.N ? r : T.N - 1; }
 
-    f32x4 ra[LA], rw[LW];
-#define SET_GLOAD(KT)                                                                                   \
+    f32x4 ra0[LA], rw0[LW], ra1[LA], rw1[LW];      // two register stages: loads run two k-tiles ahead
+    // running per-thread row pointers inside the current K segment; re-derived only when the
+    // k-tile index crosses into the next (activation, weight) segment
+    const float* pa[LA];
+    const float* pw[LW];
+    int seg_end = 0;       // first k-tile index beyond the current segment
+#define SET_SEEK(KT)                                                                                    \
     {                                                                                                   \
         const int kt_ = (KT);                                                                           \
         int s_ = 0, kbase_ = 0;                                                                         \
         _Pragma("unroll") for (int i = 0; i < GEMM_MAX_SEG - 1; ++i)                                    \
             if (i + 1 < T.nseg && kt_ >= T.kt_end[i]) { s_ = i + 1; kbase_ = T.kt_end[i]; }             \
-        const long long koff_ = (long long)(kt_ - kbase_) * GEMM_BK + scol;                             \
         const float* Ab_ = T.A[0];                                                                      \
         const float* Wb_ = T.W[0];                                                                      \
         long long lda_ = T.lda[0], ldw_ = T.ldw[0];                                                     \
+        seg_end = T.kt_end[0];                                                                          \
         _Pragma("unroll") for (int i = 1; i < GEMM_MAX_SEG; ++i)                                        \
-            if (s_ == i) { Ab_ = T.A[i]; Wb_ = T.W[i]; lda_ = T.lda[i]; ldw_ = T.ldw[i]; }              \
-        _Pragma("unroll") for (int i = 0; i < LA; ++i)                                                  \
-            ra[i] = *reinterpret_cast<const f32x4*>(Ab_ + arow[i] * lda_ + koff_);                     \
-        _Pragma("unroll") for (int i = 0; i < LW; ++i)                                                  \
-            rw[i] = *reinterpret_cast<const f32x4*>(Wb_ + wrow[i] * ldw_ + koff_);                     \
+            if (s_ == i) { Ab_ = T.A[i]; Wb_ = T.W[i]; lda_ = T.lda[i]; ldw_ = T.ldw[i]; seg_end = T.kt_end[i]; } \
+        const long long koff_ = (long long)(kt_ - kbase_) * GEMM_BK + scol;                             \
+        _Pragma("unroll") for (int i = 0; i < LA; ++i) pa[i] = Ab_ + arow[i] * lda_ + koff_;            \
+        _Pragma("unroll") for (int i = 0; i < LW; ++i) pw[i] = Wb_ + wrow[i] * ldw_ + koff_;            \
     }
-#define SET_LSTORE(BUF)                                                                                 \
+#define SET_GLOAD(RA, RW)                                                                               \
+    {                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < LA; ++i) { RA[i] = *(gptr4)(pa[i]); pa[i] += GEMM_BK; } \
+        _Pragma("unroll") for (int i = 0; i < LW; ++i) { RW[i] = *(gptr4)(pw[i]); pw[i] += GEMM_BK; } \
+    }
+#define SET_LSTORE(BUF, RA, RW)                                                                         \
     {                                                                                                   \
         float* sA_ = lds[(BUF)];                                                                        \
         float* sW_ = lds[(BUF)] + BM * LDS_STRIDE;                                                      \
         _Pragma("unroll") for (int i = 0; i < LA; ++i)                                                  \
-            *reinterpret_cast<f32x4*>(sA_ + (srow + 32 * i) * LDS_STRIDE + scol) = ra[i];              \
+            *reinterpret_cast<f32x4*>(sA_ + (srow + 32 * i) * LDS_STRIDE + scol) = RA[i];              \
         _Pragma("unroll") for (int i = 0; i < LW; ++i)                                                  \
-            *reinterpret_cast<f32x4*>(sW_ + (srow + 32 * i) * LDS_STRIDE + scol) = rw[i];              \
+            *reinterpret_cast<f32x4*>(sW_ + (srow + 32 * i) * LDS_STRIDE + scol) = RW[i];              \
     }
 
     f32x16 acc[TM][TN];
@@ -121,33 +133,63 @@ __global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int frow = lane & 31, fk = (lane >> 5) * 4;
-    int buf = 0;
-    if (kt0 < kt1) SET_GLOAD(kt0);
-    for (int kt = kt0; kt < kt1; ++kt) {
-        SET_LSTORE(buf);
-        __syncthreads();
-        if (kt + 1 < kt1) SET_GLOAD(kt + 1);
-        const float* sA = lds[buf] + (wm * TM * 32 + frow) * LDS_STRIDE + fk;
-        const float* sW = lds[buf] + BM * LDS_STRIDE + (wn * TN * 32 + frow) * LDS_STRIDE + fk;
-#pragma unroll
-        for (int kk = 0; kk < GEMM_BK / 8; ++kk) {
-            f32x4 a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(sA + i * 32 * LDS_STRIDE + kk * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(sW + j * 32 * LDS_STRIDE + kk * 8);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-                }
-        }
-        buf ^= 1;
+    // Software pipeline (one barrier per k-tile, two LDS buffers, one register stage):
+    //   iteration kt:  MFMAs of tile kt from lds[buf]   ||  ds_write tile kt+1 -> lds[buf^1]
+    //                                                    ||  global loads of tile kt+2 -> registers
+    // so the LDS stores and the HBM/L2 loads are issued in the shadow of the 64-cycle MFMAs.
+#define SET_MFMA_KK(KK)                                                                                 \
+    {                                                                                                   \
+        f32x4 a[TM], b[TN];                                                                             \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
+            a[i] = *reinterpret_cast<const f32x4*>(sA + i * 32 * LDS_STRIDE + (KK) * 8);                \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                  \
+            b[j] = *reinterpret_cast<const f32x4*>(sW + j * 32 * LDS_STRIDE + (KK) * 8);                \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                            \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);   \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);   \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);   \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);   \
+            }                                                                                           \
     }
+    // stage(kt): global loads of tile kt into a register set (no-op past the end of the slice)
+#define SET_STAGE(KT, RA, RW)                                                                           \
+    if ((KT) < kt1) {                                                                                   \
+        if ((KT) == seg_end) SET_SEEK(KT);                                                              \
+        SET_GLOAD(RA, RW);                                                                              \
+    }
+    // one k-tile: MFMAs from lds[BUF]; meanwhile registers (tile kt+1) -> lds[BUF^1], then reload them
+    // with tile kt+3
+#define SET_ITER(KT, BUF, RA, RW)                                                                       \
+    {                                                                                                   \
+        const float* sA = lds[BUF] + (wm * TM * 32 + frow) * LDS_STRIDE + fk;                           \
+        const float* sW = lds[BUF] + BM * LDS_STRIDE + (wn * TN * 32 + frow) * LDS_STRIDE + fk;         \
+        SET_MFMA_KK(0);                                                                                 \
+        if ((KT) + 1 < kt1) {                                                                           \
+            SET_LSTORE((BUF) ^ 1, RA, RW);                                                              \
+            SET_STAGE((KT) + 3, RA, RW);                                                                \
+        }                                                                                               \
+        SET_MFMA_KK(1);                                                                                 \
+        SET_MFMA_KK(2);                                                                                 \
+        SET_MFMA_KK(3);                                                                                 \
+        __syncthreads();                                                                                \
+    }
+    if (kt0 < kt1) {
+        SET_SEEK(kt0);
+        SET_GLOAD(ra0, rw0);                 // tile kt0
+        SET_STAGE(kt0 + 1, ra1, rw1);        // tile kt0+1
+        SET_LSTORE(0, ra0, rw0);
+        SET_STAGE(kt0 + 2, ra0, rw0);        // tile kt0+2
+        __syncthreads();
+    }
+    // invariant at the top of an even step: lds[0] = tile kt, ra1/rw1 = tile kt+1, ra0/rw0 = tile kt+2
+    for (int kt = kt0; kt < kt1; kt += 2) {
+        SET_ITER(kt, 0, ra1, rw1);
+        if (kt + 1 < kt1) SET_ITER(kt + 1, 1, ra0, rw0);
+    }
+#undef SET_ITER
+#undef SET_STAGE
+#undef SET_MFMA_KK
 
     // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* Cs = T.C + (long long)ks * T.slab_stride;
@@ -175,6 +217,7 @@ __global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
 }
 
 #undef SET_GLOAD
+#undef SET_SEEK
 #undef SET_LSTORE
 
 int gemm_tile_m(int M) { return M <= 32 ? 32 : (M <= 64 ? 64 : 128); }

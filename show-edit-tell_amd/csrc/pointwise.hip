@@ -14,14 +14,45 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
-// sum of the K-slabs of one GEMM output at (m, n..n+3)
+// sum of the K-slabs of one GEMM output at (m, n..n+3): slabs are added in index order (fixed,
+// deterministic); loads are issued four slabs at a time so they are in flight together
 __device__ __forceinline__ f32x4 slab_sum4(const Slabs& s, long long m, int n) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (s.n <= 0) return v;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (s.n <= 0) return acc;
     const float* p = s.p + m * s.ld + n;
-    v = ld4(p);
-    for (int i = 1; i < s.n; ++i) v += ld4(p + (long long)i * s.stride);
-    return v;
+    int i = 0;
+    for (; i + 4 <= s.n; i += 4) {
+        const f32x4 v0 = ld4(p + (long long)i * s.stride), v1 = ld4(p + (long long)(i + 1) * s.stride);
+        const f32x4 v2 = ld4(p + (long long)(i + 2) * s.stride), v3 = ld4(p + (long long)(i + 3) * s.stride);
+        acc += v0; acc += v1; acc += v2; acc += v3;
+    }
+    for (; i < s.n; ++i) acc += ld4(p + (long long)i * s.stride);
+    return acc;
+}
+
+// the same for Q column blocks of one row at once (the four gates of an LSTM row): Q x 2 loads in flight
+template <int Q>
+__device__ __forceinline__ void slab_accum(f32x4 (&acc)[Q], const Slabs& s, long long m, int col0, int colstep) {
+    if (s.n <= 0) return;
+    const float* p = s.p + m * s.ld + col0;
+    int i = 0;
+    for (; i + 2 <= s.n; i += 2) {
+        f32x4 v0[Q], v1[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            v0[q] = ld4(p + (long long)i * s.stride + q * colstep);
+            v1[q] = ld4(p + (long long)(i + 1) * s.stride + q * colstep);
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { acc[q] += v0[q]; acc[q] += v1[q]; }
+    }
+    if (i < s.n) {
+        f32x4 v0[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) v0[q] = ld4(p + (long long)i * s.stride + q * colstep);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) acc[q] += v0[q];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -40,15 +71,16 @@ __global__ void __launch_bounds__(256) lstm_pointwise_k(Slabs g0, Slabs g1, Slab
     const int j = (int)(idx - m * per_row) << 2;
     f32x4 g[4];
 #pragma unroll
+    for (int q = 0; q < 4; ++q) g[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    slab_accum<4>(g, g0, m, j, D);
+    slab_accum<4>(g, g1, m, j, D);
+    slab_accum<4>(g, g2, m, j, D);
+#pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int n = q * D + j;
-        f32x4 v = slab_sum4(g0, m, n);
-        v += slab_sum4(g1, m, n);
-        v += slab_sum4(g2, m, n);
-        if (pre) v += ld4(pre + m * ldpre + n);
-        if (b0) v += ld4(b0 + n);
-        if (b1) v += ld4(b1 + n);
-        g[q] = v;
+        if (pre) g[q] += ld4(pre + m * ldpre + n);
+        if (b0) g[q] += ld4(b0 + n);
+        if (b1) g[q] += ld4(b1 + n);
     }
     const f32x4 c = ld4(c_in + m * D + j);
     f32x4 cn, hn, og;
@@ -293,8 +325,11 @@ __global__ void __launch_bounds__(256) encoder_pointwise_k(Slabs hh, const float
     const float* xr = xg + b * ld_xg_row + (long long)pos * ld_xg_t;
     f32x4 g[4];
 #pragma unroll
+    for (int q = 0; q < 4; ++q) g[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    slab_accum<4>(g, hh, b, j, D);
+#pragma unroll
     for (int q = 0; q < 4; ++q) {
-        g[q] = slab_sum4(hh, b, q * D + j) + ld4(xr + q * D + j);
+        g[q] += ld4(xr + q * D + j);
         if (b_extra) g[q] += ld4(b_extra + q * D + j);
     }
     const f32x4 cp = ld4(c + b * D + j);
