@@ -60,14 +60,24 @@ __device__ __forceinline__ void block_softmax(float* sc, int n, int tid, int* ar
 //   alpha = softmax_t(e) ; ctx = sum_t alpha_t H[b,t,:]
 //   sel   = Mem[b,j*,:] * (alpha_j* + (1 - alpha_j*)),  j* = first argmax_t alpha     (Mem may be NULL)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) caption_attention_k(const float* att1_c, Slabs att2_c, const float* dec_bias,
-                                                           const float* w_full, const float* b_full,
-                                                           const float* mask, const float* H, const float* Mem,
-                                                           float* ctx, float* sel, float* alpha_out, int T, int Dh,
-                                                           int A) {
-    __shared__ float sc[ATT_MAX_ROWS];
-    __shared__ int s_arg;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+struct CapAttArgs {
+    const float* att1_c; Slabs att2_c; const float* dec_bias; const float* w_full; const float* b_full;
+    const float* mask; const float* H; const float* Mem; float* ctx; float* sel; float* alpha_out;
+    int T, Dh, A;
+};
+struct VisAttArgs {
+    const float* att1; Slabs att2; const float* dec_bias; const float* w_full; const float* b_full;
+    const float* X; const float* rmask; float* ctx; float* alpha_out;
+    int R, F, A, fcols, fsn;
+};
+
+__device__ __forceinline__ void caption_attention_body(const CapAttArgs& P, int b, float* sc, int* s_arg_p) {
+    const float* att1_c = P.att1_c; const Slabs att2_c = P.att2_c; const float* dec_bias = P.dec_bias;
+    const float* w_full = P.w_full; const float* b_full = P.b_full; const float* mask = P.mask;
+    const float* H = P.H; const float* Mem = P.Mem; float* ctx = P.ctx; float* sel = P.sel;
+    float* alpha_out = P.alpha_out; const int T = P.T, Dh = P.Dh, A = P.A;
+    int& s_arg = *s_arg_p;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // per-lane slice of att2_c + bias and w_full: a = lane*4 + 256*q
     const int nq = (A + 255) / 256;
     f32x4 a2[2], wf[2];
@@ -144,14 +154,20 @@ __global__ void __launch_bounds__(256) caption_attention_k(const float* att1_c, 
     }
 }
 
+__global__ void __launch_bounds__(256) caption_attention_k(const CapAttArgs P) {
+    __shared__ float sc[ATT_MAX_ROWS];
+    __shared__ int s_arg;
+    caption_attention_body(P, blockIdx.x, sc, &s_arg);
+}
+
 int caption_attention(const float* att1_c, Slabs att2_c, const float* dec_bias, const float* w_full,
                       const float* b_full, const float* mask, const float* H, const float* Mem, float* ctx,
                       float* sel, float* alpha_out, int M, int T, int Dh, int A, hipStream_t s) {
     if (T > ATT_MAX_ROWS || A > 512 || (A & 3) || (Dh & 3)) return SET_ERR_UNSUPPORTED;
     if (M <= 0) return SET_OK;
     ProfScope ps("caption_attention", s, 0.0, 4.0 * M * ((double)T * A + (double)T * Dh + 3.0 * Dh + att2_c.n * A));
-    hipLaunchKernelGGL(caption_attention_k, dim3(M), dim3(256), 0, s, att1_c, att2_c, dec_bias, w_full, b_full, mask,
-                       H, Mem, ctx, sel, alpha_out, T, Dh, A);
+    CapAttArgs P{att1_c, att2_c, dec_bias, w_full, b_full, mask, H, Mem, ctx, sel, alpha_out, T, Dh, A};
+    hipLaunchKernelGGL(caption_attention_k, dim3(M), dim3(256), 0, s, P);
     SET_LAUNCH_CHECK();
     return SET_OK;
 }
@@ -163,12 +179,11 @@ int caption_attention(const float* att1_c, Slabs att2_c, const float* dec_bias, 
 //   rmask (adaptive only): e_r = -1e10 where rmask[b,r] == 0  (editnet_adaptive.py:453)
 //   alpha = softmax_r(e) ; ctx = sum_r alpha_r X[b,r,:]   (context over the RAW features)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) visual_attention_k(const float* att1, Slabs att2, const float* dec_bias,
-                                                          const float* w_full, const float* b_full, const float* X,
-                                                          const float* rmask, float* ctx, float* alpha_out, int R,
-                                                          int F, int A, int fcols) {
-    __shared__ float sc[ATT_MAX_ROWS];
-    const int b = blockIdx.x, fs = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ void visual_attention_body(const VisAttArgs& P, int b, int fs, float* sc) {
+    const float* att1 = P.att1; const Slabs att2 = P.att2; const float* dec_bias = P.dec_bias;
+    const float* w_full = P.w_full; const float* b_full = P.b_full; const float* X = P.X; const float* rmask = P.rmask;
+    float* ctx = P.ctx; float* alpha_out = P.alpha_out; const int R = P.R, F = P.F, A = P.A, fcols = P.fcols;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nq = (A + 255) / 256;
     f32x4 a2[2], wf[2];
 #pragma unroll
@@ -237,18 +252,57 @@ __global__ void __launch_bounds__(256) visual_attention_k(const float* att1, Sla
     }
 }
 
+__global__ void __launch_bounds__(256) visual_attention_k(const VisAttArgs P) {
+    __shared__ float sc[ATT_MAX_ROWS];
+    visual_attention_body(P, blockIdx.x / P.fsn, blockIdx.x % P.fsn, sc);
+}
+
+// Both attentions of one timestep in ONE launch (they depend only on the phase-B projections and
+// are independent of each other): workgroups [0, Mv*fsn) stream the image regions, the rest score
+// the previous caption.  Saves one kernel boundary + one ~4.5 us launch floor per timestep and lets
+// the MFMA-free caption attention overlap the HBM-bound region streaming.
+__global__ void __launch_bounds__(256) step_attention_k(const VisAttArgs V, const CapAttArgs C, int nvis) {
+    __shared__ float sc[ATT_MAX_ROWS];
+    __shared__ int s_arg;
+    if ((int)blockIdx.x < nvis)
+        visual_attention_body(V, blockIdx.x / V.fsn, blockIdx.x % V.fsn, sc);
+    else
+        caption_attention_body(C, blockIdx.x - nvis, sc, &s_arg);
+}
+
+static int vis_fsn(int M, int F) {
+    // enough workgroups to cover the chip: split the feature axis while slices stay >= 1024 columns
+    int fsn = 1;
+    while (M * fsn < 512 && F / (fsn * 2) >= 1024 && (F % (fsn * 2 * 4)) == 0) fsn *= 2;
+    return fsn;
+}
+
+int step_attention(const float* att1, Slabs att2, const float* v_dec_bias, const float* v_w_full, const float* v_b_full,
+                   const float* X, const float* rmask, float* v_ctx, float* v_alpha, int R, int F,
+                   const float* att1_c, Slabs att2_c, const float* c_dec_bias, const float* c_w_full,
+                   const float* c_b_full, const float* mask, const float* H, const float* Mem, float* c_ctx, float* sel,
+                   float* c_alpha, int T, int Dh, int A, int M, hipStream_t s) {
+    if (R > ATT_MAX_ROWS || T > ATT_MAX_ROWS || A > 512 || (A & 3) || (F & 3) || (Dh & 3)) return SET_ERR_UNSUPPORTED;
+    if (M <= 0) return SET_OK;
+    const int fsn = vis_fsn(M, F);
+    VisAttArgs V{att1, att2, v_dec_bias, v_w_full, v_b_full, X, rmask, v_ctx, v_alpha, R, F, A, F / fsn, fsn};
+    CapAttArgs C{att1_c, att2_c, c_dec_bias, c_w_full, c_b_full, mask, H, Mem, c_ctx, sel, c_alpha, T, Dh, A};
+    ProfScope ps("step_attention", s, 0.0,
+                 4.0 * M * ((double)R * A * fsn + (double)R * F + F + (double)T * A + (double)T * Dh + 3.0 * Dh));
+    hipLaunchKernelGGL(step_attention_k, dim3(M * fsn + M), dim3(256), 0, s, V, C, M * fsn);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
 int visual_attention(const float* att1, Slabs att2, const float* dec_bias, const float* w_full,
                      const float* b_full, const float* X, const float* rmask, float* ctx, float* alpha_out, int M,
                      int R, int F, int A, hipStream_t s) {
     if (R > ATT_MAX_ROWS || A > 512 || (A & 3) || (F & 3)) return SET_ERR_UNSUPPORTED;
     if (M <= 0) return SET_OK;
-    // enough workgroups to cover the chip: split the feature axis while slices stay >= 1024 columns
-    int fsn = 1;
-    while (M * fsn < 512 && F / (fsn * 2) >= 1024 && (F % (fsn * 2 * 4)) == 0) fsn *= 2;
-    const int fcols = F / fsn;
+    const int fsn = vis_fsn(M, F);
+    VisAttArgs P{att1, att2, dec_bias, w_full, b_full, X, rmask, ctx, alpha_out, R, F, A, F / fsn, fsn};
     ProfScope ps("visual_attention", s, 0.0, 4.0 * M * ((double)R * A + (double)R * F + F + att2.n * A));
-    hipLaunchKernelGGL(visual_attention_k, dim3(M, fsn), dim3(256), 0, s, att1, att2, dec_bias, w_full, b_full, X,
-                       rmask, ctx, alpha_out, R, F, A, fcols);
+    hipLaunchKernelGGL(visual_attention_k, dim3(M * fsn), dim3(256), 0, s, P);
     SET_LAUNCH_CHECK();
     return SET_OK;
 }

@@ -253,10 +253,10 @@ static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const 
     b[4].add(ws.h1, D, w->cl_x2h_w, ld_x2h, D);
     plan_ksplit(b, 5, tgt);
     SET_TRY(gemm_group(b, 5, st, "gemm:B att2,tc,cg,x2h_h1"));
-    SET_TRY(caption_attention(ws.att1_c, slabs_of(b[0]), w->ca_dec_b, w->ca_full_w, w->ca_full_b, ws.mask, ws.H, ws.Mem,
-                              ws.ctx_cap, ws.sel, ws.alpha_c, bt, T, D, A, st));
-    SET_TRY(visual_attention(ws.att1, slabs_of(b[1]), w->va_dec_b, w->va_full_w, w->va_full_b, X,
-                             d->adaptive ? ws.rmask : nullptr, ws.attend_img, ws.alpha, bt, R, F, A, st));
+    SET_TRY(step_attention(ws.att1, slabs_of(b[1]), w->va_dec_b, w->va_full_w, w->va_full_b, X,
+                           d->adaptive ? ws.rmask : nullptr, ws.attend_img, ws.alpha, R, F, ws.att1_c, slabs_of(b[0]),
+                           w->ca_dec_b, w->ca_full_w, w->ca_full_b, ws.mask, ws.H, ws.Mem, ws.ctx_cap, ws.sel,
+                           ws.alpha_c, T, D, A, bt, st));
     // ---- C
     GemmProb c[3];
     c[0] = slab_prob(ws.sC0, bt, D, B);

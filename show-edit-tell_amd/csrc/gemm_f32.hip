@@ -285,7 +285,8 @@ int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag
     }
     const char* kname = bm == 128 ? "gemm_nt_f32<128,64>" : (bm == 64 ? "gemm_nt_f32<64,64>" : "gemm_nt_f32<32,128>");
     ProfScope ps(kname, stream, flops, bytes);
-    ProfScope ps2(tag ? tag : "gemm:other", stream, flops, bytes);     // per-call-site breakdown (nested)
+    static const bool sites = env_int("SET_PROFILE_SITES", 0) != 0;   // per-call-site breakdown (nested events)
+    ProfScope ps2(sites ? (tag ? tag : "gemm:other") : nullptr, stream, flops, bytes);
     dim3 grid(wg), block(256);
     if (bm == 128)
         hipLaunchKernelGGL((gemm_nt_f32<128, 64, 2, 2>), grid, block, 0, stream, L);

@@ -24,7 +24,7 @@ static hipEvent_t get_event() {
 }
 
 ProfScope::ProfScope(const char* tag, hipStream_t s, double flops, double bytes) : idx(-1), st(s) {
-    if (!g_prof_on) return;
+    if (!g_prof_on || !tag) return;
     ProfRec r{tag, get_event(), get_event(), flops, bytes};
     if (!r.a || !r.b) return;
     (void)hipEventRecord(r.a, s);
