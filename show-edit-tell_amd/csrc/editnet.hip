@@ -152,7 +152,16 @@ int editnet_encoder(const SetEditNetWeights* w, const int64_t* seq, const int64_
     SET_TRY(zero_f32(Mem, (size_t)B * T * D, st));
     SET_TRY(zero_f32(enc_h, (size_t)B * D, st));
     SET_TRY(zero_f32(enc_c, (size_t)B * D, st));
+    const bool fused = (D % 128 == 0) && env_int("SET_NO_FUSED", 0) == 0;
+    float* h_cur = enc_h;
+    float* h_nxt = s_enc;                         // (B,D) ping-pong partner (the slab region is free in the fused path)
     for (int t = 0; t < T; ++t) {
+        if (fused) {
+            SET_TRY(fused_encoder_step(h_cur, h_nxt, enc_c, w->enc_h2h_w, xg, (long long)T * 4 * D, 4 * D, w->enc_h2h_b,
+                                       lens, t, 0, H, Mem, (long long)T * D, D, 0, B, D, st));
+            float* tmp = h_cur; h_cur = h_nxt; h_nxt = tmp;
+            continue;
+        }
         GemmProb p = slab_prob(s_enc, B, 4 * D, B);
         p.add(enc_h, D, w->enc_h2h_w, D, D);
         plan_ksplit(&p, 1, tgt);
@@ -162,9 +171,10 @@ int editnet_encoder(const SetEditNetWeights* w, const int64_t* seq, const int64_
         SET_TRY(encoder_pointwise(hh, xg, (long long)T * 4 * D, 4 * D, t, lens, 0, enc_h, enc_c, H, Mem,
                                   (long long)T * D, D, 0, B, D, w->enc_h2h_b, st));
     }
+    const float* h_last = h_cur;
     {
         GemmProb p = slab_prob(s_aff, B, D, B);
-        p.add(enc_h, D, w->enc_aff_w, D, D);
+        p.add(h_last, D, w->enc_aff_w, D, D);
         plan_ksplit(&p, 1, tgt);
         SET_TRY(gemm_group(&p, 1, st));
         SET_TRY(reduce_bias_act(slabs_of(p), w->enc_aff_b, nullptr, final_hidden, D, B, D, SET_ACT_TANH, st));
@@ -257,18 +267,24 @@ static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const 
                            d->adaptive ? ws.rmask : nullptr, ws.attend_img, ws.alpha, R, F, ws.att1_c, slabs_of(b[0]),
                            w->ca_dec_b, w->ca_full_w, w->ca_full_b, ws.mask, ws.H, ws.Mem, ws.ctx_cap, ws.sel,
                            ws.alpha_c, T, D, A, bt, st));
-    // ---- C
+    // ---- C (+ context gating): fused small-tile kernel when D allows, else grouped GEMM + pointwise
+    const bool fused = (D % 64 == 0) && env_int("SET_NO_FUSED", 0) == 0;
     GemmProb c[3];
-    c[0] = slab_prob(ws.sC0, bt, D, B);
-    c[0].add(ws.ctx_cap, D, w->ca_gate_w + 2 * D, 3 * D, D);
-    c[1] = slab_prob(ws.sC1, bt, D, B);
-    c[1].add(ws.ctx_cap, D, w->ca_sc_w, D, D);
-    c[2] = slab_prob(ws.sC2, bt, D, B);
-    c[2].add(ws.sel, D, w->cl_cmem_w, D, D);
-    plan_ksplit(c, 3, tgt);
-    SET_TRY(gemm_group(c, 3, st, "gemm:C cg_ctx,sc,cmem"));
-    SET_TRY(context_gate_pointwise(slabs_of(b[3]), slabs_of(c[0]), w->ca_gate_b, slabs_of(c[1]), w->ca_sc_b,
-                                   slabs_of(b[2]), w->ca_tc_b, ws.attend_cap, bt, D, st));
+    if (fused) {
+        SET_TRY(fused_context_gate(ws.ctx_cap, w->ca_gate_w + 2 * D, 3 * D, w->ca_sc_w, slabs_of(b[3]), slabs_of(b[2]),
+                                   w->ca_gate_b, w->ca_sc_b, w->ca_tc_b, ws.attend_cap, bt, D, st));
+    } else {
+        c[0] = slab_prob(ws.sC0, bt, D, B);
+        c[0].add(ws.ctx_cap, D, w->ca_gate_w + 2 * D, 3 * D, D);
+        c[1] = slab_prob(ws.sC1, bt, D, B);
+        c[1].add(ws.ctx_cap, D, w->ca_sc_w, D, D);
+        c[2] = slab_prob(ws.sC2, bt, D, B);
+        c[2].add(ws.sel, D, w->cl_cmem_w, D, D);
+        plan_ksplit(c, 3, tgt);
+        SET_TRY(gemm_group(c, 3, st, "gemm:C cg_ctx,sc,cmem"));
+        SET_TRY(context_gate_pointwise(slabs_of(b[3]), slabs_of(c[0]), w->ca_gate_b, slabs_of(c[1]), w->ca_sc_b,
+                                       slabs_of(b[2]), w->ca_tc_b, ws.attend_cap, bt, D, st));
+    }
     // ---- D
     GemmProb dd = slab_prob(ws.sD0, bt, 4 * D, B);
     dd.add(ws.attend_cap, D, w->cl_x2h_w + D, ld_x2h, D);
@@ -277,13 +293,18 @@ static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const 
     SET_TRY(gemm_group(&dd, 1, st, "gemm:D x2h_ctx"));
     SET_TRY(lstm_pointwise(slabs_of(a[1]), slabs_of(b[4]), slabs_of(dd), nullptr, 0, w->cl_x2h_b, w->cl_h2h_b, ws.c2,
                            ws.c_new, nullptr, ws.ogate, bt, D, st));
-    // ---- E
-    GemmProb e = slab_prob(ws.sE0, bt, D, B);
-    e.add(ws.c_new, D, w->cl_cnew_w, D, D);
-    plan_ksplit(&e, 1, tgt);
-    SET_TRY(gemm_group(&e, 1, st, "gemm:E cnew"));
-    SET_TRY(copy_gate_pointwise(slabs_of(e), w->cl_cnew_b, slabs_of(c[2]), w->cl_cmem_b, ws.c_new, ws.sel, ws.ogate,
-                                ws.c2, ws.h2, bt, D, st));
+    // ---- E (+ copy gate)
+    if (fused) {
+        SET_TRY(fused_copy_gate(ws.c_new, ws.sel, ws.ogate, w->cl_cnew_w, w->cl_cmem_w, w->cl_cnew_b, w->cl_cmem_b, ws.c2,
+                                ws.h2, bt, D, st));
+    } else {
+        GemmProb e = slab_prob(ws.sE0, bt, D, B);
+        e.add(ws.c_new, D, w->cl_cnew_w, D, D);
+        plan_ksplit(&e, 1, tgt);
+        SET_TRY(gemm_group(&e, 1, st, "gemm:E cnew"));
+        SET_TRY(copy_gate_pointwise(slabs_of(e), w->cl_cnew_b, slabs_of(c[2]), w->cl_cmem_b, ws.c_new, ws.sel, ws.ogate,
+                                    ws.c2, ws.h2, bt, D, st));
+    }
     // ---- F
     const long long Vp = (long long)round_up((size_t)V, 64);
     GemmProb f = slab_prob(ws.sF0, bt, V, B);

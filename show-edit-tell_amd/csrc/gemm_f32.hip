@@ -223,21 +223,32 @@ __global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
 int gemm_tile_m(int M) { return M <= 32 ? 32 : (M <= 64 ? 64 : 128); }
 static int gemm_tile_n(int M) { return M <= 32 ? 128 : 64; }
 
-void plan_ksplit(GemmProb* probs, int n, int target_wgs) {
-    long long units = 0;
+// Split-K plan for one grouped launch: every workgroup should run about the same number of k-tiles
+// (`kper`) and the whole launch should fit the chip in ONE round: 256 CUs x 2 resident workgroups =
+// `cap_wgs` slots.  A second, partially filled round costs a full workgroup latency, so kper is the
+// smallest value (>= 4 k-tiles, to amortise the per-workgroup prologue/epilogue) for which the
+// launch has at most cap_wgs workgroups.
+void plan_ksplit(GemmProb* probs, int n, int cap_wgs) {
+    int tiles[GEMM_MAX_TASKS], kts[GEMM_MAX_TASKS], max_kt = 1;
     for (int i = 0; i < n; ++i) {
         const int bm = gemm_tile_m(probs[i].M), bn = gemm_tile_n(probs[i].M);
-        units += (long long)cdiv(probs[i].M, bm) * cdiv(probs[i].N, bn) * probs[i].ktiles();
+        tiles[i] = cdiv(probs[i].M, bm) * cdiv(probs[i].N, bn);
+        kts[i] = probs[i].ktiles();
+        if (kts[i] > max_kt) max_kt = kts[i];
     }
-    long long kper = (units + target_wgs - 1) / target_wgs;
-    if (kper < 4) kper = 4;
-    for (int i = 0; i < n; ++i) {
-        int ks = (int)((probs[i].ktiles() + kper - 1) / kper);
-        if (ks < 1) ks = 1;
+    auto split_of = [&](int i, int kper) {
+        int ks = cdiv(kts[i], kper);
         if (ks > probs[i].max_ksplit) ks = probs[i].max_ksplit;
-        if (ks > probs[i].ktiles()) ks = probs[i].ktiles();
-        probs[i].ksplit = ks;
+        if (ks > kts[i]) ks = kts[i];
+        return ks < 1 ? 1 : ks;
+    };
+    int kper = 4;
+    for (; kper < max_kt; ++kper) {
+        long long wgs = 0;
+        for (int i = 0; i < n; ++i) wgs += (long long)tiles[i] * split_of(i, kper);
+        if (wgs <= cap_wgs) break;
     }
+    for (int i = 0; i < n; ++i) probs[i].ksplit = split_of(i, kper);
 }
 
 int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag) {

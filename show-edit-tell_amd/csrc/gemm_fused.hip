@@ -1,0 +1,324 @@
+// Small-tile fp32-MFMA GEMM with a fused pointwise epilogue, for the contractions of the step that
+// are too small to amortise a split-K launch + a separate reduction kernel (K = 1024, N = 1024):
+//   * context gating   zt = sig(W_g[word,h1,ctx]), out = zt*tanh(W_sc ctx) + (1-zt)*tanh(W_tc[word,h1])
+//                      (editnet.py:378-380; the [word,h1] columns arrive as slabs from phase B)
+//   * copy gate        copy = sig(W_n c_new + W_m sel), c2, h2            (editnet.py:281-283)
+//   * encoder LSTM     gates = h W_hh^T + (hoisted x W_xh^T + b), cell update, H/M stores
+//                      (editnet.py:333-338; nn.LSTM directions of dcnet.py:233)
+// One workgroup owns a 32(rows) x 32(columns) output tile of up to two accumulators over the FULL K,
+// so no slabs are written and the epilogue runs in the same launch.  The 4 waves split every
+// BK-wide k-tile between them (intra-workgroup split-K: wave w takes 8-wide k-blocks w, w+4, ...),
+// operands are staged coalesced through LDS (row stride BK+4: conflict-free b128 access), the
+// partial accumulators are combined through LDS in fixed wave order (deterministic).
+#include "set_common.h"
+
+namespace set {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const f32x4 __attribute__((address_space(1)))* gptr4;
+
+enum { EPI_CTXGATE = 0, EPI_COPYGATE = 1, EPI_ENCLSTM = 2 };
+
+struct FusedArgs {
+    // accumulator a = A[a] (M,K) x W[a] (N rows, K)^T ; both accumulators share K
+    const float* A[2];
+    const float* W[2];
+    long long lda[2], ldw[2];
+    int K, M, N;          // N = output columns (hidden units for ENCLSTM)
+    int gate_stride;      // ENCLSTM: W row of (gate q, unit u) = q*gate_stride + u ; tile = 8 units x 4 gates
+    // epilogue operands
+    Slabs s0, s1;         // CTXGATE: s0 = context_gate[word,h1] slabs, s1 = tc_affine slabs
+    const float *b0, *b1, *b2;          // CTXGATE: b_gate, b_sc, b_tc ; COPYGATE: b_cnew, b_cmem ; ENCLSTM: b_extra
+    const float *e0, *e1, *e2;          // COPYGATE: c_new, sel, ogate ; ENCLSTM: xg, h_in, (unused)
+    float *o0, *o1, *o2, *o3;           // CTXGATE: out ; COPYGATE: c2, h2 ; ENCLSTM: h_out, c (in place), H, Mem
+    const int64_t* lens;                // ENCLSTM
+    long long ld_xg_row, ld_xg_t, ld_out_b, ld_out_t;
+    int t, reverse, out_col0;
+};
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+
+template <int NACC, bool SHARED_A, int BK, int EPI>
+__global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
+    constexpr int STRIDE = BK + 4;
+    constexpr int NA = SHARED_A ? 1 : NACC;
+    constexpr int TILE = 32 * STRIDE;                       // floats per staged operand tile
+    constexpr int STAGE = (NA + NACC) * TILE;
+    constexpr int LPT = BK / 32;                            // float4 loads per thread per operand tile
+    constexpr int RED = 4 * NACC * 32 * 33;                 // cross-wave reduction scratch
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // fused_lds_bytes<...>() bytes
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (EPI == EPI_ENCLSTM) ? (P.N + 7) / 8 : (P.N + 31) / 32;
+    const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
+    const int m0 = tm * 32;
+    const int n0 = (EPI == EPI_ENCLSTM) ? tn * 8 : tn * 32;
+
+    // staging: thread -> row (tid / (BK/4)) .. covers 32 rows x BK floats with LPT float4 per thread
+    constexpr int TPR = BK / 4;                             // threads per row
+    constexpr int RPP = 256 / TPR;                          // rows per pass
+    const int srow = tid / TPR, scol = (tid % TPR) * 4;
+    gptr4 pa[NA][LPT];
+    gptr4 pw[NACC][LPT];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            int r = m0 + srow + RPP * i;
+            r = r < P.M ? r : P.M - 1;
+            pa[a][i] = (gptr4)(P.A[a] + (long long)r * P.lda[a] + scol);
+        }
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int j = srow + RPP * i;                   // tile column 0..31
+            long long wr;
+            if (EPI == EPI_ENCLSTM) {
+                int u = n0 + (j & 7);
+                u = u < P.N ? u : P.N - 1;
+                wr = (long long)(j >> 3) * P.gate_stride + u;
+            } else {
+                int c = n0 + j;
+                wr = c < P.N ? c : P.N - 1;
+            }
+            pw[a][i] = (gptr4)(P.W[a] + wr * P.ldw[a] + scol);
+        }
+
+    f32x4 ra0[NA][LPT], rw0[NACC][LPT], ra1[NA][LPT], rw1[NACC][LPT];   // two register stages
+#define FS_GLOAD(RA, RW)                                                                                \
+    {                                                                                                   \
+        _Pragma("unroll") for (int a = 0; a < NA; ++a)                                                  \
+            _Pragma("unroll") for (int i = 0; i < LPT; ++i) { RA[a][i] = *pa[a][i]; pa[a][i] += BK / 4; } \
+        _Pragma("unroll") for (int a = 0; a < NACC; ++a)                                                \
+            _Pragma("unroll") for (int i = 0; i < LPT; ++i) { RW[a][i] = *pw[a][i]; pw[a][i] += BK / 4; } \
+    }
+#define FS_LSTORE(BUF, RA, RW)                                                                          \
+    {                                                                                                   \
+        float* base_ = lds + (BUF) * STAGE;                                                             \
+        _Pragma("unroll") for (int a = 0; a < NA; ++a)                                                  \
+            _Pragma("unroll") for (int i = 0; i < LPT; ++i)                                             \
+                *reinterpret_cast<f32x4*>(base_ + a * TILE + (srow + RPP * i) * STRIDE + scol) = RA[a][i]; \
+        _Pragma("unroll") for (int a = 0; a < NACC; ++a)                                                \
+            _Pragma("unroll") for (int i = 0; i < LPT; ++i)                                             \
+                *reinterpret_cast<f32x4*>(base_ + (NA + a) * TILE + (srow + RPP * i) * STRIDE + scol) = RW[a][i]; \
+    }
+
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
+
+    const int nkt = P.K / BK;
+    const int frow = lane & 31, fk = (lane >> 5) * 4;
+    FS_GLOAD(ra0, rw0);                                  // tile 0
+    if (nkt > 1) FS_GLOAD(ra1, rw1);                     // tile 1
+
+    // ---- epilogue operands do not depend on the contraction: fetch them now, under the k-loop
+    const int erow = tid >> 3, ec4 = (tid & 7) * 4, eu = tid & 7;
+    const long long em = m0 + erow;
+    const bool erow_ok = em < P.M;
+    f32x4 pre0 = {0.f, 0.f, 0.f, 0.f}, pre1 = {0.f, 0.f, 0.f, 0.f}, pre2 = {0.f, 0.f, 0.f, 0.f};
+    float eg[4] = {0.f, 0.f, 0.f, 0.f}, ecp = 0.f, ehin = 0.f;
+    int elen = 0, epos = 0;
+    if (EPI == EPI_CTXGATE) {
+        if (erow_ok && n0 + ec4 < P.N) {                 // N % 4 == 0 (host check)
+            for (int i = 0; i < P.s0.n; ++i) pre0 += *(gptr4)(P.s0.p + (long long)i * P.s0.stride + em * P.s0.ld + n0 + ec4);
+            for (int i = 0; i < P.s1.n; ++i) pre1 += *(gptr4)(P.s1.p + (long long)i * P.s1.stride + em * P.s1.ld + n0 + ec4);
+        }
+    } else if (EPI == EPI_COPYGATE) {
+        if (erow_ok && n0 + ec4 < P.N) {
+            pre0 = *(gptr4)(P.e0 + em * P.N + n0 + ec4);
+            pre1 = *(gptr4)(P.e1 + em * P.N + n0 + ec4);
+            pre2 = *(gptr4)(P.e2 + em * P.N + n0 + ec4);
+        }
+    } else {
+        const int unit = n0 + eu;
+        if (erow_ok && unit < P.N) {
+            elen = (int)P.lens[em];
+            ehin = P.e1[em * P.N + unit];
+            if (P.t < elen) {
+                epos = P.reverse ? (elen - 1 - P.t) : P.t;
+                const float* xr = P.e0 + em * P.ld_xg_row + (long long)epos * P.ld_xg_t;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    eg[q] = xr[q * P.N + unit];
+                    if (P.b0) eg[q] += P.b0[q * P.N + unit];
+                }
+                ecp = P.o1[em * P.N + unit];
+            }
+        }
+    }
+
+    FS_LSTORE(0, ra0, rw0);
+    if (nkt > 2) FS_GLOAD(ra0, rw0);                     // tile 2
+    __syncthreads();
+    // invariant at an even step kt: lds[0] = tile kt, ra1 = tile kt+1, ra0 = tile kt+2
+#define FS_ITER(KT, BUF, RA, RW)                                                                        \
+    {                                                                                                   \
+        const float* sb = lds + (BUF) * STAGE;                                                          \
+        _Pragma("unroll") for (int kb = 0; kb < BK / 32; ++kb) {                                        \
+            const int koff = (wave + 4 * kb) * 8 + fk;                                                  \
+            f32x4 a[NA], b[NACC];                                                                       \
+            _Pragma("unroll") for (int x = 0; x < NA; ++x)                                              \
+                a[x] = *reinterpret_cast<const f32x4*>(sb + x * TILE + frow * STRIDE + koff);           \
+            _Pragma("unroll") for (int x = 0; x < NACC; ++x)                                            \
+                b[x] = *reinterpret_cast<const f32x4*>(sb + (NA + x) * TILE + frow * STRIDE + koff);    \
+            _Pragma("unroll") for (int x = 0; x < NACC; ++x) {                                          \
+                const f32x4 av = a[SHARED_A ? 0 : x];                                                   \
+                acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b[x].x, acc[x], 0, 0, 0);           \
+                acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b[x].y, acc[x], 0, 0, 0);           \
+                acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b[x].z, acc[x], 0, 0, 0);           \
+                acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b[x].w, acc[x], 0, 0, 0);           \
+            }                                                                                           \
+            if (kb == 0 && (KT) + 1 < nkt) {                                                            \
+                FS_LSTORE((BUF) ^ 1, RA, RW);                                                           \
+                if ((KT) + 3 < nkt) FS_GLOAD(RA, RW);                                                   \
+            }                                                                                           \
+        }                                                                                               \
+        __syncthreads();                                                                                \
+    }
+    for (int kt = 0; kt < nkt; kt += 2) {
+        FS_ITER(kt, 0, ra1, rw1);
+        if (kt + 1 < nkt) FS_ITER(kt + 1, 1, ra0, rw0);
+    }
+#undef FS_ITER
+#undef FS_GLOAD
+#undef FS_LSTORE
+
+    // ---- cross-wave reduction through LDS: red[wave][acc][row][33]
+    float* red = lds;
+#pragma unroll
+    for (int x = 0; x < NACC; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31;
+            red[((wave * NACC + x) * 32 + row) * 33 + col] = acc[x][r];
+        }
+    __syncthreads();
+    auto rsum = [&](int x, int row, int col) {
+        float v = red[((0 * NACC + x) * 32 + row) * 33 + col];
+        v += red[((1 * NACC + x) * 32 + row) * 33 + col];
+        v += red[((2 * NACC + x) * 32 + row) * 33 + col];
+        v += red[((3 * NACC + x) * 32 + row) * 33 + col];
+        return v;
+    };
+
+    if (EPI == EPI_ENCLSTM) {
+        // thread -> (row = tid/8, unit = tid%8); tile columns q*8+u hold gate q of unit u
+        const int unit = n0 + eu;
+        if (erow_ok && unit < P.N) {
+            const int D = P.N;
+            if (P.t < elen) {
+                float g[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g[q] = rsum(0, erow, q * 8 + eu) + eg[q];
+                const float cn = sigm(g[1]) * ecp + sigm(g[0]) * tanhf(g[2]);
+                const float hn = sigm(g[3]) * tanhf(cn);
+                P.o1[em * D + unit] = cn;
+                P.o0[em * D + unit] = hn;
+                P.o2[em * P.ld_out_b + (long long)epos * P.ld_out_t + P.out_col0 + unit] = hn;
+                if (P.o3) P.o3[em * P.ld_out_b + (long long)epos * P.ld_out_t + P.out_col0 + unit] = cn;
+            } else {
+                P.o0[em * D + unit] = ehin;                  // finished rows carry their state
+            }
+        }
+        return;
+    }
+
+    // CTXGATE / COPYGATE: thread -> (row = tid/8, 4 consecutive columns)
+    if (!erow_ok || n0 + ec4 >= P.N) return;
+    f32x4 out0, out1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int n = n0 + ec4 + e;
+        if (EPI == EPI_CTXGATE) {
+            // reference: one Linear over cat([word, h1, ctx]); [word,h1] slabs first, then the ctx part
+            const float z = (pre0[e] + rsum(0, erow, ec4 + e)) + P.b0[n];
+            const float sv = rsum(1, erow, ec4 + e) + P.b1[n];
+            const float tt = pre1[e] + P.b2[n];
+            const float zt = sigm(z);
+            out0[e] = zt * tanhf(sv) + (1.f - zt) * tanhf(tt);
+        } else {
+            const float a = rsum(0, erow, ec4 + e) + P.b0[n];
+            const float b = rsum(1, erow, ec4 + e) + P.b1[n];
+            const float cg = sigm(a + b);
+            const float co = cg * pre1[e] + (1.f - cg) * pre0[e];
+            out0[e] = co;
+            out1[e] = pre2[e] * tanhf(co);
+        }
+    }
+    *reinterpret_cast<f32x4*>(P.o0 + em * P.N + n0 + ec4) = out0;
+    if (EPI == EPI_COPYGATE) *reinterpret_cast<f32x4*>(P.o1 + em * P.N + n0 + ec4) = out1;
+}
+
+template <int NACC, bool SHARED_A, int BK>
+constexpr int fused_lds_bytes() {
+    constexpr int stage = ((SHARED_A ? 1 : NACC) + NACC) * 32 * (BK + 4);
+    constexpr int red = 4 * NACC * 32 * 33;
+    return 4 * ((2 * stage > red) ? 2 * stage : red);
+}
+
+template <int NACC, bool SHARED_A, int BK, int EPI>
+static int launch_fused(const FusedArgs& P, int grid, hipStream_t s) {
+    constexpr int bytes = fused_lds_bytes<NACC, SHARED_A, BK>();
+    static bool configured = false;          // raise the dynamic-LDS cap once (idempotent)
+    if (!configured) {
+        SET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fused_k<NACC, SHARED_A, BK, EPI>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        configured = true;
+    }
+    hipLaunchKernelGGL((gemm_fused_k<NACC, SHARED_A, BK, EPI>), dim3(grid), dim3(256), bytes, s, P);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+// context gating fused with its ctx-side contractions (phase C of the step)
+int fused_context_gate(const float* ctx, const float* w_gate_ctx, long long ld_gate, const float* w_sc, Slabs cg_ab,
+                       Slabs tc, const float* b_gate, const float* b_sc, const float* b_tc, float* out, int M, int D,
+                       hipStream_t s) {
+    if (D % 64) return SET_ERR_UNSUPPORTED;
+    FusedArgs P{};
+    P.A[0] = ctx; P.A[1] = ctx; P.lda[0] = P.lda[1] = D;
+    P.W[0] = w_gate_ctx; P.ldw[0] = ld_gate; P.W[1] = w_sc; P.ldw[1] = D;
+    P.K = D; P.M = M; P.N = D;
+    P.s0 = cg_ab; P.s1 = tc; P.b0 = b_gate; P.b1 = b_sc; P.b2 = b_tc; P.o0 = out;
+    const int grid = cdiv(M, 32) * cdiv(D, 32);
+    ProfScope ps("fused_context_gate", s, 4.0 * M * D * D, 4.0 * (2.0 * D * D + 2.0 * M * D));
+    return launch_fused<2, true, 64, EPI_CTXGATE>(P, grid, s);
+}
+
+// copy gate fused with gate_cnew(c_new) and gate_cmem(sel) (phase E of the step)
+int fused_copy_gate(const float* c_new, const float* sel, const float* ogate, const float* w_cnew, const float* w_cmem,
+                    const float* b_cnew, const float* b_cmem, float* c_out, float* h_out, int M, int D, hipStream_t s) {
+    if (D % 64) return SET_ERR_UNSUPPORTED;
+    FusedArgs P{};
+    P.A[0] = c_new; P.A[1] = sel; P.lda[0] = P.lda[1] = D;
+    P.W[0] = w_cnew; P.W[1] = w_cmem; P.ldw[0] = P.ldw[1] = D;
+    P.K = D; P.M = M; P.N = D;
+    P.b0 = b_cnew; P.b1 = b_cmem; P.e0 = c_new; P.e1 = sel; P.e2 = ogate; P.o0 = c_out; P.o1 = h_out;
+    const int grid = cdiv(M, 32) * cdiv(D, 32);
+    ProfScope ps("fused_copy_gate", s, 4.0 * M * D * D, 4.0 * (2.0 * D * D + 6.0 * M * D));
+    return launch_fused<2, false, 64, EPI_COPYGATE>(P, grid, s);
+}
+
+// one encoder timestep: gates = h_in W_hh^T + xg[b,pos] + b_extra -> (h_out, c, H[b,pos], Mem[b,pos])
+int fused_encoder_step(const float* h_in, float* h_out, float* c, const float* w_hh, const float* xg,
+                       long long ld_xg_row, long long ld_xg_t, const float* b_extra, const int64_t* lens, int t,
+                       int reverse, float* H, float* Mem, long long ld_out_b, long long ld_out_t, int out_col0, int B,
+                       int D, hipStream_t s) {
+    if (D % 128) return SET_ERR_UNSUPPORTED;
+    FusedArgs P{};
+    P.A[0] = h_in; P.lda[0] = D; P.W[0] = w_hh; P.ldw[0] = D;
+    P.K = D; P.M = B; P.N = D; P.gate_stride = D;
+    P.b0 = b_extra; P.e0 = xg; P.e1 = h_in; P.o0 = h_out; P.o1 = c; P.o2 = H; P.o3 = Mem; P.lens = lens;
+    P.ld_xg_row = ld_xg_row; P.ld_xg_t = ld_xg_t; P.ld_out_b = ld_out_b; P.ld_out_t = ld_out_t;
+    P.t = t; P.reverse = reverse; P.out_col0 = out_col0;
+    const int grid = cdiv(B, 32) * cdiv(D, 8);
+    ProfScope ps("fused_encoder_step", s, 8.0 * B * D * D, 4.0 * (4.0 * D * D + 8.0 * B * D));
+    return launch_fused<1, true, 128, EPI_ENCLSTM>(P, grid, s);
+}
+
+}  // namespace set

@@ -146,6 +146,17 @@ int step_attention(const float* att1, Slabs att2, const float* v_dec_bias, const
 int region_masks(const float* X, const float* fe, float* rmask, int B, int R, int F, int D, hipStream_t s);
 int select_rows(const float* Mem, const float* alpha, float* sel, int M, int T, int D, hipStream_t s);
 
+// gemm_fused.hip: small-tile GEMMs with fused pointwise epilogues (no slabs)
+int fused_context_gate(const float* ctx, const float* w_gate_ctx, long long ld_gate, const float* w_sc, Slabs cg_ab,
+                       Slabs tc, const float* b_gate, const float* b_sc, const float* b_tc, float* out, int M, int D,
+                       hipStream_t s);
+int fused_copy_gate(const float* c_new, const float* sel, const float* ogate, const float* w_cnew, const float* w_cmem,
+                    const float* b_cnew, const float* b_cmem, float* c_out, float* h_out, int M, int D, hipStream_t s);
+int fused_encoder_step(const float* h_in, float* h_out, float* c, const float* w_hh, const float* xg,
+                       long long ld_xg_row, long long ld_xg_t, const float* b_extra, const int64_t* lens, int t,
+                       int reverse, float* H, float* Mem, long long ld_out_b, long long ld_out_t, int out_col0, int B,
+                       int D, hipStream_t s);
+
 // epilogue.hip
 int greedy_pick(Slabs logits, const float* bias, int V, int t, int max_len, long long end_idx,
                 long long* seq, float* seq_logp, long long* it, int* unfinished, int* alive,
