@@ -41,11 +41,28 @@ PEAK_FP32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x
 PEAK_HBM_GBS = 8000.0
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (tools/pmc_bench.sh -> tools/pmc_traffic.py); counters cannot be read from inside this process."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_bench_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except OSError:
+        return None
+
+
 def cpu_baseline(seconds_budget=20.0):
     """Oracle (numpy port of the reference CPU path) on the host cores, bounded sample."""
     import numpy as np
     from oracle import editnet_np as EN
     from show_edit_tell_amd import synth
+    threads = int(os.environ.get("SET_CPU_THREADS", "0")) or min(os.cpu_count() or 1, 32)
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=threads)
+    except Exception:
+        limiter, threads = None, os.cpu_count()
     sd = synth.editnet_state(14, V, D, A, F, emb_scale=3.0, fc_scale=8.0, gain=3.0)
     P = EN.cast_params(sd)
     X = synth.features(25, B, R, F)
@@ -59,9 +76,11 @@ def cpu_baseline(seconds_budget=20.0):
         el = time.time() - t0
         if el > seconds_budget or n >= 10:
             break
-    return dict(value=round(n * STEPS_PER_DECODE / el, 3), unit="decode-steps/sec", cores=os.cpu_count(),
+    if limiter is not None:
+        limiter.restore_original_limits()
+    return dict(value=round(n * STEPS_PER_DECODE / el, 3), unit="decode-steps/sec", cores=threads,
                 kind="port", sample="%d full greedy decodes (prologue + 19 timesteps) of the B=128 workload, numpy fp32 "
-                "(OpenBLAS, all host threads), %.1f s" % (n, el))
+                "(OpenBLAS, %d threads of %d host cpus), %.1f s" % (n, threads, os.cpu_count(), el))
 
 
 def main():
@@ -171,7 +190,10 @@ def main():
             line["roofline"] = {
                 "kernel": "gemm_nt_f32<128,64,2,2> (v_mfma_f32_32x32x2_f32)", "bound": "mfma",
                 "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                "traffic": (lambda t: None if t is None else round(t["traffic_bytes_per_launch"] / 1e6, 2))(pmc_traffic()),
+                "traffic_unit": "MB HBM per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_bench_traffic.json)",
+                "algorithmic_MB_per_launch": round(g["bytes"] / g["launches"] / 1e6, 2),
                 "launches": g["launches"], "avg_us_per_launch": round(1e3 * g["ms"] / g["launches"], 2),
                 "algorithmic_gflop_per_launch": round(g["flops"] / g["launches"] / 1e9, 4),
                 "algorithmic_GBs": round(g["bytes"] / (g["ms"] * 1e-3) / 1e9, 1),
