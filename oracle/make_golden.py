@@ -141,6 +141,24 @@ def make_editnet(name, adaptive=False):
         sc = pack_padded_sequence(T_(pred), dl, batch_first=True).data
         tg = pack_padded_sequence(caps_s[:, 1:], dl, batch_first=True).data
         out["xe_loss"] = np.float64(torch.nn.CrossEntropyLoss()(sc.double(), tg).item())
+    # ---- a13: gradients of the XE loss (eval-mode dropout so they are deterministic), reference autograd
+    if not adaptive and not big:
+        from torch.nn.utils.rnn import pack_padded_sequence as _pps
+        dec_xe.zero_grad()
+        predg, caps_g, dlg, _ = dec_xe(X, caps, clen, prev, plen, False, 0.0)
+        lossg = torch.nn.CrossEntropyLoss()(_pps(predg, dlg, batch_first=True).data,
+                                            _pps(caps_g[:, 1:], dlg, batch_first=True).data)
+        lossg.backward()
+        out["grad_loss"] = np.float64(lossg.item())
+        for k_, p_ in dec_xe.named_parameters():
+            g_ = _np(p_.grad)
+            out["gradnorm." + k_] = np.float64(np.sqrt((g_.astype(np.float64) ** 2).sum()))
+            if small:
+                out["grad." + k_] = g_
+            else:
+                out["gradslice." + k_] = g_.reshape(-1)[:: max(1, g_.size // 64)][:64].copy()
+        dec_xe.zero_grad()
+    with torch.no_grad():
         # ---- greedy decode (a10)
         if adaptive:
             # free-running loop with the supplied image_mean: restate editnet_rl.py:497-547 over the

@@ -7,9 +7,13 @@ loops (`editnet.py:551-740`) drop in.  The modules hold parameters in ordinary t
 through the C ABI in include/set_hip.h (csrc/libset_hip.so).  There is no PyTorch fallback:
 CPU tensors, non-fp32 parameters or a missing library raise.
 
-Scope of this file: eval-mode forward (teacher-forced XE loop and the per-operator calls used by
-beam search).  Train-mode (dropout / autograd) raises NotImplementedError until the backward
-kernels land.
+Two execution paths:
+  * no-grad (inference / evaluation / the greedy baseline of SCST): the whole loop runs inside the
+    C library (`set_editnet_xe_forward`, `set_editnet_greedy`), loop invariants hoisted.
+  * grad-enabled (training, or eval-mode gradient checks): `_forward_autograd` follows the
+    reference loop (`editnet.py:479-548`) step by step over autograd-wrapped HIP operators
+    (`autograd_ops.py`: HIP forward, PyTorch-autograd backward), with the reference's three dropout
+    sites and scheduled sampling.
 """
 from __future__ import annotations
 
@@ -371,10 +375,12 @@ class DecoderC(nn.Module):
                 previous_cap_length, use_ss=False, ss_prob=0.0, image_mean=None):
         """Teacher-forced XE forward, reference editnet.py:479-548.  Returns
         (predictions (B,max(decode_lengths),V), encoded_captions sorted, decode_lengths, sort_ind)."""
-        _no_train(self, "DecoderC.forward")
-        if use_ss and ss_prob > 0.0:
-            raise NotImplementedError("scheduled sampling is a train-mode feature (editnet.py:508-520)")
         _require_cuda(image_features, "image features")
+        if torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters())):
+            return self._forward_autograd(image_features, encoded_captions, caption_lengths,
+                                          encoded_previous_captions, previous_cap_length, use_ss, ss_prob, image_mean)
+        if self.training:
+            raise NotImplementedError("train-mode forward under torch.no_grad() is not supported; use .eval()")
         lib = _lib.load()
         dev = image_features.device
         batch_size = encoded_captions.size(0)
@@ -394,4 +400,92 @@ class DecoderC(nn.Module):
         check(lib.set_editnet_xe_forward(C.byref(w), C.byref(dims), ptr(X), ptr(mean), ptr(encoded_captions),
                                          encoded_captions.shape[1], dl, ptr(prev), ptr(plen), ptr(predictions),
                                          ptr(ws), ws.numel(), stream_of(dev)), "set_editnet_xe_forward")
+        return predictions, encoded_captions, decode_lengths, sort_ind
+
+
+    # ---- grad-enabled path -------------------------------------------------------------------
+    def _encoder_autograd(self, seq, seq_len):
+        """CaptionEncoderC.forward (editnet.py:319-348) over autograd ops; rows advance while t < len."""
+        from . import autograd_ops as A
+        enc, cell = self.caption_encoder, self.caption_encoder.lstm_encoder_cell
+        lens = seq_len.reshape(-1)
+        tmax = int(lens.max().item())
+        B, D = seq.shape[0], enc.enc_hid_dim
+        emb = self.embed.dropout(A.embed_relu(seq[:, :tmax], self.embed.embedding.weight))
+        h = torch.zeros(B, D, device=seq.device)
+        c = torch.zeros(B, D, device=seq.device)
+        Hs, Ms = [], []
+        for t in range(tmax):
+            m = (lens > t).float().unsqueeze(1)
+            hn, cn = A.lstm_cell(emb[:, t], h, c, cell.x2h.weight, cell.h2h.weight, cell.x2h.bias, cell.h2h.bias)
+            h = m * hn + (1 - m) * h
+            c = m * cn + (1 - m) * c
+            Hs.append(m * hn)
+            Ms.append(m * cn)
+        H, M = torch.stack(Hs, 1), torch.stack(Ms, 1)
+        mask = (M.sum(2) != 0).float()
+        final_hidden = A.linear(h, enc.affine_hn.weight, enc.affine_hn.bias, _lib.ACT_TANH)
+        return H, M, final_hidden, mask
+
+    def _forward_autograd(self, image_features, encoded_captions, caption_lengths, encoded_previous_captions,
+                          previous_cap_length, use_ss, ss_prob, image_mean=None):
+        """The reference loop (editnet.py:479-548), one autograd-wrapped HIP operator per module call."""
+        from . import autograd_ops as A
+        if self._adaptive:
+            raise NotImplementedError("training with adaptive features is not built yet")
+        dev = image_features.device
+        batch_size = encoded_captions.size(0)
+        caption_lengths, sort_ind = caption_lengths.squeeze(1).sort(dim=0, descending=True)
+        X = _f32c(image_features[sort_ind])
+        encoded_captions = encoded_captions[sort_ind]
+        prev = encoded_previous_captions[sort_ind]
+        plen = previous_cap_length[sort_ind]
+        h1, c1 = self.init_hidden_state(batch_size)
+        h2, c2 = self.init_hidden_state(batch_size)
+        decode_lengths = (caption_lengths - 1).tolist()
+        preds_t = []
+        H, M, final_hidden, mask = self._encoder_autograd(prev, plen)
+        mean = X.mean(1) if image_mean is None else image_mean[sort_ind]
+        ca, va, cl, al = self.caption_attention, self.visual_attention, self.copy_lstm, self.attention_lstm
+        E = self.embed.embedding.weight
+        att1_eval = None
+        if not self.training:            # dropout inactive: features_att(att_embed(X)) is loop invariant
+            att1_eval = A.linear(A.linear(X, va.att_embed[0].weight, va.att_embed[0].bias, _lib.ACT_RELU),
+                                 va.features_att.weight, va.features_att.bias)
+        prev_scores = None
+        for t in range(max(decode_lengths)):
+            bt = sum([l > t for l in decode_lengths])
+            it = encoded_captions[:bt, t]
+            if use_ss and t >= 1 and ss_prob > 0.0:                                   # editnet.py:508-520
+                sample_mask = torch.zeros(bt, device=dev).uniform_(0, 1) < ss_prob
+                if sample_mask.sum() != 0:
+                    sample_ind = sample_mask.nonzero().view(-1)
+                    it = it.clone()
+                    prob_prev = torch.exp(prev_scores[:bt].detach())
+                    it.index_copy_(0, sample_ind, torch.multinomial(prob_prev, 1).view(-1).index_select(0, sample_ind))
+            emb = self.embed.dropout(A.embed_relu(it, E))
+            x1 = torch.cat([emb, final_hidden[:bt], h2[:bt], mean[:bt]], 1)
+            h1, c1 = A.lstm_cell(x1, h1[:bt], c1[:bt], al.weight_ih, al.weight_hh, al.bias_ih, al.bias_hh)
+            attend_cap, alpha_c = A.caption_attention(
+                H[:bt], h1, emb, mask[:bt], ca.cap_features_att.weight, ca.cap_features_att.bias,
+                ca.cap_decoder_att.weight, ca.cap_decoder_att.bias, ca.cap_full_att.weight, ca.cap_full_att.bias,
+                ca.context_gate.weight, ca.context_gate.bias, ca.sc_affine.weight, ca.sc_affine.bias,
+                ca.tc_affine.weight, ca.tc_affine.bias)
+            if att1_eval is not None:
+                att1 = att1_eval[:bt]
+            else:                                                                     # fresh dropout mask per step
+                fe = va.att_embed[2](A.linear(X[:bt], va.att_embed[0].weight, va.att_embed[0].bias, _lib.ACT_RELU))
+                att1 = A.linear(fe, va.features_att.weight, va.features_att.bias)
+            attend_img = A.visual_attention_from_att1(X[:bt], att1, h1, va.decoder_att.weight, va.decoder_att.bias,
+                                                      va.full_att.weight, va.full_att.bias)
+            sel = A.select(M[:bt], alpha_c)
+            h2, c2 = A.copy_lstm(torch.cat([h1, attend_cap, attend_img], 1), h2[:bt], c2[:bt], sel, cl.x2h.weight,
+                                 cl.x2h.bias, cl.h2h.weight, cl.h2h.bias, cl.gate_cnew.weight, cl.gate_cnew.bias,
+                                 cl.gate_cmem.weight, cl.gate_cmem.bias)
+            preds = A.linear(self.dropout(h2), self.fc.weight, self.fc.bias)
+            prev_scores = preds
+            if bt < batch_size:
+                preds = torch.cat([preds, preds.new_zeros(batch_size - bt, preds.shape[1])], 0)
+            preds_t.append(preds)
+        predictions = torch.stack(preds_t, 1)
         return predictions, encoded_captions, decode_lengths, sort_ind

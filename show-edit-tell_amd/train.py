@@ -1,0 +1,75 @@
+"""XE training step of the reference's `train()` (editnet.py:551-593) with data-parallel gradient
+all-reduce: one process per GPU, `torch.distributed` backend "nccl" (= RCCL over
+xGMI), weights replicated, batch sharded.
+
+Single-process big-batch semantics are reproduced exactly: every rank normalises its summed token
+loss by the GLOBAL token count (one scalar all-reduce) and gradients are SUM-reduced, so the
+reduced gradient equals the gradient of CrossEntropyLoss(mean) over the concatenated batch; then
+`clip_grad_norm_(0.25)` and the optimizer step run identically on every rank.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch.nn.utils.rnn import pack_padded_sequence
+
+GRAD_CLIP = 0.25                     # editnet.py:580
+BUCKET_BYTES = 64 << 20              # xGMI rings are per-link bound: few, large buckets
+
+
+def xe_loss_sum(scores, caps_sorted, decode_lengths):
+    """Summed token cross-entropy over the packed rows + token count (editnet.py:571-577)."""
+    targets = caps_sorted[:, 1:]
+    sc = pack_padded_sequence(scores, decode_lengths, batch_first=True).data
+    tg = pack_padded_sequence(targets, decode_lengths, batch_first=True).data
+    return F.cross_entropy(sc, tg, reduction="sum"), sc.shape[0], sc, tg
+
+
+def allreduce_gradients(params, group=None, bucket_bytes=BUCKET_BYTES):
+    """SUM all-reduce of .grad over the process group in flat buckets (no-op without a group)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0
+    grads = [p.grad for p in params if p.grad is not None]
+    n_buckets, i = 0, 0
+    while i < len(grads):
+        bucket, size = [], 0
+        while i < len(grads) and (not bucket or size + grads[i].numel() * grads[i].element_size() <= bucket_bytes):
+            bucket.append(grads[i])
+            size += grads[i].numel() * grads[i].element_size()
+            i += 1
+        flat = torch.cat([g.reshape(-1) for g in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        off = 0
+        for g in bucket:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+        n_buckets += 1
+    return n_buckets
+
+
+def global_token_count(n_local, device, group=None):
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return n_local
+    t = torch.tensor([float(n_local)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return int(t.item())
+
+
+def xe_train_step(decoder, optimizer, image_features, caps, caplens, previous_caption, prev_caplen, use_ss=False,
+                  ss_prob=0.0, group=None):
+    """One step of editnet.py:558-581 on this rank's shard.  Returns (global mean loss, local tokens)."""
+    decoder.train()
+    scores, caps_sorted, decode_lengths, _ = decoder(image_features, caps, caplens, previous_caption, prev_caplen,
+                                                     use_ss, ss_prob)
+    loss_sum, n_tok, _, _ = xe_loss_sum(scores, caps_sorted, decode_lengths)
+    n_glob = global_token_count(n_tok, image_features.device, group)
+    loss = loss_sum / n_glob
+    optimizer.zero_grad()
+    loss.backward()
+    params = [p for p in decoder.parameters() if p.requires_grad]
+    allreduce_gradients(params, group)
+    torch.nn.utils.clip_grad_norm_(params, GRAD_CLIP)
+    optimizer.step()
+    return float(loss.detach()) , n_tok
