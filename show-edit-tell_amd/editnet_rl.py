@@ -11,6 +11,8 @@ from __future__ import annotations
 import ctypes as C
 
 import torch
+import torch.nn as nn
+import torch.nn.functional as F
 
 from . import _lib
 from ._lib import check, ptr, stream_of
@@ -26,10 +28,15 @@ class DecoderC(_DecoderXE):
 
     def forward(self, word_map, encoded_previous_captions, previous_cap_length, image_features, sample_max=True,
                 sample_rl=False, image_mean=None):
-        if sample_rl:
-            raise NotImplementedError("multinomial sampling rollout (editnet_rl.py:524-528) is not built yet")
+        _require_cuda(image_features, "image features")
+        if sample_rl or (torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters()))):
+            if not torch.is_grad_enabled() and self.training:
+                raise NotImplementedError("train-mode rollout under torch.no_grad() is not supported; use .eval()")
+            return self._rollout_autograd(word_map, encoded_previous_captions, previous_cap_length, image_features,
+                                          sample_max, sample_rl, image_mean)
         if self.training:
-            raise NotImplementedError("train-mode rollout (dropout active) is not built yet; call .eval()")
+            raise NotImplementedError("train-mode greedy rollout under torch.no_grad(): call .eval() first "
+                                      "(the reference does, editnet_rl.py:665)")
         _require_cuda(image_features, "image features")
         lib = _lib.load()
         dev = image_features.device
@@ -48,3 +55,80 @@ class DecoderC(_DecoderXE):
                                      int(word_map['<start>']), int(word_map['<end>']), max_len, ptr(seq),
                                      ptr(seq_logp), ptr(ws), ws.numel(), stream_of(dev)), "set_editnet_greedy")
         return seq, seq_logp
+
+    def _rollout_autograd(self, word_map, encoded_previous_captions, previous_cap_length, image_features, sample_max,
+                          sample_rl, image_mean=None):
+        """The reference loop editnet_rl.py:485-549 over autograd-wrapped HIP operators: used for the
+        sampled SCST rollout (train mode, dropout active, gradients flow through seqLogprobs) and for
+        multinomial sampling in general.  Sampling uses torch.multinomial on the device."""
+        from . import autograd_ops as A
+        if self._adaptive:
+            raise NotImplementedError("rollout with adaptive features is not built yet")
+        dev = image_features.device
+        X = _f32c(image_features)
+        B, max_len = X.shape[0], self.max_len
+        seq = torch.zeros(B, max_len, dtype=torch.long, device=dev)
+        logps = []
+        it = torch.full((B,), int(word_map['<start>']), dtype=torch.long, device=dev)
+        h1, c1 = self.init_hidden_state(B)
+        h2, c2 = self.init_hidden_state(B)
+        H, M, final_hidden, mask = self._encoder_autograd(encoded_previous_captions, previous_cap_length)
+        mean = X.mean(1) if image_mean is None else image_mean
+        ca, va, cl, al = self.caption_attention, self.visual_attention, self.copy_lstm, self.attention_lstm
+        E = self.embed.embedding.weight
+        att1_eval = None
+        if not self.training:
+            att1_eval = A.linear(A.linear(X, va.att_embed[0].weight, va.att_embed[0].bias, _lib.ACT_RELU),
+                                 va.features_att.weight, va.features_att.bias)
+        unfinished = None
+        for t in range(max_len + 1):
+            emb = self.embed.dropout(A.embed_relu(it, E))
+            h1, c1 = A.lstm_cell(torch.cat([emb, final_hidden, h2, mean], 1), h1, c1, al.weight_ih, al.weight_hh,
+                                 al.bias_ih, al.bias_hh)
+            attend_cap, alpha_c = A.caption_attention(
+                H, h1, emb, mask, ca.cap_features_att.weight, ca.cap_features_att.bias, ca.cap_decoder_att.weight,
+                ca.cap_decoder_att.bias, ca.cap_full_att.weight, ca.cap_full_att.bias, ca.context_gate.weight,
+                ca.context_gate.bias, ca.sc_affine.weight, ca.sc_affine.bias, ca.tc_affine.weight, ca.tc_affine.bias)
+            if att1_eval is not None:
+                att1 = att1_eval
+            else:
+                fe = va.att_embed[2](A.linear(X, va.att_embed[0].weight, va.att_embed[0].bias, _lib.ACT_RELU))
+                att1 = A.linear(fe, va.features_att.weight, va.features_att.bias)
+            attend_img = A.visual_attention_from_att1(X, att1, h1, va.decoder_att.weight, va.decoder_att.bias,
+                                                      va.full_att.weight, va.full_att.bias)
+            sel = A.select(M, alpha_c)
+            h2, c2 = A.copy_lstm(torch.cat([h1, attend_cap, attend_img], 1), h2, c2, sel, cl.x2h.weight, cl.x2h.bias,
+                                 cl.h2h.weight, cl.h2h.bias, cl.gate_cnew.weight, cl.gate_cnew.bias,
+                                 cl.gate_cmem.weight, cl.gate_cmem.bias)
+            logprobs = F.log_softmax(A.linear(self.dropout(h2), self.fc.weight, self.fc.bias), dim=1)
+            if t == max_len:
+                break
+            if sample_max:
+                sample_logp, it = torch.max(logprobs, 1)
+            if sample_rl:
+                it = torch.multinomial(torch.exp(logprobs.detach()), 1)
+                sample_logp = logprobs.gather(1, it).view(-1)
+                it = it.view(-1)
+            it = it.clone()
+            it[it == int(word_map['<end>'])] = 0
+            unfinished = (it > 0) if t == 0 else unfinished * (it > 0)
+            it = it * unfinished.type_as(it)
+            seq[:, t] = it
+            logps.append(sample_logp.view(-1))
+            if unfinished.sum() == 0:
+                break
+        seq_logp = torch.stack(logps, 1)
+        if seq_logp.shape[1] < max_len:
+            seq_logp = torch.cat([seq_logp, seq_logp.new_zeros(B, max_len - seq_logp.shape[1])], 1)
+        return seq, seq_logp
+
+
+class RewardCriterion(nn.Module):
+    """reference editnet_rl.py:553-573 (a loss on the path's output; plain tensor ops)."""
+
+    def forward(self, sample_logprobs, seq, reward):
+        sample_logprobs = sample_logprobs.reshape(-1)
+        reward = reward.reshape(-1)
+        mask = (seq > 0).float()
+        mask = torch.cat([mask.new_ones(mask.size(0), 1), mask[:, :-1]], 1).reshape(-1)
+        return torch.sum(-sample_logprobs * reward * mask) / torch.sum(mask)
