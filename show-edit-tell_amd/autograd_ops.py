@@ -250,3 +250,34 @@ def copy_lstm(x, h2, c2, cmem, x2h_w, x2h_b, h2h_w, h2h_b, cnew_w, cnew_b, cmem_
         return torch.sigmoid(o) * torch.tanh(adaptive), adaptive
 
     return _apply(hip, formula, 2, x, h2, c2, cmem, x2h_w, x2h_b, h2h_w, h2h_b, cnew_w, cnew_b, cmem_w, cmem_b)
+
+
+# ------------------------------------------------------------------------------------------------
+# DCNet CaptionAttention.forward (dcnet.py:254-270): additive attention without gating
+# ------------------------------------------------------------------------------------------------
+def dcnet_caption_attention(feats, h1, mask, feat_w, feat_b, dec_w, dec_b, full_w, full_b):
+    def hip(feats, h1, mask, feat_w, feat_b, dec_w, dec_b, full_w, full_b):
+        lib = _lib.load()
+        feats, h1, mask = _c(feats), _c(h1), _c(mask)
+        M, T, Dh = feats.shape
+        D, A = h1.shape[1], dec_w.shape[0]
+        w = EditNetWeights()
+        w.ca_feat_w, w.ca_feat_b, w.ca_dec_w, w.ca_dec_b = feat_w.data_ptr(), feat_b.data_ptr(), dec_w.data_ptr(), dec_b.data_ptr()
+        w.ca_full_w, w.ca_full_b = full_w.data_ptr(), full_b.data_ptr()
+        ctx = torch.empty(M, Dh, dtype=torch.float32, device=feats.device)
+        ws = torch.empty(lib.set_caption_attention_workspace_bytes(M, T, max(Dh, D), A), dtype=torch.uint8,
+                         device=feats.device)
+        check(lib.set_caption_attention_f32(C.byref(w), ptr(feats), None, ptr(h1), None, ptr(mask), ptr(ctx), None, M,
+                                            T, Dh, D, A, ptr(ws), ws.numel(), stream_of(feats.device)),
+              "set_caption_attention_f32")
+        return ctx
+
+    def formula(feats, h1, mask, feat_w, feat_b, dec_w, dec_b, full_w, full_b):
+        att1 = F.linear(feats, feat_w, feat_b)
+        att2 = F.linear(h1, dec_w, dec_b)
+        e = F.linear(torch.tanh(att1 + att2.unsqueeze(1)), full_w, full_b).squeeze(2)
+        e = e.masked_fill(mask == 0, -1e10)
+        alpha = F.softmax(e, dim=1)
+        return (feats * alpha.unsqueeze(2)).sum(1)
+
+    return _apply(hip, formula, 1, feats, h1, mask, feat_w, feat_b, dec_w, dec_b, full_w, full_b)

@@ -168,8 +168,11 @@ class DAE(nn.Module):
 
     def forward(self, encoded_captions, caption_lengths, encoded_previous_captions, previous_cap_length):
         """reference dcnet.py:303-350; returns (predictions, encoded_captions sorted, decode_lengths, sort_ind)."""
-        _no_train(self, "DAE.forward")
         _require_cuda(encoded_captions, "captions")
+        if torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters())):
+            return self._forward_autograd(encoded_captions, caption_lengths, encoded_previous_captions,
+                                          previous_cap_length)
+        _no_train(self, "DAE.forward")
         lib = _lib.load()
         dev = encoded_captions.device
         batch_size = encoded_captions.size(0)
@@ -188,3 +191,71 @@ class DAE(nn.Module):
                                        ptr(prev), ptr(plen), ptr(predictions), ptr(ws), ws.numel(), stream_of(dev)),
               "set_dcnet_xe_forward")
         return predictions, encoded_captions, decode_lengths, sort_ind
+
+
+    # ---- grad-enabled path (HIP forward operators, autograd backward) ------------------------
+    def _encoder_autograd(self, src, src_len):
+        """CaptionEncoder.forward (dcnet.py:220-243): packed BiLSTM == per-row masked recurrences."""
+        from . import autograd_ops as A
+        enc = self.caption_encoder
+        lstm = enc.lstm_encoder
+        lens = src_len.reshape(-1)
+        tmax = int(lens.max().item())
+        B, Cc = src.shape[0], enc.enc_hid_dim
+        emb = self.embed.dropout(A.embed_relu(src[:, :tmax], self.embed.embedding.weight))
+        dev = src.device
+        outs = []
+        finals = []
+        for sfx, reverse in (("", False), ("_reverse", True)):
+            w_ih, w_hh = getattr(lstm, "weight_ih_l0" + sfx), getattr(lstm, "weight_hh_l0" + sfx)
+            b_ih, b_hh = getattr(lstm, "bias_ih_l0" + sfx), getattr(lstm, "bias_hh_l0" + sfx)
+            h = torch.zeros(B, Cc, device=dev)
+            c = torch.zeros(B, Cc, device=dev)
+            cols = [None] * tmax
+            for t in (range(tmax - 1, -1, -1) if reverse else range(tmax)):
+                m = (lens > t).float().unsqueeze(1)
+                hn, cn = A.lstm_cell(emb[:, t], h, c, w_ih, w_hh, b_ih, b_hh)
+                h = m * hn + (1 - m) * h
+                c = m * cn + (1 - m) * c
+                cols[t] = m * hn
+            outs.append(torch.stack(cols, 1))
+            finals.append(h)
+        outputs = torch.cat(outs, 2)
+        mask = (outputs.sum(2) != 0).float()
+        final_hidden = A.linear(torch.cat(finals, 1), enc.concat.weight, enc.concat.bias, _lib.ACT_TANH)
+        return outputs, final_hidden, mask
+
+    def _step_autograd(self, emb, final_hidden, enc, mask, h1, c1, h2, c2):
+        from . import autograd_ops as A
+        al, ll, ca = self.attention_lstm, self.language_lstm, self.caption_attention
+        h1, c1 = A.lstm_cell(torch.cat([emb, final_hidden, h2], 1), h1, c1, al.weight_ih, al.weight_hh, al.bias_ih,
+                             al.bias_hh)
+        attend_cap = A.dcnet_caption_attention(enc, h1, mask, ca.cap_features_att.weight, ca.cap_features_att.bias,
+                                               ca.cap_decoder_att.weight, ca.cap_decoder_att.bias,
+                                               ca.cap_full_att.weight, ca.cap_full_att.bias)
+        h2, c2 = A.lstm_cell(torch.cat([h1, attend_cap], 1), h2, c2, ll.weight_ih, ll.weight_hh, ll.bias_ih, ll.bias_hh)
+        return h1, c1, h2, c2
+
+    def _forward_autograd(self, encoded_captions, caption_lengths, encoded_previous_captions, previous_cap_length):
+        """dcnet.py:303-350 over autograd ops."""
+        from . import autograd_ops as A
+        batch_size = encoded_captions.size(0)
+        caption_lengths, sort_ind = caption_lengths.squeeze(1).sort(dim=0, descending=True)
+        encoded_captions = encoded_captions[sort_ind]
+        prev = encoded_previous_captions[sort_ind]
+        plen = previous_cap_length[sort_ind]
+        h1, c1 = self.init_hidden_state(batch_size)
+        h2, c2 = self.init_hidden_state(batch_size)
+        decode_lengths = (caption_lengths - 1).tolist()
+        embeddings = self.embed.dropout(A.embed_relu(encoded_captions, self.embed.embedding.weight))
+        enc, final_hidden, mask = self._encoder_autograd(prev, plen)
+        preds_t = []
+        for t in range(max(decode_lengths)):
+            bt = sum([l > t for l in decode_lengths])
+            h1, c1, h2, c2 = self._step_autograd(embeddings[:bt, t], final_hidden[:bt], enc[:bt], mask[:bt], h1[:bt],
+                                                 c1[:bt], h2[:bt], c2[:bt])
+            preds = A.linear(self.dropout(h2), self.fc.weight, self.fc.bias)
+            if bt < batch_size:
+                preds = torch.cat([preds, preds.new_zeros(batch_size - bt, preds.shape[1])], 0)
+            preds_t.append(preds)
+        return torch.stack(preds_t, 1), encoded_captions, decode_lengths, sort_ind

@@ -19,10 +19,13 @@ class DAE(_DAE_XE):
     max_len = 18
 
     def forward(self, word_map, encoded_previous_captions, previous_cap_length, sample_max=True, sample_rl=False):
-        if sample_rl:
-            raise NotImplementedError("multinomial sampling rollout (dcnet_rl.py:322-326) is not built yet")
+        _require_cuda(encoded_previous_captions, "previous captions")
+        if sample_rl or (torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters()))):
+            if not torch.is_grad_enabled() and self.training:
+                raise NotImplementedError("train-mode rollout under torch.no_grad() is not supported; use .eval()")
+            return self._rollout_autograd(word_map, encoded_previous_captions, previous_cap_length, sample_max, sample_rl)
         if self.training:
-            raise NotImplementedError("train-mode rollout (dropout active) is not built yet; call .eval()")
+            raise NotImplementedError("train-mode greedy rollout under torch.no_grad(): call .eval() first")
         _require_cuda(encoded_previous_captions, "previous captions")
         lib = _lib.load()
         dev = encoded_previous_captions.device
@@ -38,6 +41,48 @@ class DAE(_DAE_XE):
                                    int(word_map['<end>']), max_len, ptr(seq), ptr(seq_logp), ptr(ws), ws.numel(),
                                    stream_of(dev)), "set_dcnet_greedy")
         return seq, seq_logp
+
+
+def _dae_rollout(self, word_map, encoded_previous_captions, previous_cap_length, sample_max, sample_rl):
+    """dcnet_rl.py:286-346 over autograd-wrapped HIP operators (sampled SCST rollout / multinomial sampling)."""
+    import torch.nn.functional as F
+    from . import autograd_ops as A
+    dev = encoded_previous_captions.device
+    B, max_len = encoded_previous_captions.shape[0], self.max_len
+    seq = torch.zeros(B, max_len, dtype=torch.long, device=dev)
+    logps = []
+    it = torch.full((B,), int(word_map['<start>']), dtype=torch.long, device=dev)
+    h1, c1 = self.init_hidden_state(B)
+    h2, c2 = self.init_hidden_state(B)
+    enc, final_hidden, mask = self._encoder_autograd(encoded_previous_captions, previous_cap_length)
+    unfinished = None
+    for t in range(max_len + 1):
+        emb = self.embed.dropout(A.embed_relu(it, self.embed.embedding.weight))
+        h1, c1, h2, c2 = self._step_autograd(emb, final_hidden, enc, mask, h1, c1, h2, c2)
+        logprobs = F.log_softmax(A.linear(self.dropout(h2), self.fc.weight, self.fc.bias), dim=1)
+        if t == max_len:
+            break
+        if sample_max:
+            sample_logp, it = torch.max(logprobs, 1)
+        if sample_rl:
+            it = torch.multinomial(torch.exp(logprobs.detach()), 1)
+            sample_logp = logprobs.gather(1, it).view(-1)
+            it = it.view(-1)
+        it = it.clone()
+        it[it == int(word_map['<end>'])] = 0
+        unfinished = (it > 0) if t == 0 else unfinished * (it > 0)
+        it = it * unfinished.type_as(it)
+        seq[:, t] = it
+        logps.append(sample_logp.view(-1))
+        if unfinished.sum() == 0:
+            break
+    seq_logp = torch.stack(logps, 1)
+    if seq_logp.shape[1] < max_len:
+        seq_logp = torch.cat([seq_logp, seq_logp.new_zeros(B, max_len - seq_logp.shape[1])], 1)
+    return seq, seq_logp
+
+
+DAE._rollout_autograd = _dae_rollout
 
 
 class DAEWithAR(nn.Module):
