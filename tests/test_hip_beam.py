@@ -1,0 +1,48 @@
+"""GPU: the beam-search callers (evaluate() / evaluate_full() mirrors) over the HIP operator API
+against the oracle's hand-stated numpy beam search."""
+import numpy as np
+import pytest
+import torch
+
+from hip_adapter import editnet_modules, load_numpy_state, to_dev
+from oracle import beam_np, cases, dcnet_np as DN, editnet_np as EN
+
+pytestmark = pytest.mark.gpu
+
+
+def _boosted(sd, V, boost):
+    sd = dict(sd)
+    sd["fc.bias"] = sd["fc.bias"].copy()
+    sd["fc.bias"][V - 1] += np.float32(boost)
+    return sd
+
+
+def test_beam_search_editnet_and_ensemble():
+    from show_edit_tell_amd import dcnet, editnet, evaluate
+    d = cases.build_editnet("editnet_small")
+    c, wm = d["case"], d["wm"]
+    # <end> boosted so that some hypotheses finish early and others run to the step limit
+    sd_e = _boosted(d["sd"], c["V"], 3.0)
+    sd_d = _boosted(cases.synth.dcnet_state(17, c["V"], c["D"], c["A"], c["D"] // 2, c["D"], 3.0, 8.0, 3.0), c["V"], 3.0)
+    xe = load_numpy_state(editnet.DecoderC(wm, c["D"], c["D"], c["D"], c["A"], c["F"]), sd_e)
+    dae = load_numpy_state(dcnet.DAE(wm, None, c["D"], c["A"], c["D"] // 2, c["D"]), sd_d)
+    Pe, Pd = EN.cast_params(sd_e), DN.cast_params(sd_d)
+    finished = 0
+    for b in range(c["B"]):
+        X1, prev1, plen1 = d["X"][b:b + 1], d["prev"][b:b + 1], d["plen"][b:b + 1]
+        for ens in (False, True):
+            if ens:
+                seq_o, sc_o, margin = beam_np.beam_ensemble(Pe, Pd, X1, prev1, plen1, wm["<start>"], wm["<end>"], 3)
+                seq, sc = evaluate.beam_search_ensemble(xe, dae, to_dev(X1), to_dev(prev1), to_dev(plen1), wm, 3)
+            else:
+                seq_o, sc_o, margin = beam_np.beam_editnet(Pe, X1, prev1, plen1, wm["<start>"], wm["<end>"], 3)
+                seq, sc = evaluate.beam_search_editnet(xe, to_dev(X1), to_dev(prev1), to_dev(plen1), wm, 3)
+            if margin is None:                  # ran into the step limit (editnet.py:702-704,711)
+                assert np.isnan(sc) and len(seq) == 18 and seq[:4] == seq_o[:4], (b, ens, seq, seq_o)
+            else:
+                assert abs(sc - sc_o) < 1e-3, (b, ens, sc, sc_o)
+                if margin > 1e-3:
+                    assert seq == seq_o, (b, ens, seq, seq_o)
+                    finished += 1
+            assert evaluate.sentence(seq, wm) == " ".join("w%d" % w for w in seq if 0 < w < c["V"] - 3)
+    assert finished >= 2
