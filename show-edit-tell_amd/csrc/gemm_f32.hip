@@ -27,7 +27,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // counts on lgkmcnt and would make every LDS wait drain the HBM loads)
 typedef const f32x4 __attribute__((address_space(1)))* gptr4;
 
-constexpr int LDS_STRIDE = 36;   // floats per staged row (32 + 4 pad): banks r*36 mod 64 distinct per lane group
+// LDS rows are 32 floats (128 B) UNPADDED; the 16-byte chunk c of row r is stored at chunk c ^ ((r >> 1) & 7).
+// ds_write_b128 (8 lanes = one row) and the MFMA fragment ds_read_b128 (lane groups of 16 rows, one chunk
+// each) are then both bank-conflict-free, and a 128x64x32 stage pair is 48 KB -> three workgroups per CU.
+constexpr int LDS_STRIDE = 32;
 
 struct GemmTask {
     const float* A[GEMM_MAX_SEG];
@@ -81,6 +84,7 @@ __global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
 
     // ---- staging assignment: thread -> (row = tid/8 + 32*i, 16-byte column = tid%8)
     const int srow = tid >> 3, scol = (tid & 7) * 4;
+    const int sswz = ((tid & 7) ^ ((srow >> 1) & 7)) * 4;          // swizzled chunk (rows srow+32i share (r>>1)&7)
     int arow[LA], wrow[LW];
 #pragma unroll
     for (int i = 0; i < LA; ++i) { int r = m0 + srow + 32 * i; arow[i] = r < T.M ? r : T.M - 1; }
@@ -119,9 +123,9 @@ __global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
         float* sA_ = lds[(BUF)];                                                                        \
         float* sW_ = lds[(BUF)] + BM * LDS_STRIDE;                                                      \
         _Pragma("unroll") for (int i = 0; i < LA; ++i)                                                  \
-            *reinterpret_cast<f32x4*>(sA_ + (srow + 32 * i) * LDS_STRIDE + scol) = RA[i];              \
+            *reinterpret_cast<f32x4*>(sA_ + (srow + 32 * i) * LDS_STRIDE + sswz) = RA[i];              \
         _Pragma("unroll") for (int i = 0; i < LW; ++i)                                                  \
-            *reinterpret_cast<f32x4*>(sW_ + (srow + 32 * i) * LDS_STRIDE + scol) = RW[i];              \
+            *reinterpret_cast<f32x4*>(sW_ + (srow + 32 * i) * LDS_STRIDE + sswz) = RW[i];              \
     }
 
     f32x16 acc[TM][TN];
@@ -132,7 +136,10 @@ __global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int frow = lane & 31, fk = (lane >> 5) * 4;
+    const int frow = lane & 31;
+    int fo[4];                                                    // swizzled float offset of k-chunk 2*kk + (lane>>5)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) fo[kk] = (((kk * 2 + (lane >> 5)) ^ ((frow >> 1) & 7)) * 4);
     // Software pipeline (one barrier per k-tile, two LDS buffers, one register stage):
     //   iteration kt:  MFMAs of tile kt from lds[buf]   ||  ds_write tile kt+1 -> lds[buf^1]
     //                                                    ||  global loads of tile kt+2 -> registers
@@ -141,9 +148,9 @@ __global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
     {                                                                                                   \
         f32x4 a[TM], b[TN];                                                                             \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
-            a[i] = *reinterpret_cast<const f32x4*>(sA + i * 32 * LDS_STRIDE + (KK) * 8);                \
+            a[i] = *reinterpret_cast<const f32x4*>(sA + i * 32 * LDS_STRIDE + fo[KK]);                  \
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                  \
-            b[j] = *reinterpret_cast<const f32x4*>(sW + j * 32 * LDS_STRIDE + (KK) * 8);                \
+            b[j] = *reinterpret_cast<const f32x4*>(sW + j * 32 * LDS_STRIDE + fo[KK]);                  \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
             _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                            \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);   \
@@ -162,8 +169,8 @@ __global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
     // with tile kt+3
 #define SET_ITER(KT, BUF, RA, RW)                                                                       \
     {                                                                                                   \
-        const float* sA = lds[BUF] + (wm * TM * 32 + frow) * LDS_STRIDE + fk;                           \
-        const float* sW = lds[BUF] + BM * LDS_STRIDE + (wn * TN * 32 + frow) * LDS_STRIDE + fk;         \
+        const float* sA = lds[BUF] + (wm * TM * 32 + frow) * LDS_STRIDE;                                \
+        const float* sW = lds[BUF] + BM * LDS_STRIDE + (wn * TN * 32 + frow) * LDS_STRIDE;              \
         SET_MFMA_KK(0);                                                                                 \
         if ((KT) + 1 < kt1) {                                                                           \
             SET_LSTORE((BUF) ^ 1, RA, RW);                                                              \

@@ -351,15 +351,23 @@ class DecoderC(nn.Module):
                            V=self.vocab_size, maxT=maxT, adaptive=self._adaptive)
 
     def _workspace(self, dims):
+        """One workspace per (dims, device, stream): concurrent decodes on different streams must not share
+        recurrent state or split-K slabs."""
         lib = _lib.load()
-        key = tuple(getattr(dims, f) for f, _ in EditNetDims._fields_) + (str(self.fc.weight.device),)
-        if self._ws_key != key:
+        dev = self.fc.weight.device
+        key = tuple(getattr(dims, f) for f, _ in EditNetDims._fields_) + (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+        cache = self.__dict__.setdefault("_ws_cache", {})
+        ws = cache.get(key)
+        if ws is None:
             n = lib.set_editnet_workspace_bytes(C.byref(dims))
             if n == 0:
                 raise _lib.SetError("unsupported EditNet dims %r (contraction dims must be multiples of 32)" % (key,))
-            self._ws = torch.empty(n, dtype=torch.uint8, device=self.fc.weight.device)
-            self._ws_key = key
-        return self._ws
+            if len(cache) >= 8:
+                cache.clear()
+            ws = torch.empty(n, dtype=torch.uint8, device=dev)
+            cache[key] = ws
+        self._ws, self._ws_key = ws, key
+        return ws
 
     def ws_tensor(self, dims, name, shape, dtype=torch.float32):
         """View of a named workspace tensor (debug / tests)."""
