@@ -103,13 +103,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the decode path has no CPU fallback")
+    # SET_BENCH_BACKEND=gloo + SET_BENCH_ONE_DEVICE=1: exercise the multi-rank code path on a 1-GPU box
+    backend = os.environ.get("SET_BENCH_BACKEND", "nccl")
+    if os.environ.get("SET_BENCH_ONE_DEVICE"):
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the decode path has no CPU fallback")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -157,7 +164,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
 
