@@ -74,7 +74,8 @@ EDITNET_WEIGHT_FIELDS = (
 
 
 class EditNetWeights(C.Structure):
-    _fields_ = [(f, C.c_void_p) for f, _ in EDITNET_WEIGHT_FIELDS]
+    # the state_dict tensors + the optional derived token table (include/set_hip.h)
+    _fields_ = [(f, C.c_void_p) for f, _ in EDITNET_WEIGHT_FIELDS] + [("tok_table", C.c_void_p)]
 
 
 class ProfileEntry(C.Structure):
@@ -147,6 +148,9 @@ PROTOTYPES = {
     "set_profile_enable": (_I, [_I]),
     "set_profile_report": (_I, [_P, _I]),
     "set_editnet_workspace_bytes": (_Z, [C.POINTER(EditNetDims)]),
+    "set_editnet_token_table_bytes": (_Z, [C.POINTER(EditNetDims)]),
+    "set_editnet_token_table_workspace_bytes": (_Z, [C.POINTER(EditNetDims)]),
+    "set_editnet_build_token_table": (_I, [C.POINTER(EditNetWeights), C.POINTER(EditNetDims), _P, _P, _Z, _P]),
     "set_editnet_begin": (_I, [C.POINTER(EditNetWeights), C.POINTER(EditNetDims), _P, _P, _P, _P, _P, _Z, _P]),
     "set_editnet_step": (_I, [C.POINTER(EditNetWeights), C.POINTER(EditNetDims), _P, _P, _L, _I, _P, _L, _P, _Z, _P]),
     "set_editnet_greedy_pick": (_I, [C.POINTER(EditNetWeights), C.POINTER(EditNetDims), _P, _L, _I, _L, _P, _P, _I,

@@ -229,15 +229,26 @@ static int begin_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const
 // One timestep for rows [0,bt).  ws.emb must already hold relu(E[token]).  The vocabulary
 // projection is left as split-K slabs (`*logits_out`, bias NOT yet added) unless `dst` is given,
 // in which case (bt,V) logits with bias are written to dst (leading stride ld_dst).
-static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X, int bt, EditNetWs& ws, float* dst,
+static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X, int bt, EditNetWs& ws,
+                     const long long* tok_ids, long long tok_stride, float* dst,
                      long long ld_dst, Slabs* logits_out, hipStream_t st) {
     const int B = d->B, T = d->T, R = d->R, F = d->F, D = d->D, A = d->A, V = d->V;
     const int tgt = gemm_target_wgs();
     const long long ld_ih = 3LL * D + F, ld_x2h = 2LL * D + F;
     // ---- A
+    // token-only contractions folded into the (V,6D) table (inference): their K-segments disappear and the
+    // consuming pointwise kernels add the gathered table row instead
+    const bool fusedk = (D % 64 == 0) && env_int("SET_NO_FUSED", 0) == 0;
+    const bool tab = w->tok_table != nullptr && tok_ids != nullptr && fusedk;
+    RowGather g_gates, g_tc, g_cg;
+    if (tab) {
+        g_gates = RowGather{w->tok_table, tok_ids, tok_stride, 6LL * D, 0};
+        g_tc = RowGather{w->tok_table, tok_ids, tok_stride, 6LL * D, 4 * D};
+        g_cg = RowGather{w->tok_table, tok_ids, tok_stride, 6LL * D, 5 * D};
+    }
     GemmProb a[2];
     a[0] = slab_prob(ws.sA0, bt, 4 * D, B);
-    a[0].add(ws.emb, D, w->al_wih, ld_ih, D);
+    if (!tab) a[0].add(ws.emb, D, w->al_wih, ld_ih, D);
     a[0].add(ws.h2, D, w->al_wih + 2 * D, ld_ih, D);
     a[0].add(ws.h1, D, w->al_whh, D, D);
     a[1] = slab_prob(ws.sA1, bt, 4 * D, B);
@@ -246,7 +257,7 @@ static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const 
     SET_TRY(gemm_group(a, 2, st, "gemm:A gates1+h2h"));
     const Slabs none{nullptr, 0, 0, 0};
     SET_TRY(lstm_pointwise(slabs_of(a[0]), none, none, ws.pre1, 4 * D, nullptr, nullptr, ws.c1, ws.c1, ws.h1, nullptr,
-                           bt, D, st));
+                           bt, D, st, g_gates));
     // ---- B
     GemmProb b[5];
     b[0] = slab_prob(ws.sB0, bt, A, B);
@@ -254,10 +265,10 @@ static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const 
     b[1] = slab_prob(ws.sB1, bt, A, B);
     b[1].add(ws.h1, D, w->va_dec_w, D, D);
     b[2] = slab_prob(ws.sB2, bt, D, B);
-    b[2].add(ws.emb, D, w->ca_tc_w, 2 * D, D);
+    if (!tab) b[2].add(ws.emb, D, w->ca_tc_w, 2 * D, D);
     b[2].add(ws.h1, D, w->ca_tc_w + D, 2 * D, D);
     b[3] = slab_prob(ws.sB3, bt, D, B);
-    b[3].add(ws.emb, D, w->ca_gate_w, 3 * D, D);
+    if (!tab) b[3].add(ws.emb, D, w->ca_gate_w, 3 * D, D);
     b[3].add(ws.h1, D, w->ca_gate_w + D, 3 * D, D);
     b[4] = slab_prob(ws.sB4, bt, 4 * D, B);
     b[4].add(ws.h1, D, w->cl_x2h_w, ld_x2h, D);
@@ -268,11 +279,11 @@ static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const 
                            w->ca_dec_b, w->ca_full_w, w->ca_full_b, ws.mask, ws.H, ws.Mem, ws.ctx_cap, ws.sel,
                            ws.alpha_c, T, D, A, bt, st));
     // ---- C (+ context gating): fused small-tile kernel when D allows, else grouped GEMM + pointwise
-    const bool fused = (D % 64 == 0) && env_int("SET_NO_FUSED", 0) == 0;
+    const bool fused = fusedk;
     GemmProb c[3];
     if (fused) {
         SET_TRY(fused_context_gate(ws.ctx_cap, w->ca_gate_w + 2 * D, 3 * D, w->ca_sc_w, slabs_of(b[3]), slabs_of(b[2]),
-                                   w->ca_gate_b, w->ca_sc_b, w->ca_tc_b, ws.attend_cap, bt, D, st));
+                                   w->ca_gate_b, w->ca_sc_b, w->ca_tc_b, ws.attend_cap, bt, D, st, g_cg, g_tc));
     } else {
         c[0] = slab_prob(ws.sC0, bt, D, B);
         c[0].add(ws.ctx_cap, D, w->ca_gate_w + 2 * D, 3 * D, D);
@@ -360,7 +371,8 @@ int set_editnet_step(const SetEditNetWeights* w, const SetEditNetDims* d, const 
     if (bt <= 0 || bt > d->B || ld_logits < d->V) return SET_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (tokens) SET_TRY(embed_relu(w->embed, tokens, tokens_stride, W.emb, d->D, bt, d->D, d->V, st));
-    return step_impl(w, d, X, bt, W, logits, ld_logits, nullptr, st);
+    return step_impl(w, d, X, bt, W, tokens ? (const long long*)tokens : W.it, tokens ? tokens_stride : 1, logits,
+                     ld_logits, nullptr, st);
 }
 
 int set_editnet_greedy_pick(const SetEditNetWeights* w, const SetEditNetDims* d, const float* logits,
@@ -394,7 +406,7 @@ int set_editnet_greedy(const SetEditNetWeights* w, const SetEditNetDims* d, cons
     // the reference runs max_len + 1 timesteps and discards the last one (editnet_rl.py:503,517-518)
     for (int t = 0; t <= max_len; ++t) {
         Slabs lg;
-        SET_TRY(step_impl(w, d, X, B, W, nullptr, 0, &lg, st));
+        SET_TRY(step_impl(w, d, X, B, W, W.it, 1, nullptr, 0, &lg, st));
         if (t == max_len) break;
         SET_TRY(greedy_pick(lg, w->fc_b, d->V, t, max_len, end_idx,
                             (long long*)seq, seq_logp, W.it, W.unfinished, W.alive, w->embed, W.emb, d->D, B, st));
@@ -423,9 +435,43 @@ int set_editnet_xe_forward(const SetEditNetWeights* w, const SetEditNetDims* d, 
         while (bt < B && host_decode_lengths[bt] > t) ++bt;       // editnet.py:506
         if (bt == 0) break;
         SET_TRY(embed_relu(w->embed, caps + t, caps_stride, W.emb, d->D, bt, d->D, V, st));
-        SET_TRY(step_impl(w, d, X, bt, W, predictions + (size_t)t * V, (long long)maxT * V, nullptr, st));
+        SET_TRY(step_impl(w, d, X, bt, W, (const long long*)(caps + t), caps_stride, predictions + (size_t)t * V,
+                          (long long)maxT * V, nullptr, st));
     }
     return SET_OK;
+}
+
+size_t set_editnet_token_table_bytes(const SetEditNetDims* d) {
+    if (check_dims(d) != SET_OK) return 0;
+    return sizeof(float) * (size_t)d->V * 6 * d->D;
+}
+
+size_t set_editnet_token_table_workspace_bytes(const SetEditNetDims* d) {
+    if (check_dims(d) != SET_OK) return 0;
+    return round_up(sizeof(float) * (size_t)d->V * d->D, 256) + round_up(sizeof(long long) * (size_t)d->V, 256) + 256;
+}
+
+int set_editnet_build_token_table(const SetEditNetWeights* w, const SetEditNetDims* d, float* table, void* ws,
+                                  size_t ws_bytes, void* stream) {
+    if (!w || !table || !ws) return SET_ERR_ARG;
+    SET_TRY(check_dims(d));
+    if (!aligned16(ws) || !aligned16(table)) return SET_ERR_ARG;
+    if (ws_bytes < set_editnet_token_table_workspace_bytes(d) - 256) return SET_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int V = d->V, D = d->D;
+    Carver cv(ws);
+    float* remb = cv.take<float>((size_t)V * D);
+    long long* ids = cv.take<long long>((size_t)V);
+    SET_TRY(iota_i64(ids, V, st));
+    SET_TRY(embed_relu(w->embed, (const int64_t*)ids, 1, remb, D, V, D, V, st));           // relu(E), all rows
+    GemmProb p[3];
+    p[0] = direct_prob(table, 6LL * D, V, 4 * D, nullptr, SET_ACT_NONE);
+    p[0].add(remb, D, w->al_wih, 3LL * D + d->F, D);
+    p[1] = direct_prob(table + 4 * D, 6LL * D, V, D, nullptr, SET_ACT_NONE);
+    p[1].add(remb, D, w->ca_tc_w, 2 * D, D);
+    p[2] = direct_prob(table + 5 * D, 6LL * D, V, D, nullptr, SET_ACT_NONE);
+    p[2].add(remb, D, w->ca_gate_w, 3 * D, D);
+    return gemm_group(p, 3, st, "gemm:token table");
 }
 
 void* set_editnet_ws_tensor(const SetEditNetDims* d, void* ws, const char* name) {

@@ -170,4 +170,15 @@ int set_tokens(long long* it, long long value, int* unfinished, int* alive, int 
     return SET_OK;
 }
 
+__global__ void __launch_bounds__(256) iota_i64_k(long long* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+
+int iota_i64(long long* p, int n, hipStream_t s) {
+    hipLaunchKernelGGL(iota_i64_k, dim3(cdiv(n, 256)), dim3(256), 0, s, p, n);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
 }  // namespace set

@@ -35,6 +35,7 @@ struct FusedArgs {
     const int64_t* lens;                // ENCLSTM
     long long ld_xg_row, ld_xg_t, ld_out_b, ld_out_t;
     int t, reverse, out_col0;
+    RowGather g0, g1;                   // CTXGATE: token-table addends of z and of the tc_affine term
 };
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
@@ -127,6 +128,8 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
         if (erow_ok && n0 + ec4 < P.N) {                 // N % 4 == 0 (host check)
             for (int i = 0; i < P.s0.n; ++i) pre0 += *(gptr4)(P.s0.p + (long long)i * P.s0.stride + em * P.s0.ld + n0 + ec4);
             for (int i = 0; i < P.s1.n; ++i) pre1 += *(gptr4)(P.s1.p + (long long)i * P.s1.stride + em * P.s1.ld + n0 + ec4);
+            if (P.g0.tab) pre0 += *(gptr4)(P.g0.tab + P.g0.ids[em * P.g0.id_stride] * P.g0.ld + P.g0.col0 + n0 + ec4);
+            if (P.g1.tab) pre1 += *(gptr4)(P.g1.tab + P.g1.ids[em * P.g1.id_stride] * P.g1.ld + P.g1.col0 + n0 + ec4);
         }
     } else if (EPI == EPI_COPYGATE) {
         if (erow_ok && n0 + ec4 < P.N) {
@@ -278,13 +281,14 @@ static int launch_fused(const FusedArgs& P, int grid, hipStream_t s) {
 // context gating fused with its ctx-side contractions (phase C of the step)
 int fused_context_gate(const float* ctx, const float* w_gate_ctx, long long ld_gate, const float* w_sc, Slabs cg_ab,
                        Slabs tc, const float* b_gate, const float* b_sc, const float* b_tc, float* out, int M, int D,
-                       hipStream_t s) {
+                       hipStream_t s, RowGather gz, RowGather gtc) {
     if (D % 64) return SET_ERR_UNSUPPORTED;
     FusedArgs P{};
     P.A[0] = ctx; P.A[1] = ctx; P.lda[0] = P.lda[1] = D;
     P.W[0] = w_gate_ctx; P.ldw[0] = ld_gate; P.W[1] = w_sc; P.ldw[1] = D;
     P.K = D; P.M = M; P.N = D;
     P.s0 = cg_ab; P.s1 = tc; P.b0 = b_gate; P.b1 = b_sc; P.b2 = b_tc; P.o0 = out;
+    P.g0 = gz; P.g1 = gtc;
     const int grid = cdiv(M, 32) * cdiv(D, 32);
     ProfScope ps("fused_context_gate", s, 4.0 * M * D * D, 4.0 * (2.0 * D * D + 2.0 * M * D));
     return launch_fused<2, true, 64, EPI_CTXGATE>(P, grid, s);

@@ -63,7 +63,7 @@ __device__ __forceinline__ void slab_accum(f32x4 (&acc)[Q], const Slabs& s, long
 __global__ void __launch_bounds__(256) lstm_pointwise_k(Slabs g0, Slabs g1, Slabs g2, const float* pre,
                                                         long long ldpre, const float* b0, const float* b1,
                                                         const float* c_in, float* c_out, float* h_out,
-                                                        float* ogate_out, int M, int D) {
+                                                        float* ogate_out, int M, int D, RowGather gt) {
     const int per_row = D >> 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)M * per_row) return;
@@ -79,6 +79,7 @@ __global__ void __launch_bounds__(256) lstm_pointwise_k(Slabs g0, Slabs g1, Slab
     for (int q = 0; q < 4; ++q) {
         const int n = q * D + j;
         if (pre) g[q] += ld4(pre + m * ldpre + n);
+        if (gt.tab) g[q] += ld4(gt.tab + gt.ids[m * gt.id_stride] * gt.ld + gt.col0 + n);
         if (b0) g[q] += ld4(b0 + n);
         if (b1) g[q] += ld4(b1 + n);
     }
@@ -98,12 +99,12 @@ __global__ void __launch_bounds__(256) lstm_pointwise_k(Slabs g0, Slabs g1, Slab
 
 int lstm_pointwise(Slabs g0, Slabs g1, Slabs g2, const float* pre, long long ldpre, const float* b0,
                    const float* b1, const float* c_in, float* c_out, float* h_out, float* ogate_out, int M,
-                   int D, hipStream_t s) {
+                   int D, hipStream_t s, RowGather gt) {
     if (D & 3) return SET_ERR_UNSUPPORTED;
     const long long n = (long long)M * (D >> 2);
     ProfScope ps("lstm_pointwise", s, 0.0, 4.0 * M * D * (4.0 * (g0.n + g1.n + g2.n + (pre ? 1 : 0)) + 3.0));
     hipLaunchKernelGGL(lstm_pointwise_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g0, g1, g2, pre,
-                       ldpre, b0, b1, c_in, c_out, h_out, ogate_out, M, D);
+                       ldpre, b0, b1, c_in, c_out, h_out, ogate_out, M, D, gt);
     SET_LAUNCH_CHECK();
     return SET_OK;
 }

@@ -109,10 +109,18 @@ int editnet_encoder(const SetEditNetWeights* w, const int64_t* seq, const int64_
                     float* final_hidden, float* mask, int B, int T, int D, int V, float* emb_seq, float* xg,
                     float* enc_h, float* enc_c, float* s_enc, float* s_aff, hipStream_t st);
 
+// a per-row gathered addend: value(m, n) = tab[ids[m*id_stride]*ld + col0 + n]   (tab == NULL: none)
+struct RowGather {
+    const float* tab = nullptr;
+    const long long* ids = nullptr;
+    long long id_stride = 1, ld = 0;
+    int col0 = 0;
+};
+
 // pointwise.hip
 int lstm_pointwise(Slabs g0, Slabs g1, Slabs g2, const float* pre, long long ldpre, const float* b0,
                    const float* b1, const float* c_in, float* c_out, float* h_out, float* ogate_out,
-                   int M, int D, hipStream_t s);
+                   int M, int D, hipStream_t s, RowGather gt = RowGather());
 int context_gate_pointwise(Slabs cg_a, Slabs cg_b, const float* cg_bias, Slabs sc, const float* sc_bias,
                            Slabs tc, const float* tc_bias, float* out, int M, int D, hipStream_t s);
 int copy_gate_pointwise(Slabs gn, const float* bn, Slabs gm, const float* bm, const float* c_new,
@@ -149,7 +157,7 @@ int select_rows(const float* Mem, const float* alpha, float* sel, int M, int T, 
 // gemm_fused.hip: small-tile GEMMs with fused pointwise epilogues (no slabs)
 int fused_context_gate(const float* ctx, const float* w_gate_ctx, long long ld_gate, const float* w_sc, Slabs cg_ab,
                        Slabs tc, const float* b_gate, const float* b_sc, const float* b_tc, float* out, int M, int D,
-                       hipStream_t s);
+                       hipStream_t s, RowGather gz = RowGather(), RowGather gtc = RowGather());
 int fused_copy_gate(const float* c_new, const float* sel, const float* ogate, const float* w_cnew, const float* w_cmem,
                     const float* b_cnew, const float* b_cmem, float* c_out, float* h_out, int M, int D, hipStream_t s);
 int fused_encoder_step(const float* h_in, float* h_out, float* c, const float* w_hh, const float* xg,
@@ -161,6 +169,7 @@ int fused_encoder_step(const float* h_in, float* h_out, float* c, const float* w
 int greedy_pick(Slabs logits, const float* bias, int V, int t, int max_len, long long end_idx,
                 long long* seq, float* seq_logp, long long* it, int* unfinished, int* alive,
                 const float* table, float* emb_out, int D, int B, hipStream_t s);
+int iota_i64(long long* p, int n, hipStream_t s);
 int set_tokens(long long* it, long long value, int* unfinished, int* alive, int n_alive, int B,
                hipStream_t s);
 

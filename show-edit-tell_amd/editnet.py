@@ -341,10 +341,47 @@ class DecoderC(nn.Module):
         return h, c
 
     # ---- runtime plumbing ------------------------------------------------------------------
-    def _weights(self):
+    def _weights(self, dims=None):
+        """Pack the parameter pointers; with `dims`, also attach the inference-time token table when it
+        is valid (see _token_table)."""
         dev = self.fc.weight.device
         params = dict(self.named_parameters())
-        return _lib.pack_weights(EditNetWeights, EDITNET_WEIGHT_FIELDS, params, dev)
+        w = _lib.pack_weights(EditNetWeights, EDITNET_WEIGHT_FIELDS, params, dev)
+        if dims is not None:
+            tab = self._token_table(dims)
+            if tab is not None:
+                w.tok_table = tab.data_ptr()
+        return w
+
+    # The three contractions of the step whose only input is the current token are folded into a
+    # (V,6D) table (include/set_hip.h: tok_table).  The table is derived from four parameter tensors
+    # and is rebuilt whenever any of them changes (tensor._version / data_ptr); it is only built once
+    # the same weights have been seen on two consecutive no-grad calls, so SCST training (weights
+    # change every iteration) never pays for it.  SET_TOKEN_TABLE=0 disables, =1 forces.
+    def _token_table(self, dims):
+        import os
+        mode = os.environ.get("SET_TOKEN_TABLE", "auto")
+        if mode == "0" or dims.D % 64:
+            return None
+        src = (self.embed.embedding.weight, self.attention_lstm.weight_ih, self.caption_attention.tc_affine.weight,
+               self.caption_attention.context_gate.weight)
+        sig = tuple((t.data_ptr(), t._version) for t in src)
+        st = self.__dict__.setdefault("_tok_state", {"sig": None, "seen": 0, "table": None})
+        if st["sig"] != sig:
+            st.update(sig=sig, seen=1, table=None)
+        else:
+            st["seen"] += 1
+        if st["table"] is None and (mode == "1" or st["seen"] >= 2):
+            lib = _lib.load()
+            dev = self.fc.weight.device
+            table = torch.empty(lib.set_editnet_token_table_bytes(C.byref(dims)) // 4, dtype=torch.float32, device=dev)
+            ws = torch.empty(lib.set_editnet_token_table_workspace_bytes(C.byref(dims)), dtype=torch.uint8, device=dev)
+            w = _lib.pack_weights(EditNetWeights, EDITNET_WEIGHT_FIELDS, dict(self.named_parameters()), dev)
+            check(lib.set_editnet_build_token_table(C.byref(w), C.byref(dims), ptr(table), ptr(ws), ws.numel(),
+                                                    stream_of(dev)), "set_editnet_build_token_table")
+            torch.cuda.current_stream(dev).synchronize()        # other streams may use the table next
+            st["table"] = table
+        return st["table"]
 
     def _dims(self, B, T, R, maxT):
         return EditNetDims(B=B, T=T, R=R, F=self._image_features_dim, D=self.decoder_dim, A=self._attention_dim,
@@ -402,7 +439,7 @@ class DecoderC(nn.Module):
         maxT = max(decode_lengths)
         dims = self._dims(batch_size, prev.shape[1], X.shape[1], maxT)
         ws = self._workspace(dims)
-        w = self._weights()
+        w = self._weights(dims)
         predictions = torch.empty(batch_size, maxT, self.vocab_size, dtype=torch.float32, device=dev)
         dl = (C.c_int * batch_size)(*decode_lengths)
         check(lib.set_editnet_xe_forward(C.byref(w), C.byref(dims), ptr(X), ptr(mean), ptr(encoded_captions),

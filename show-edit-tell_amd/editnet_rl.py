@@ -48,7 +48,7 @@ class DecoderC(_DecoderXE):
         max_len = self.max_len
         dims = self._dims(B, prev.shape[1], X.shape[1], max_len + 1)
         ws = self._workspace(dims)
-        w = self._weights()
+        w = self._weights(dims)
         seq = torch.empty(B, max_len, dtype=torch.long, device=dev)
         seq_logp = torch.empty(B, max_len, dtype=torch.float32, device=dev)
         check(lib.set_editnet_greedy(C.byref(w), C.byref(dims), ptr(X), ptr(mean), ptr(prev), ptr(plen),

@@ -87,3 +87,26 @@ def test_step_intermediates_vs_oracle(name):
                 got = got[:, :Tm]
             parity.assert_close(got, want, 1e-4, "step %d %s" % (t, k))
         parity.assert_close(_np(logits), o["logits"], parity.LOGIT_TOL, "step %d logits" % t)
+
+
+@pytest.mark.parametrize("name", ["editnet_small", "editnet_full_b4"])
+def test_token_table_folding(name, monkeypatch):
+    """The inference-time token table (folded token-only contractions) kicks in on the second call with
+    unchanged weights, keeps parity with the goldens, and is dropped when a source weight changes."""
+    d, xe, rl = editnet_modules(name)
+    c, g = d["case"], parity.load(name)
+    args = (d["wm"], to_dev(d["prev"]), to_dev(d["plen"]), to_dev(d["X"]), True, False)
+    with torch.no_grad():
+        for i in range(3):
+            seq, logp = rl(*args)
+            assert (rl._tok_state["table"] is not None) == (i >= 1)
+            parity.check_greedy(_np(seq), _np(logp), g)
+        pred, caps_s, dl, sort_ind = xe(to_dev(d["X"]), to_dev(d["caps"]), to_dev(d["clen"]), to_dev(d["prev"]),
+                                        to_dev(d["plen"]), False, 0.0)
+        pred, caps_s, dl, sort_ind = xe(to_dev(d["X"]), to_dev(d["caps"]), to_dev(d["clen"]), to_dev(d["prev"]),
+                                        to_dev(d["plen"]), False, 0.0)
+        assert xe._tok_state["table"] is not None
+        parity.check_xe(_np(pred), dl, _np(sort_ind), g, c["V"], small=c["D"] < 1024)
+        rl.embed.embedding.weight.mul_(1.0)            # in-place update bumps the version -> table invalid
+        rl(*args)
+        assert rl._tok_state["table"] is None
