@@ -102,16 +102,18 @@ typedef struct SetEditNetWeights {
     const float *cl_cnew_w, *cl_cnew_b;     /* copy_lstm.gate_cnew (D,D)                            */
     const float *cl_cmem_w, *cl_cmem_b;     /* copy_lstm.gate_cmem (D,D)                            */
     const float *fc_w, *fc_b;               /* fc (V,D)                                             */
-    /* optional DERIVED tensor (NULL = unused): token table (V,6D) built by set_editnet_build_token_table,
-     * row v = relu(E[v]) x [W_ih[:, :D] ; tc_affine.W[:, :D] ; context_gate.W[:, :D]]^T — the three
-     * contractions of the step whose input is only the current token (editnet.py:527,378-379).  Valid
-     * while embed / attention_lstm.weight_ih / tc_affine / context_gate are unchanged (inference). */
+    /* optional DERIVED tensor (NULL = unused): token table (V,10D) built by set_editnet_build_token_table,
+     * row v = relu(E[v]) x [W_ih[:, :D] ; tc_affine.W[:, :D] ; context_gate.W[:, :D] ; enc.x2h.W]^T
+     * (+ enc.x2h.bias on the last 4D columns) — the contractions whose input is only a token: three of
+     * the decode step (editnet.py:527,378-379) and the encoder's input projection (editnet.py:335).
+     * Valid while embed / attention_lstm.weight_ih / tc_affine / context_gate / lstm_encoder_cell.x2h
+     * are unchanged (inference). */
     const float* tok_table;
 } SetEditNetWeights;
 
 size_t set_editnet_workspace_bytes(const SetEditNetDims* d);
 
-/* Inference-time folding of the token-only contractions into a (V,6D) lookup table (see tok_table). */
+/* Inference-time folding of the token-only contractions into a (V,10D) lookup table (see tok_table). */
 size_t set_editnet_token_table_bytes(const SetEditNetDims* d);          /* bytes of the table itself   */
 size_t set_editnet_token_table_workspace_bytes(const SetEditNetDims* d);
 int set_editnet_build_token_table(const SetEditNetWeights* w, const SetEditNetDims* d, float* table,

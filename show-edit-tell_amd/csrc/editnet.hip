@@ -142,8 +142,11 @@ int editnet_encoder(const SetEditNetWeights* w, const int64_t* seq, const int64_
                     float* final_hidden, float* mask, int B, int T, int D, int V, float* emb_seq, float* xg,
                     float* enc_h, float* enc_c, float* s_enc, float* s_aff, hipStream_t st) {
     const int tgt = gemm_target_wgs();
-    SET_TRY(embed_relu(w->embed, seq, 1, emb_seq, D, B * T, D, V, st));
-    {
+    const bool fused = (D % 128 == 0) && env_int("SET_NO_FUSED", 0) == 0;
+    // with the token table the hoisted input projection x W_xh^T + b_xh is a row gather done by the step kernel
+    const bool tab = fused && w->tok_table != nullptr;
+    if (!tab) {
+        SET_TRY(embed_relu(w->embed, seq, 1, emb_seq, D, B * T, D, V, st));
         GemmProb p = direct_prob(xg, 4 * D, B * T, 4 * D, w->enc_x2h_b, SET_ACT_NONE);
         p.add(emb_seq, D, w->enc_x2h_w, D, D);
         SET_TRY(gemm_group(&p, 1, st, "gemm:enc x2h"));
@@ -152,13 +155,16 @@ int editnet_encoder(const SetEditNetWeights* w, const int64_t* seq, const int64_
     SET_TRY(zero_f32(Mem, (size_t)B * T * D, st));
     SET_TRY(zero_f32(enc_h, (size_t)B * D, st));
     SET_TRY(zero_f32(enc_c, (size_t)B * D, st));
-    const bool fused = (D % 128 == 0) && env_int("SET_NO_FUSED", 0) == 0;
     float* h_cur = enc_h;
     float* h_nxt = s_enc;                         // (B,D) ping-pong partner (the slab region is free in the fused path)
     for (int t = 0; t < T; ++t) {
         if (fused) {
-            SET_TRY(fused_encoder_step(h_cur, h_nxt, enc_c, w->enc_h2h_w, xg, (long long)T * 4 * D, 4 * D, w->enc_h2h_b,
-                                       lens, t, 0, H, Mem, (long long)T * D, D, 0, B, D, st));
+            if (tab)
+                SET_TRY(fused_encoder_step(h_cur, h_nxt, enc_c, w->enc_h2h_w, w->tok_table + 6 * D, 10LL * D, 0,
+                                           w->enc_h2h_b, lens, t, 0, H, Mem, (long long)T * D, D, 0, B, D, st, seq, T));
+            else
+                SET_TRY(fused_encoder_step(h_cur, h_nxt, enc_c, w->enc_h2h_w, xg, (long long)T * 4 * D, 4 * D,
+                                           w->enc_h2h_b, lens, t, 0, H, Mem, (long long)T * D, D, 0, B, D, st));
             float* tmp = h_cur; h_cur = h_nxt; h_nxt = tmp;
             continue;
         }
@@ -242,9 +248,9 @@ static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const 
     const bool tab = w->tok_table != nullptr && tok_ids != nullptr && fusedk;
     RowGather g_gates, g_tc, g_cg;
     if (tab) {
-        g_gates = RowGather{w->tok_table, tok_ids, tok_stride, 6LL * D, 0};
-        g_tc = RowGather{w->tok_table, tok_ids, tok_stride, 6LL * D, 4 * D};
-        g_cg = RowGather{w->tok_table, tok_ids, tok_stride, 6LL * D, 5 * D};
+        g_gates = RowGather{w->tok_table, tok_ids, tok_stride, 10LL * D, 0};
+        g_tc = RowGather{w->tok_table, tok_ids, tok_stride, 10LL * D, 4 * D};
+        g_cg = RowGather{w->tok_table, tok_ids, tok_stride, 10LL * D, 5 * D};
     }
     GemmProb a[2];
     a[0] = slab_prob(ws.sA0, bt, 4 * D, B);
@@ -443,7 +449,7 @@ int set_editnet_xe_forward(const SetEditNetWeights* w, const SetEditNetDims* d, 
 
 size_t set_editnet_token_table_bytes(const SetEditNetDims* d) {
     if (check_dims(d) != SET_OK) return 0;
-    return sizeof(float) * (size_t)d->V * 6 * d->D;
+    return sizeof(float) * (size_t)d->V * 10 * d->D;
 }
 
 size_t set_editnet_token_table_workspace_bytes(const SetEditNetDims* d) {
@@ -464,14 +470,16 @@ int set_editnet_build_token_table(const SetEditNetWeights* w, const SetEditNetDi
     long long* ids = cv.take<long long>((size_t)V);
     SET_TRY(iota_i64(ids, V, st));
     SET_TRY(embed_relu(w->embed, (const int64_t*)ids, 1, remb, D, V, D, V, st));           // relu(E), all rows
-    GemmProb p[3];
-    p[0] = direct_prob(table, 6LL * D, V, 4 * D, nullptr, SET_ACT_NONE);
+    GemmProb p[4];
+    p[0] = direct_prob(table, 10LL * D, V, 4 * D, nullptr, SET_ACT_NONE);
     p[0].add(remb, D, w->al_wih, 3LL * D + d->F, D);
-    p[1] = direct_prob(table + 4 * D, 6LL * D, V, D, nullptr, SET_ACT_NONE);
+    p[1] = direct_prob(table + 4 * D, 10LL * D, V, D, nullptr, SET_ACT_NONE);
     p[1].add(remb, D, w->ca_tc_w, 2 * D, D);
-    p[2] = direct_prob(table + 5 * D, 6LL * D, V, D, nullptr, SET_ACT_NONE);
+    p[2] = direct_prob(table + 5 * D, 10LL * D, V, D, nullptr, SET_ACT_NONE);
     p[2].add(remb, D, w->ca_gate_w, 3 * D, D);
-    return gemm_group(p, 3, st, "gemm:token table");
+    p[3] = direct_prob(table + 6 * D, 10LL * D, V, 4 * D, w->enc_x2h_b, SET_ACT_NONE);
+    p[3].add(remb, D, w->enc_x2h_w, D, D);
+    return gemm_group(p, 4, st, "gemm:token table");
 }
 
 void* set_editnet_ws_tensor(const SetEditNetDims* d, void* ws, const char* name) {

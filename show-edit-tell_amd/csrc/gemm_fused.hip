@@ -36,6 +36,7 @@ struct FusedArgs {
     long long ld_xg_row, ld_xg_t, ld_out_b, ld_out_t;
     int t, reverse, out_col0;
     RowGather g0, g1;                   // CTXGATE: token-table addends of z and of the tc_affine term
+    const int64_t* seq; int seq_T;      // ENCLSTM with a token table: xg row = e0 + seq[m*seq_T + pos] * ld_xg_row
 };
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
@@ -144,7 +145,8 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
             ehin = P.e1[em * P.N + unit];
             if (P.t < elen) {
                 epos = P.reverse ? (elen - 1 - P.t) : P.t;
-                const float* xr = P.e0 + em * P.ld_xg_row + (long long)epos * P.ld_xg_t;
+                const float* xr = P.seq ? P.e0 + P.seq[em * P.seq_T + epos] * P.ld_xg_row
+                                        : P.e0 + em * P.ld_xg_row + (long long)epos * P.ld_xg_t;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     eg[q] = xr[q * P.N + unit];
@@ -312,14 +314,14 @@ int fused_copy_gate(const float* c_new, const float* sel, const float* ogate, co
 int fused_encoder_step(const float* h_in, float* h_out, float* c, const float* w_hh, const float* xg,
                        long long ld_xg_row, long long ld_xg_t, const float* b_extra, const int64_t* lens, int t,
                        int reverse, float* H, float* Mem, long long ld_out_b, long long ld_out_t, int out_col0, int B,
-                       int D, hipStream_t s) {
+                       int D, hipStream_t s, const int64_t* seq, int seq_T) {
     if (D % 128) return SET_ERR_UNSUPPORTED;
     FusedArgs P{};
     P.A[0] = h_in; P.lda[0] = D; P.W[0] = w_hh; P.ldw[0] = D;
     P.K = D; P.M = B; P.N = D; P.gate_stride = D;
     P.b0 = b_extra; P.e0 = xg; P.e1 = h_in; P.o0 = h_out; P.o1 = c; P.o2 = H; P.o3 = Mem; P.lens = lens;
     P.ld_xg_row = ld_xg_row; P.ld_xg_t = ld_xg_t; P.ld_out_b = ld_out_b; P.ld_out_t = ld_out_t;
-    P.t = t; P.reverse = reverse; P.out_col0 = out_col0;
+    P.t = t; P.reverse = reverse; P.out_col0 = out_col0; P.seq = seq; P.seq_T = seq_T;
     const int grid = cdiv(B, 32) * cdiv(D, 8);
     ProfScope ps("fused_encoder_step", s, 8.0 * B * D * D, 4.0 * (4.0 * D * D + 8.0 * B * D));
     return launch_fused<1, true, 128, EPI_ENCLSTM>(P, grid, s);

@@ -163,7 +163,7 @@ int fused_copy_gate(const float* c_new, const float* sel, const float* ogate, co
 int fused_encoder_step(const float* h_in, float* h_out, float* c, const float* w_hh, const float* xg,
                        long long ld_xg_row, long long ld_xg_t, const float* b_extra, const int64_t* lens, int t,
                        int reverse, float* H, float* Mem, long long ld_out_b, long long ld_out_t, int out_col0, int B,
-                       int D, hipStream_t s);
+                       int D, hipStream_t s, const int64_t* seq = nullptr, int seq_T = 0);
 
 // epilogue.hip
 int greedy_pick(Slabs logits, const float* bias, int V, int t, int max_len, long long end_idx,

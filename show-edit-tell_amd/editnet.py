@@ -354,7 +354,7 @@ class DecoderC(nn.Module):
         return w
 
     # The three contractions of the step whose only input is the current token are folded into a
-    # (V,6D) table (include/set_hip.h: tok_table).  The table is derived from four parameter tensors
+    # (V,10D) table (include/set_hip.h: tok_table).  The table is derived from six parameter tensors
     # and is rebuilt whenever any of them changes (tensor._version / data_ptr); it is only built once
     # the same weights have been seen on two consecutive no-grad calls, so SCST training (weights
     # change every iteration) never pays for it.  SET_TOKEN_TABLE=0 disables, =1 forces.
@@ -363,8 +363,9 @@ class DecoderC(nn.Module):
         mode = os.environ.get("SET_TOKEN_TABLE", "auto")
         if mode == "0" or dims.D % 64:
             return None
+        cell = self.caption_encoder.lstm_encoder_cell
         src = (self.embed.embedding.weight, self.attention_lstm.weight_ih, self.caption_attention.tc_affine.weight,
-               self.caption_attention.context_gate.weight)
+               self.caption_attention.context_gate.weight, cell.x2h.weight, cell.x2h.bias)
         sig = tuple((t.data_ptr(), t._version) for t in src)
         st = self.__dict__.setdefault("_tok_state", {"sig": None, "seen": 0, "table": None})
         if st["sig"] != sig:
