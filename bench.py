@@ -177,6 +177,22 @@ def main():
             torch.cuda.synchronize(dev)
             single = time.perf_counter() - ts
             streams = keep
+        # secondary figure: teacher-forced XE forward (editnet.py:479-548, eval mode), same batch, 19 timesteps
+        xe_rate = None
+        if rank == 0:
+            from show_edit_tell_amd import editnet
+            caps_np, clen_np = synth.captions(seed, B, V, 20, 20)
+            caps, clen = torch.from_numpy(caps_np).to(dev), torch.from_numpy(clen_np).to(dev)
+            xe_fwd = lambda: editnet.DecoderC.forward(dec, X, caps, clen, prev, plen, False, 0.0)
+            for _ in range(2):
+                xe_fwd()
+            torch.cuda.synchronize(dev)
+            tx = time.perf_counter()
+            nx = max(3, args.steps // 4)
+            for _ in range(nx):
+                xe_fwd()
+            torch.cuda.synchronize(dev)
+            xe_rate = nx * STEPS_PER_DECODE / (time.perf_counter() - tx)
         prof = None
         if rank == 0 and not args.no_profile:
             keep, streams = streams, None                 # per-kernel timing is taken on ONE stream
@@ -219,6 +235,7 @@ def main():
                    "single_stream_decode_steps_per_sec": (None if single is None else
                                                           round(args.steps * STEPS_PER_DECODE / single, 2)),
                    "single_stream_ms_per_step": None if single is None else round(1e3 * single / args.steps, 4),
+                   "xe_forward_single_stream_decode_steps_per_sec": None if xe_rate is None else round(xe_rate, 2),
                    "distinct_tokens_in_last_batch": int(torch.unique(seq).numel())},
     }
     if prof is not None:

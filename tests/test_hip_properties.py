@@ -77,3 +77,14 @@ def test_xe_rows_beyond_decode_length_are_zero_and_prefix_consistent(setup):
         assert not pred[b, L:].any()
         assert np.abs(pred[b, :L]).max() > 0
     assert list(dl) == sorted(dl, reverse=True)
+
+
+def test_device_prefetcher_roundtrip(setup):
+    from show_edit_tell_amd.pipeline import DevicePrefetcher
+    d, xe, rl, X, prev, plen = setup
+    host = [(torch.from_numpy(d["X"][i * 32:(i + 1) * 32].copy()), torch.from_numpy(d["prev"][i * 32:(i + 1) * 32].copy()))
+            for i in range(4)]
+    got = list(DevicePrefetcher(host, X.device, depth=2))
+    assert len(got) == 4
+    for (hx, hp), (dx, dp) in zip(host, got):
+        assert dx.is_cuda and torch.equal(dx.cpu(), hx) and torch.equal(dp.cpu(), hp)
