@@ -138,3 +138,116 @@ def sentence(seq, word_map):
     rev = {v: k for k, v in word_map.items()}
     skip = {word_map['<start>'], word_map['<end>'], word_map['<pad>']}
     return ' '.join(rev[w] for w in seq if w not in skip)
+
+
+# ------------------------------------------------------------------------------------------------
+# the same beam search for MANY images at once (the reference is batch 1).
+# The decode step of all NI*k hypotheses is one call of the fused HIP step (`set_editnet_step`); the
+# per-sequence prologue runs once per image and its invariants are replicated k times; the beam
+# bookkeeping is vectorised torch on the device (top-k over k*V per image, parent/word split,
+# completed-hypothesis tracking, state re-indexing).  Semantics per image are those of
+# editnet.py:643-713: k shrinks as hypotheses emit <end>; the answer is the best COMPLETED
+# hypothesis (first maximum), or seqs[0][:18] if the step limit is hit.
+# ------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def beam_search_editnet_batched(decoder, image_features, previous_caption, prev_caplen, word_map, beam_size=3,
+                                max_steps=50):
+    """image_features (NI,R,F), previous_caption (NI,T), prev_caplen (NI,1) -> list of NI token lists."""
+    import ctypes as C
+    from . import _lib
+    from ._lib import check, ptr, stream_of
+    decoder.eval()
+    lib = _lib.load()
+    dev = image_features.device
+    X = image_features.float().contiguous()
+    prev = previous_caption.long().contiguous()
+    plen = prev_caplen.reshape(-1).long().contiguous()
+    NI, R, Fd = X.shape
+    T, k, V, D = prev.shape[1], beam_size, decoder.vocab_size, decoder.decoder_dim
+    A = decoder._attention_dim
+    start, end = int(word_map['<start>']), int(word_map['<end>'])
+    st = stream_of(dev)
+    # 1. prologue once per image
+    d_img = decoder._dims(NI, T, R, max_steps + 1)
+    w = decoder._weights(d_img)
+    ws_img = torch.empty(lib.set_editnet_workspace_bytes(C.byref(d_img)), dtype=torch.uint8, device=dev)
+    check(lib.set_editnet_begin(C.byref(w), C.byref(d_img), ptr(X), None, ptr(prev), ptr(plen), ptr(ws_img),
+                                ws_img.numel(), st), "set_editnet_begin")
+
+    def view(ws, dims, name, shape):
+        p = lib.set_editnet_ws_tensor(C.byref(dims), ptr(ws), name.encode())
+        off = p - ws.data_ptr()
+        n = 4
+        for s_ in shape:
+            n *= s_
+        return ws[off:off + n].view(torch.float32).view(*shape)
+
+    # 2. replicate the per-image invariants k times into the hypothesis workspace (rows i*k + j)
+    B = NI * k
+    d_b = decoder._dims(B, T, R, max_steps + 1)
+    ws_b = torch.empty(lib.set_editnet_workspace_bytes(C.byref(d_b)), dtype=torch.uint8, device=dev)
+    for name, shp in (("H", (T, D)), ("M", (T, D)), ("mask", (T,)), ("att1", (R, A)), ("att1_c", (T, A)),
+                      ("pre1", (4 * D,)), ("rmask", (R,))):
+        view(ws_b, d_b, name, (B,) + shp).copy_(view(ws_img, d_img, name, (NI,) + shp).repeat_interleave(k, 0))
+    Xk = X.repeat_interleave(k, 0).contiguous()
+    states = [view(ws_b, d_b, n, (B, D)) for n in ("h1", "c1", "h2", "c2")]
+    for s_ in states:
+        s_.zero_()
+    # 3. search
+    neg = float("-inf")
+    scores = torch.full((NI, k), neg, device=dev)
+    scores[:, 0] = 0.0                                   # step 1: all k rows are identical, only row 0 counts
+    k_left = torch.full((NI,), k, dtype=torch.long, device=dev)
+    words = torch.full((B,), start, dtype=torch.long, device=dev)
+    seqs = torch.full((NI, k, 1), start, dtype=torch.long, device=dev)
+    best_score = torch.full((NI,), neg, device=dev)
+    best_seq = torch.zeros(NI, max_steps + 2, dtype=torch.long, device=dev)
+    best_len = torch.zeros(NI, dtype=torch.long, device=dev)
+    logits = torch.empty(B, V, dtype=torch.float32, device=dev)
+    ar = torch.arange(k, device=dev)
+    base = (torch.arange(NI, device=dev) * k).unsqueeze(1)
+    infinite = torch.zeros(NI, dtype=torch.bool, device=dev)
+    step = 1
+    while True:
+        check(lib.set_editnet_step(C.byref(w), C.byref(d_b), ptr(Xk), ptr(words), 1, B, ptr(logits), V, ptr(ws_b),
+                                   ws_b.numel(), st), "set_editnet_step")
+        cand = scores.unsqueeze(2) + F.log_softmax(logits, dim=1).view(NI, k, V)
+        top_s, top_i = cand.view(NI, k * V).topk(k, 1, True, True)
+        parent, word = top_i // V, top_i % V
+        valid = ar.unsqueeze(0) < k_left.unsqueeze(1)                       # only the first k_left picks count
+        is_end = valid & (word == end)
+        new_seqs = torch.cat([seqs.gather(1, parent.unsqueeze(2).expand(-1, -1, seqs.shape[2])), word.unsqueeze(2)], 2)
+        # completed hypotheses: first maximum over time (complete_seqs_scores.index(max(...)))
+        comp = torch.where(is_end, top_s, torch.full_like(top_s, neg))
+        c_best, c_arg = comp.max(1)
+        upd = c_best > best_score
+        if bool(upd.any()):
+            L = new_seqs.shape[2]
+            sel = new_seqs[torch.arange(NI, device=dev), c_arg]
+            best_seq[upd, :L] = sel[upd]
+            best_len[upd] = L
+            best_score[upd] = c_best[upd]
+        k_left = k_left - is_end.sum(1)
+        live = valid & ~is_end
+        order = torch.sort((~live).to(torch.int8), dim=1, stable=True)[1]   # live picks first, selection order kept
+        parent, word, top_s, live = parent.gather(1, order), word.gather(1, order), top_s.gather(1, order), live.gather(1, order)
+        seqs = new_seqs.gather(1, order.unsqueeze(2).expand(-1, -1, new_seqs.shape[2]))
+        scores = torch.where(live, top_s, torch.full_like(top_s, neg))
+        rows = (base + parent).reshape(-1)
+        for s_ in states:
+            s_.copy_(s_[rows])
+        words = torch.where(live, word, torch.zeros_like(word)).reshape(-1).contiguous()
+        if int(k_left.max()) == 0:
+            break
+        if step > max_steps:
+            infinite = k_left > 0
+            break
+        step += 1
+    out = []
+    seqs_c, best_c, len_c, inf_c = seqs.cpu(), best_seq.cpu(), best_len.cpu(), infinite.cpu()
+    for i in range(NI):
+        if bool(inf_c[i]):
+            out.append(seqs_c[i, 0, :18].tolist())
+        else:
+            out.append(best_c[i, :int(len_c[i])].tolist())
+    return out

