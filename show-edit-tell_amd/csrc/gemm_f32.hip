@@ -144,19 +144,21 @@ __global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
     //   iteration kt:  MFMAs of tile kt from lds[buf]   ||  ds_write tile kt+1 -> lds[buf^1]
     //                                                    ||  global loads of tile kt+2 -> registers
     // so the LDS stores and the HBM/L2 loads are issued in the shadow of the 64-cycle MFMAs.
-#define SET_MFMA_KK(KK)                                                                                 \
+#define SET_FRAG_LOAD(KK, FA, FB)                                                                        \
     {                                                                                                   \
-        f32x4 a[TM], b[TN];                                                                             \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
-            a[i] = *reinterpret_cast<const f32x4*>(sA + i * 32 * LDS_STRIDE + fo[KK]);                  \
+            FA[i] = *reinterpret_cast<const f32x4*>(sA + i * 32 * LDS_STRIDE + fo[KK]);                 \
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                  \
-            b[j] = *reinterpret_cast<const f32x4*>(sW + j * 32 * LDS_STRIDE + fo[KK]);                  \
+            FB[j] = *reinterpret_cast<const f32x4*>(sW + j * 32 * LDS_STRIDE + fo[KK]);                 \
+    }
+#define SET_FRAG_MFMA(FA, FB)                                                                           \
+    {                                                                                                   \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
             _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                            \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);   \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);   \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);   \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);   \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].x, FB[j].x, acc[i][j], 0, 0, 0); \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].y, FB[j].y, acc[i][j], 0, 0, 0); \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].z, FB[j].z, acc[i][j], 0, 0, 0); \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].w, FB[j].w, acc[i][j], 0, 0, 0); \
             }                                                                                           \
     }
     // stage(kt): global loads of tile kt into a register set (no-op past the end of the slice)
@@ -171,14 +173,19 @@ __global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
     {                                                                                                   \
         const float* sA = lds[BUF] + (wm * TM * 32 + frow) * LDS_STRIDE;                                \
         const float* sW = lds[BUF] + BM * LDS_STRIDE + (wn * TN * 32 + frow) * LDS_STRIDE;              \
-        SET_MFMA_KK(0);                                                                                 \
+        f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];     /* fragments of k-block kk+1 are fetched from LDS */ \
+        SET_FRAG_LOAD(0, fa0, fb0);                   /* before the MFMAs of k-block kk are issued      */ \
+        SET_FRAG_LOAD(1, fa1, fb1);                                                                     \
+        SET_FRAG_MFMA(fa0, fb0);                                                                        \
         if ((KT) + 1 < kt1) {                                                                           \
             SET_LSTORE((BUF) ^ 1, RA, RW);                                                              \
             SET_STAGE((KT) + 3, RA, RW);                                                                \
         }                                                                                               \
-        SET_MFMA_KK(1);                                                                                 \
-        SET_MFMA_KK(2);                                                                                 \
-        SET_MFMA_KK(3);                                                                                 \
+        SET_FRAG_LOAD(2, fa0, fb0);                                                                     \
+        SET_FRAG_MFMA(fa1, fb1);                                                                        \
+        SET_FRAG_LOAD(3, fa1, fb1);                                                                     \
+        SET_FRAG_MFMA(fa0, fb0);                                                                        \
+        SET_FRAG_MFMA(fa1, fb1);                                                                        \
         __syncthreads();                                                                                \
     }
     if (kt0 < kt1) {
@@ -196,7 +203,8 @@ __global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
     }
 #undef SET_ITER
 #undef SET_STAGE
-#undef SET_MFMA_KK
+#undef SET_FRAG_LOAD
+#undef SET_FRAG_MFMA
 
     // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* Cs = T.C + (long long)ks * T.slab_stride;
@@ -228,7 +236,8 @@ __global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
 #undef SET_LSTORE
 
 int gemm_tile_m(int M) { return M <= 32 ? 32 : (M <= 64 ? 64 : 128); }
-static int gemm_tile_n(int M) { return M <= 32 ? 128 : 64; }
+static int gemm_bn128() { static int v = env_int("SET_GEMM_BN128", 0); return v; }
+static int gemm_tile_n(int M) { return (M <= 32 || (M > 64 && gemm_bn128())) ? 128 : 64; }
 
 // Split-K plan for one grouped launch: every workgroup should run about the same number of k-tiles
 // (`kper`) and the whole launch should fit the chip in ONE round: 256 CUs x 2 resident workgroups =
@@ -306,7 +315,9 @@ int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag
     static const bool sites = env_int("SET_PROFILE_SITES", 0) != 0;   // per-call-site breakdown (nested events)
     ProfScope ps2(sites ? (tag ? tag : "gemm:other") : nullptr, stream, flops, bytes);
     dim3 grid(wg), block(256);
-    if (bm == 128)
+    if (bm == 128 && bn == 128)
+        hipLaunchKernelGGL((gemm_nt_f32<128, 128, 2, 2>), grid, block, 0, stream, L);
+    else if (bm == 128)
         hipLaunchKernelGGL((gemm_nt_f32<128, 64, 2, 2>), grid, block, 0, stream, L);
     else if (bm == 64)
         hipLaunchKernelGGL((gemm_nt_f32<64, 64, 2, 2>), grid, block, 0, stream, L);
