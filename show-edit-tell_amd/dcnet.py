@@ -169,10 +169,9 @@ class DAE(nn.Module):
     def forward(self, encoded_captions, caption_lengths, encoded_previous_captions, previous_cap_length):
         """reference dcnet.py:303-350; returns (predictions, encoded_captions sorted, decode_lengths, sort_ind)."""
         _require_cuda(encoded_captions, "captions")
-        if torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters())):
+        if self.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
             return self._forward_autograd(encoded_captions, caption_lengths, encoded_previous_captions,
                                           previous_cap_length)
-        _no_train(self, "DAE.forward")
         lib = _lib.load()
         dev = encoded_captions.device
         batch_size = encoded_captions.size(0)

@@ -20,13 +20,9 @@ class DAE(_DAE_XE):
 
     def forward(self, word_map, encoded_previous_captions, previous_cap_length, sample_max=True, sample_rl=False):
         _require_cuda(encoded_previous_captions, "previous captions")
-        if sample_rl or (torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters()))):
-            if not torch.is_grad_enabled() and self.training:
-                raise NotImplementedError("train-mode rollout under torch.no_grad() is not supported; use .eval()")
+        if (sample_rl or self.training
+                or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))):
             return self._rollout_autograd(word_map, encoded_previous_captions, previous_cap_length, sample_max, sample_rl)
-        if self.training:
-            raise NotImplementedError("train-mode greedy rollout under torch.no_grad(): call .eval() first")
-        _require_cuda(encoded_previous_captions, "previous captions")
         lib = _lib.load()
         dev = encoded_previous_captions.device
         prev = _i64c(encoded_previous_captions)

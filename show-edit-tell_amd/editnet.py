@@ -422,11 +422,12 @@ class DecoderC(nn.Module):
         """Teacher-forced XE forward, reference editnet.py:479-548.  Returns
         (predictions (B,max(decode_lengths),V), encoded_captions sorted, decode_lengths, sort_ind)."""
         _require_cuda(image_features, "image features")
-        if torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters())):
+        # the fused C path is the eval-mode, no-grad, teacher-forced loop; everything else (train mode =
+        # dropout, scheduled sampling, gradients) follows the reference loop over the HIP operators
+        if (self.training or (use_ss and ss_prob > 0.0)
+                or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))):
             return self._forward_autograd(image_features, encoded_captions, caption_lengths,
                                           encoded_previous_captions, previous_cap_length, use_ss, ss_prob, image_mean)
-        if self.training:
-            raise NotImplementedError("train-mode forward under torch.no_grad() is not supported; use .eval()")
         lib = _lib.load()
         dev = image_features.device
         batch_size = encoded_captions.size(0)

@@ -29,15 +29,10 @@ class DecoderC(_DecoderXE):
     def forward(self, word_map, encoded_previous_captions, previous_cap_length, image_features, sample_max=True,
                 sample_rl=False, image_mean=None):
         _require_cuda(image_features, "image features")
-        if sample_rl or (torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters()))):
-            if not torch.is_grad_enabled() and self.training:
-                raise NotImplementedError("train-mode rollout under torch.no_grad() is not supported; use .eval()")
+        if (sample_rl or self.training
+                or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))):
             return self._rollout_autograd(word_map, encoded_previous_captions, previous_cap_length, image_features,
                                           sample_max, sample_rl, image_mean)
-        if self.training:
-            raise NotImplementedError("train-mode greedy rollout under torch.no_grad(): call .eval() first "
-                                      "(the reference does, editnet_rl.py:665)")
-        _require_cuda(image_features, "image features")
         lib = _lib.load()
         dev = image_features.device
         X = _f32c(image_features)
