@@ -95,7 +95,20 @@ static int begin_impl(const SetDcnetWeights* w, const SetDcnetDims* d, const int
     SET_TRY(zero_f32(ws.cf, (size_t)B * C, st));
     SET_TRY(zero_f32(ws.hb, (size_t)B * C, st));
     SET_TRY(zero_f32(ws.cb, (size_t)B * C, st));
+    const bool fused = (C % 128 == 0) && env_int("SET_NO_FUSED", 0) == 0;
+    float *hf_cur = ws.hf, *hf_nxt = ws.s_ef, *hb_cur = ws.hb, *hb_nxt = ws.s_eb;   // ping-pong (slab regions are free)
     for (int t = 0; t < T; ++t) {
+        if (fused) {
+            SET_TRY(fused_encoder_step(hf_cur, hf_nxt, ws.cf, w->enc_whh_f, ws.xg_f, (long long)T * 4 * C, 4 * C,
+                                       w->enc_bhh_f, prevlen, t, 0, ws.enc, nullptr, (long long)T * 2 * C, 2 * C, 0, B, C,
+                                       st));
+            SET_TRY(fused_encoder_step(hb_cur, hb_nxt, ws.cb, w->enc_whh_b, ws.xg_b, (long long)T * 4 * C, 4 * C,
+                                       w->enc_bhh_b, prevlen, t, 1, ws.enc, nullptr, (long long)T * 2 * C, 2 * C, C, B, C,
+                                       st));
+            float* tmp = hf_cur; hf_cur = hf_nxt; hf_nxt = tmp;
+            tmp = hb_cur; hb_cur = hb_nxt; hb_nxt = tmp;
+            continue;
+        }
         GemmProb p[2];
         p[0] = slab_prob(ws.s_ef, B, 4 * C, B);
         p[0].add(ws.hf, C, w->enc_whh_f, C, C);
@@ -112,8 +125,8 @@ static int begin_impl(const SetDcnetWeights* w, const SetDcnetDims* d, const int
     }
     {
         GemmProb p = slab_prob(ws.s_cat, B, 2 * C, B);                 // tanh(concat([h_fwd, h_bwd])) dcnet.py:241-242
-        p.add(ws.hf, C, w->enc_cat_w, 2 * C, C);
-        p.add(ws.hb, C, w->enc_cat_w + C, 2 * C, C);
+        p.add(hf_cur, C, w->enc_cat_w, 2 * C, C);
+        p.add(hb_cur, C, w->enc_cat_w + C, 2 * C, C);
         plan_ksplit(&p, 1, tgt);
         SET_TRY(gemm_group(&p, 1, st));
         SET_TRY(reduce_bias_act(slabs_of(p), w->enc_cat_b, nullptr, ws.final_hidden, 2 * C, B, 2 * C, SET_ACT_TANH, st));
