@@ -269,6 +269,48 @@ int set_caption_encoder_f32(const SetEditNetWeights* w, const int64_t* seq, cons
                             float* H, float* Mem, float* final_hidden, float* mask, int B, int T,
                             int D, int V, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training support (the reference's backward is PyTorch autograd over a1-a12,
+ * editnet.py:579).  `*_train_f32` = the operator forward that additionally stores what its
+ * backward needs (POST-activation gates i,f,g,o; copy gate; context-gate factors); `*_bwd_f32` =
+ * the hand-written pointwise / attention part of the operator's backward.  The plain dX = dY W and
+ * dW = dY^T X contractions between them are library GEMMs on the PyTorch side (autograd_ops.py).
+ * ------------------------------------------------------------------------------------------ */
+int set_lstm_cell_train_f32(const float* x, int64_t ldx, int Kx, const float* h, const float* c,
+                            const float* w_ih, int64_t ld_wih, const float* w_hh, const float* b_ih,
+                            const float* b_hh, float* h_out, float* c_out, float* gates_out, int M, int D,
+                            void* ws, size_t ws_bytes, void* stream);
+/* dgates (M,4D) = pre-activation gate gradients, dc_prev (M,D); dh / dc may be NULL (zero) */
+int set_lstm_cell_bwd_f32(const float* dh, const float* dc, const float* gates, const float* c_prev,
+                          const float* c_new, float* dgates, float* dc_prev, int M, int D, void* stream);
+int set_copy_lstm_train_f32(const SetEditNetWeights* w, const float* x, int64_t ldx, int Kx,
+                            const float* h2, const float* c2, const float* c_memory, float* h_out,
+                            float* c_out, float* gates, float* c_new, float* cg, int M, int D, void* ws,
+                            size_t ws_bytes, void* stream);
+/* stage 1 of CopyLSTMCellC backward: du (copy-gate pre-activation grad), direct grads of c_memory and
+ * c_new, o-gate pre-activation grad; stage 2 (after dcn += du W_n) is set_lstm_gates_bwd_f32 */
+int set_copy_gate_bwd_f32(const float* dh, const float* dadp, const float* ogate, const float* adp,
+                          const float* cg, const float* cmem, const float* c_new, float* du,
+                          float* dcm_direct, float* dcn_direct, float* do_pre, int M, int D, void* stream);
+int set_lstm_gates_bwd_f32(const float* dcn, const float* do_pre, const float* gates, const float* c_prev,
+                           float* dgates, float* dc_prev, int M, int D, void* stream);
+int set_caption_attention_train_f32(const SetEditNetWeights* w, const float* H, const float* att1_c,
+                                    const float* h1, const float* word, const float* mask, float* gated,
+                                    float* alpha_c, float* ctx, float* zt, float* s, float* t, int M, int T,
+                                    int Dh, int D, int A, void* ws, size_t ws_bytes, void* stream);
+int set_context_gate_bwd_f32(const float* dout, const float* zt, const float* s, const float* t, float* dz,
+                             float* ds, float* dt, int M, int D, void* stream);
+/* additive-attention backward (use_tanh=1: caption attention, 0: visual attention with ReLU).
+ * values (M,L,Dv) are the attended rows (H or X); att2 (M,A) includes the decoder-projection bias.
+ * Outputs datt1 (M,L,A), datt2 (M,A), dwfull_part (M,A; sum over M = d full_att.weight),
+ * dvalues (M,L,Dv) or NULL, de (M,L) or NULL (sum = d full_att.bias). */
+int set_attention_bwd_f32(const float* dctx, const float* dalpha_ext, const float* alpha,
+                          const float* values, const float* att1, const float* att2, const float* w_full,
+                          float* datt1, float* datt2, float* dwfull_part, float* dvalues, float* de, int M,
+                          int L, int Dv, int A, int use_tanh, void* stream);
+int set_select_bwd_f32(const float* dsel, const float* Mem, const float* alpha, float* dM, float* dalpha,
+                       int M, int T, int D, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -183,6 +183,17 @@ PROTOTYPES = {
     "set_select_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "set_copy_lstm_workspace_bytes": (_Z, [_I, _I, _I]),
     "set_copy_lstm_f32": (_I, [C.POINTER(EditNetWeights), _P, _L, _I, _P, _P, _P, _P, _P, _I, _I, _P, _Z, _P]),
+    "set_lstm_cell_train_f32": (_I, [_P, _L, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _I, _I, _P, _Z, _P]),
+    "set_lstm_cell_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "set_copy_lstm_train_f32": (_I, [C.POINTER(EditNetWeights), _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P,
+                                     _Z, _P]),
+    "set_copy_gate_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "set_lstm_gates_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "set_caption_attention_train_f32": (_I, [C.POINTER(EditNetWeights), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I,
+                                             _I, _I, _I, _I, _P, _Z, _P]),
+    "set_context_gate_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "set_attention_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "set_select_bwd_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "set_caption_encoder_workspace_bytes": (_Z, [_I, _I, _I]),
     "set_caption_encoder_f32": (_I, [C.POINTER(EditNetWeights), _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),
 }

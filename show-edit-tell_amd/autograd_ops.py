@@ -1,20 +1,20 @@
-"""Autograd wrappers of the operator-level HIP entry points.
+"""Autograd wrappers of the operator-level HIP entry points (SURVEY.md §8 rows a1-a7, a13).
 
-Forward of every op runs the gfx950 kernels through the C ABI (include/set_hip.h).  Backward is
-PyTorch autograd over a differentiable restatement of the same operator, re-evaluated from the
-saved inputs (recompute-in-backward, like activation checkpointing): BASELINE.json's north star
-keeps autograd on the PyTorch-ROCm host side; hand-written backward kernels are the next round
-(DESIGN.md §0 row a13).  Gradient parity is tested against the reference's own autograd
-(tests/golden/*: `grad.*`), not against these formulas.
-
-Each formula cites the reference lines it restates; none of them is used in any forward pass.
+Forward of every operator runs the gfx950 kernels through the C ABI (`*_train_f32` variants keep
+what the backward needs).  Backward: the pointwise / attention part of each operator is a
+hand-written HIP kernel (`csrc/backward.hip`: `set_lstm_cell_bwd_f32`, `set_copy_gate_bwd_f32`,
+`set_lstm_gates_bwd_f32`, `set_context_gate_bwd_f32`, `set_attention_bwd_f32`,
+`set_select_bwd_f32`); the plain contractions between them (dX = dY W, dW = dY^T X, bias column
+sums) are library GEMMs through torch (`torch.mm` = rocBLAS/hipBLASLt) — BASELINE.json's north star
+keeps autograd on the PyTorch-ROCm host side, and "plain library GEMMs" are the one place the
+design rules allow a vendor library.  Gradient parity is tested against the REFERENCE's own
+autograd (tests/golden `grad.*`, tests/test_hip_train.py).
 """
 from __future__ import annotations
 
 import ctypes as C
 
 import torch
-import torch.nn.functional as F
 
 from . import _lib
 from ._lib import EditNetWeights, check, ptr, stream_of
@@ -24,260 +24,337 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-class _HipFn(torch.autograd.Function):
-    """forward: `hip(*inputs)` (no grad); backward: autograd over `formula(*inputs)`."""
-
-    @staticmethod
-    def forward(ctx, hip, formula, nout, *inputs):
-        with torch.no_grad():
-            outs = hip(*inputs)
-        if not isinstance(outs, tuple):
-            outs = (outs,)
-        ctx.formula = formula
-        ctx.is_tensor = [isinstance(t, torch.Tensor) for t in inputs]
-        ctx.consts = [None if isinstance(t, torch.Tensor) else t for t in inputs]
-        ctx.save_for_backward(*[t for t in inputs if isinstance(t, torch.Tensor)])
-        ctx.nout = nout
-        return outs if nout > 1 else outs[0]
-
-    @staticmethod
-    def backward(ctx, *grads):
-        saved = list(ctx.saved_tensors)
-        inputs, k = [], 0
-        for is_t, cst in zip(ctx.is_tensor, ctx.consts):
-            if is_t:
-                t = saved[k]
-                k += 1
-                inputs.append(t.detach().requires_grad_(t.is_floating_point()))
-            else:
-                inputs.append(cst)
-        need = [i for i, (is_t, t) in enumerate(zip(ctx.is_tensor, inputs))
-                if is_t and t.requires_grad and ctx.needs_input_grad[3 + i]]
-        with torch.enable_grad():
-            outs = ctx.formula(*inputs)
-        if not isinstance(outs, tuple):
-            outs = (outs,)
-        pairs = [(o, g) for o, g in zip(outs, grads) if g is not None and o.requires_grad]
-        gin = [None] * len(inputs)
-        if pairs and need:
-            res = torch.autograd.grad([o for o, _ in pairs], [inputs[i] for i in need], [g for _, g in pairs],
-                                      allow_unused=True)
-            for i, r in zip(need, res):
-                gin[i] = r
-        return (None, None, None) + tuple(gin)
+def _ws(lib_fn, *dims, device):
+    return torch.empty(max(16, lib_fn(*dims)), dtype=torch.uint8, device=device)
 
 
-def _apply(hip, formula, nout, *inputs):
-    return _HipFn.apply(hip, formula, nout, *inputs)
+def _colsum(t):
+    return t.sum(0)
 
 
 # ------------------------------------------------------------------------------------------------
 # nn.Linear (+ activation)
 # ------------------------------------------------------------------------------------------------
-def linear(x, weight, bias, act=_lib.ACT_NONE):
-    def hip(x, w, b):
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, act):
         lib = _lib.load()
         x2 = _c(x.reshape(-1, x.shape[-1]))
         M, K, N = x2.shape[0], x2.shape[1], w.shape[0]
         y = torch.empty(M, N, dtype=torch.float32, device=x.device)
-        ws = torch.empty(max(16, lib.set_linear_workspace_bytes(M, N, K)), dtype=torch.uint8, device=x.device)
+        ws = _ws(lib.set_linear_workspace_bytes, M, N, K, device=x.device)
         check(lib.set_linear_f32(ptr(x2), K, ptr(w), K, ptr(b), ptr(y), N, M, N, K, act, ptr(ws), ws.numel(),
                                  stream_of(x.device)), "set_linear_f32")
+        ctx.act, ctx.xshape = act, x.shape
+        ctx.save_for_backward(x2, w, y if act != _lib.ACT_NONE else None)
         return y.reshape(*x.shape[:-1], N)
 
-    def formula(x, w, b):
-        y = F.linear(x, w, b)
-        if act == _lib.ACT_RELU:
-            y = torch.relu(y)
-        elif act == _lib.ACT_TANH:
-            y = torch.tanh(y)
-        elif act == _lib.ACT_SIGMOID:
-            y = torch.sigmoid(y)
-        return y
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, y = ctx.saved_tensors
+        dy = _c(dy).reshape(-1, dy.shape[-1])
+        if ctx.act == _lib.ACT_RELU:
+            dy = dy * (y > 0)
+        elif ctx.act == _lib.ACT_TANH:
+            dy = dy * (1 - y * y)
+        elif ctx.act == _lib.ACT_SIGMOID:
+            dy = dy * y * (1 - y)
+        dx = dy.mm(w).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dw = dy.t().mm(x2) if ctx.needs_input_grad[1] else None
+        db = _colsum(dy) if ctx.needs_input_grad[2] else None
+        return dx, dw, db, None
 
-    return _apply(hip, formula, 1, x, weight, bias)
+
+def linear(x, weight, bias, act=_lib.ACT_NONE):
+    return _Linear.apply(x, weight, bias, act)
 
 
 # ------------------------------------------------------------------------------------------------
 # EmbeddingC.forward without the dropout (editnet.py:301-302)
 # ------------------------------------------------------------------------------------------------
-def embed_relu(ids, table):
-    def hip(ids, table):
+class _EmbedRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, table):
         lib = _lib.load()
         ids_c = _c(ids)
         n, D = ids_c.numel(), table.shape[1]
         out = torch.empty(tuple(ids_c.shape) + (D,), dtype=torch.float32, device=ids.device)
         check(lib.set_embed_relu_f32(ptr(table), ptr(ids_c), 1, ptr(out), D, n, D, table.shape[0],
                                      stream_of(ids.device)), "set_embed_relu_f32")
+        ctx.save_for_backward(ids_c, out)
+        ctx.V = table.shape[0]
         return out
 
-    return _apply(hip, lambda ids, table: torch.relu(F.embedding(ids, table)), 1, ids, table)
+    @staticmethod
+    def backward(ctx, dout):
+        ids, out = ctx.saved_tensors
+        D = out.shape[-1]
+        g = (dout * (out > 0)).reshape(-1, D)
+        dt = torch.zeros(ctx.V, D, dtype=torch.float32, device=out.device)
+        dt.index_add_(0, ids.reshape(-1), g)
+        return None, dt
+
+
+def embed_relu(ids, table):
+    return _EmbedRelu.apply(ids, table)
 
 
 # ------------------------------------------------------------------------------------------------
 # nn.LSTMCell / LSTMCellC (editnet.py:226-244)
 # ------------------------------------------------------------------------------------------------
-def _lstm_formula(x, h, c, w_ih, w_hh, b_ih, b_hh):
-    gates = F.linear(x, w_ih, b_ih) + F.linear(h, w_hh, b_hh)
-    i, f, g, o = gates.chunk(4, 1)
-    c_new = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
-    return torch.sigmoid(o) * torch.tanh(c_new), c_new
-
-
-def lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh):
-    def hip(x, h, c, w_ih, w_hh, b_ih, b_hh):
+class _LstmCell(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, h, c, w_ih, w_hh, b_ih, b_hh):
         lib = _lib.load()
         x, h, c = _c(x), _c(h), _c(c)
         M, K, D = x.shape[0], x.shape[1], h.shape[1]
         h_new, c_new = torch.empty_like(h), torch.empty_like(c)
-        ws = torch.empty(lib.set_lstm_cell_workspace_bytes(M, D, K), dtype=torch.uint8, device=x.device)
-        check(lib.set_lstm_cell_f32(ptr(x), K, K, ptr(h), ptr(c), ptr(w_ih), K, ptr(w_hh), ptr(b_ih), ptr(b_hh),
-                                    ptr(h_new), ptr(c_new), M, D, ptr(ws), ws.numel(), stream_of(x.device)),
-              "set_lstm_cell_f32")
+        gates = torch.empty(M, 4 * D, dtype=torch.float32, device=x.device)
+        ws = _ws(lib.set_lstm_cell_workspace_bytes, M, D, K, device=x.device)
+        check(lib.set_lstm_cell_train_f32(ptr(x), K, K, ptr(h), ptr(c), ptr(w_ih), K, ptr(w_hh), ptr(b_ih), ptr(b_hh),
+                                          ptr(h_new), ptr(c_new), ptr(gates), M, D, ptr(ws), ws.numel(),
+                                          stream_of(x.device)), "set_lstm_cell_train_f32")
+        ctx.save_for_backward(x, h, c, w_ih, w_hh, gates, c_new)
         return h_new, c_new
 
-    return _apply(hip, _lstm_formula, 2, x, h, c, w_ih, w_hh, b_ih, b_hh)
-
-
-# ------------------------------------------------------------------------------------------------
-# CaptionAttentionC.forward (editnet.py:364-381)
-# ------------------------------------------------------------------------------------------------
-def caption_attention(H, h1, word, mask, feat_w, feat_b, dec_w, dec_b, full_w, full_b, gate_w, gate_b, sc_w, sc_b,
-                      tc_w, tc_b):
-    def hip(H, h1, word, mask, feat_w, feat_b, dec_w, dec_b, full_w, full_b, gate_w, gate_b, sc_w, sc_b, tc_w, tc_b):
+    @staticmethod
+    def backward(ctx, dh, dc):
+        x, h, c, w_ih, w_hh, gates, c_new = ctx.saved_tensors
         lib = _lib.load()
-        H, h1, word, mask = _c(H), _c(h1), _c(word), _c(mask)
+        M, D = h.shape
+        dg = torch.empty_like(gates)
+        dcp = torch.empty_like(c)
+        check(lib.set_lstm_cell_bwd_f32(ptr(None if dh is None else _c(dh)), ptr(None if dc is None else _c(dc)),
+                                        ptr(gates), ptr(c), ptr(c_new), ptr(dg), ptr(dcp), M, D,
+                                        stream_of(h.device)), "set_lstm_cell_bwd_f32")
+        db = _colsum(dg)
+        return dg.mm(w_ih), dg.mm(w_hh), dcp, dg.t().mm(x), dg.t().mm(h), db, db
+
+
+def lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh):
+    return _LstmCell.apply(x, h, c, w_ih, w_hh, b_ih, b_hh)
+
+
+# ------------------------------------------------------------------------------------------------
+# additive attention backward shared by the caption (tanh) and visual (relu) attentions
+# ------------------------------------------------------------------------------------------------
+def _attention_bwd(dctx, dalpha_ext, alpha, values, att1, att2, w_full, use_tanh, want_dvalues):
+    lib = _lib.load()
+    M, L, Dv = values.shape
+    A = att1.shape[2]
+    dev = values.device
+    datt1 = torch.empty(M, L, A, dtype=torch.float32, device=dev)
+    datt2 = torch.empty(M, A, dtype=torch.float32, device=dev)
+    dwf = torch.empty(M, A, dtype=torch.float32, device=dev)
+    de = torch.empty(M, L, dtype=torch.float32, device=dev)
+    dval = torch.empty(M, L, Dv, dtype=torch.float32, device=dev) if want_dvalues else None
+    check(lib.set_attention_bwd_f32(ptr(_c(dctx)), ptr(None if dalpha_ext is None else _c(dalpha_ext)), ptr(alpha),
+                                    ptr(values), ptr(att1), ptr(att2), ptr(_c(w_full.reshape(-1))), ptr(datt1),
+                                    ptr(datt2), ptr(dwf), ptr(dval), ptr(de), M, L, Dv, A, 1 if use_tanh else 0,
+                                    stream_of(dev)), "set_attention_bwd_f32")
+    return datt1, datt2, dwf.sum(0, keepdim=True), dval, de.sum().reshape(1)
+
+
+# ------------------------------------------------------------------------------------------------
+# CaptionAttentionC.forward (editnet.py:364-381) with the loop-invariant att1_c = cap_features_att(H)
+# passed in (its gradient accumulates over the timesteps and flows once through `linear`)
+# ------------------------------------------------------------------------------------------------
+class _CaptionAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, H, att1_c, h1, word, mask, dec_w, dec_b, full_w, full_b, gate_w, gate_b, sc_w, sc_b, tc_w, tc_b):
+        lib = _lib.load()
+        H, att1_c, h1, word, mask = _c(H), _c(att1_c), _c(h1), _c(word), _c(mask)
         M, T, D = H.shape
         A = dec_w.shape[0]
+        dev = H.device
         w = EditNetWeights()
-        w.ca_feat_w, w.ca_feat_b, w.ca_dec_w, w.ca_dec_b = feat_w.data_ptr(), feat_b.data_ptr(), dec_w.data_ptr(), dec_b.data_ptr()
+        w.ca_dec_w, w.ca_dec_b = dec_w.data_ptr(), dec_b.data_ptr()
         w.ca_full_w, w.ca_full_b, w.ca_gate_w, w.ca_gate_b = full_w.data_ptr(), full_b.data_ptr(), gate_w.data_ptr(), gate_b.data_ptr()
         w.ca_sc_w, w.ca_sc_b, w.ca_tc_w, w.ca_tc_b = sc_w.data_ptr(), sc_b.data_ptr(), tc_w.data_ptr(), tc_b.data_ptr()
-        gated = torch.empty(M, D, dtype=torch.float32, device=H.device)
-        alpha = torch.empty(M, T, dtype=torch.float32, device=H.device)
-        ws = torch.empty(lib.set_caption_attention_workspace_bytes(M, T, D, A), dtype=torch.uint8, device=H.device)
-        check(lib.set_caption_attention_f32(C.byref(w), ptr(H), None, ptr(h1), ptr(word), ptr(mask), ptr(gated),
-                                            ptr(alpha), M, T, D, D, A, ptr(ws), ws.numel(), stream_of(H.device)),
-              "set_caption_attention_f32")
+        gated, cx, zt, s, t = (torch.empty(M, D, dtype=torch.float32, device=dev) for _ in range(5))
+        alpha = torch.empty(M, T, dtype=torch.float32, device=dev)
+        ws = _ws(lib.set_caption_attention_workspace_bytes, M, T, D, A, device=dev)
+        check(lib.set_caption_attention_train_f32(C.byref(w), ptr(H), ptr(att1_c), ptr(h1), ptr(word), ptr(mask),
+                                                  ptr(gated), ptr(alpha), ptr(cx), ptr(zt), ptr(s), ptr(t), M, T, D, D, A,
+                                                  ptr(ws), ws.numel(), stream_of(dev)), "set_caption_attention_train_f32")
+        ctx.save_for_backward(H, att1_c, h1, word, dec_w, dec_b, full_w, gate_w, sc_w, tc_w, alpha, cx, zt, s, t)
         return gated, alpha
 
-    def formula(H, h1, word, mask, feat_w, feat_b, dec_w, dec_b, full_w, full_b, gate_w, gate_b, sc_w, sc_b, tc_w, tc_b):
-        att1 = F.linear(H, feat_w, feat_b)
-        att2 = F.linear(h1, dec_w, dec_b)
-        e = F.linear(torch.tanh(att1 + att2.unsqueeze(1)), full_w, full_b).squeeze(2)
-        e = e.masked_fill(mask == 0, -1e10)
-        alpha = F.softmax(e, dim=1)
-        ctx = (H * alpha.unsqueeze(2)).sum(1)
-        zt = torch.sigmoid(F.linear(torch.cat([word, h1, ctx], 1), gate_w, gate_b))
-        out = zt * torch.tanh(F.linear(ctx, sc_w, sc_b)) + (1 - zt) * torch.tanh(F.linear(torch.cat([word, h1], 1), tc_w, tc_b))
-        return out, alpha
-
-    return _apply(hip, formula, 2, H, h1, word, mask, feat_w, feat_b, dec_w, dec_b, full_w, full_b, gate_w, gate_b,
-                  sc_w, sc_b, tc_w, tc_b)
-
-
-# ------------------------------------------------------------------------------------------------
-# VisualAttentionC.forward given att1 = features_att(att_embed(X)) (editnet.py:443-446)
-# ------------------------------------------------------------------------------------------------
-def visual_attention_from_att1(X, att1, h1, dec_w, dec_b, full_w, full_b):
-    def hip(X, att1, h1, dec_w, dec_b, full_w, full_b):
+    @staticmethod
+    def backward(ctx, dgated, dalpha):
+        H, att1_c, h1, word, dec_w, dec_b, full_w, gate_w, sc_w, tc_w, alpha, cx, zt, s, t = ctx.saved_tensors
         lib = _lib.load()
-        X, att1, h1 = _c(X), _c(att1), _c(h1)
-        M, R, Fd = X.shape
-        D, A = dec_w.shape[1], dec_w.shape[0]
-        w = EditNetWeights()
-        w.va_dec_w, w.va_dec_b, w.va_full_w, w.va_full_b = dec_w.data_ptr(), dec_b.data_ptr(), full_w.data_ptr(), full_b.data_ptr()
-        ctx = torch.empty(M, Fd, dtype=torch.float32, device=X.device)
-        ws = torch.empty(lib.set_visual_attention_workspace_bytes(M, R, Fd, D, A), dtype=torch.uint8, device=X.device)
-        check(lib.set_visual_attention_f32(C.byref(w), ptr(X), ptr(att1), ptr(h1), ptr(ctx), None, M, R, Fd, D, A, 0,
-                                           ptr(ws), ws.numel(), stream_of(X.device)), "set_visual_attention_f32")
-        return ctx
-
-    def formula(X, att1, h1, dec_w, dec_b, full_w, full_b):
-        att2 = F.linear(h1, dec_w, dec_b)
-        e = F.linear(torch.relu(att1 + att2.unsqueeze(1)), full_w, full_b).squeeze(2)
-        alpha = F.softmax(e, dim=1)
-        return (X * alpha.unsqueeze(2)).sum(1)
-
-    return _apply(hip, formula, 1, X, att1, h1, dec_w, dec_b, full_w, full_b)
-
-
-# ------------------------------------------------------------------------------------------------
-# SelectC.forward, hard mode (editnet.py:409-420): straight-through weight on the arg-max row
-# ------------------------------------------------------------------------------------------------
-def select(Mem, alpha):
-    def hip(Mem, alpha):
-        lib = _lib.load()
-        Mem, alpha = _c(Mem), _c(alpha)
-        B, T, D = Mem.shape
-        sel = torch.empty(B, D, dtype=torch.float32, device=Mem.device)
-        check(lib.set_select_f32(ptr(Mem), ptr(alpha), ptr(sel), B, T, D, stream_of(Mem.device)), "set_select_f32")
-        return sel
-
-    def formula(Mem, alpha):
-        a_d = alpha.detach()
-        val, idx = a_d.max(1)
-        onehot = torch.zeros_like(a_d).scatter_(1, idx.unsqueeze(1), 1.0)
-        w = alpha * onehot + onehot * (1 - val).unsqueeze(1)
-        return (w.unsqueeze(2) * Mem).sum(1)
-
-    return _apply(hip, formula, 1, Mem, alpha)
+        M, D = cx.shape
+        dev = H.device
+        dz, ds, dt = (torch.empty(M, D, dtype=torch.float32, device=dev) for _ in range(3))
+        check(lib.set_context_gate_bwd_f32(ptr(_c(dgated)), ptr(zt), ptr(s), ptr(t), ptr(dz), ptr(ds), ptr(dt), M, D,
+                                           stream_of(dev)), "set_context_gate_bwd_f32")
+        dctx = dz.mm(gate_w[:, 2 * D:]) + ds.mm(sc_w)
+        dword = dz.mm(gate_w[:, :D]) + dt.mm(tc_w[:, :D])
+        dh1 = dz.mm(gate_w[:, D:2 * D]) + dt.mm(tc_w[:, D:])
+        wh = torch.cat([word, h1], 1)
+        d_gate_w = dz.t().mm(torch.cat([wh, cx], 1))
+        d_sc_w = ds.t().mm(cx)
+        d_tc_w = dt.t().mm(wh)
+        att2 = torch.addmm(dec_b, h1, dec_w.t())
+        datt1, datt2, dfull_w, dH, dfull_b = _attention_bwd(dctx, dalpha, alpha, H, att1_c, att2, full_w, True, True)
+        dh1 = dh1 + datt2.mm(dec_w)
+        return (dH, datt1, dh1, dword, None, datt2.t().mm(h1), _colsum(datt2), dfull_w, dfull_b, d_gate_w, _colsum(dz),
+                d_sc_w, _colsum(ds), d_tc_w, _colsum(dt))
 
 
-# ------------------------------------------------------------------------------------------------
-# CopyLSTMCellC.forward (editnet.py:265-285)
-# ------------------------------------------------------------------------------------------------
-def copy_lstm(x, h2, c2, cmem, x2h_w, x2h_b, h2h_w, h2h_b, cnew_w, cnew_b, cmem_w, cmem_b):
-    def hip(x, h2, c2, cmem, x2h_w, x2h_b, h2h_w, h2h_b, cnew_w, cnew_b, cmem_w, cmem_b):
-        lib = _lib.load()
-        x, h2, c2, cmem = _c(x), _c(h2), _c(c2), _c(cmem)
-        M, K, D = x.shape[0], x.shape[1], h2.shape[1]
-        w = EditNetWeights()
-        w.cl_x2h_w, w.cl_x2h_b, w.cl_h2h_w, w.cl_h2h_b = x2h_w.data_ptr(), x2h_b.data_ptr(), h2h_w.data_ptr(), h2h_b.data_ptr()
-        w.cl_cnew_w, w.cl_cnew_b, w.cl_cmem_w, w.cl_cmem_b = cnew_w.data_ptr(), cnew_b.data_ptr(), cmem_w.data_ptr(), cmem_b.data_ptr()
-        h_new, c_new = torch.empty_like(h2), torch.empty_like(c2)
-        ws = torch.empty(lib.set_copy_lstm_workspace_bytes(M, D, K), dtype=torch.uint8, device=x.device)
-        check(lib.set_copy_lstm_f32(C.byref(w), ptr(x), K, K, ptr(h2), ptr(c2), ptr(cmem), ptr(h_new), ptr(c_new), M, D,
-                                    ptr(ws), ws.numel(), stream_of(x.device)), "set_copy_lstm_f32")
-        return h_new, c_new
-
-    def formula(x, h2, c2, cmem, x2h_w, x2h_b, h2h_w, h2h_b, cnew_w, cnew_b, cmem_w, cmem_b):
-        gates = F.linear(x, x2h_w, x2h_b) + F.linear(h2, h2h_w, h2h_b)
-        i, f, g, o = gates.chunk(4, 1)
-        c_new = torch.sigmoid(f) * c2 + torch.sigmoid(i) * torch.tanh(g)
-        copy = torch.sigmoid(F.linear(c_new, cnew_w, cnew_b) + F.linear(cmem, cmem_w, cmem_b))
-        adaptive = copy * cmem + (1 - copy) * c_new
-        return torch.sigmoid(o) * torch.tanh(adaptive), adaptive
-
-    return _apply(hip, formula, 2, x, h2, c2, cmem, x2h_w, x2h_b, h2h_w, h2h_b, cnew_w, cnew_b, cmem_w, cmem_b)
+def caption_attention(H, h1, word, mask, feat_w, feat_b, dec_w, dec_b, full_w, full_b, gate_w, gate_b, sc_w, sc_b,
+                      tc_w, tc_b, att1_c=None):
+    if att1_c is None:
+        att1_c = linear(H, feat_w, feat_b)
+    return _CaptionAttention.apply(H, att1_c, h1, word, mask, dec_w, dec_b, full_w, full_b, gate_w, gate_b, sc_w, sc_b,
+                                   tc_w, tc_b)
 
 
 # ------------------------------------------------------------------------------------------------
 # DCNet CaptionAttention.forward (dcnet.py:254-270): additive attention without gating
 # ------------------------------------------------------------------------------------------------
-def dcnet_caption_attention(feats, h1, mask, feat_w, feat_b, dec_w, dec_b, full_w, full_b):
-    def hip(feats, h1, mask, feat_w, feat_b, dec_w, dec_b, full_w, full_b):
+class _DcnetCaptionAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, att1_c, h1, mask, dec_w, dec_b, full_w, full_b):
         lib = _lib.load()
-        feats, h1, mask = _c(feats), _c(h1), _c(mask)
+        feats, att1_c, h1, mask = _c(feats), _c(att1_c), _c(h1), _c(mask)
         M, T, Dh = feats.shape
         D, A = h1.shape[1], dec_w.shape[0]
-        w = EditNetWeights()
-        w.ca_feat_w, w.ca_feat_b, w.ca_dec_w, w.ca_dec_b = feat_w.data_ptr(), feat_b.data_ptr(), dec_w.data_ptr(), dec_b.data_ptr()
-        w.ca_full_w, w.ca_full_b = full_w.data_ptr(), full_b.data_ptr()
-        ctx = torch.empty(M, Dh, dtype=torch.float32, device=feats.device)
-        ws = torch.empty(lib.set_caption_attention_workspace_bytes(M, T, max(Dh, D), A), dtype=torch.uint8,
-                         device=feats.device)
-        check(lib.set_caption_attention_f32(C.byref(w), ptr(feats), None, ptr(h1), None, ptr(mask), ptr(ctx), None, M,
-                                            T, Dh, D, A, ptr(ws), ws.numel(), stream_of(feats.device)),
+        dev = feats.device
+        w = EditNetWeights()          # gate weights stay NULL -> plain context
+        w.ca_dec_w, w.ca_dec_b, w.ca_full_w, w.ca_full_b = dec_w.data_ptr(), dec_b.data_ptr(), full_w.data_ptr(), full_b.data_ptr()
+        cx = torch.empty(M, Dh, dtype=torch.float32, device=dev)
+        alpha = torch.empty(M, T, dtype=torch.float32, device=dev)
+        ws = _ws(lib.set_caption_attention_workspace_bytes, M, T, max(Dh, D), A, device=dev)
+        check(lib.set_caption_attention_f32(C.byref(w), ptr(feats), ptr(att1_c), ptr(h1), None, ptr(mask), ptr(cx),
+                                            ptr(alpha), M, T, Dh, D, A, ptr(ws), ws.numel(), stream_of(dev)),
               "set_caption_attention_f32")
-        return ctx
+        ctx.save_for_backward(feats, att1_c, h1, dec_w, dec_b, full_w, alpha)
+        return cx
 
-    def formula(feats, h1, mask, feat_w, feat_b, dec_w, dec_b, full_w, full_b):
-        att1 = F.linear(feats, feat_w, feat_b)
-        att2 = F.linear(h1, dec_w, dec_b)
-        e = F.linear(torch.tanh(att1 + att2.unsqueeze(1)), full_w, full_b).squeeze(2)
-        e = e.masked_fill(mask == 0, -1e10)
-        alpha = F.softmax(e, dim=1)
-        return (feats * alpha.unsqueeze(2)).sum(1)
+    @staticmethod
+    def backward(ctx, dctx):
+        feats, att1_c, h1, dec_w, dec_b, full_w, alpha = ctx.saved_tensors
+        att2 = torch.addmm(dec_b, h1, dec_w.t())
+        datt1, datt2, dfull_w, dF, dfull_b = _attention_bwd(dctx, None, alpha, feats, att1_c, att2, full_w, True, True)
+        return dF, datt1, datt2.mm(dec_w), None, datt2.t().mm(h1), _colsum(datt2), dfull_w, dfull_b
 
-    return _apply(hip, formula, 1, feats, h1, mask, feat_w, feat_b, dec_w, dec_b, full_w, full_b)
+
+def dcnet_caption_attention(feats, h1, mask, feat_w, feat_b, dec_w, dec_b, full_w, full_b, att1_c=None):
+    if att1_c is None:
+        att1_c = linear(feats, feat_w, feat_b)
+    return _DcnetCaptionAttention.apply(feats, att1_c, h1, mask, dec_w, dec_b, full_w, full_b)
+
+
+# ------------------------------------------------------------------------------------------------
+# VisualAttentionC.forward given att1 = features_att(att_embed(X)) (editnet.py:443-446)
+# ------------------------------------------------------------------------------------------------
+class _VisualAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, att1, h1, dec_w, dec_b, full_w, full_b):
+        lib = _lib.load()
+        X, att1, h1 = _c(X), _c(att1), _c(h1)
+        M, R, Fd = X.shape
+        D, A = dec_w.shape[1], dec_w.shape[0]
+        dev = X.device
+        w = EditNetWeights()
+        w.va_dec_w, w.va_dec_b, w.va_full_w, w.va_full_b = dec_w.data_ptr(), dec_b.data_ptr(), full_w.data_ptr(), full_b.data_ptr()
+        cx = torch.empty(M, Fd, dtype=torch.float32, device=dev)
+        alpha = torch.empty(M, R, dtype=torch.float32, device=dev)
+        ws = _ws(lib.set_visual_attention_workspace_bytes, M, R, Fd, D, A, device=dev)
+        check(lib.set_visual_attention_f32(C.byref(w), ptr(X), ptr(att1), ptr(h1), ptr(cx), ptr(alpha), M, R, Fd, D, A, 0,
+                                           ptr(ws), ws.numel(), stream_of(dev)), "set_visual_attention_f32")
+        ctx.save_for_backward(X, att1, h1, dec_w, dec_b, full_w, alpha)
+        return cx
+
+    @staticmethod
+    def backward(ctx, dctx):
+        X, att1, h1, dec_w, dec_b, full_w, alpha = ctx.saved_tensors
+        att2 = torch.addmm(dec_b, h1, dec_w.t())
+        datt1, datt2, dfull_w, _, dfull_b = _attention_bwd(dctx, None, alpha, X, att1, att2, full_w, False, False)
+        return None, datt1, datt2.mm(dec_w), datt2.t().mm(h1), _colsum(datt2), dfull_w, dfull_b
+
+
+def visual_attention_from_att1(X, att1, h1, dec_w, dec_b, full_w, full_b):
+    return _VisualAttention.apply(X, att1, h1, dec_w, dec_b, full_w, full_b)
+
+
+# ------------------------------------------------------------------------------------------------
+# SelectC.forward, hard mode (editnet.py:409-420): straight-through weight on the arg-max row
+# ------------------------------------------------------------------------------------------------
+class _Select(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Mem, alpha):
+        lib = _lib.load()
+        Mem, alpha = _c(Mem), _c(alpha)
+        B, T, D = Mem.shape
+        sel = torch.empty(B, D, dtype=torch.float32, device=Mem.device)
+        check(lib.set_select_f32(ptr(Mem), ptr(alpha), ptr(sel), B, T, D, stream_of(Mem.device)), "set_select_f32")
+        ctx.save_for_backward(Mem, alpha)
+        return sel
+
+    @staticmethod
+    def backward(ctx, dsel):
+        Mem, alpha = ctx.saved_tensors
+        lib = _lib.load()
+        B, T, D = Mem.shape
+        dM = torch.empty_like(Mem)
+        dalpha = torch.empty_like(alpha)
+        check(lib.set_select_bwd_f32(ptr(_c(dsel)), ptr(Mem), ptr(alpha), ptr(dM), ptr(dalpha), B, T, D,
+                                     stream_of(Mem.device)), "set_select_bwd_f32")
+        return dM, dalpha
+
+
+def select(Mem, alpha):
+    return _Select.apply(Mem, alpha)
+
+
+# ------------------------------------------------------------------------------------------------
+# CopyLSTMCellC.forward (editnet.py:265-285)
+# ------------------------------------------------------------------------------------------------
+class _CopyLstm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, h2, c2, cmem, x2h_w, x2h_b, h2h_w, h2h_b, cnew_w, cnew_b, cmem_w, cmem_b):
+        lib = _lib.load()
+        x, h2, c2, cmem = _c(x), _c(h2), _c(c2), _c(cmem)
+        M, K, D = x.shape[0], x.shape[1], h2.shape[1]
+        dev = x.device
+        w = EditNetWeights()
+        w.cl_x2h_w, w.cl_x2h_b, w.cl_h2h_w, w.cl_h2h_b = x2h_w.data_ptr(), x2h_b.data_ptr(), h2h_w.data_ptr(), h2h_b.data_ptr()
+        w.cl_cnew_w, w.cl_cnew_b, w.cl_cmem_w, w.cl_cmem_b = cnew_w.data_ptr(), cnew_b.data_ptr(), cmem_w.data_ptr(), cmem_b.data_ptr()
+        h_new, adp, c_new, cg = (torch.empty(M, D, dtype=torch.float32, device=dev) for _ in range(4))
+        gates = torch.empty(M, 4 * D, dtype=torch.float32, device=dev)
+        ws = _ws(lib.set_copy_lstm_workspace_bytes, M, D, K, device=dev)
+        check(lib.set_copy_lstm_train_f32(C.byref(w), ptr(x), K, K, ptr(h2), ptr(c2), ptr(cmem), ptr(h_new), ptr(adp),
+                                          ptr(gates), ptr(c_new), ptr(cg), M, D, ptr(ws), ws.numel(), stream_of(dev)),
+              "set_copy_lstm_train_f32")
+        ctx.save_for_backward(x, h2, c2, cmem, x2h_w, h2h_w, cnew_w, cmem_w, gates, c_new, cg, adp)
+        return h_new, adp
+
+    @staticmethod
+    def backward(ctx, dh, dadp):
+        x, h2, c2, cmem, x2h_w, h2h_w, cnew_w, cmem_w, gates, c_new, cg, adp = ctx.saved_tensors
+        lib = _lib.load()
+        M, D = h2.shape
+        dev = x.device
+        st = stream_of(dev)
+        du, dcm, dcn, dop = (torch.empty(M, D, dtype=torch.float32, device=dev) for _ in range(4))
+        ogate = gates[:, 3 * D:].contiguous()
+        check(lib.set_copy_gate_bwd_f32(ptr(None if dh is None else _c(dh)), ptr(None if dadp is None else _c(dadp)),
+                                        ptr(ogate), ptr(adp), ptr(cg), ptr(cmem), ptr(c_new), ptr(du), ptr(dcm), ptr(dcn),
+                                        ptr(dop), M, D, st), "set_copy_gate_bwd_f32")
+        dcn = dcn + du.mm(cnew_w)
+        dcm = dcm + du.mm(cmem_w)
+        dgw = torch.empty_like(gates)
+        dc2 = torch.empty_like(c2)
+        check(lib.set_lstm_gates_bwd_f32(ptr(dcn), ptr(dop), ptr(gates), ptr(c2), ptr(dgw), ptr(dc2), M, D, st),
+              "set_lstm_gates_bwd_f32")
+        dbu = _colsum(du)
+        dbg = _colsum(dgw)
+        return (dgw.mm(x2h_w), dgw.mm(h2h_w), dc2, dcm, dgw.t().mm(x), dbg, dgw.t().mm(h2), dbg, du.t().mm(c_new), dbu,
+                du.t().mm(cmem), dbu)
+
+
+def copy_lstm(x, h2, c2, cmem, x2h_w, x2h_b, h2h_w, h2h_b, cnew_w, cnew_b, cmem_w, cmem_b):
+    return _CopyLstm.apply(x, h2, c2, cmem, x2h_w, x2h_b, h2h_w, h2h_b, cnew_w, cnew_b, cmem_w, cmem_b)

@@ -1,0 +1,334 @@
+// Backward (gradient) kernels of the decode-step operators + their C ABI.
+// The reference has no backward code: it is PyTorch autograd over a1-a12 (editnet.py:579).  Here the
+// pointwise / attention parts of every operator's backward are hand-written HIP kernels; the plain
+// dX = dY W and dW = dY^T X contractions of the backward stay library GEMMs on the PyTorch side
+// (autograd_ops.py), as BASELINE.json's north star keeps autograd host-side.
+// Conventions: `gates` holds POST-activation (i, f, g, o) as saved by the train-mode forward;
+// every kernel handles one float4 of hidden units per thread; all outputs are fully overwritten.
+#include "set_common.h"
+
+namespace set {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 ldb4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void stb4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LSTM cell backward (nn.LSTMCell / LSTMCellC, editnet.py:235-242):
+//   c' = f c + i g ; h' = o tanh(c')
+//   given dh' and dc' (external, may be NULL):  dct = dc' + dh' o (1 - tanh^2 c')
+//   d pre-activations: di = dct g i(1-i), df = dct c f(1-f), dg = dct i (1-g^2), do = dh' tanh(c') o(1-o)
+//   dc_prev = dct f
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) lstm_cell_bwd_k(const float* dh, const float* dc_in, const float* gates,
+                                                       const float* c_prev, const float* c_new, float* dgates,
+                                                       float* dc_prev, int M, int D) {
+    const int per_row = D >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)M * per_row) return;
+    const long long m = idx / per_row;
+    const int j = (int)(idx - m * per_row) << 2;
+    const float* gr = gates + m * 4 * D + j;
+    const f32x4 gi = ldb4(gr), gf = ldb4(gr + D), gg = ldb4(gr + 2 * D), go = ldb4(gr + 3 * D);
+    const f32x4 cp = ldb4(c_prev + m * D + j), cn = ldb4(c_new + m * D + j);
+    f32x4 dhv = {0.f, 0.f, 0.f, 0.f}, dcv = {0.f, 0.f, 0.f, 0.f};
+    if (dh) dhv = ldb4(dh + m * D + j);
+    if (dc_in) dcv = ldb4(dc_in + m * D + j);
+    f32x4 di, df, dg, dou, dcp;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float tc = tanhf(cn[e]);
+        const float dct = dcv[e] + dhv[e] * go[e] * (1.f - tc * tc);
+        di[e] = dct * gg[e] * gi[e] * (1.f - gi[e]);
+        df[e] = dct * cp[e] * gf[e] * (1.f - gf[e]);
+        dg[e] = dct * gi[e] * (1.f - gg[e] * gg[e]);
+        dou[e] = dhv[e] * tc * go[e] * (1.f - go[e]);
+        dcp[e] = dct * gf[e];
+    }
+    float* dr = dgates + m * 4 * D + j;
+    stb4(dr, di); stb4(dr + D, df); stb4(dr + 2 * D, dg); stb4(dr + 3 * D, dou);
+    stb4(dc_prev + m * D + j, dcp);
+}
+
+// ---------------------------------------------------------------------------------------------
+// CopyLSTMCellC backward, stage 1 (editnet.py:281-283):
+//   cg = sig(u) ; adp = cg cm + (1-cg) cn ; h = o tanh(adp)
+//   given dh and dadp (external, may be NULL):
+//     dadp_t = dadp + dh o (1 - tanh^2 adp) ; do_pre = dh tanh(adp) o(1-o)
+//     du = dadp_t (cm - cn) cg (1-cg) ; dcm_direct = dadp_t cg ; dcn_direct = dadp_t (1-cg)
+// stage 2 (after dcn = dcn_direct + du W_n on the host side) is lstm_gates_bwd_k.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) copy_gate_bwd_k(const float* dh, const float* dadp_in, const float* ogate,
+                                                       const float* adp, const float* cg, const float* cmem,
+                                                       const float* c_new, float* du, float* dcm_direct,
+                                                       float* dcn_direct, float* do_pre, int M, int D) {
+    const int per_row = D >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)M * per_row) return;
+    const long long o = idx * 4;
+    f32x4 dhv = {0.f, 0.f, 0.f, 0.f}, dav = {0.f, 0.f, 0.f, 0.f};
+    if (dh) dhv = ldb4(dh + o);
+    if (dadp_in) dav = ldb4(dadp_in + o);
+    const f32x4 og = ldb4(ogate + o), ad = ldb4(adp + o), g = ldb4(cg + o), cm = ldb4(cmem + o), cn = ldb4(c_new + o);
+    f32x4 duv, dcm, dcn, dop;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float ta = tanhf(ad[e]);
+        const float dat = dav[e] + dhv[e] * og[e] * (1.f - ta * ta);
+        dop[e] = dhv[e] * ta * og[e] * (1.f - og[e]);
+        duv[e] = dat * (cm[e] - cn[e]) * g[e] * (1.f - g[e]);
+        dcm[e] = dat * g[e];
+        dcn[e] = dat * (1.f - g[e]);
+    }
+    stb4(du + o, duv); stb4(dcm_direct + o, dcm); stb4(dcn_direct + o, dcn); stb4(do_pre + o, dop);
+}
+
+// LSTM gate backward given the gradient of the new cell state and the o-gate pre-activation gradient
+__global__ void __launch_bounds__(256) lstm_gates_bwd_k(const float* dcn, const float* do_pre, const float* gates,
+                                                        const float* c_prev, float* dgates, float* dc_prev, int M,
+                                                        int D) {
+    const int per_row = D >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)M * per_row) return;
+    const long long m = idx / per_row;
+    const int j = (int)(idx - m * per_row) << 2;
+    const float* gr = gates + m * 4 * D + j;
+    const f32x4 gi = ldb4(gr), gf = ldb4(gr + D), gg = ldb4(gr + 2 * D);
+    const f32x4 cp = ldb4(c_prev + m * D + j), dct = ldb4(dcn + m * D + j), dop = ldb4(do_pre + m * D + j);
+    f32x4 di, df, dg, dcp;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        di[e] = dct[e] * gg[e] * gi[e] * (1.f - gi[e]);
+        df[e] = dct[e] * cp[e] * gf[e] * (1.f - gf[e]);
+        dg[e] = dct[e] * gi[e] * (1.f - gg[e] * gg[e]);
+        dcp[e] = dct[e] * gf[e];
+    }
+    float* dr = dgates + m * 4 * D + j;
+    stb4(dr, di); stb4(dr + D, df); stb4(dr + 2 * D, dg); stb4(dr + 3 * D, dop);
+    stb4(dc_prev + m * D + j, dcp);
+}
+
+// ---------------------------------------------------------------------------------------------
+// context gating backward (editnet.py:378-380): out = zt s + (1-zt) t, zt = sig(z), s = tanh(.), t = tanh(.)
+//   dz_pre = dout (s - t) zt (1-zt) ; ds_pre = dout zt (1-s^2) ; dt_pre = dout (1-zt)(1-t^2)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) context_gate_bwd_k(const float* dout, const float* zt, const float* s,
+                                                          const float* t, float* dz, float* ds, float* dt, long long n4) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n4) return;
+    const long long o = idx * 4;
+    const f32x4 d = ldb4(dout + o), z = ldb4(zt + o), sv = ldb4(s + o), tv = ldb4(t + o);
+    f32x4 a, b, c;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        a[e] = d[e] * (sv[e] - tv[e]) * z[e] * (1.f - z[e]);
+        b[e] = d[e] * z[e] * (1.f - sv[e] * sv[e]);
+        c[e] = d[e] * (1.f - z[e]) * (1.f - tv[e] * tv[e]);
+    }
+    stb4(dz + o, a); stb4(ds + o, b); stb4(dt + o, c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// additive attention backward (caption: tanh, editnet.py:370-376 ; visual: relu, :443-446).
+// One workgroup per sample.  Given dctx (M,Dv) and an optional external dalpha (M,L):
+//   dalpha_l = <dctx, V_l> + dalpha_ext_l ; de = alpha (dalpha - sum alpha dalpha)
+//   dpre[l,a] = de_l w_full[a] act'(att1[l,a] + att2[a])        -> datt1 (M,L,A), datt2 = sum_l dpre (M,A)
+//   dwfull_part[a] = sum_l de_l act(att1[l,a] + att2[a])         (M,A), reduced over M by the caller
+//   dV_l = alpha_l dctx   (only when dV != NULL: the caption features get gradient, the image features do not)
+// att2 already contains the decoder-projection bias.
+// ---------------------------------------------------------------------------------------------
+constexpr int ATTB_MAX = 256;
+template <bool TANH>
+__global__ void __launch_bounds__(256) attention_bwd_k(const float* dctx, const float* dalpha_ext, const float* alpha,
+                                                       const float* Vals, const float* att1, const float* att2,
+                                                       const float* w_full, float* datt1, float* datt2,
+                                                       float* dwfull_part, float* dV, float* de_out, int L, int Dv,
+                                                       int A) {
+    __shared__ float s_da[ATTB_MAX];
+    __shared__ float s_de[ATTB_MAX];
+    __shared__ float s_dot;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* dc = dctx + (long long)b * Dv;
+    // dalpha_l = <dctx, V_l>: one wave per row
+    for (int l = wave; l < L; l += 4) {
+        const float* vr = Vals + ((long long)b * L + l) * Dv;
+        float s = 0.f;
+        for (int d = lane * 4; d < Dv; d += 256) {
+            const f32x4 x = ldb4(vr + d), y = ldb4(dc + d);
+            s += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+        }
+        s = wsum(s);
+        if (lane == 0) s_da[l] = s + (dalpha_ext ? dalpha_ext[(long long)b * L + l] : 0.f);
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float s = 0.f;
+        for (int l = tid; l < L; l += 64) s += alpha[(long long)b * L + l] * s_da[l];
+        s = wsum(s);
+        if (tid == 0) s_dot = s;
+    }
+    __syncthreads();
+    for (int l = tid; l < L; l += 256) {
+        const float a = alpha[(long long)b * L + l];
+        const float de = a * (s_da[l] - s_dot);
+        s_de[l] = de;
+        if (de_out) de_out[(long long)b * L + l] = de;
+    }
+    __syncthreads();
+    // datt1 / datt2 / dwfull: thread -> attention columns a = tid*4 .. (A <= 1024)
+    for (int a = tid * 4; a < A; a += 1024) {
+        const f32x4 w = ldb4(w_full + a), a2 = ldb4(att2 + (long long)b * A + a);
+        f32x4 acc2 = {0.f, 0.f, 0.f, 0.f}, accw = {0.f, 0.f, 0.f, 0.f};
+        for (int l = 0; l < L; ++l) {
+            const f32x4 p = ldb4(att1 + ((long long)b * L + l) * A + a) + a2;
+            const float de = s_de[l];
+            f32x4 dp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float act, dact;
+                if (TANH) { act = tanhf(p[e]); dact = 1.f - act * act; }
+                else { act = p[e] > 0.f ? p[e] : 0.f; dact = p[e] > 0.f ? 1.f : 0.f; }
+                dp[e] = de * w[e] * dact;
+                accw[e] += de * act;
+            }
+            acc2 += dp;
+            stb4(datt1 + ((long long)b * L + l) * A + a, dp);
+        }
+        stb4(datt2 + (long long)b * A + a, acc2);
+        stb4(dwfull_part + (long long)b * A + a, accw);
+    }
+    if (dV) {
+        for (int d = tid * 4; d < Dv; d += 1024) {
+            const f32x4 y = ldb4(dc + d);
+            for (int l = 0; l < L; ++l) stb4(dV + ((long long)b * L + l) * Dv + d, y * alpha[(long long)b * L + l]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SelectC backward (editnet.py:409-420): sel = w M[j*], w = a + (1 - a_detached)
+//   dM[b, j*] = w dsel ; dalpha[b, j*] = <dsel, M[b, j*]> ; zero elsewhere
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) select_bwd_k(const float* dsel, const float* Mem, const float* alpha, float* dM,
+                                                    float* dalpha, int T, int D) {
+    __shared__ int s_arg;
+    __shared__ float s_val, s_red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 64) {
+        float best = -INFINITY; int bi = 0x7fffffff;
+        for (int t = tid; t < T; t += 64) { const float a = alpha[(long long)b * T + t]; if (a > best) { best = a; bi = t; } }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (tid == 0) { s_arg = bi; s_val = best; }
+    }
+    __syncthreads();
+    const int js = s_arg;
+    const float w = s_val * 1.f + (1.f - s_val);
+    float dot = 0.f;
+    for (int t = 0; t < T; ++t)
+        for (int d = tid * 4; d < D; d += 1024) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (t == js) {
+                const f32x4 g = ldb4(dsel + (long long)b * D + d), m = ldb4(Mem + ((long long)b * T + t) * D + d);
+                v = g * w;
+                dot += g[0] * m[0] + g[1] * m[1] + g[2] * m[2] + g[3] * m[3];
+            }
+            stb4(dM + ((long long)b * T + t) * D + d, v);
+        }
+    dot = wsum(dot);
+    if (lane == 0) s_red[wave] = dot;
+    __syncthreads();
+    for (int t = tid; t < T; t += 256)
+        dalpha[(long long)b * T + t] = (t == js) ? ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) : 0.f;
+}
+
+}  // namespace set
+
+using namespace set;
+
+extern "C" {
+
+int set_lstm_cell_bwd_f32(const float* dh, const float* dc, const float* gates, const float* c_prev, const float* c_new,
+                          float* dgates, float* dc_prev, int M, int D, void* stream) {
+    if (!gates || !c_prev || !c_new || !dgates || !dc_prev || M <= 0 || D <= 0) return SET_ERR_ARG;
+    if (D & 3) return SET_ERR_UNSUPPORTED;
+    const long long n = (long long)M * (D >> 2);
+    ProfScope ps("lstm_cell_bwd", (hipStream_t)stream, 0.0, 4.0 * M * D * 13.0);
+    hipLaunchKernelGGL(lstm_cell_bwd_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dh, dc, gates,
+                       c_prev, c_new, dgates, dc_prev, M, D);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+int set_copy_gate_bwd_f32(const float* dh, const float* dadp, const float* ogate, const float* adp, const float* cg,
+                          const float* cmem, const float* c_new, float* du, float* dcm_direct, float* dcn_direct,
+                          float* do_pre, int M, int D, void* stream) {
+    if (!ogate || !adp || !cg || !cmem || !c_new || !du || !dcm_direct || !dcn_direct || !do_pre || M <= 0 || D <= 0)
+        return SET_ERR_ARG;
+    if (D & 3) return SET_ERR_UNSUPPORTED;
+    const long long n = (long long)M * (D >> 2);
+    hipLaunchKernelGGL(copy_gate_bwd_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dh, dadp, ogate,
+                       adp, cg, cmem, c_new, du, dcm_direct, dcn_direct, do_pre, M, D);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+int set_lstm_gates_bwd_f32(const float* dcn, const float* do_pre, const float* gates, const float* c_prev, float* dgates,
+                           float* dc_prev, int M, int D, void* stream) {
+    if (!dcn || !do_pre || !gates || !c_prev || !dgates || !dc_prev || M <= 0 || D <= 0) return SET_ERR_ARG;
+    if (D & 3) return SET_ERR_UNSUPPORTED;
+    const long long n = (long long)M * (D >> 2);
+    hipLaunchKernelGGL(lstm_gates_bwd_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dcn, do_pre,
+                       gates, c_prev, dgates, dc_prev, M, D);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+int set_context_gate_bwd_f32(const float* dout, const float* zt, const float* s, const float* t, float* dz, float* ds,
+                             float* dt, int M, int D, void* stream) {
+    if (!dout || !zt || !s || !t || !dz || !ds || !dt || M <= 0 || D <= 0) return SET_ERR_ARG;
+    if (D & 3) return SET_ERR_UNSUPPORTED;
+    const long long n = (long long)M * (D >> 2);
+    hipLaunchKernelGGL(context_gate_bwd_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dout, zt, s,
+                       t, dz, ds, dt, n);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+int set_attention_bwd_f32(const float* dctx, const float* dalpha_ext, const float* alpha, const float* values,
+                          const float* att1, const float* att2, const float* w_full, float* datt1, float* datt2,
+                          float* dwfull_part, float* dvalues, float* de, int M, int L, int Dv, int A, int use_tanh,
+                          void* stream) {
+    if (!dctx || !alpha || !values || !att1 || !att2 || !w_full || !datt1 || !datt2 || !dwfull_part || M <= 0)
+        return SET_ERR_ARG;
+    if (L > ATTB_MAX || (A & 3) || (Dv & 3) || A > 1024) return SET_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (use_tanh)
+        hipLaunchKernelGGL(attention_bwd_k<true>, dim3(M), dim3(256), 0, st, dctx, dalpha_ext, alpha, values, att1, att2,
+                           w_full, datt1, datt2, dwfull_part, dvalues, de, L, Dv, A);
+    else
+        hipLaunchKernelGGL(attention_bwd_k<false>, dim3(M), dim3(256), 0, st, dctx, dalpha_ext, alpha, values, att1, att2,
+                           w_full, datt1, datt2, dwfull_part, dvalues, de, L, Dv, A);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+int set_select_bwd_f32(const float* dsel, const float* Mem, const float* alpha, float* dM, float* dalpha, int M, int T,
+                       int D, void* stream) {
+    if (!dsel || !Mem || !alpha || !dM || !dalpha || M <= 0 || T <= 0 || D <= 0) return SET_ERR_ARG;
+    if (D & 3) return SET_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(select_bwd_k, dim3(M), dim3(256), 0, (hipStream_t)stream, dsel, Mem, alpha, dM, dalpha, T, D);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+}  // extern "C"

@@ -51,9 +51,9 @@ size_t set_lstm_cell_workspace_bytes(int M, int D, int Kx) {
     return fbytes(KS * (size_t)M * 4 * D) + 256;
 }
 
-int set_lstm_cell_f32(const float* x, int64_t ldx, int Kx, const float* h, const float* c, const float* w_ih,
-                      int64_t ld_wih, const float* w_hh, const float* b_ih, const float* b_hh, float* h_out,
-                      float* c_out, int M, int D, void* ws, size_t ws_bytes, void* stream) {
+static int lstm_cell_impl(const float* x, int64_t ldx, int Kx, const float* h, const float* c, const float* w_ih,
+                          int64_t ld_wih, const float* w_hh, const float* b_ih, const float* b_hh, float* h_out,
+                          float* c_out, float* gates_out, int M, int D, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !h || !c || !w_ih || !w_hh || !h_out || !c_out || M <= 0 || D <= 0 || Kx <= 0) return SET_ERR_ARG;
     if (!ws || !aligned16(ws) || ws_bytes < set_lstm_cell_workspace_bytes(M, D, Kx) - 256) return SET_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -63,7 +63,23 @@ int set_lstm_cell_f32(const float* x, int64_t ldx, int Kx, const float* h, const
     plan_ksplit(&p, 1, gemm_target_wgs());
     SET_TRY(gemm_group(&p, 1, st));
     const Slabs none{nullptr, 0, 0, 0};
-    return lstm_pointwise(slabs_of(p), none, none, nullptr, 0, b_ih, b_hh, c, c_out, h_out, nullptr, M, D, st);
+    return lstm_pointwise(slabs_of(p), none, none, nullptr, 0, b_ih, b_hh, c, c_out, h_out, nullptr, M, D, st,
+                          RowGather(), gates_out);
+}
+
+int set_lstm_cell_f32(const float* x, int64_t ldx, int Kx, const float* h, const float* c, const float* w_ih,
+                      int64_t ld_wih, const float* w_hh, const float* b_ih, const float* b_hh, float* h_out,
+                      float* c_out, int M, int D, void* ws, size_t ws_bytes, void* stream) {
+    return lstm_cell_impl(x, ldx, Kx, h, c, w_ih, ld_wih, w_hh, b_ih, b_hh, h_out, c_out, nullptr, M, D, ws, ws_bytes,
+                          stream);
+}
+
+int set_lstm_cell_train_f32(const float* x, int64_t ldx, int Kx, const float* h, const float* c, const float* w_ih,
+                            int64_t ld_wih, const float* w_hh, const float* b_ih, const float* b_hh, float* h_out,
+                            float* c_out, float* gates_out, int M, int D, void* ws, size_t ws_bytes, void* stream) {
+    if (!gates_out) return SET_ERR_ARG;
+    return lstm_cell_impl(x, ldx, Kx, h, c, w_ih, ld_wih, w_hh, b_ih, b_hh, h_out, c_out, gates_out, M, D, ws, ws_bytes,
+                          stream);
 }
 
 // ------------------------------------------------------------------------------- CaptionAttentionC
@@ -73,9 +89,10 @@ size_t set_caption_attention_workspace_bytes(int M, int T, int Dh, int A) {
            fbytes((size_t)M * Dh) + 256;
 }
 
-int set_caption_attention_f32(const SetEditNetWeights* w, const float* H, const float* att1_c, const float* h1,
-                              const float* word, const float* mask, float* gated, float* alpha_c, int M, int T,
-                              int Dh, int D, int A, void* ws, size_t ws_bytes, void* stream) {
+static int caption_attention_impl(const SetEditNetWeights* w, const float* H, const float* att1_c, const float* h1,
+                                  const float* word, const float* mask, float* gated, float* alpha_c, float* ctx_out,
+                                  float* zt_out, float* s_out, float* t_out, int M, int T, int Dh, int D, int A,
+                                  void* ws, size_t ws_bytes, void* stream) {
     if (!w || !H || !h1 || !mask || !gated || M <= 0 || T <= 0 || Dh <= 0 || D <= 0 || A <= 0) return SET_ERR_ARG;
     if (!ws || !aligned16(ws) || ws_bytes < set_caption_attention_workspace_bytes(M, T, Dh, A) - 256)
         return SET_ERR_WORKSPACE;
@@ -91,6 +108,7 @@ int set_caption_attention_f32(const SetEditNetWeights* w, const float* H, const 
     float* s_cgb = cv.take<float>(KS * (size_t)M * Dh);
     float* s_sc = cv.take<float>(KS * (size_t)M * Dh);
     float* ctx = cv.take<float>((size_t)M * Dh);
+    if (ctx_out) ctx = ctx_out;
     if (!att1_c) {                                                     // editnet.py:370 / dcnet.py:261
         GemmProb p = direct_prob(a1, A, M * T, A, w->ca_feat_b, SET_ACT_NONE);
         p.add(H, Dh, w->ca_feat_w, Dh, Dh);
@@ -123,7 +141,23 @@ int set_caption_attention_f32(const SetEditNetWeights* w, const float* H, const 
     plan_ksplit(c, 2, tgt);
     SET_TRY(gemm_group(c, 2, st));
     return context_gate_pointwise(slabs_of(b[2]), slabs_of(c[0]), w->ca_gate_b, slabs_of(c[1]), w->ca_sc_b,
-                                  slabs_of(b[1]), w->ca_tc_b, gated, M, D, st);
+                                  slabs_of(b[1]), w->ca_tc_b, gated, M, D, st, zt_out, s_out, t_out);
+}
+
+int set_caption_attention_f32(const SetEditNetWeights* w, const float* H, const float* att1_c, const float* h1,
+                              const float* word, const float* mask, float* gated, float* alpha_c, int M, int T,
+                              int Dh, int D, int A, void* ws, size_t ws_bytes, void* stream) {
+    return caption_attention_impl(w, H, att1_c, h1, word, mask, gated, alpha_c, nullptr, nullptr, nullptr, nullptr, M, T,
+                                  Dh, D, A, ws, ws_bytes, stream);
+}
+
+int set_caption_attention_train_f32(const SetEditNetWeights* w, const float* H, const float* att1_c, const float* h1,
+                                    const float* word, const float* mask, float* gated, float* alpha_c, float* ctx,
+                                    float* zt, float* s, float* t, int M, int T, int Dh, int D, int A, void* ws,
+                                    size_t ws_bytes, void* stream) {
+    if (!ctx || !zt || !s || !t || !alpha_c || !att1_c) return SET_ERR_ARG;
+    return caption_attention_impl(w, H, att1_c, h1, word, mask, gated, alpha_c, ctx, zt, s, t, M, T, Dh, D, A, ws, ws_bytes,
+                                  stream);
 }
 
 // ------------------------------------------------------------------------------- VisualAttentionC
@@ -179,9 +213,9 @@ size_t set_copy_lstm_workspace_bytes(int M, int D, int Kx) {
     return fbytes(KS * (size_t)M * 4 * D) + 2 * fbytes(KS * (size_t)M * D) + 2 * fbytes((size_t)M * D) + 256;
 }
 
-int set_copy_lstm_f32(const SetEditNetWeights* w, const float* x, int64_t ldx, int Kx, const float* h2,
-                      const float* c2, const float* c_memory, float* h_out, float* c_out, int M, int D, void* ws,
-                      size_t ws_bytes, void* stream) {
+static int copy_lstm_impl(const SetEditNetWeights* w, const float* x, int64_t ldx, int Kx, const float* h2,
+                          const float* c2, const float* c_memory, float* h_out, float* c_out, float* gates_out,
+                          float* cnew_out, float* cg_out, int M, int D, void* ws, size_t ws_bytes, void* stream) {
     if (!w || !x || !h2 || !c2 || !c_memory || !h_out || !c_out || M <= 0 || D <= 0 || Kx <= 0) return SET_ERR_ARG;
     if (!ws || !aligned16(ws) || ws_bytes < set_copy_lstm_workspace_bytes(M, D, Kx) - 256) return SET_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -192,6 +226,7 @@ int set_copy_lstm_f32(const SetEditNetWeights* w, const float* x, int64_t ldx, i
     float* s_n = cv.take<float>(KS * (size_t)M * D);
     float* c_new = cv.take<float>((size_t)M * D);
     float* ogate = cv.take<float>((size_t)M * D);
+    if (cnew_out) c_new = cnew_out;
     GemmProb a[2];
     a[0] = slab_prob(s_g, M, 4 * D, M);
     a[0].add(x, ldx, w->cl_x2h_w, Kx, Kx);
@@ -202,13 +237,27 @@ int set_copy_lstm_f32(const SetEditNetWeights* w, const float* x, int64_t ldx, i
     SET_TRY(gemm_group(a, 2, st));
     const Slabs none{nullptr, 0, 0, 0};
     SET_TRY(lstm_pointwise(slabs_of(a[0]), none, none, nullptr, 0, w->cl_x2h_b, w->cl_h2h_b, c2, c_new, nullptr, ogate,
-                           M, D, st));
+                           M, D, st, RowGather(), gates_out));
     GemmProb e = slab_prob(s_n, M, D, M);
     e.add(c_new, D, w->cl_cnew_w, D, D);
     plan_ksplit(&e, 1, tgt);
     SET_TRY(gemm_group(&e, 1, st));
     return copy_gate_pointwise(slabs_of(e), w->cl_cnew_b, slabs_of(a[1]), w->cl_cmem_b, c_new, c_memory, ogate, c_out,
-                               h_out, M, D, st);
+                               h_out, M, D, st, cg_out);
+}
+
+int set_copy_lstm_f32(const SetEditNetWeights* w, const float* x, int64_t ldx, int Kx, const float* h2,
+                      const float* c2, const float* c_memory, float* h_out, float* c_out, int M, int D, void* ws,
+                      size_t ws_bytes, void* stream) {
+    return copy_lstm_impl(w, x, ldx, Kx, h2, c2, c_memory, h_out, c_out, nullptr, nullptr, nullptr, M, D, ws, ws_bytes,
+                          stream);
+}
+
+int set_copy_lstm_train_f32(const SetEditNetWeights* w, const float* x, int64_t ldx, int Kx, const float* h2,
+                            const float* c2, const float* c_memory, float* h_out, float* c_out, float* gates,
+                            float* c_new, float* cg, int M, int D, void* ws, size_t ws_bytes, void* stream) {
+    if (!gates || !c_new || !cg) return SET_ERR_ARG;
+    return copy_lstm_impl(w, x, ldx, Kx, h2, c2, c_memory, h_out, c_out, gates, c_new, cg, M, D, ws, ws_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------- CaptionEncoderC

@@ -63,7 +63,8 @@ __device__ __forceinline__ void slab_accum(f32x4 (&acc)[Q], const Slabs& s, long
 __global__ void __launch_bounds__(256) lstm_pointwise_k(Slabs g0, Slabs g1, Slabs g2, const float* pre,
                                                         long long ldpre, const float* b0, const float* b1,
                                                         const float* c_in, float* c_out, float* h_out,
-                                                        float* ogate_out, int M, int D, RowGather gt) {
+                                                        float* ogate_out, int M, int D, RowGather gt,
+                                                        float* gates_out) {
     const int per_row = D >> 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)M * per_row) return;
@@ -95,16 +96,23 @@ __global__ void __launch_bounds__(256) lstm_pointwise_k(Slabs g0, Slabs g1, Slab
     st4(c_out + m * D + j, cn);
     if (h_out) st4(h_out + m * D + j, hn);
     if (ogate_out) st4(ogate_out + m * D + j, og);
+    if (gates_out) {                      // POST-activation i, f, g, o for the backward kernels
+        f32x4 ai, af, ag;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ai[e] = sigmoidf_(g[0][e]); af[e] = sigmoidf_(g[1][e]); ag[e] = tanhf(g[2][e]); }
+        float* gr = gates_out + m * 4 * D + j;
+        st4(gr, ai); st4(gr + D, af); st4(gr + 2 * D, ag); st4(gr + 3 * D, og);
+    }
 }
 
 int lstm_pointwise(Slabs g0, Slabs g1, Slabs g2, const float* pre, long long ldpre, const float* b0,
                    const float* b1, const float* c_in, float* c_out, float* h_out, float* ogate_out, int M,
-                   int D, hipStream_t s, RowGather gt) {
+                   int D, hipStream_t s, RowGather gt, float* gates_out) {
     if (D & 3) return SET_ERR_UNSUPPORTED;
     const long long n = (long long)M * (D >> 2);
     ProfScope ps("lstm_pointwise", s, 0.0, 4.0 * M * D * (4.0 * (g0.n + g1.n + g2.n + (pre ? 1 : 0)) + 3.0));
     hipLaunchKernelGGL(lstm_pointwise_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g0, g1, g2, pre,
-                       ldpre, b0, b1, c_in, c_out, h_out, ogate_out, M, D, gt);
+                       ldpre, b0, b1, c_in, c_out, h_out, ogate_out, M, D, gt, gates_out);
     SET_LAUNCH_CHECK();
     return SET_OK;
 }
@@ -115,7 +123,8 @@ int lstm_pointwise(Slabs g0, Slabs g1, Slabs g2, const float* pre, long long ldp
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) context_gate_k(Slabs cg_a, Slabs cg_b, const float* cg_bias, Slabs sc,
                                                       const float* sc_bias, Slabs tc, const float* tc_bias,
-                                                      float* out, int M, int D) {
+                                                      float* out, int M, int D, float* zt_out, float* s_out,
+                                                      float* t_out) {
     const int per_row = D >> 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)M * per_row) return;
@@ -126,22 +135,25 @@ __global__ void __launch_bounds__(256) context_gate_k(Slabs cg_a, Slabs cg_b, co
     z += ld4(cg_bias + j);
     f32x4 s = slab_sum4(sc, m, j) + ld4(sc_bias + j);
     f32x4 t = slab_sum4(tc, m, j) + ld4(tc_bias + j);
-    f32x4 o;
+    f32x4 o, zs, ss, ts;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float zt = sigmoidf_(z[e]);
-        o[e] = zt * tanhf(s[e]) + (1.f - zt) * tanhf(t[e]);
+        zs[e] = zt; ss[e] = tanhf(s[e]); ts[e] = tanhf(t[e]);
+        o[e] = zt * ss[e] + (1.f - zt) * ts[e];
     }
     st4(out + m * D + j, o);
+    if (zt_out) { st4(zt_out + m * D + j, zs); st4(s_out + m * D + j, ss); st4(t_out + m * D + j, ts); }
 }
 
 int context_gate_pointwise(Slabs cg_a, Slabs cg_b, const float* cg_bias, Slabs sc, const float* sc_bias,
-                           Slabs tc, const float* tc_bias, float* out, int M, int D, hipStream_t s) {
+                           Slabs tc, const float* tc_bias, float* out, int M, int D, hipStream_t s, float* zt_out,
+                           float* s_out, float* t_out) {
     if (D & 3) return SET_ERR_UNSUPPORTED;
     const long long n = (long long)M * (D >> 2);
     ProfScope ps("context_gate", s, 0.0, 4.0 * M * D * (cg_a.n + cg_b.n + sc.n + tc.n + 1.0));
     hipLaunchKernelGGL(context_gate_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cg_a, cg_b, cg_bias,
-                       sc, sc_bias, tc, tc_bias, out, M, D);
+                       sc, sc_bias, tc, tc_bias, out, M, D, zt_out, s_out, t_out);
     SET_LAUNCH_CHECK();
     return SET_OK;
 }
@@ -152,7 +164,7 @@ int context_gate_pointwise(Slabs cg_a, Slabs cg_b, const float* cg_bias, Slabs s
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) copy_gate_k(Slabs gn, const float* bn, Slabs gm, const float* bm,
                                                    const float* c_new, const float* sel, const float* ogate,
-                                                   float* c_out, float* h_out, int M, int D) {
+                                                   float* c_out, float* h_out, int M, int D, float* cg_out) {
     const int per_row = D >> 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)M * per_row) return;
@@ -162,25 +174,27 @@ __global__ void __launch_bounds__(256) copy_gate_k(Slabs gn, const float* bn, Sl
     f32x4 a = slab_sum4(gn, m, j) + ld4(bn + j);
     f32x4 b = slab_sum4(gm, m, j) + ld4(bm + j);
     const f32x4 cn = ld4(c_new + m * D + j), sm = ld4(sel + m * D + j), og = ld4(ogate + m * D + j);
-    f32x4 co, ho;
+    f32x4 co, ho, cgs;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float cg = sigmoidf_(a[e] + b[e]);
+        cgs[e] = cg;
         co[e] = cg * sm[e] + (1.f - cg) * cn[e];
         ho[e] = og[e] * tanhf(co[e]);
     }
     st4(c_out + m * D + j, co);
     st4(h_out + m * D + j, ho);
+    if (cg_out) st4(cg_out + m * D + j, cgs);
 }
 
 int copy_gate_pointwise(Slabs gn, const float* bn, Slabs gm, const float* bm, const float* c_new,
                         const float* sel, const float* ogate, float* c_out, float* h_out, int M, int D,
-                        hipStream_t s) {
+                        hipStream_t s, float* cg_out) {
     if (D & 3) return SET_ERR_UNSUPPORTED;
     const long long n = (long long)M * (D >> 2);
     ProfScope ps("copy_gate", s, 0.0, 4.0 * M * D * (gn.n + gm.n + 5.0));
     hipLaunchKernelGGL(copy_gate_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gn, bn, gm, bm, c_new,
-                       sel, ogate, c_out, h_out, M, D);
+                       sel, ogate, c_out, h_out, M, D, cg_out);
     SET_LAUNCH_CHECK();
     return SET_OK;
 }

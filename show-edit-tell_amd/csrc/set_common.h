@@ -120,12 +120,13 @@ struct RowGather {
 // pointwise.hip
 int lstm_pointwise(Slabs g0, Slabs g1, Slabs g2, const float* pre, long long ldpre, const float* b0,
                    const float* b1, const float* c_in, float* c_out, float* h_out, float* ogate_out,
-                   int M, int D, hipStream_t s, RowGather gt = RowGather());
+                   int M, int D, hipStream_t s, RowGather gt = RowGather(), float* gates_out = nullptr);
 int context_gate_pointwise(Slabs cg_a, Slabs cg_b, const float* cg_bias, Slabs sc, const float* sc_bias,
-                           Slabs tc, const float* tc_bias, float* out, int M, int D, hipStream_t s);
+                           Slabs tc, const float* tc_bias, float* out, int M, int D, hipStream_t s,
+                           float* zt_out = nullptr, float* s_out = nullptr, float* t_out = nullptr);
 int copy_gate_pointwise(Slabs gn, const float* bn, Slabs gm, const float* bm, const float* c_new,
                         const float* sel, const float* ogate, float* c_out, float* h_out, int M, int D,
-                        hipStream_t s);
+                        hipStream_t s, float* cg_out = nullptr);
 int reduce_bias_act(Slabs in, const float* b0, const float* b1, float* out, long long ldo, int M, int N,
                     int act, hipStream_t s);
 int embed_relu(const float* table, const int64_t* ids, long long ids_stride, float* out, long long ldo,

@@ -224,14 +224,14 @@ class DAE(nn.Module):
         final_hidden = A.linear(torch.cat(finals, 1), enc.concat.weight, enc.concat.bias, _lib.ACT_TANH)
         return outputs, final_hidden, mask
 
-    def _step_autograd(self, emb, final_hidden, enc, mask, h1, c1, h2, c2):
+    def _step_autograd(self, emb, final_hidden, enc, mask, h1, c1, h2, c2, att1_c=None):
         from . import autograd_ops as A
         al, ll, ca = self.attention_lstm, self.language_lstm, self.caption_attention
         h1, c1 = A.lstm_cell(torch.cat([emb, final_hidden, h2], 1), h1, c1, al.weight_ih, al.weight_hh, al.bias_ih,
                              al.bias_hh)
         attend_cap = A.dcnet_caption_attention(enc, h1, mask, ca.cap_features_att.weight, ca.cap_features_att.bias,
                                                ca.cap_decoder_att.weight, ca.cap_decoder_att.bias,
-                                               ca.cap_full_att.weight, ca.cap_full_att.bias)
+                                               ca.cap_full_att.weight, ca.cap_full_att.bias, att1_c=att1_c)
         h2, c2 = A.lstm_cell(torch.cat([h1, attend_cap], 1), h2, c2, ll.weight_ih, ll.weight_hh, ll.bias_ih, ll.bias_hh)
         return h1, c1, h2, c2
 
@@ -248,11 +248,13 @@ class DAE(nn.Module):
         decode_lengths = (caption_lengths - 1).tolist()
         embeddings = self.embed.dropout(A.embed_relu(encoded_captions, self.embed.embedding.weight))
         enc, final_hidden, mask = self._encoder_autograd(prev, plen)
+        ca = self.caption_attention
+        att1_c = A.linear(enc, ca.cap_features_att.weight, ca.cap_features_att.bias)       # loop invariant (dcnet.py:261)
         preds_t = []
         for t in range(max(decode_lengths)):
             bt = sum([l > t for l in decode_lengths])
             h1, c1, h2, c2 = self._step_autograd(embeddings[:bt, t], final_hidden[:bt], enc[:bt], mask[:bt], h1[:bt],
-                                                 c1[:bt], h2[:bt], c2[:bt])
+                                                 c1[:bt], h2[:bt], c2[:bt], att1_c[:bt])
             preds = A.linear(self.dropout(h2), self.fc.weight, self.fc.bias)
             if bt < batch_size:
                 preds = torch.cat([preds, preds.new_zeros(batch_size - bt, preds.shape[1])], 0)

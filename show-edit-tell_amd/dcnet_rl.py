@@ -51,10 +51,12 @@ def _dae_rollout(self, word_map, encoded_previous_captions, previous_cap_length,
     h1, c1 = self.init_hidden_state(B)
     h2, c2 = self.init_hidden_state(B)
     enc, final_hidden, mask = self._encoder_autograd(encoded_previous_captions, previous_cap_length)
+    ca = self.caption_attention
+    att1_c = A.linear(enc, ca.cap_features_att.weight, ca.cap_features_att.bias)
     unfinished = None
     for t in range(max_len + 1):
         emb = self.embed.dropout(A.embed_relu(it, self.embed.embedding.weight))
-        h1, c1, h2, c2 = self._step_autograd(emb, final_hidden, enc, mask, h1, c1, h2, c2)
+        h1, c1, h2, c2 = self._step_autograd(emb, final_hidden, enc, mask, h1, c1, h2, c2, att1_c)
         logprobs = F.log_softmax(A.linear(self.dropout(h2), self.fc.weight, self.fc.bias), dim=1)
         if t == max_len:
             break

@@ -495,6 +495,7 @@ class DecoderC(nn.Module):
         mean = X.mean(1) if image_mean is None else image_mean[sort_ind]
         ca, va, cl, al = self.caption_attention, self.visual_attention, self.copy_lstm, self.attention_lstm
         E = self.embed.embedding.weight
+        att1_c_all = A.linear(H, ca.cap_features_att.weight, ca.cap_features_att.bias)   # loop invariant (editnet.py:370)
         att1_eval = None
         if not self.training:            # dropout inactive: features_att(att_embed(X)) is loop invariant
             att1_eval = A.linear(A.linear(X, va.att_embed[0].weight, va.att_embed[0].bias, _lib.ACT_RELU),
@@ -517,7 +518,7 @@ class DecoderC(nn.Module):
                 H[:bt], h1, emb, mask[:bt], ca.cap_features_att.weight, ca.cap_features_att.bias,
                 ca.cap_decoder_att.weight, ca.cap_decoder_att.bias, ca.cap_full_att.weight, ca.cap_full_att.bias,
                 ca.context_gate.weight, ca.context_gate.bias, ca.sc_affine.weight, ca.sc_affine.bias,
-                ca.tc_affine.weight, ca.tc_affine.bias)
+                ca.tc_affine.weight, ca.tc_affine.bias, att1_c=att1_c_all[:bt])
             if att1_eval is not None:
                 att1 = att1_eval[:bt]
             else:                                                                     # fresh dropout mask per step

@@ -71,6 +71,7 @@ class DecoderC(_DecoderXE):
         mean = X.mean(1) if image_mean is None else image_mean
         ca, va, cl, al = self.caption_attention, self.visual_attention, self.copy_lstm, self.attention_lstm
         E = self.embed.embedding.weight
+        att1_c_all = A.linear(H, ca.cap_features_att.weight, ca.cap_features_att.bias)
         att1_eval = None
         if not self.training:
             att1_eval = A.linear(A.linear(X, va.att_embed[0].weight, va.att_embed[0].bias, _lib.ACT_RELU),
@@ -83,7 +84,8 @@ class DecoderC(_DecoderXE):
             attend_cap, alpha_c = A.caption_attention(
                 H, h1, emb, mask, ca.cap_features_att.weight, ca.cap_features_att.bias, ca.cap_decoder_att.weight,
                 ca.cap_decoder_att.bias, ca.cap_full_att.weight, ca.cap_full_att.bias, ca.context_gate.weight,
-                ca.context_gate.bias, ca.sc_affine.weight, ca.sc_affine.bias, ca.tc_affine.weight, ca.tc_affine.bias)
+                ca.context_gate.bias, ca.sc_affine.weight, ca.sc_affine.bias, ca.tc_affine.weight, ca.tc_affine.bias,
+                att1_c=att1_c_all)
             if att1_eval is not None:
                 att1 = att1_eval
             else:
