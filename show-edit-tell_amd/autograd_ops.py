@@ -32,6 +32,35 @@ def _colsum(t):
     return t.sum(0)
 
 
+import os as _os
+_FUSED_WGRAD = _os.environ.get("SET_FUSED_WGRAD", "1") != "0"
+
+
+def _wgrad(param, dy, x):
+    """Weight gradient dW = dy^T x, accumulated IN PLACE into param.grad (fused weight-gradient
+    accumulation): returning dW to autograd would make it allocate a weight-sized temporary and run a
+    separate weight-sized add per timestep (19 x 355 MB per training step).  Returns None so autograd
+    skips its own accumulation.  Leaf parameters only; anything else gets the gradient returned."""
+    if not _FUSED_WGRAD or not (isinstance(param, torch.nn.Parameter) and param.is_leaf):
+        return dy.t().mm(x)
+    if param.grad is None:
+        param.grad = dy.t().mm(x)
+    else:
+        param.grad.addmm_(dy.t(), x)
+    return None
+
+
+def _bgrad(param, dy):
+    g = dy.sum(0).reshape(param.shape)
+    if not _FUSED_WGRAD or not (isinstance(param, torch.nn.Parameter) and param.is_leaf):
+        return g
+    if param.grad is None:
+        param.grad = g
+    else:
+        param.grad.add_(g)
+    return None
+
+
 # ------------------------------------------------------------------------------------------------
 # nn.Linear (+ activation)
 # ------------------------------------------------------------------------------------------------
@@ -46,6 +75,7 @@ class _Linear(torch.autograd.Function):
         check(lib.set_linear_f32(ptr(x2), K, ptr(w), K, ptr(b), ptr(y), N, M, N, K, act, ptr(ws), ws.numel(),
                                  stream_of(x.device)), "set_linear_f32")
         ctx.act, ctx.xshape = act, x.shape
+        ctx.params = (w, b)
         ctx.save_for_backward(x2, w, y if act != _lib.ACT_NONE else None)
         return y.reshape(*x.shape[:-1], N)
 
@@ -59,9 +89,10 @@ class _Linear(torch.autograd.Function):
             dy = dy * (1 - y * y)
         elif ctx.act == _lib.ACT_SIGMOID:
             dy = dy * y * (1 - y)
+        pw, pb = ctx.params
         dx = dy.mm(w).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dw = dy.t().mm(x2) if ctx.needs_input_grad[1] else None
-        db = _colsum(dy) if ctx.needs_input_grad[2] else None
+        dw = _wgrad(pw, dy, x2) if ctx.needs_input_grad[1] else None
+        db = _bgrad(pb, dy) if ctx.needs_input_grad[2] else None
         return dx, dw, db, None
 
 
@@ -114,6 +145,7 @@ class _LstmCell(torch.autograd.Function):
         check(lib.set_lstm_cell_train_f32(ptr(x), K, K, ptr(h), ptr(c), ptr(w_ih), K, ptr(w_hh), ptr(b_ih), ptr(b_hh),
                                           ptr(h_new), ptr(c_new), ptr(gates), M, D, ptr(ws), ws.numel(),
                                           stream_of(x.device)), "set_lstm_cell_train_f32")
+        ctx.params = (w_ih, w_hh, b_ih, b_hh)
         ctx.save_for_backward(x, h, c, w_ih, w_hh, gates, c_new)
         return h_new, c_new
 
@@ -127,8 +159,9 @@ class _LstmCell(torch.autograd.Function):
         check(lib.set_lstm_cell_bwd_f32(ptr(None if dh is None else _c(dh)), ptr(None if dc is None else _c(dc)),
                                         ptr(gates), ptr(c), ptr(c_new), ptr(dg), ptr(dcp), M, D,
                                         stream_of(h.device)), "set_lstm_cell_bwd_f32")
-        db = _colsum(dg)
-        return dg.mm(w_ih), dg.mm(w_hh), dcp, dg.t().mm(x), dg.t().mm(h), db, db
+        p_ih, p_hh, pb_ih, pb_hh = ctx.params
+        return (dg.mm(w_ih), dg.mm(w_hh), dcp, _wgrad(p_ih, dg, x), _wgrad(p_hh, dg, h), _bgrad(pb_ih, dg),
+                _bgrad(pb_hh, dg))
 
 
 def lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh):
@@ -177,6 +210,7 @@ class _CaptionAttention(torch.autograd.Function):
         check(lib.set_caption_attention_train_f32(C.byref(w), ptr(H), ptr(att1_c), ptr(h1), ptr(word), ptr(mask),
                                                   ptr(gated), ptr(alpha), ptr(cx), ptr(zt), ptr(s), ptr(t), M, T, D, D, A,
                                                   ptr(ws), ws.numel(), stream_of(dev)), "set_caption_attention_train_f32")
+        ctx.params = (dec_w, dec_b, gate_w, gate_b, sc_w, sc_b, tc_w, tc_b)
         ctx.save_for_backward(H, att1_c, h1, word, dec_w, dec_b, full_w, gate_w, sc_w, tc_w, alpha, cx, zt, s, t)
         return gated, alpha
 
@@ -192,15 +226,16 @@ class _CaptionAttention(torch.autograd.Function):
         dctx = dz.mm(gate_w[:, 2 * D:]) + ds.mm(sc_w)
         dword = dz.mm(gate_w[:, :D]) + dt.mm(tc_w[:, :D])
         dh1 = dz.mm(gate_w[:, D:2 * D]) + dt.mm(tc_w[:, D:])
+        p_dec_w, p_dec_b, p_gate_w, p_gate_b, p_sc_w, p_sc_b, p_tc_w, p_tc_b = ctx.params
         wh = torch.cat([word, h1], 1)
-        d_gate_w = dz.t().mm(torch.cat([wh, cx], 1))
-        d_sc_w = ds.t().mm(cx)
-        d_tc_w = dt.t().mm(wh)
+        d_gate_w = _wgrad(p_gate_w, dz, torch.cat([wh, cx], 1))
+        d_sc_w = _wgrad(p_sc_w, ds, cx)
+        d_tc_w = _wgrad(p_tc_w, dt, wh)
         att2 = torch.addmm(dec_b, h1, dec_w.t())
         datt1, datt2, dfull_w, dH, dfull_b = _attention_bwd(dctx, dalpha, alpha, H, att1_c, att2, full_w, True, True)
         dh1 = dh1 + datt2.mm(dec_w)
-        return (dH, datt1, dh1, dword, None, datt2.t().mm(h1), _colsum(datt2), dfull_w, dfull_b, d_gate_w, _colsum(dz),
-                d_sc_w, _colsum(ds), d_tc_w, _colsum(dt))
+        return (dH, datt1, dh1, dword, None, _wgrad(p_dec_w, datt2, h1), _bgrad(p_dec_b, datt2), dfull_w, dfull_b,
+                d_gate_w, _bgrad(p_gate_b, dz), d_sc_w, _bgrad(p_sc_b, ds), d_tc_w, _bgrad(p_tc_b, dt))
 
 
 def caption_attention(H, h1, word, mask, feat_w, feat_b, dec_w, dec_b, full_w, full_b, gate_w, gate_b, sc_w, sc_b,
@@ -230,6 +265,7 @@ class _DcnetCaptionAttention(torch.autograd.Function):
         check(lib.set_caption_attention_f32(C.byref(w), ptr(feats), ptr(att1_c), ptr(h1), None, ptr(mask), ptr(cx),
                                             ptr(alpha), M, T, Dh, D, A, ptr(ws), ws.numel(), stream_of(dev)),
               "set_caption_attention_f32")
+        ctx.params = (dec_w, dec_b)
         ctx.save_for_backward(feats, att1_c, h1, dec_w, dec_b, full_w, alpha)
         return cx
 
@@ -238,7 +274,8 @@ class _DcnetCaptionAttention(torch.autograd.Function):
         feats, att1_c, h1, dec_w, dec_b, full_w, alpha = ctx.saved_tensors
         att2 = torch.addmm(dec_b, h1, dec_w.t())
         datt1, datt2, dfull_w, dF, dfull_b = _attention_bwd(dctx, None, alpha, feats, att1_c, att2, full_w, True, True)
-        return dF, datt1, datt2.mm(dec_w), None, datt2.t().mm(h1), _colsum(datt2), dfull_w, dfull_b
+        return (dF, datt1, datt2.mm(dec_w), None, _wgrad(ctx.params[0], datt2, h1), _bgrad(ctx.params[1], datt2), dfull_w,
+                dfull_b)
 
 
 def dcnet_caption_attention(feats, h1, mask, feat_w, feat_b, dec_w, dec_b, full_w, full_b, att1_c=None):
@@ -265,6 +302,7 @@ class _VisualAttention(torch.autograd.Function):
         ws = _ws(lib.set_visual_attention_workspace_bytes, M, R, Fd, D, A, device=dev)
         check(lib.set_visual_attention_f32(C.byref(w), ptr(X), ptr(att1), ptr(h1), ptr(cx), ptr(alpha), M, R, Fd, D, A, 0,
                                            ptr(ws), ws.numel(), stream_of(dev)), "set_visual_attention_f32")
+        ctx.params = (dec_w, dec_b)
         ctx.save_for_backward(X, att1, h1, dec_w, dec_b, full_w, alpha)
         return cx
 
@@ -273,7 +311,8 @@ class _VisualAttention(torch.autograd.Function):
         X, att1, h1, dec_w, dec_b, full_w, alpha = ctx.saved_tensors
         att2 = torch.addmm(dec_b, h1, dec_w.t())
         datt1, datt2, dfull_w, _, dfull_b = _attention_bwd(dctx, None, alpha, X, att1, att2, full_w, False, False)
-        return None, datt1, datt2.mm(dec_w), datt2.t().mm(h1), _colsum(datt2), dfull_w, dfull_b
+        return (None, datt1, datt2.mm(dec_w), _wgrad(ctx.params[0], datt2, h1), _bgrad(ctx.params[1], datt2), dfull_w,
+                dfull_b)
 
 
 def visual_attention_from_att1(X, att1, h1, dec_w, dec_b, full_w, full_b):
@@ -329,6 +368,7 @@ class _CopyLstm(torch.autograd.Function):
         check(lib.set_copy_lstm_train_f32(C.byref(w), ptr(x), K, K, ptr(h2), ptr(c2), ptr(cmem), ptr(h_new), ptr(adp),
                                           ptr(gates), ptr(c_new), ptr(cg), M, D, ptr(ws), ws.numel(), stream_of(dev)),
               "set_copy_lstm_train_f32")
+        ctx.params = (x2h_w, x2h_b, h2h_w, h2h_b, cnew_w, cnew_b, cmem_w, cmem_b)
         ctx.save_for_backward(x, h2, c2, cmem, x2h_w, h2h_w, cnew_w, cmem_w, gates, c_new, cg, adp)
         return h_new, adp
 
@@ -350,10 +390,9 @@ class _CopyLstm(torch.autograd.Function):
         dc2 = torch.empty_like(c2)
         check(lib.set_lstm_gates_bwd_f32(ptr(dcn), ptr(dop), ptr(gates), ptr(c2), ptr(dgw), ptr(dc2), M, D, st),
               "set_lstm_gates_bwd_f32")
-        dbu = _colsum(du)
-        dbg = _colsum(dgw)
-        return (dgw.mm(x2h_w), dgw.mm(h2h_w), dc2, dcm, dgw.t().mm(x), dbg, dgw.t().mm(h2), dbg, du.t().mm(c_new), dbu,
-                du.t().mm(cmem), dbu)
+        p = ctx.params
+        return (dgw.mm(x2h_w), dgw.mm(h2h_w), dc2, dcm, _wgrad(p[0], dgw, x), _bgrad(p[1], dgw), _wgrad(p[2], dgw, h2),
+                _bgrad(p[3], dgw), _wgrad(p[4], du, c_new), _bgrad(p[5], du), _wgrad(p[6], du, cmem), _bgrad(p[7], du))
 
 
 def copy_lstm(x, h2, c2, cmem, x2h_w, x2h_b, h2h_w, h2h_b, cnew_w, cnew_b, cmem_w, cmem_b):
