@@ -311,6 +311,17 @@ int set_attention_bwd_f32(const float* dctx, const float* dalpha_ext, const floa
 int set_select_bwd_f32(const float* dsel, const float* Mem, const float* alpha, float* dM, float* dalpha,
                        int M, int T, int D, void* stream);
 
+/* General-layout fp32 GEMM on the MFMA pipe, used for the Linear backward (replaces the cuBLAS calls
+ * autograd makes for nn.Linear / nn.LSTMCell: dX = dY.W and dW += dY^T.X):
+ *     C[m,n] (+)= sum_k a(m,k) * b(n,k)
+ *     a(m,k) = a_kminor ? A[k*lda + m] : A[m*lda + k];   b(n,k) = b_kminor ? B[k*ldb + n] : B[n*ldb + k]
+ * accumulate != 0 adds into C (in-place .grad accumulation).  `ws` is scratch for split-K slabs (may be
+ * NULL: the contraction is then never split).  Leading dimensions are multiples of 4 floats; a k-minor
+ * operand needs its own dimension (M or N) to be a multiple of 4, a k-major one needs K % 4 == 0. */
+int set_gemm_f32(const float* A, long long lda, int a_kminor, const float* B, long long ldb, int b_kminor,
+                 float* C, long long ldc, int M, int N, int K, int accumulate, void* ws, size_t ws_bytes,
+                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,9 +5,10 @@ what the backward needs).  Backward: the pointwise / attention part of each oper
 hand-written HIP kernel (`csrc/backward.hip`: `set_lstm_cell_bwd_f32`, `set_copy_gate_bwd_f32`,
 `set_lstm_gates_bwd_f32`, `set_context_gate_bwd_f32`, `set_attention_bwd_f32`,
 `set_select_bwd_f32`); the plain contractions between them (dX = dY W, dW = dY^T X, bias column
-sums) are library GEMMs through torch (`torch.mm` = rocBLAS/hipBLASLt) — BASELINE.json's north star
-keeps autograd on the PyTorch-ROCm host side, and "plain library GEMMs" are the one place the
-design rules allow a vendor library.  Gradient parity is tested against the REFERENCE's own
+sums) run on the package's general-layout fp32 MFMA kernel (`csrc/gemm_gen.hip`, `set_gemm_f32`:
+dX = dY.W reads W in place as a k-minor operand, dW += dY^T.X accumulates straight into `.grad`).
+Inside `deferred_param_grads()` the parameter gradients of all timesteps are contracted in ONE GEMM per
+parameter.  Gradient parity is tested against the REFERENCE's own
 autograd (tests/golden `grad.*`, tests/test_hip_train.py).
 """
 from __future__ import annotations
@@ -28,12 +29,118 @@ def _ws(lib_fn, *dims, device):
     return torch.empty(max(16, lib_fn(*dims)), dtype=torch.uint8, device=device)
 
 
-def _colsum(t):
-    return t.sum(0)
-
-
+import contextlib
 import os as _os
+
 _FUSED_WGRAD = _os.environ.get("SET_FUSED_WGRAD", "1") != "0"
+# 1 (default): the Linear-backward contractions run on this package's fp32 MFMA kernel (set_gemm_f32);
+# 0: on torch.mm (rocBLAS) -- kept only as an A/B switch for benchmarking, both are GPU paths.
+_NATIVE_GEMM = _os.environ.get("SET_NATIVE_BWD_GEMM", "1") != "0"
+_GEMM_WS_BYTES = 64 << 20
+_gemm_ws = {}
+
+
+def _scratch(device):
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _gemm_ws.get(key)
+    if ws is None:
+        ws = _gemm_ws[key] = torch.empty(_GEMM_WS_BYTES, dtype=torch.uint8, device=device)
+    return ws
+
+
+def _mat(t):
+    """(tensor, leading dimension) of a 2-D fp32 operand the GEMM can read in place (unit inner stride,
+    16-byte aligned rows); anything else is made contiguous first."""
+    if t.stride(1) != 1 or t.stride(0) % 4 or t.data_ptr() % 16 or t.stride(0) < t.shape[1]:
+        t = t.contiguous()
+    return t, t.stride(0)
+
+
+def gemm(a, a_kminor, b, b_kminor, M, N, K, out=None, accumulate=False):
+    """out[m,n] (+)= sum_k a(m,k) b(n,k) through set_gemm_f32 (see include/set_hip.h for the layouts)."""
+    lib = _lib.load()
+    a, lda = _mat(a)
+    b, ldb = _mat(b)
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+        accumulate = False
+    ws = _scratch(a.device)
+    check(lib.set_gemm_f32(ptr(a), lda, int(a_kminor), ptr(b), ldb, int(b_kminor), ptr(out), out.stride(0), M, N, K,
+                           int(accumulate), ptr(ws), ws.numel(), stream_of(a.device)), "set_gemm_f32")
+    return out
+
+
+def _native_ok(*ts):
+    return _NATIVE_GEMM and all(t.is_cuda and t.dtype == torch.float32 for t in ts)
+
+
+def _dgrad(dy, w, out=None):
+    """dX (+)= dy . w   (dy: (M, N), w: (N, K) possibly a column slice of a wider weight) -> (M, K);
+    accumulates into `out` (a tensor this backward owns) when given"""
+    M, N = dy.shape
+    K = w.shape[1]
+    if not _native_ok(dy, w) or (N & 3) or (K & 3) or K < 4 or (out is not None and not out.is_contiguous()):
+        return dy.mm(w) if out is None else out.addmm_(dy, w)
+    return gemm(dy, False, w, True, M, K, N, out=out, accumulate=out is not None)
+
+
+def _wgrad_mm(dy, x, out=None):
+    """dW (+)= dy^T . x   (dy: (M, N), x: (M, K)) -> (N, K); accumulates into `out` when given"""
+    M, N = dy.shape
+    K = x.shape[1]
+    if not _native_ok(dy, x) or (N & 3) or (K & 3) or N < 4 or K < 4 or (out is not None and not out.is_contiguous()):
+        if out is None:
+            return dy.t().mm(x)
+        return out.addmm_(dy.t(), x)
+    return gemm(dy, True, x, True, N, K, M, out=out, accumulate=out is not None)
+
+
+# ---- deferred (time-batched) parameter gradients -----------------------------------------------------
+# Inside `deferred_param_grads()` the per-timestep weight/bias gradient contributions are only recorded;
+# on exit every parameter gets ONE contraction over all timesteps (dW += cat(dy)^T . cat(x): contraction
+# length 19 x B instead of 19 GEMMs of length B that each re-read and re-write the whole .grad).
+_deferred = None
+
+
+@contextlib.contextmanager
+def deferred_param_grads():
+    global _deferred
+    if _deferred is not None or not _FUSED_WGRAD:
+        yield
+        return
+    _deferred = {}
+    try:
+        yield
+        pending, cat_cache = _deferred, {}
+
+        def cat(ts):
+            if len(ts) == 1:
+                return ts[0]
+            key = tuple(id(t) for t in ts)
+            if key not in cat_cache:
+                cat_cache[key] = torch.cat(ts, 0)
+            return cat_cache[key]
+
+        for param, (dys, xs) in pending.values():
+            dy = cat(dys)
+            if xs is None:
+                g = dy.sum(0).reshape(param.shape)
+                if param.grad is None:
+                    param.grad = g
+                else:
+                    param.grad.add_(g)
+            else:
+                x = cat(xs)
+                if param.grad is None:
+                    param.grad = _wgrad_mm(dy, x)
+                else:
+                    _wgrad_mm(dy, x, out=param.grad)
+    finally:
+        _deferred = None
+
+
+def _is_leaf_param(param):
+    return _FUSED_WGRAD and isinstance(param, torch.nn.Parameter) and param.is_leaf
 
 
 def _wgrad(param, dy, x):
@@ -41,19 +148,27 @@ def _wgrad(param, dy, x):
     accumulation): returning dW to autograd would make it allocate a weight-sized temporary and run a
     separate weight-sized add per timestep (19 x 355 MB per training step).  Returns None so autograd
     skips its own accumulation.  Leaf parameters only; anything else gets the gradient returned."""
-    if not _FUSED_WGRAD or not (isinstance(param, torch.nn.Parameter) and param.is_leaf):
-        return dy.t().mm(x)
-    if param.grad is None:
-        param.grad = dy.t().mm(x)
+    if not _is_leaf_param(param):
+        return _wgrad_mm(dy, x)
+    if _deferred is not None:
+        ent = _deferred.setdefault(id(param), (param, ([], [])))
+        ent[1][0].append(dy)
+        ent[1][1].append(x)
+    elif param.grad is None:
+        param.grad = _wgrad_mm(dy, x)
     else:
-        param.grad.addmm_(dy.t(), x)
+        _wgrad_mm(dy, x, out=param.grad)
     return None
 
 
 def _bgrad(param, dy):
+    if not _is_leaf_param(param):
+        return dy.sum(0).reshape(param.shape)
+    if _deferred is not None:
+        ent = _deferred.setdefault(id(param), (param, ([], None)))
+        ent[1][0].append(dy)
+        return None
     g = dy.sum(0).reshape(param.shape)
-    if not _FUSED_WGRAD or not (isinstance(param, torch.nn.Parameter) and param.is_leaf):
-        return g
     if param.grad is None:
         param.grad = g
     else:
@@ -90,7 +205,7 @@ class _Linear(torch.autograd.Function):
         elif ctx.act == _lib.ACT_SIGMOID:
             dy = dy * y * (1 - y)
         pw, pb = ctx.params
-        dx = dy.mm(w).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dx = _dgrad(dy, w).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
         dw = _wgrad(pw, dy, x2) if ctx.needs_input_grad[1] else None
         db = _bgrad(pb, dy) if ctx.needs_input_grad[2] else None
         return dx, dw, db, None
@@ -146,6 +261,7 @@ class _LstmCell(torch.autograd.Function):
                                           ptr(h_new), ptr(c_new), ptr(gates), M, D, ptr(ws), ws.numel(),
                                           stream_of(x.device)), "set_lstm_cell_train_f32")
         ctx.params = (w_ih, w_hh, b_ih, b_hh)
+        ctx.set_materialize_grads(False)          # a missing dh / dc reaches the kernel as NULL, not as a zero tensor
         ctx.save_for_backward(x, h, c, w_ih, w_hh, gates, c_new)
         return h_new, c_new
 
@@ -160,7 +276,7 @@ class _LstmCell(torch.autograd.Function):
                                         ptr(gates), ptr(c), ptr(c_new), ptr(dg), ptr(dcp), M, D,
                                         stream_of(h.device)), "set_lstm_cell_bwd_f32")
         p_ih, p_hh, pb_ih, pb_hh = ctx.params
-        return (dg.mm(w_ih), dg.mm(w_hh), dcp, _wgrad(p_ih, dg, x), _wgrad(p_hh, dg, h), _bgrad(pb_ih, dg),
+        return (_dgrad(dg, w_ih), _dgrad(dg, w_hh), dcp, _wgrad(p_ih, dg, x), _wgrad(p_hh, dg, h), _bgrad(pb_ih, dg),
                 _bgrad(pb_hh, dg))
 
 
@@ -211,6 +327,7 @@ class _CaptionAttention(torch.autograd.Function):
                                                   ptr(gated), ptr(alpha), ptr(cx), ptr(zt), ptr(s), ptr(t), M, T, D, D, A,
                                                   ptr(ws), ws.numel(), stream_of(dev)), "set_caption_attention_train_f32")
         ctx.params = (dec_w, dec_b, gate_w, gate_b, sc_w, sc_b, tc_w, tc_b)
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(H, att1_c, h1, word, dec_w, dec_b, full_w, gate_w, sc_w, tc_w, alpha, cx, zt, s, t)
         return gated, alpha
 
@@ -220,12 +337,14 @@ class _CaptionAttention(torch.autograd.Function):
         lib = _lib.load()
         M, D = cx.shape
         dev = H.device
+        if dgated is None:
+            dgated = torch.zeros_like(cx)
         dz, ds, dt = (torch.empty(M, D, dtype=torch.float32, device=dev) for _ in range(3))
         check(lib.set_context_gate_bwd_f32(ptr(_c(dgated)), ptr(zt), ptr(s), ptr(t), ptr(dz), ptr(ds), ptr(dt), M, D,
                                            stream_of(dev)), "set_context_gate_bwd_f32")
-        dctx = dz.mm(gate_w[:, 2 * D:]) + ds.mm(sc_w)
-        dword = dz.mm(gate_w[:, :D]) + dt.mm(tc_w[:, :D])
-        dh1 = dz.mm(gate_w[:, D:2 * D]) + dt.mm(tc_w[:, D:])
+        dctx = _dgrad(ds, sc_w, out=_dgrad(dz, gate_w[:, 2 * D:]))
+        dword = _dgrad(dt, tc_w[:, :D], out=_dgrad(dz, gate_w[:, :D]))
+        dh1 = _dgrad(dt, tc_w[:, D:], out=_dgrad(dz, gate_w[:, D:2 * D]))
         p_dec_w, p_dec_b, p_gate_w, p_gate_b, p_sc_w, p_sc_b, p_tc_w, p_tc_b = ctx.params
         wh = torch.cat([word, h1], 1)
         d_gate_w = _wgrad(p_gate_w, dz, torch.cat([wh, cx], 1))
@@ -233,7 +352,7 @@ class _CaptionAttention(torch.autograd.Function):
         d_tc_w = _wgrad(p_tc_w, dt, wh)
         att2 = torch.addmm(dec_b, h1, dec_w.t())
         datt1, datt2, dfull_w, dH, dfull_b = _attention_bwd(dctx, dalpha, alpha, H, att1_c, att2, full_w, True, True)
-        dh1 = dh1 + datt2.mm(dec_w)
+        dh1 = _dgrad(datt2, dec_w, out=dh1)
         return (dH, datt1, dh1, dword, None, _wgrad(p_dec_w, datt2, h1), _bgrad(p_dec_b, datt2), dfull_w, dfull_b,
                 d_gate_w, _bgrad(p_gate_b, dz), d_sc_w, _bgrad(p_sc_b, ds), d_tc_w, _bgrad(p_tc_b, dt))
 
@@ -274,7 +393,7 @@ class _DcnetCaptionAttention(torch.autograd.Function):
         feats, att1_c, h1, dec_w, dec_b, full_w, alpha = ctx.saved_tensors
         att2 = torch.addmm(dec_b, h1, dec_w.t())
         datt1, datt2, dfull_w, dF, dfull_b = _attention_bwd(dctx, None, alpha, feats, att1_c, att2, full_w, True, True)
-        return (dF, datt1, datt2.mm(dec_w), None, _wgrad(ctx.params[0], datt2, h1), _bgrad(ctx.params[1], datt2), dfull_w,
+        return (dF, datt1, _dgrad(datt2, dec_w), None, _wgrad(ctx.params[0], datt2, h1), _bgrad(ctx.params[1], datt2), dfull_w,
                 dfull_b)
 
 
@@ -311,7 +430,7 @@ class _VisualAttention(torch.autograd.Function):
         X, att1, h1, dec_w, dec_b, full_w, alpha = ctx.saved_tensors
         att2 = torch.addmm(dec_b, h1, dec_w.t())
         datt1, datt2, dfull_w, _, dfull_b = _attention_bwd(dctx, None, alpha, X, att1, att2, full_w, False, False)
-        return (None, datt1, datt2.mm(dec_w), _wgrad(ctx.params[0], datt2, h1), _bgrad(ctx.params[1], datt2), dfull_w,
+        return (None, datt1, _dgrad(datt2, dec_w), _wgrad(ctx.params[0], datt2, h1), _bgrad(ctx.params[1], datt2), dfull_w,
                 dfull_b)
 
 
@@ -369,6 +488,7 @@ class _CopyLstm(torch.autograd.Function):
                                           ptr(gates), ptr(c_new), ptr(cg), M, D, ptr(ws), ws.numel(), stream_of(dev)),
               "set_copy_lstm_train_f32")
         ctx.params = (x2h_w, x2h_b, h2h_w, h2h_b, cnew_w, cnew_b, cmem_w, cmem_b)
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(x, h2, c2, cmem, x2h_w, h2h_w, cnew_w, cmem_w, gates, c_new, cg, adp)
         return h_new, adp
 
@@ -384,14 +504,14 @@ class _CopyLstm(torch.autograd.Function):
         check(lib.set_copy_gate_bwd_f32(ptr(None if dh is None else _c(dh)), ptr(None if dadp is None else _c(dadp)),
                                         ptr(ogate), ptr(adp), ptr(cg), ptr(cmem), ptr(c_new), ptr(du), ptr(dcm), ptr(dcn),
                                         ptr(dop), M, D, st), "set_copy_gate_bwd_f32")
-        dcn = dcn + du.mm(cnew_w)
-        dcm = dcm + du.mm(cmem_w)
+        _dgrad(du, cnew_w, out=dcn)
+        _dgrad(du, cmem_w, out=dcm)
         dgw = torch.empty_like(gates)
         dc2 = torch.empty_like(c2)
         check(lib.set_lstm_gates_bwd_f32(ptr(dcn), ptr(dop), ptr(gates), ptr(c2), ptr(dgw), ptr(dc2), M, D, st),
               "set_lstm_gates_bwd_f32")
         p = ctx.params
-        return (dgw.mm(x2h_w), dgw.mm(h2h_w), dc2, dcm, _wgrad(p[0], dgw, x), _bgrad(p[1], dgw), _wgrad(p[2], dgw, h2),
+        return (_dgrad(dgw, x2h_w), _dgrad(dgw, h2h_w), dc2, dcm, _wgrad(p[0], dgw, x), _bgrad(p[1], dgw), _wgrad(p[2], dgw, h2),
                 _bgrad(p[3], dgw), _wgrad(p[4], du, c_new), _bgrad(p[5], du), _wgrad(p[6], du, cmem), _bgrad(p[7], du))
 
 

@@ -331,4 +331,10 @@ int set_select_bwd_f32(const float* dsel, const float* Mem, const float* alpha, 
     return SET_OK;
 }
 
+int set_gemm_f32(const float* A, long long lda, int a_kminor, const float* B, long long ldb, int b_kminor, float* C,
+                 long long ldc, int M, int N, int K, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    return gemm_gen(A, lda, a_kminor, B, ldb, b_kminor, C, ldc, M, N, K, accumulate, ws, ws_bytes,
+                    (hipStream_t)stream);
+}
+
 }  // extern "C"

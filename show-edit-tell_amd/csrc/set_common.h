@@ -79,6 +79,9 @@ struct GemmProb {
 // similar length; problems with max_ksplit == 1 keep a fused bias/activation epilogue
 void plan_ksplit(GemmProb* probs, int n, int target_wgs);
 int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag = nullptr);
+// gemm_gen.hip: C (+)= a . b^T with either operand stored k-major or k-minor (training backward)
+int gemm_gen(const float* A, long long lda, int a_kminor, const float* B, long long ldb, int b_kminor, float* C,
+             long long ldc, int M, int N, int K, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
 int gemm_tile_m(int M);   // BM the launcher will pick for M rows
 
 // ---------------------------------------------------------------------------------------------

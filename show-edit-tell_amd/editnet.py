@@ -501,6 +501,14 @@ class DecoderC(nn.Module):
             att1_eval = A.linear(A.linear(X, va.att_embed[0].weight, va.att_embed[0].bias, _lib.ACT_RELU),
                                  va.features_att.weight, va.features_att.bias)
         prev_scores = None
+
+        def head(x, n):                  # x[:n] without a SliceBackward (zero-fill + copy of the whole tensor) when n is all rows
+            return x if x.shape[0] == n else x[:n]
+
+        # fc over all timesteps in ONE contraction (the weight is read once, not 19 times) when no step needs
+        # the previous step's scores and no sequence finishes early
+        batch_fc = not use_ss and min(decode_lengths) == max(decode_lengths)
+        h2_t = []
         for t in range(max(decode_lengths)):
             bt = sum([l > t for l in decode_lengths])
             it = encoded_captions[:bt, t]
@@ -512,28 +520,34 @@ class DecoderC(nn.Module):
                     prob_prev = torch.exp(prev_scores[:bt].detach())
                     it.index_copy_(0, sample_ind, torch.multinomial(prob_prev, 1).view(-1).index_select(0, sample_ind))
             emb = self.embed.dropout(A.embed_relu(it, E))
-            x1 = torch.cat([emb, final_hidden[:bt], h2[:bt], mean[:bt]], 1)
-            h1, c1 = A.lstm_cell(x1, h1[:bt], c1[:bt], al.weight_ih, al.weight_hh, al.bias_ih, al.bias_hh)
+            x1 = torch.cat([emb, head(final_hidden, bt), head(h2, bt), head(mean, bt)], 1)
+            h1, c1 = A.lstm_cell(x1, head(h1, bt), head(c1, bt), al.weight_ih, al.weight_hh, al.bias_ih, al.bias_hh)
             attend_cap, alpha_c = A.caption_attention(
-                H[:bt], h1, emb, mask[:bt], ca.cap_features_att.weight, ca.cap_features_att.bias,
+                head(H, bt), h1, emb, head(mask, bt), ca.cap_features_att.weight, ca.cap_features_att.bias,
                 ca.cap_decoder_att.weight, ca.cap_decoder_att.bias, ca.cap_full_att.weight, ca.cap_full_att.bias,
                 ca.context_gate.weight, ca.context_gate.bias, ca.sc_affine.weight, ca.sc_affine.bias,
-                ca.tc_affine.weight, ca.tc_affine.bias, att1_c=att1_c_all[:bt])
+                ca.tc_affine.weight, ca.tc_affine.bias, att1_c=head(att1_c_all, bt))
             if att1_eval is not None:
-                att1 = att1_eval[:bt]
+                att1 = head(att1_eval, bt)
             else:                                                                     # fresh dropout mask per step
-                fe = va.att_embed[2](A.linear(X[:bt], va.att_embed[0].weight, va.att_embed[0].bias, _lib.ACT_RELU))
+                fe = va.att_embed[2](A.linear(head(X, bt), va.att_embed[0].weight, va.att_embed[0].bias, _lib.ACT_RELU))
                 att1 = A.linear(fe, va.features_att.weight, va.features_att.bias)
-            attend_img = A.visual_attention_from_att1(X[:bt], att1, h1, va.decoder_att.weight, va.decoder_att.bias,
+            attend_img = A.visual_attention_from_att1(head(X, bt), att1, h1, va.decoder_att.weight, va.decoder_att.bias,
                                                       va.full_att.weight, va.full_att.bias)
-            sel = A.select(M[:bt], alpha_c)
-            h2, c2 = A.copy_lstm(torch.cat([h1, attend_cap, attend_img], 1), h2[:bt], c2[:bt], sel, cl.x2h.weight,
-                                 cl.x2h.bias, cl.h2h.weight, cl.h2h.bias, cl.gate_cnew.weight, cl.gate_cnew.bias,
-                                 cl.gate_cmem.weight, cl.gate_cmem.bias)
+            sel = A.select(head(M, bt), alpha_c)
+            h2, c2 = A.copy_lstm(torch.cat([h1, attend_cap, attend_img], 1), head(h2, bt), head(c2, bt), sel,
+                                 cl.x2h.weight, cl.x2h.bias, cl.h2h.weight, cl.h2h.bias, cl.gate_cnew.weight,
+                                 cl.gate_cnew.bias, cl.gate_cmem.weight, cl.gate_cmem.bias)
+            if batch_fc:
+                h2_t.append(self.dropout(h2))
+                continue
             preds = A.linear(self.dropout(h2), self.fc.weight, self.fc.bias)
             prev_scores = preds
             if bt < batch_size:
                 preds = torch.cat([preds, preds.new_zeros(batch_size - bt, preds.shape[1])], 0)
             preds_t.append(preds)
+        if batch_fc:                     # (T, B, V) computed at once; returned as its (B, T, V) view
+            predictions = A.linear(torch.stack(h2_t, 0), self.fc.weight, self.fc.bias).transpose(0, 1)
+            return predictions, encoded_captions, decode_lengths, sort_ind
         predictions = torch.stack(preds_t, 1)
         return predictions, encoded_captions, decode_lengths, sort_ind

@@ -67,7 +67,9 @@ def xe_train_step(decoder, optimizer, image_features, caps, caplens, previous_ca
     n_glob = global_token_count(n_tok, image_features.device, group)
     loss = loss_sum / n_glob
     optimizer.zero_grad()
-    loss.backward()
+    from .autograd_ops import deferred_param_grads
+    with deferred_param_grads():          # one weight-gradient contraction per parameter over all timesteps
+        loss.backward()
     params = [p for p in decoder.parameters() if p.requires_grad]
     allreduce_gradients(params, group)
     torch.nn.utils.clip_grad_norm_(params, GRAD_CLIP)

@@ -11,8 +11,11 @@ from hip_adapter import editnet_modules, to_dev
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("deferred", [False, True])
 @pytest.mark.parametrize("name", ["editnet_small", "editnet_full_b4"])
-def test_xe_gradients_vs_reference_autograd(name):
+def test_xe_gradients_vs_reference_autograd(name, deferred):
+    import contextlib
+    from show_edit_tell_amd.autograd_ops import deferred_param_grads
     from show_edit_tell_amd.train import xe_loss_sum
     d, xe, rl = editnet_modules(name)
     g = parity.load(name)
@@ -23,7 +26,8 @@ def test_xe_gradients_vs_reference_autograd(name):
     loss_sum, n_tok, _, _ = xe_loss_sum(pred, caps_s, dl)
     loss = loss_sum / n_tok
     assert abs(float(loss.detach()) - float(g["grad_loss"])) < 1e-4
-    loss.backward()
+    with (deferred_param_grads() if deferred else contextlib.nullcontext()):   # time-batched weight gradients
+        loss.backward()
     # absolute floor: gradients that are mathematically zero (softmax shift invariance makes
     # d/d full_att.bias == 0) are pure rounding noise in both implementations
     floor = 1e-6 * max(float(g["gradnorm." + k]) for k, _ in xe.named_parameters())

@@ -47,7 +47,7 @@ def main():
         print(json.dumps({"metric": "XE train step (fwd+bwd+allreduce+clip+Adam), 19 timesteps", "n_gpus": world, "batch_per_gpu": B,
                           "ms_per_train_step": round(1e3 * el / a.steps, 2),
                           "decode_steps_per_sec": round(world * a.steps * 19 / el, 2), "loss": loss,
-                          "note": "forward = HIP operators through the C ABI (train mode, un-hoisted); backward = HIP pointwise/attention kernels + library GEMMs via torch autograd"}))
+                          "note": "forward = HIP operators through the C ABI (train mode, un-hoisted); backward = HIP pointwise/attention kernels + set_gemm_f32 (fp32 MFMA) contractions, time-batched weight gradients"}))
     if dist: dist.destroy_process_group()
 if __name__ == "__main__":
     main()
