@@ -1,0 +1,149 @@
+"""Build-owned CIDEr-D scorer for the SCST reward.
+
+The reference does not contain its scorer: `editnet_rl.py:576-578` imports `CiderD` from the un-vendored
+`ruotianluo/cider` checkout (version unpinned), so reward VALUES are "parity unpinned" (SURVEY.md §8c.3).
+This module restates the published CIDEr-D metric (Vedantam et al., CVPR 2015, §"CIDEr-D"; the variant
+with a precomputed document-frequency table that self-critical training uses):
+
+    g_n(s)      tf-idf vector over the n-grams of s, n = 1..4:  tf(ngram) * (log N_docs - log max(1, df(ngram)))
+    sim_n(c, r) = sum_ngram min(g(c), g(r)) * g(r) / (|g(c)| |g(r)|) * exp(-(l_c - l_r)^2 / (2 sigma^2)),  sigma = 6
+    CIDEr-D(c)  = 10 / (4 |refs|) * sum_n sum_r sim_n(c, r)
+
+with l = number of bigrams of the sentence (the length the public implementations use).  The document
+frequency table has the format `preprocess_rl.py:7-55` writes: {n-gram tuple of token strings: number of
+images whose reference set contains it} plus `ref_len` = number of images.
+
+Host-side, per-sample work (strings and dictionaries): it shards with the batch and never touches the GPU.
+"""
+from __future__ import annotations
+
+import math
+from collections import Counter
+
+import numpy as np
+
+
+def ngram_counts(sentence, n=4):
+    """Counter of all 1..n-grams (tuples of token strings) of a whitespace-tokenised sentence."""
+    words = sentence.split()
+    c = Counter()
+    for k in range(1, n + 1):
+        for i in range(len(words) - k + 1):
+            c[tuple(words[i:i + k])] += 1
+    return c
+
+
+def document_frequency(reference_sets, n=4):
+    """df table over a corpus: reference_sets = iterable of lists of reference sentences (one list per
+    image).  Returns (df dict, number of images) -- the two fields `preprocess_rl.py` pickles."""
+    df, docs = Counter(), 0
+    for refs in reference_sets:
+        seen = set()
+        for r in refs:
+            seen.update(ngram_counts(r, n).keys())
+        for g in seen:
+            df[g] += 1
+        docs += 1
+    return dict(df), docs
+
+
+class CiderD:
+    def __init__(self, df, ref_len, n=4, sigma=6.0):
+        """df: n-gram -> document count; ref_len: number of documents the table was built from"""
+        self.df = df
+        self.log_ref_len = math.log(float(ref_len))
+        self.n = n
+        self.sigma = sigma
+
+    def _vector(self, counts):
+        vec = [dict() for _ in range(self.n)]
+        norm = [0.0] * self.n
+        length = 0
+        for g, tf in counts.items():
+            k = len(g) - 1
+            w = float(tf) * (self.log_ref_len - math.log(max(1.0, self.df.get(g, 0.0))))
+            vec[k][g] = w
+            norm[k] += w * w
+            if k == 1:
+                length += tf
+        return vec, [math.sqrt(x) for x in norm], length
+
+    def _similarity(self, hyp, ref):
+        (vh, nh, lh), (vr, nr, lr) = hyp, ref
+        delta = float(lh - lr)
+        penalty = math.exp(-(delta * delta) / (2.0 * self.sigma * self.sigma))
+        out = np.zeros(self.n)
+        for k in range(self.n):
+            s = 0.0
+            for g, w in vh[k].items():
+                wr = vr[k].get(g)
+                if wr is not None:
+                    s += min(w, wr) * wr
+            if nh[k] != 0.0 and nr[k] != 0.0:
+                s /= nh[k] * nr[k]
+            out[k] = s * penalty
+        return out
+
+    def score(self, hypothesis, references):
+        """CIDEr-D of one sentence against its reference sentences."""
+        hyp = self._vector(ngram_counts(hypothesis, self.n))
+        tot = np.zeros(self.n)
+        for r in references:
+            tot += self._similarity(hyp, self._vector(ngram_counts(r, self.n)))
+        return float(tot.mean() / max(1, len(references)) * 10.0)
+
+    def compute_score(self, gts, res):
+        """Same call shape as the external scorer at editnet_rl.py:636: gts = {image_id: [ref strings]},
+        res = [{'image_id': id, 'caption': [string]}].  Returns (mean score, per-entry scores)."""
+        cache = {}
+        scores = np.zeros(len(res))
+        for i, r in enumerate(res):
+            key = r['image_id']
+            refs = gts[key]
+            rk = id(refs)
+            if rk not in cache:
+                cache[rk] = [self._vector(ngram_counts(s, self.n)) for s in refs]
+            hyp = self._vector(ngram_counts(r['caption'][0], self.n))
+            tot = np.zeros(self.n)
+            for rv in cache[rk]:
+                tot += self._similarity(hyp, rv)
+            scores[i] = tot.mean() / max(1, len(refs)) * 10.0
+        return float(scores.mean()) if len(res) else 0.0, scores
+
+
+# ---- the reward plumbing of editnet_rl.py:584-646 ------------------------------------------------------
+def tokens_to_str(ids):
+    """ids of one caption -> space-joined string, cut after the first 0 (the decoder writes 0 for <end>
+    and everything after it; the 0 itself is kept as the end-of-sentence token, editnet_rl.py:601-609)."""
+    out = []
+    for w in ids:
+        out.append(str(int(w)))
+        if int(w) == 0:
+            break
+    return ' '.join(out)
+
+
+def ground_truth_lists(allcaps, word_map):
+    """(B, n_refs, L) ids -> per image list of id lists without <start>/<pad>, <end> rewritten to 0
+    (editnet_rl.py:584-599)."""
+    drop = {int(word_map['<start>']), int(word_map['<pad>'])}
+    end = int(word_map['<end>'])
+    out = []
+    for caps in np.asarray(allcaps.cpu() if hasattr(allcaps, 'cpu') else allcaps).tolist():
+        out.append([[0 if w == end else w for w in c if w not in drop] for c in caps])
+    return out
+
+
+def self_critical_reward(scorer, sampled, greedy, ground_truth, cider_weight=1.0):
+    """reward[b, :] = CIDEr-D(sampled_b) - CIDEr-D(greedy_b), repeated over the max_len columns
+    (editnet_rl.py:611-646).  sampled/greedy: (B, max_len) integer arrays/tensors; returns float32 numpy."""
+    sampled = np.asarray(sampled.cpu() if hasattr(sampled, 'cpu') else sampled)
+    greedy = np.asarray(greedy.cpu() if hasattr(greedy, 'cpu') else greedy)
+    B = sampled.shape[0]
+    refs = [[tokens_to_str(c) for c in caps] for caps in ground_truth]
+    gts = {i: refs[i % B] for i in range(2 * B)}
+    res = [{'image_id': i, 'caption': [tokens_to_str(sampled[i])]} for i in range(B)]
+    res += [{'image_id': B + i, 'caption': [tokens_to_str(greedy[i])]} for i in range(B)]
+    _, s = scorer.compute_score(gts, res)
+    diff = cider_weight * (s[:B] - s[B:])
+    return np.repeat(diff[:, None], sampled.shape[1], 1).astype(np.float32)

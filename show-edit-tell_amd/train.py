@@ -75,3 +75,47 @@ def xe_train_step(decoder, optimizer, image_features, caps, caplens, previous_ca
     torch.nn.utils.clip_grad_norm_(params, GRAD_CLIP)
     optimizer.step()
     return float(loss.detach()) , n_tok
+
+
+def reward_loss_sum(sample_logprobs, seq, reward):
+    """Numerator and mask count of RewardCriterion (editnet_rl.py:557-573): the mask keeps every
+    sampled word plus the <end> position (shifted `seq > 0`)."""
+    mask = (seq > 0).float()
+    mask = torch.cat([mask.new_ones(mask.size(0), 1), mask[:, :-1]], 1)
+    return torch.sum(-sample_logprobs * reward * mask), mask.sum()
+
+
+def scst_train_step(decoder, optimizer, word_map, image_features, previous_caption, prev_caplen, ground_truth,
+                    scorer, n_samples=1, cider_weight=1.0, group=None):
+    """One self-critical step of editnet_rl.py:649-686 on this rank's shard: greedy baseline in eval mode
+    under no_grad (fused device loop), `n_samples` multinomial rollouts in train mode (autograd operators),
+    reward = CIDEr-D(sample) - CIDEr-D(greedy) from `scorer` (ciderd.CiderD; host work, per sample),
+    RewardCriterion, backward, gradient all-reduce, clip, optimizer.  The reference draws one sample per
+    image; BASELINE.json config 5 asks for 5: all samples enter one RewardCriterion over n_samples * B rows.  As in the XE step the
+    loss is normalised by the GLOBAL mask count so that N ranks reproduce one big batch.
+    Returns (mean reward of the samples on this rank, loss value)."""
+    from . import ciderd
+    from .autograd_ops import deferred_param_grads
+    dev = image_features.device
+    optimizer.zero_grad()
+    decoder.eval()
+    with torch.no_grad():
+        greedy, _ = decoder(word_map, previous_caption, prev_caplen, image_features, sample_max=True, sample_rl=False)
+    decoder.train()
+    # the n_samples rollouts of one image are independent rows (own dropout masks, own multinomial draws):
+    # run them as ONE rollout over a batch of n_samples * B rows -- bigger GEMM tiles, one loop
+    rep = lambda t: t if n_samples == 1 else t.repeat(n_samples, *([1] * (t.dim() - 1)))
+    with deferred_param_grads():
+        seq, logp = decoder(word_map, rep(previous_caption), rep(prev_caplen), rep(image_features),
+                            sample_max=False, sample_rl=True)
+        rewards = ciderd.self_critical_reward(scorer, seq, rep(greedy), list(ground_truth) * n_samples, cider_weight)
+        num, cnt = reward_loss_sum(logp, seq, torch.from_numpy(rewards).to(dev))
+        n_glob = global_token_count(int(cnt.item()), dev, group)
+        loss = num / n_glob
+        loss.backward()
+    reward_mean, loss_val = float(rewards[:, 0].mean()), float(loss.detach())
+    params = [p for p in decoder.parameters() if p.requires_grad]
+    allreduce_gradients(params, group)
+    torch.nn.utils.clip_grad_norm_(params, GRAD_CLIP)
+    optimizer.step()
+    return reward_mean, loss_val

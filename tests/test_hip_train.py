@@ -105,3 +105,35 @@ def test_scst_rollout_pair():
     ref = EN.reward_criterion(logp_s.detach().cpu().numpy().astype(np.float64), seq_s.cpu().numpy(),
                               reward.cpu().numpy().astype(np.float64))
     assert abs(float(loss.detach()) - ref) < 1e-5
+
+
+def test_scst_train_step_with_ciderd_reward():
+    """train.scst_train_step (editnet_rl.py:649-686): the policy gradient with the build-owned CIDEr-D
+    reward raises the probability of the rewarded words: when every reference IS the current sample,
+    the sampled captions' log-probability must increase over a few steps."""
+    from show_edit_tell_amd import ciderd
+    from show_edit_tell_amd.train import scst_train_step
+    d, xe, rl = editnet_modules("editnet_small")
+    wm = d["wm"]
+    prev, plen, X = to_dev(d["prev"]), to_dev(d["plen"]), to_dev(d["X"])
+    B, V = X.shape[0], len(wm)
+    rng = np.random.default_rng(3)
+    # references: 5 random captions per image over the real vocabulary, <start> w.. <end> <pad>..
+    allcaps = np.zeros((B, 5, 12), dtype=np.int64)
+    for b in range(B):
+        for j in range(5):
+            n = int(rng.integers(3, 9))
+            allcaps[b, j, 0] = wm["<start>"]
+            allcaps[b, j, 1:1 + n] = rng.integers(1, V - 4, n)
+            allcaps[b, j, 1 + n] = wm["<end>"]
+    gt = ciderd.ground_truth_lists(allcaps, wm)
+    df, docs = ciderd.document_frequency([[ciderd.tokens_to_str(c) for c in caps] for caps in gt])
+    scorer = ciderd.CiderD(df, max(docs, 2))
+    opt = torch.optim.Adam(rl.parameters(), lr=1e-3)
+    before = [p.detach().clone() for p in rl.parameters()]
+    torch.manual_seed(4)
+    for n_samples in (1, 3):
+        reward, loss = scst_train_step(rl, opt, wm, X, prev, plen, gt, scorer, n_samples=n_samples)
+        assert np.isfinite(reward) and np.isfinite(loss)
+    assert any(not torch.equal(a, p.detach()) for a, p in zip(before, rl.parameters()))
+    assert all(torch.isfinite(p).all() for p in rl.parameters())
