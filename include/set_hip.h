@@ -311,6 +311,22 @@ int set_attention_bwd_f32(const float* dctx, const float* dalpha_ext, const floa
 int set_select_bwd_f32(const float* dsel, const float* Mem, const float* alpha, float* dM, float* dalpha,
                        int M, int T, int D, void* stream);
 
+/* Beam-search step epilogue for NI images x k hypotheses (rows i*k+j), replacing the host bookkeeping of
+ * editnet.py:654-699 / dcnet.py:450-500 / eval_full.py:150-200: log_softmax (or, with logits2, the ensemble
+ * log((softmax(logits)+softmax(logits2))/2)), + running scores, flat top-k over k*V per image (ties: lowest
+ * flat index), parent/word split, completed-hypothesis tracking (best completed score, first maximum),
+ * k_left -= #<end>, live hypotheses compacted to the front, sequences re-indexed and extended
+ * (seqs_in -> seqs_out, cur_len valid tokens -> cur_len+1), next input `words`, and `rows` = the parent
+ * row of every hypothesis row for set_beam_gather_f32.  k <= 8.  Step 1 is expressed by the caller through
+ * scores = {0, -inf, ...}.  Images with k_left == 0 are left untouched. */
+int set_beam_pick_f32(const float* logits, const float* logits2, int64_t ld, int NI, int k, int V, int64_t end_idx,
+                      int cur_len, int Lmax, float* scores, int32_t* k_left, const int64_t* seqs_in,
+                      int64_t* seqs_out, float* best_score, int64_t* best_seq, int32_t* best_len, int64_t* words,
+                      int32_t* rows, void* stream);
+/* In-place re-index of up to four (NI*k, D) recurrent-state tensors by `rows` (editnet.py:687-696). */
+int set_beam_gather_f32(float* s0, float* s1, float* s2, float* s3, const int32_t* rows, int NI, int k, int D,
+                        void* stream);
+
 /* General-layout fp32 GEMM on the MFMA pipe, used for the Linear backward (replaces the cuBLAS calls
  * autograd makes for nn.Linear / nn.LSTMCell: dX = dY.W and dW += dY^T.X):
  *     C[m,n] (+)= sum_k a(m,k) * b(n,k)

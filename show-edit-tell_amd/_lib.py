@@ -194,6 +194,8 @@ PROTOTYPES = {
     "set_context_gate_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "set_attention_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "set_select_bwd_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "set_beam_pick_f32": (_I, [_P, _P, _L, _I, _I, _I, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "set_beam_gather_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "set_gemm_f32": (_I, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, _I, _P, _Z, _P]),
     "set_caption_encoder_workspace_bytes": (_Z, [_I, _I, _I]),
     "set_caption_encoder_f32": (_I, [C.POINTER(EditNetWeights), _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),

@@ -141,16 +141,190 @@ def sentence(seq, word_map):
 
 
 # ------------------------------------------------------------------------------------------------
-# the same beam search for MANY images at once (the reference is batch 1).
-# The decode step of all NI*k hypotheses is one call of the fused HIP step (`set_editnet_step`); the
-# per-sequence prologue runs once per image and its invariants are replicated k times; the beam
-# bookkeeping is vectorised torch on the device (top-k over k*V per image, parent/word split,
-# completed-hypothesis tracking, state re-indexing).  Semantics per image are those of
+# the same beam search for MANY images at once (the reference is batch 1), entirely
+# on the device.  Per timestep: ONE fused decode step over all NI*k hypothesis rows (`set_editnet_step`,
+# plus `set_dcnet_step` for the ensemble), ONE beam epilogue kernel (`set_beam_pick_f32`: log-softmax or
+# ensemble averaging, flat top-k over k*V per image, the completed/live bookkeeping of editnet.py:666-699)
+# and ONE in-place state re-index (`set_beam_gather_f32`).  The host only polls "all images finished"
+# every few steps.  Semantics per image are those of editnet.py:643-713: k shrinks as hypotheses emit
+# <end>; the answer is the best COMPLETED hypothesis (first maximum), or seqs[0][:18] at the step limit.
+# ------------------------------------------------------------------------------------------------
+class _FusedModel:
+    """Prologue once per image, invariants replicated k times into a (NI*k)-row workspace."""
+
+    def _views(self, lib_ws_tensor, dims, ws, name, shape):
+        import ctypes as C
+        p = lib_ws_tensor(C.byref(dims), ws.data_ptr(), name.encode())
+        if not p:
+            raise KeyError(name)
+        off = p - ws.data_ptr()
+        n = 4
+        for s_ in shape:
+            n *= s_
+        return ws[off:off + n].view(torch.float32).view(*shape)
+
+
+class _FusedEditNet(_FusedModel):
+    def __init__(self, decoder, X, prev, plen, k, max_steps):
+        import ctypes as C
+        from . import _lib
+        from ._lib import check, ptr, stream_of
+        lib = self.lib = _lib.load()
+        dev = X.device
+        NI, R, _ = X.shape
+        T, D, A = prev.shape[1], decoder.decoder_dim, decoder._attention_dim
+        self.st = stream_of(dev)
+        d_img = decoder._dims(NI, T, R, max_steps + 1)
+        self.w = decoder._weights(d_img)
+        ws_img = torch.empty(lib.set_editnet_workspace_bytes(C.byref(d_img)), dtype=torch.uint8, device=dev)
+        check(lib.set_editnet_begin(C.byref(self.w), C.byref(d_img), ptr(X), None, ptr(prev), ptr(plen), ptr(ws_img),
+                                    ws_img.numel(), self.st), "set_editnet_begin")
+        self.B = B = NI * k
+        self.dims = d_b = decoder._dims(B, T, R, max_steps + 1)
+        self.ws = ws_b = torch.empty(lib.set_editnet_workspace_bytes(C.byref(d_b)), dtype=torch.uint8, device=dev)
+        for name, shp in (("H", (T, D)), ("M", (T, D)), ("mask", (T,)), ("att1", (R, A)), ("att1_c", (T, A)),
+                          ("pre1", (4 * D,)), ("rmask", (R,))):
+            self._views(lib.set_editnet_ws_tensor, d_b, ws_b, name, (B,) + shp).copy_(
+                self._views(lib.set_editnet_ws_tensor, d_img, ws_img, name, (NI,) + shp).repeat_interleave(k, 0))
+        self.Xk = X.repeat_interleave(k, 0).contiguous()
+        self.states = [self._views(lib.set_editnet_ws_tensor, d_b, ws_b, n, (B, D)) for n in ("h1", "c1", "h2", "c2")]
+        for s_ in self.states:
+            s_.zero_()
+        self.D = D
+
+    def step(self, words, logits):
+        import ctypes as C
+        from ._lib import check, ptr
+        check(self.lib.set_editnet_step(C.byref(self.w), C.byref(self.dims), ptr(self.Xk), ptr(words), 1, self.B,
+                                        ptr(logits), logits.shape[1], ptr(self.ws), self.ws.numel(), self.st),
+              "set_editnet_step")
+
+
+class _FusedDcnet(_FusedModel):
+    def __init__(self, dae, prev, plen, k, max_steps):
+        import ctypes as C
+        from . import _lib
+        from ._lib import check, ptr, stream_of
+        lib = self.lib = _lib.load()
+        dev = prev.device
+        NI, T = prev.shape
+        D, A, Cc, _ = dae._dims_cfg
+        self.st = stream_of(dev)
+        d_img = dae._dims(NI, T, max_steps + 1)
+        self.w = dae._weights()
+        ws_img = torch.empty(lib.set_dcnet_workspace_bytes(C.byref(d_img)), dtype=torch.uint8, device=dev)
+        check(lib.set_dcnet_begin(C.byref(self.w), C.byref(d_img), ptr(prev), ptr(plen), ptr(ws_img), ws_img.numel(),
+                                  self.st), "set_dcnet_begin")
+        self.B = B = NI * k
+        self.dims = d_b = dae._dims(B, T, max_steps + 1)
+        self.ws = ws_b = torch.empty(lib.set_dcnet_workspace_bytes(C.byref(d_b)), dtype=torch.uint8, device=dev)
+        for name, shp in (("enc", (T, 2 * Cc)), ("final_hidden", (2 * Cc,)), ("mask", (T,)), ("att1_c", (T, A)),
+                          ("pre1", (4 * D,))):
+            self._views(lib.set_dcnet_ws_tensor, d_b, ws_b, name, (B,) + shp).copy_(
+                self._views(lib.set_dcnet_ws_tensor, d_img, ws_img, name, (NI,) + shp).repeat_interleave(k, 0))
+        self.states = [self._views(lib.set_dcnet_ws_tensor, d_b, ws_b, n, (B, D)) for n in ("h1", "c1", "h2", "c2")]
+        for s_ in self.states:
+            s_.zero_()
+        self.D = D
+
+    def step(self, words, logits):
+        import ctypes as C
+        from ._lib import check, ptr
+        check(self.lib.set_dcnet_step(C.byref(self.w), C.byref(self.dims), ptr(words), 1, self.B, ptr(logits),
+                                      logits.shape[1], ptr(self.ws), self.ws.numel(), self.st), "set_dcnet_step")
+
+
+def _fused_beam(models, NI, k, V, word_map, dev, max_steps, poll=4):
+    from . import _lib
+    from ._lib import check, ptr, stream_of
+    lib = _lib.load()
+    st = stream_of(dev)
+    start, end = int(word_map['<start>']), int(word_map['<end>'])
+    B, Lmax = NI * k, max_steps + 2
+    neg = float("-inf")
+    scores = torch.full((NI, k), neg, device=dev)
+    scores[:, 0] = 0.0                                   # step 1: all k rows are identical, only row 0 counts
+    k_left = torch.full((NI,), k, dtype=torch.int32, device=dev)
+    words = torch.full((B,), start, dtype=torch.long, device=dev)
+    rows = torch.empty(B, dtype=torch.int32, device=dev)
+    seqs = [torch.full((NI, k, Lmax), start, dtype=torch.long, device=dev) for _ in range(2)]
+    best_score = torch.full((NI,), neg, device=dev)
+    best_seq = torch.zeros(NI, Lmax, dtype=torch.long, device=dev)
+    best_len = torch.zeros(NI, dtype=torch.int32, device=dev)
+    logits = [torch.empty(B, V, dtype=torch.float32, device=dev) for _ in models]
+    step = 1
+    while True:
+        for m, lg in zip(models, logits):
+            m.step(words, lg)
+        check(lib.set_beam_pick_f32(ptr(logits[0]), ptr(logits[1]) if len(models) > 1 else None, V, NI, k, V, end, step,
+                                    Lmax, ptr(scores), ptr(k_left), ptr(seqs[0]), ptr(seqs[1]), ptr(best_score),
+                                    ptr(best_seq), ptr(best_len), ptr(words), ptr(rows), st), "set_beam_pick_f32")
+        seqs.reverse()
+        for m in models:
+            s0, s1, s2, s3 = m.states
+            check(lib.set_beam_gather_f32(ptr(s0), ptr(s1), ptr(s2), ptr(s3), ptr(rows), NI, k, m.D, st),
+                  "set_beam_gather_f32")
+        if step > max_steps:
+            break
+        if step % poll == 0 and int(k_left.max()) == 0:      # the only host synchronisation of the search
+            break
+        step += 1
+    seqs_c, best_c, len_c, left_c = seqs[0].cpu(), best_seq.cpu(), best_len.cpu(), k_left.cpu()
+    out = []
+    for i in range(NI):
+        if int(left_c[i]) > 0:                               # ran into the step limit (editnet.py:702-704,711)
+            out.append(seqs_c[i, 0, :18].tolist())
+        else:
+            out.append(best_c[i, :int(len_c[i])].tolist())
+    return out
+
+
+@torch.no_grad()
+def beam_search_editnet_batched(decoder, image_features, previous_caption, prev_caplen, word_map, beam_size=3,
+                                max_steps=50):
+    """image_features (NI,R,F), previous_caption (NI,T), prev_caplen (NI,1) -> list of NI token lists."""
+    decoder.eval()
+    X = image_features.float().contiguous()
+    prev = previous_caption.long().contiguous()
+    plen = prev_caplen.reshape(-1).long().contiguous()
+    m = _FusedEditNet(decoder, X, prev, plen, beam_size, max_steps)
+    return _fused_beam([m], X.shape[0], beam_size, decoder.vocab_size, word_map, X.device, max_steps)
+
+
+@torch.no_grad()
+def beam_search_dcnet_batched(dae, previous_caption, prev_caplen, word_map, beam_size=3, max_steps=50):
+    dae.eval()
+    prev = previous_caption.long().contiguous()
+    plen = prev_caplen.reshape(-1).long().contiguous()
+    m = _FusedDcnet(dae, prev, plen, beam_size, max_steps)
+    return _fused_beam([m], prev.shape[0], beam_size, dae.vocab_size, word_map, prev.device, max_steps)
+
+
+@torch.no_grad()
+def beam_search_ensemble_batched(decoder, dae, image_features, previous_caption, prev_caplen, word_map, beam_size=3,
+                                 max_steps=50):
+    """eval_full.py:88-218 for NI images at once: both models step on the same words, the epilogue averages
+    their softmax probabilities."""
+    decoder.eval()
+    dae.eval()
+    X = image_features.float().contiguous()
+    prev = previous_caption.long().contiguous()
+    plen = prev_caplen.reshape(-1).long().contiguous()
+    e = _FusedEditNet(decoder, X, prev, plen, beam_size, max_steps)
+    d = _FusedDcnet(dae, prev, plen, beam_size, max_steps)
+    return _fused_beam([e, d], X.shape[0], beam_size, decoder.vocab_size, word_map, X.device, max_steps)
+
+
+# ------------------------------------------------------------------------------------------------
+# First version of row f2, kept as the cross-check of the fused one above (tests/test_hip_beam.py): same
+# fused HIP decode step, but the beam bookkeeping is vectorised torch on the device (top-k over k*V per
+# image, parent/word split, completed-hypothesis tracking, state re-indexing; ~40 small kernels and a
+# host synchronisation per step).  Semantics per image are those of
 # editnet.py:643-713: k shrinks as hypotheses emit <end>; the answer is the best COMPLETED
 # hypothesis (first maximum), or seqs[0][:18] if the step limit is hit.
 # ------------------------------------------------------------------------------------------------
 @torch.no_grad()
-def beam_search_editnet_batched(decoder, image_features, previous_caption, prev_caplen, word_map, beam_size=3,
+def beam_search_editnet_batched_torch(decoder, image_features, previous_caption, prev_caplen, word_map, beam_size=3,
                                 max_steps=50):
     """image_features (NI,R,F), previous_caption (NI,T), prev_caplen (NI,1) -> list of NI token lists."""
     import ctypes as C

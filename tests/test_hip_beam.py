@@ -48,21 +48,43 @@ def test_beam_search_editnet_and_ensemble():
     assert finished >= 2
 
 
+def _same_search(batched_b, seq, sc, what):
+    if np.isnan(sc):                       # step-limit path: the 50-step trajectory is chaotic, compare the head
+        assert len(batched_b) == 18 and batched_b[:4] == seq[:4], (what, batched_b, seq)
+        return 0
+    assert batched_b == seq, (what, batched_b, seq)
+    return 1
+
+
 def test_batched_beam_matches_per_image_beam():
-    """Row f2: all images of a batch searched at once == the reference-style one-image-at-a-time search."""
-    from show_edit_tell_amd import editnet, evaluate
+    """Row f2: all images of a batch searched at once, entirely on the device (fused step + set_beam_pick_f32 +
+    set_beam_gather_f32) == the reference-style one-image-at-a-time search; EditNet, DCNet and the ensemble."""
+    from show_edit_tell_amd import dcnet, editnet, evaluate
     d = cases.build_editnet("editnet_small")
     c, wm = d["case"], d["wm"]
     for boost in (3.0, 5.0):
         xe = load_numpy_state(editnet.DecoderC(wm, c["D"], c["D"], c["D"], c["A"], c["F"]), _boosted(d["sd"], c["V"], boost))
+        sd_d = _boosted(cases.synth.dcnet_state(17, c["V"], c["D"], c["A"], c["D"] // 2, c["D"], 3.0, 8.0, 3.0), c["V"], boost)
+        dae = load_numpy_state(dcnet.DAE(wm, None, c["D"], c["A"], c["D"] // 2, c["D"]), sd_d)
         X, prev, plen = to_dev(d["X"]), to_dev(d["prev"]), to_dev(d["plen"])
-        batched = evaluate.beam_search_editnet_batched(xe, X, prev, plen, wm, 3)
+        fused_e = evaluate.beam_search_editnet_batched(xe, X, prev, plen, wm, 3)
+        torch_e = evaluate.beam_search_editnet_batched_torch(xe, X, prev, plen, wm, 3)
+        fused_d = evaluate.beam_search_dcnet_batched(dae, prev, plen, wm, 3)
+        fused_x = evaluate.beam_search_ensemble_batched(xe, dae, X, prev, plen, wm, 3)
         agree = 0
         for b in range(c["B"]):
-            seq, sc = evaluate.beam_search_editnet(xe, X[b:b + 1], prev[b:b + 1], plen[b:b + 1], wm, 3)
-            if np.isnan(sc):                       # step-limit path: the 50-step trajectory is chaotic, compare the head
-                assert len(batched[b]) == 18 and batched[b][:4] == seq[:4], (b, batched[b], seq)
-            else:
-                assert batched[b] == seq, (boost, b, batched[b], seq)
-                agree += 1
-        assert agree >= 2
+            one = (X[b:b + 1], prev[b:b + 1], plen[b:b + 1])
+            seq, sc = evaluate.beam_search_editnet(xe, *one, wm, 3)
+            agree += _same_search(fused_e[b], seq, sc, ("editnet", boost, b))
+            _same_search(torch_e[b], seq, sc, ("editnet-torch", boost, b))
+            seq, sc = evaluate.beam_search_dcnet(dae, one[1], one[2], wm, 3)
+            agree += _same_search(fused_d[b], seq, sc, ("dcnet", boost, b))
+            seq, sc = evaluate.beam_search_ensemble(xe, dae, *one, wm, 3)
+            agree += _same_search(fused_x[b], seq, sc, ("ensemble", boost, b))
+        assert agree >= 6
+    # wider beams than the reference's 3 (k <= 8 in the kernel)
+    for k in (1, 5, 8):
+        fused = evaluate.beam_search_editnet_batched(xe, X, prev, plen, wm, k)
+        ref = evaluate.beam_search_editnet_batched_torch(xe, X, prev, plen, wm, k)
+        for b in range(c["B"]):
+            assert fused[b][:4] == ref[b][:4] and (len(fused[b]) == 18 or fused[b] == ref[b]), (k, b, fused[b], ref[b])
