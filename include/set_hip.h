@@ -254,6 +254,11 @@ size_t set_visual_attention_workspace_bytes(int M, int R, int F, int D, int A);
 int set_visual_attention_f32(const SetEditNetWeights* w, const float* X, const float* att1,
                              const float* h1, float* ctx, float* alpha, int M, int R, int F, int D,
                              int A, int adaptive, void* ws, size_t ws_bytes, void* stream);
+/* Same with att1 (M,R,A) required and the region mask rmask (M,R; 1 = valid, NULL = no masking) supplied
+ * by the caller instead of re-derived (grad-enabled adaptive path); ws >= the size above. */
+int set_visual_attention_masked_f32(const SetEditNetWeights* w, const float* X, const float* att1,
+                                    const float* rmask, const float* h1, float* ctx, float* alpha, int M,
+                                    int R, int F, int D, int A, void* ws, size_t ws_bytes, void* stream);
 /* SelectC.forward hard mode (editnet.py:403-421): sel = M[b,j*] * (a + (1-a)), j* = argmax alpha_c */
 int set_select_f32(const float* Mem, const float* alpha_c, float* sel, int M, int T, int D,
                    void* stream);

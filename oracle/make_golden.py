@@ -142,12 +142,17 @@ def make_editnet(name, adaptive=False):
         tg = pack_padded_sequence(caps_s[:, 1:], dl, batch_first=True).data
         out["xe_loss"] = np.float64(torch.nn.CrossEntropyLoss()(sc.double(), tg).item())
     # ---- a13: gradients of the XE loss (eval-mode dropout so they are deterministic), reference autograd
-    if not adaptive and not big:
+    if not big and (not adaptive or small):
         from torch.nn.utils.rnn import pack_padded_sequence as _pps
         dec_xe.zero_grad()
-        predg, caps_g, dlg, _ = dec_xe(X, caps, clen, prev, plen, False, 0.0)
+        if adaptive:     # the adaptive train() adds MSE(decoder_last_hidden, gd_final_hidden) (editnet_adaptive.py:594-596)
+            predg, caps_g, dlg, _, gdg, lastg = dec_xe(X, T_(d["image_mean"]), caps, clen, prev, plen, False, 0.0)
+        else:
+            predg, caps_g, dlg, _ = dec_xe(X, caps, clen, prev, plen, False, 0.0)
         lossg = torch.nn.CrossEntropyLoss()(_pps(predg, dlg, batch_first=True).data,
                                             _pps(caps_g[:, 1:], dlg, batch_first=True).data)
+        if adaptive:
+            lossg = lossg + torch.nn.MSELoss()(lastg, gdg)
         lossg.backward()
         out["grad_loss"] = np.float64(lossg.item())
         for k_, p_ in dec_xe.named_parameters():

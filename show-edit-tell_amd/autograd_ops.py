@@ -408,9 +408,10 @@ def dcnet_caption_attention(feats, h1, mask, feat_w, feat_b, dec_w, dec_b, full_
 # ------------------------------------------------------------------------------------------------
 class _VisualAttention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, X, att1, h1, dec_w, dec_b, full_w, full_b):
+    def forward(ctx, X, att1, h1, dec_w, dec_b, full_w, full_b, rmask):
         lib = _lib.load()
         X, att1, h1 = _c(X), _c(att1), _c(h1)
+        rmask = None if rmask is None else _c(rmask.float())
         M, R, Fd = X.shape
         D, A = dec_w.shape[1], dec_w.shape[0]
         dev = X.device
@@ -419,8 +420,9 @@ class _VisualAttention(torch.autograd.Function):
         cx = torch.empty(M, Fd, dtype=torch.float32, device=dev)
         alpha = torch.empty(M, R, dtype=torch.float32, device=dev)
         ws = _ws(lib.set_visual_attention_workspace_bytes, M, R, Fd, D, A, device=dev)
-        check(lib.set_visual_attention_f32(C.byref(w), ptr(X), ptr(att1), ptr(h1), ptr(cx), ptr(alpha), M, R, Fd, D, A, 0,
-                                           ptr(ws), ws.numel(), stream_of(dev)), "set_visual_attention_f32")
+        check(lib.set_visual_attention_masked_f32(C.byref(w), ptr(X), ptr(att1), ptr(rmask), ptr(h1), ptr(cx), ptr(alpha),
+                                                  M, R, Fd, D, A, ptr(ws), ws.numel(), stream_of(dev)),
+              "set_visual_attention_masked_f32")
         ctx.params = (dec_w, dec_b)
         ctx.save_for_backward(X, att1, h1, dec_w, dec_b, full_w, alpha)
         return cx
@@ -431,11 +433,13 @@ class _VisualAttention(torch.autograd.Function):
         att2 = torch.addmm(dec_b, h1, dec_w.t())
         datt1, datt2, dfull_w, _, dfull_b = _attention_bwd(dctx, None, alpha, X, att1, att2, full_w, False, False)
         return (None, datt1, _dgrad(datt2, dec_w), _wgrad(ctx.params[0], datt2, h1), _bgrad(ctx.params[1], datt2), dfull_w,
-                dfull_b)
+                dfull_b, None)
 
 
-def visual_attention_from_att1(X, att1, h1, dec_w, dec_b, full_w, full_b):
-    return _VisualAttention.apply(X, att1, h1, dec_w, dec_b, full_w, full_b)
+def visual_attention_from_att1(X, att1, h1, dec_w, dec_b, full_w, full_b, rmask=None):
+    """rmask (M,R) 0/1: the adaptive model's valid-region mask (editnet_adaptive.py:449-453); masked regions get
+    alpha == 0 exactly, so the shared attention backward needs no mask of its own."""
+    return _VisualAttention.apply(X, att1, h1, dec_w, dec_b, full_w, full_b, rmask)
 
 
 # ------------------------------------------------------------------------------------------------

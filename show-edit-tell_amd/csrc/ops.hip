@@ -200,6 +200,24 @@ int set_visual_attention_f32(const SetEditNetWeights* w, const float* X, const f
                             ctx, alpha, M, R, F, A, st);
 }
 
+// masked variant for the grad-enabled adaptive path: att1 and the region mask (att_embed(X).sum(2) != 0,
+// editnet_adaptive.py:449-453) are supplied by the caller, nothing is recomputed
+int set_visual_attention_masked_f32(const SetEditNetWeights* w, const float* X, const float* att1, const float* rmask,
+                                    const float* h1, float* ctx, float* alpha, int M, int R, int F, int D, int A,
+                                    void* ws, size_t ws_bytes, void* stream) {
+    if (!w || !X || !att1 || !h1 || !ctx || M <= 0 || R <= 0 || F <= 0 || D <= 0 || A <= 0) return SET_ERR_ARG;
+    if (!ws || !aligned16(ws) || ws_bytes < fbytes(KS * (size_t)M * A)) return SET_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    Carver cv(ws);
+    float* s_att2 = cv.take<float>(KS * (size_t)M * A);
+    GemmProb b = slab_prob(s_att2, M, A, M);
+    b.add(h1, D, w->va_dec_w, D, D);
+    plan_ksplit(&b, 1, gemm_target_wgs());
+    SET_TRY(gemm_group(&b, 1, st));
+    return visual_attention(att1, slabs_of(b), w->va_dec_b, w->va_full_w, w->va_full_b, X, rmask, ctx, alpha, M, R, F,
+                            A, st);
+}
+
 // ------------------------------------------------------------------------------- SelectC
 int set_select_f32(const float* Mem, const float* alpha_c, float* sel, int M, int T, int D, void* stream) {
     if (!Mem || !alpha_c || !sel || M <= 0 || T <= 0 || D <= 0) return SET_ERR_ARG;

@@ -478,8 +478,6 @@ class DecoderC(nn.Module):
                           previous_cap_length, use_ss, ss_prob, image_mean=None):
         """The reference loop (editnet.py:479-548), one autograd-wrapped HIP operator per module call."""
         from . import autograd_ops as A
-        if self._adaptive:
-            raise NotImplementedError("training with adaptive features is not built yet")
         dev = image_features.device
         batch_size = encoded_captions.size(0)
         caption_lengths, sort_ind = caption_lengths.squeeze(1).sort(dim=0, descending=True)
@@ -496,11 +494,23 @@ class DecoderC(nn.Module):
         ca, va, cl, al = self.caption_attention, self.visual_attention, self.copy_lstm, self.attention_lstm
         E = self.embed.embedding.weight
         att1_c_all = A.linear(H, ca.cap_features_att.weight, ca.cap_features_att.bias)   # loop invariant (editnet.py:370)
-        att1_eval = None
+        # adaptive features (editnet_adaptive.py:438-453): att_embed only sees the valid (non-zero) regions, the
+        # padded ones stay exactly zero; the score mask is re-derived from the embedded rows
+        valid = (X.sum(2) != 0).float().unsqueeze(2) if self._adaptive else None
+
+        def embed_regions(Xb, vb):
+            fe = va.att_embed[2](A.linear(Xb, va.att_embed[0].weight, va.att_embed[0].bias, _lib.ACT_RELU))
+            if vb is None:
+                return fe, None
+            fe = fe * vb
+            return fe, (fe.detach().sum(2) != 0).float()
+
+        att1_eval = rmask_eval = None
         if not self.training:            # dropout inactive: features_att(att_embed(X)) is loop invariant
-            att1_eval = A.linear(A.linear(X, va.att_embed[0].weight, va.att_embed[0].bias, _lib.ACT_RELU),
-                                 va.features_att.weight, va.features_att.bias)
+            fe, rmask_eval = embed_regions(X, valid)
+            att1_eval = A.linear(fe, va.features_att.weight, va.features_att.bias)
         prev_scores = None
+        last_parts = []                  # rows leaving the batch after this step, with their final h2 (adaptive :560)
 
         def head(x, n):                  # x[:n] without a SliceBackward (zero-fill + copy of the whole tensor) when n is all rows
             return x if x.shape[0] == n else x[:n]
@@ -528,16 +538,19 @@ class DecoderC(nn.Module):
                 ca.context_gate.weight, ca.context_gate.bias, ca.sc_affine.weight, ca.sc_affine.bias,
                 ca.tc_affine.weight, ca.tc_affine.bias, att1_c=head(att1_c_all, bt))
             if att1_eval is not None:
-                att1 = head(att1_eval, bt)
+                att1, rmask = head(att1_eval, bt), (None if rmask_eval is None else head(rmask_eval, bt))
             else:                                                                     # fresh dropout mask per step
-                fe = va.att_embed[2](A.linear(head(X, bt), va.att_embed[0].weight, va.att_embed[0].bias, _lib.ACT_RELU))
+                fe, rmask = embed_regions(head(X, bt), None if valid is None else head(valid, bt))
                 att1 = A.linear(fe, va.features_att.weight, va.features_att.bias)
             attend_img = A.visual_attention_from_att1(head(X, bt), att1, h1, va.decoder_att.weight, va.decoder_att.bias,
-                                                      va.full_att.weight, va.full_att.bias)
+                                                      va.full_att.weight, va.full_att.bias, rmask)
             sel = A.select(head(M, bt), alpha_c)
             h2, c2 = A.copy_lstm(torch.cat([h1, attend_cap, attend_img], 1), head(h2, bt), head(c2, bt), sel,
                                  cl.x2h.weight, cl.x2h.bias, cl.h2h.weight, cl.h2h.bias, cl.gate_cnew.weight,
                                  cl.gate_cnew.bias, cl.gate_cmem.weight, cl.gate_cmem.bias)
+            bt_next = sum([l > t + 1 for l in decode_lengths])
+            if bt_next < bt:
+                last_parts.append(h2[bt_next:bt])
             if batch_fc:
                 h2_t.append(self.dropout(h2))
                 continue
@@ -546,6 +559,7 @@ class DecoderC(nn.Module):
             if bt < batch_size:
                 preds = torch.cat([preds, preds.new_zeros(batch_size - bt, preds.shape[1])], 0)
             preds_t.append(preds)
+        self._last_hidden = torch.cat(last_parts[::-1], 0)     # row order: the longest captions leave last
         if batch_fc:                     # (T, B, V) computed at once; returned as its (B, T, V) view
             predictions = A.linear(torch.stack(h2_t, 0), self.fc.weight, self.fc.bias).transpose(0, 1)
             return predictions, encoded_captions, decode_lengths, sort_ind

@@ -32,9 +32,13 @@ class DecoderC(_DecoderXE):
             image_features, encoded_captions, caption_lengths, encoded_previous_captions, previous_cap_length,
             use_ss, ss_prob, image_mean=image_mean)
         B = caps_sorted.shape[0]
+        sorted_lengths = caption_lengths.squeeze(1)[sort_ind].unsqueeze(1)
+        if pred.requires_grad:           # grad-enabled path: both extra outputs stay in the autograd graph (MSE loss :594-596)
+            decoder_last_hidden = self._last_hidden
+            _, _, gd_final_hidden, _ = self._encoder_autograd(caps_sorted, sorted_lengths)
+            return pred, caps_sorted, decode_lengths, sort_ind, gd_final_hidden, decoder_last_hidden
         dims = self._dims(B, encoded_previous_captions.shape[1], image_features.shape[1], max(decode_lengths))
         # decoder_last_hidden[:bt] = h2 at every step (:560) == the h2 state left in the workspace
         decoder_last_hidden = self.ws_tensor(dims, "h2", (B, self.decoder_dim)).clone()
-        sorted_lengths = caption_lengths.squeeze(1)[sort_ind].unsqueeze(1)
         _, _, gd_final_hidden, _ = self.caption_encoder(caps_sorted, sorted_lengths)          # :516
         return pred, caps_sorted, decode_lengths, sort_ind, gd_final_hidden, decoder_last_hidden

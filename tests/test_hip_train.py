@@ -28,6 +28,10 @@ def test_xe_gradients_vs_reference_autograd(name, deferred):
     assert abs(float(loss.detach()) - float(g["grad_loss"])) < 1e-4
     with (deferred_param_grads() if deferred else contextlib.nullcontext()):   # time-batched weight gradients
         loss.backward()
+    _check_grads(xe, g, name)
+
+
+def _check_grads(xe, g, name):
     # absolute floor: gradients that are mathematically zero (softmax shift invariance makes
     # d/d full_att.bias == 0) are pure rounding noise in both implementations
     floor = 1e-6 * max(float(g["gradnorm." + k]) for k, _ in xe.named_parameters())
@@ -137,3 +141,34 @@ def test_scst_train_step_with_ciderd_reward():
         assert np.isfinite(reward) and np.isfinite(loss)
     assert any(not torch.equal(a, p.detach()) for a, p in zip(before, rl.parameters()))
     assert all(torch.isfinite(p).all() for p in rl.parameters())
+
+
+def test_adaptive_xe_gradients_vs_reference_autograd():
+    """Adaptive features (10-100 zero-padded regions): gradients of CE + MSE(decoder_last_hidden, gd_final_hidden)
+    (adaptive_features/editnet_adaptive.py:584-598) through the masked visual attention, against the reference."""
+    from hip_adapter import adaptive_module
+    from show_edit_tell_amd.autograd_ops import deferred_param_grads
+    from show_edit_tell_amd.train import xe_loss_sum
+    name = "editnet_adaptive_small"
+    d, xe = adaptive_module(name)
+    g = parity.load(name)
+    xe.eval()
+    pred, caps_s, dl, sort_ind, gd_fh, last_h = xe(to_dev(d["X"]), to_dev(d["image_mean"]), to_dev(d["caps"]),
+                                                   to_dev(d["clen"]), to_dev(d["prev"]), to_dev(d["plen"]), False, 0.0)
+    assert pred.requires_grad and gd_fh.requires_grad and last_h.requires_grad
+    assert np.abs(last_h.detach().cpu().numpy() - g["xe_last_hidden"]).max() < 2e-5
+    assert np.abs(gd_fh.detach().cpu().numpy() - g["xe_gd_final"]).max() < 2e-5
+    loss_sum, n_tok, _, _ = xe_loss_sum(pred, caps_s, dl)
+    loss = loss_sum / n_tok + torch.nn.functional.mse_loss(last_h, gd_fh)
+    assert abs(float(loss.detach()) - float(g["grad_loss"])) < 1e-4
+    with deferred_param_grads():
+        loss.backward()
+    _check_grads(xe, g, name)
+    # train mode (dropout on the region embedding) runs and masks the padded regions
+    xe.train()
+    xe.zero_grad()
+    pred, caps_s, dl, *_ = xe(to_dev(d["X"]), to_dev(d["image_mean"]), to_dev(d["caps"]), to_dev(d["clen"]),
+                              to_dev(d["prev"]), to_dev(d["plen"]), True, 0.25)
+    ls, n, _, _ = xe_loss_sum(pred, caps_s, dl)
+    (ls / n).backward()
+    assert all(torch.isfinite(p.grad).all() for p in xe.parameters() if p.grad is not None)
