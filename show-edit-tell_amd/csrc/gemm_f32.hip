@@ -17,7 +17,10 @@
 //     workgroup; the consuming pointwise kernel adds the slabs in a fixed order).
 //   * K may be a concatenation of up to three (activation, weight-column-block) segments, so
 //     cat([emb, h2, h1]) x [W_ih[:, :D] | W_ih[:, 2D:3D] | W_hh] needs no copies of weights.
+#include <cstdlib>
+#include <cstring>
 #include "set_common.h"
+#include "split3.h"
 
 namespace set {
 
@@ -235,6 +238,204 @@ __global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
 #undef SET_SEEK
 #undef SET_LSTORE
 
+// ---------------------------------------------------------------------------------------------
+// EXPERIMENTAL, opt-in (SET_GEMM_SPLIT=1; never the default, never the headline number): the same grouped
+// GEMM on the bf16 matrix pipe with every fp32 operand split EXACTLY into three bf16 values
+//      x = hi + mid + lo        (8 + 8 + 8 significand bits, by truncation and exact fp32 subtraction)
+// and six of the nine partial products accumulated in fp32 (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; the
+// dropped ones are <= 2^-24 relative, i.e. at the level of one fp32 rounding).  v_mfma_f32_32x32x16_bf16 has 16x
+// the rate of v_mfma_f32_32x32x2_f32, so six of them cost 2.67x less matrix-pipe time than the fp32 chain.
+// Splitting happens on the fly when a k-tile is staged into LDS (weights stay fp32 in HBM, nothing is
+// repacked); LDS holds three bf16 planes per operand, 64-B rows, 16-B chunks XOR-swizzled by (row>>2)&3 so
+// that the ds_write_b64 of the staging and the ds_read_b128 of the fragments are bank-conflict-free.
+// Same task descriptors, K segments, split-K slabs and epilogue as gemm_nt_f32<128,64>.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256) gemm_nt_split_bf16(const GemmLaunch L) {
+    constexpr int BM = 128, BN = 64, TM = 2, LA = 4, LW = 2;
+    constexpr int ROWB = 64;                              // bytes per LDS row (32 bf16)
+    constexpr int PLANE_A = BM * ROWB, PLANE_W = BN * ROWB;
+    constexpr int BUF = 3 * (PLANE_A + PLANE_W);          // 36 KB per stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+
+    int ti = 0;
+#pragma unroll
+    for (int i = 1; i < GEMM_MAX_TASKS; ++i)
+        if (i < L.ntasks && (int)blockIdx.x >= L.t[i].wg_begin) ti = i;
+    const GemmTask& T = L.t[ti];
+    const int local = (int)blockIdx.x - T.wg_begin;
+    const int ks = local % T.ksplit;
+    const int tile = local / T.ksplit;
+    const int tn = tile % T.tiles_n, tm = tile / T.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kt0 = (int)(((long long)ks * T.ktiles) / T.ksplit);
+    const int kt1 = (int)(((long long)(ks + 1) * T.ktiles) / T.ksplit);
+
+    const int srow = tid >> 3, kc = tid & 7, scol = kc * 4;
+    // byte offset of this thread's 8-byte store inside a plane row
+    const int soff = srow * ROWB + (((kc >> 1) ^ ((srow >> 2) & 3)) << 4) + ((kc & 1) << 3);
+    int arow[LA], wrow[LW];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) { int r = m0 + srow + 32 * i; arow[i] = r < T.M ? r : T.M - 1; }
+#pragma unroll
+    for (int i = 0; i < LW; ++i) { int r = n0 + srow + 32 * i; wrow[i] = r < T.N ? r : T.N - 1; }
+
+    f32x4 ra0[LA], rw0[LW], ra1[LA], rw1[LW];
+    const float* pa[LA];
+    const float* pw[LW];
+    int seg_end = 0;
+#define SPL_SEEK(KT)                                                                                    \
+    {                                                                                                   \
+        const int kt_ = (KT);                                                                           \
+        int s_ = 0, kbase_ = 0;                                                                         \
+        _Pragma("unroll") for (int i = 0; i < GEMM_MAX_SEG - 1; ++i)                                    \
+            if (i + 1 < T.nseg && kt_ >= T.kt_end[i]) { s_ = i + 1; kbase_ = T.kt_end[i]; }             \
+        const float* Ab_ = T.A[0];                                                                      \
+        const float* Wb_ = T.W[0];                                                                      \
+        long long lda_ = T.lda[0], ldw_ = T.ldw[0];                                                     \
+        seg_end = T.kt_end[0];                                                                          \
+        _Pragma("unroll") for (int i = 1; i < GEMM_MAX_SEG; ++i)                                        \
+            if (s_ == i) { Ab_ = T.A[i]; Wb_ = T.W[i]; lda_ = T.lda[i]; ldw_ = T.ldw[i]; seg_end = T.kt_end[i]; } \
+        const long long koff_ = (long long)(kt_ - kbase_) * GEMM_BK + scol;                             \
+        _Pragma("unroll") for (int i = 0; i < LA; ++i) pa[i] = Ab_ + arow[i] * lda_ + koff_;            \
+        _Pragma("unroll") for (int i = 0; i < LW; ++i) pw[i] = Wb_ + wrow[i] * ldw_ + koff_;            \
+    }
+#define SPL_GLOAD(RA, RW)                                                                           \
+    {                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < LA; ++i) { RA[i] = *(gptr4)(pa[i]); pa[i] += GEMM_BK; } \
+        _Pragma("unroll") for (int i = 0; i < LW; ++i) { RW[i] = *(gptr4)(pw[i]); pw[i] += GEMM_BK; } \
+    }
+#define SPL_STAGE(KT, RA, RW)                                                                       \
+    if ((KT) < kt1) {                                                                                   \
+        if ((KT) == seg_end) SPL_SEEK(KT);                                                              \
+        SPL_GLOAD(RA, RW);                                                                          \
+    }
+    // registers (fp32) -> three bf16 planes in LDS
+#define SPL_LSTORE(B, RA, RW)                                                                       \
+    {                                                                                                   \
+        char* sA_ = smem + (B) * BUF + soff;                                                            \
+        char* sW_ = smem + (B) * BUF + 3 * PLANE_A + soff;                                              \
+        _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                \
+            u32x2 h_, m_, l_;                                                                           \
+            split3(RA[i], h_, m_, l_);                                                                  \
+            *reinterpret_cast<u32x2*>(sA_ + i * 32 * ROWB) = h_;                                        \
+            *reinterpret_cast<u32x2*>(sA_ + i * 32 * ROWB + PLANE_A) = m_;                              \
+            *reinterpret_cast<u32x2*>(sA_ + i * 32 * ROWB + 2 * PLANE_A) = l_;                          \
+        }                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < LW; ++i) {                                                \
+            u32x2 h_, m_, l_;                                                                           \
+            split3(RW[i], h_, m_, l_);                                                                  \
+            *reinterpret_cast<u32x2*>(sW_ + i * 32 * ROWB) = h_;                                        \
+            *reinterpret_cast<u32x2*>(sW_ + i * 32 * ROWB + PLANE_W) = m_;                              \
+            *reinterpret_cast<u32x2*>(sW_ + i * 32 * ROWB + 2 * PLANE_W) = l_;                          \
+        }                                                                                               \
+    }
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    const int frow = lane & 31;
+    const int fsw = (frow >> 2) & 3;
+    // byte offsets of this lane's fragment rows (A: 2 sub-tiles, W: 1) and of its chunk in k16-step 0 / 1
+    const int fa0 = (wm * 64 + frow) * ROWB, fw0 = (wn * 32 + frow) * ROWB;
+    const int fc[2] = {(((lane >> 5)) ^ fsw) << 4, ((2 + (lane >> 5)) ^ fsw) << 4};
+#define SPL_FRAG(S, FA, FW)                                                                             \
+    {                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
+            _Pragma("unroll") for (int p = 0; p < 3; ++p)                                               \
+                FA[i][p] = *reinterpret_cast<const u32x4*>(sA + p * PLANE_A + fa0 + i * 32 * ROWB + fc[S]); \
+        _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                   \
+            FW[p] = *reinterpret_cast<const u32x4*>(sW + p * PLANE_W + fw0 + fc[S]);                    \
+    }
+#define SPL_MM(I, PA, PW) acc[I] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                             \
+        __builtin_bit_cast(bf16x8, fa_[I][PA]), __builtin_bit_cast(bf16x8, fw_[PW]), acc[I], 0, 0, 0)
+    // six products per sub-tile, smallest first; the two sub-tiles alternate so consecutive MFMAs are independent
+#define SPL_MFMA(FA, FW)                                                                                \
+    {                                                                                                   \
+        auto& fa_ = FA; auto& fw_ = FW;                                                                 \
+        SPL_MM(0, 0, 2); SPL_MM(1, 0, 2);                                                               \
+        SPL_MM(0, 2, 0); SPL_MM(1, 2, 0);                                                               \
+        SPL_MM(0, 1, 1); SPL_MM(1, 1, 1);                                                               \
+        SPL_MM(0, 0, 1); SPL_MM(1, 0, 1);                                                               \
+        SPL_MM(0, 1, 0); SPL_MM(1, 1, 0);                                                               \
+        SPL_MM(0, 0, 0); SPL_MM(1, 0, 0);                                                               \
+    }
+    // One k-tile.  The split of tile kt+1 (VALU) and its LDS stores are issued IN BETWEEN the 24 MFMAs of tile kt
+    // (sched_group_barrier pins the interleave: the matrix pipe runs 32 cycles per MFMA, enough for ~7 VALU
+    // issues), so the conversion work hides under the matrix pipe instead of alternating with it.  The store
+    // is unconditional: on the last tile it writes stale registers into the buffer nobody reads again.
+#define SPL_ITER(KT, B, RA, RW)                                                                     \
+    {                                                                                                   \
+        const char* sA = smem + (B) * BUF;                                                              \
+        const char* sW = smem + (B) * BUF + 3 * PLANE_A;                                                \
+        u32x4 fA0[TM][3], fW0[3], fA1[TM][3], fW1[3];                                                   \
+        SPL_FRAG(0, fA0, fW0);                                                                          \
+        SPL_FRAG(1, fA1, fW1);                                                                          \
+        SPL_LSTORE((B) ^ 1, RA, RW);                                                                \
+        SPL_MFMA(fA0, fW0);                                                                             \
+        SPL_MFMA(fA1, fW1);                                                                             \
+        _Pragma("unroll") for (int q_ = 0; q_ < 24; ++q_) {                                             \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          \
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                                          \
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                          \
+        }                                                                                               \
+        SPL_STAGE((KT) + 3, RA, RW);                                                                \
+        __syncthreads();                                                                                \
+    }
+    if (kt0 < kt1) {
+        SPL_SEEK(kt0);
+        SPL_GLOAD(ra0, rw0);
+        SPL_STAGE(kt0 + 1, ra1, rw1);
+        SPL_LSTORE(0, ra0, rw0);
+        SPL_STAGE(kt0 + 2, ra0, rw0);
+        __syncthreads();
+    }
+    for (int kt = kt0; kt < kt1; kt += 2) {
+        SPL_ITER(kt, 0, ra1, rw1);
+        if (kt + 1 < kt1) SPL_ITER(kt + 1, 1, ra0, rw0);
+    }
+#undef SPL_ITER
+#undef SPL_MFMA
+#undef SPL_MM
+#undef SPL_FRAG
+#undef SPL_LSTORE
+#undef SPL_STAGE
+#undef SPL_GLOAD
+#undef SPL_SEEK
+
+    float* Cs = T.C + (long long)ks * T.slab_stride;
+    const bool fused = (T.ksplit == 1);
+    const int crow0 = m0 + wm * 64 + 4 * (lane >> 5);
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col < T.N) {
+        const float bv = (fused && T.bias) ? T.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = crow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                if (row < T.M) {
+                    float v = acc[i][r];
+                    if (fused) v = apply_act(v + bv, T.act);
+                    Cs[(long long)row * T.ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+static int gemm_split_mode() { static int v = env_int("SET_GEMM_SPLIT", 0); return v; }
+
 int gemm_tile_m(int M) { return M <= 32 ? 32 : (M <= 64 ? 64 : 128); }
 static int gemm_bn128() { static int v = env_int("SET_GEMM_BN128", 0); return v; }
 static int gemm_tile_n(int M) { return (M <= 32 || (M > 64 && gemm_bn128())) ? 128 : 64; }
@@ -315,7 +516,18 @@ int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag
     static const bool sites = env_int("SET_PROFILE_SITES", 0) != 0;   // per-call-site breakdown (nested events)
     ProfScope ps2(sites ? (tag ? tag : "gemm:other") : nullptr, stream, flops, bytes);
     dim3 grid(wg), block(256);
-    if (bm == 128 && bn == 128)
+    static const char* split_tag = getenv("SET_GEMM_SPLIT_TAG");     // debug: restrict the split kernel to one call site
+    const bool split_here = gemm_split_mode() && (!split_tag || !*split_tag || strstr(tag ? tag : "untagged", split_tag));
+    if (bm == 128 && bn == 64 && split_here) {
+        constexpr int kLds = 2 * 3 * (128 + 64) * 64;
+        static bool attr_set = false;
+        if (!attr_set) {
+            SET_HIP_TRY(hipFuncSetAttribute((const void*)gemm_nt_split_bf16, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            kLds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(gemm_nt_split_bf16, grid, block, kLds, stream, L);
+    } else if (bm == 128 && bn == 128)
         hipLaunchKernelGGL((gemm_nt_f32<128, 128, 2, 2>), grid, block, 0, stream, L);
     else if (bm == 128)
         hipLaunchKernelGGL((gemm_nt_f32<128, 64, 2, 2>), grid, block, 0, stream, L);

@@ -88,3 +88,20 @@ def test_device_prefetcher_roundtrip(setup):
     assert len(got) == 4
     for (hx, hp), (dx, dp) in zip(host, got):
         assert dx.is_cuda and torch.equal(dx.cpu(), hx) and torch.equal(dp.cpu(), hp)
+
+
+def test_split_precision_gemm_keeps_parity():
+    """The opt-in bf16x3 split-precision GEMM (SET_GEMM_SPLIT=1, csrc/gemm_f32.hip) must be fp32-grade: rerun the
+    golden parity tests of the full-size model (greedy tokens bit-exact, logits within 1e-4) and the fp64 linear
+    check with the switch on.  The switch is read once per process, hence the child process."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, SET_GEMM_SPLIT="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+           os.path.join(root, "tests", "test_hip_editnet.py"), os.path.join(root, "tests", "test_hip_ops.py"),
+           "-k", "full_b128 or full_b4 or v9490 or linear_shapes or token_table"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout and "failed" not in out.stdout

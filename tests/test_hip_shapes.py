@@ -39,10 +39,20 @@ def test_fused_paths_vs_oracle(B, T, R, D, A, F, V):
         seq, logp = rl(wm, to_dev(prev), to_dev(plen), to_dev(X), True, False)
         pred, caps_s, dl, sort_ind = xe(to_dev(X), to_dev(caps), to_dev(clen), to_dev(prev), to_dev(plen), False, 0.0)
     # XE forward: compare per original sample (sort ties may differ)
-    pred_o, _, dl_o, sort_o = EN.xe_forward(P, X, caps, clen, prev, plen)
+    xtr = []
+    pred_o, _, dl_o, sort_o = EN.xe_forward(P, X, caps, clen, prev, plen, trace=xtr)
     inv, inv_o = parity.unsort(sort_ind.cpu().numpy()), parity.unsort(sort_o)
     assert sorted(dl) == sorted(dl_o)
-    parity.assert_close(pred.cpu().numpy()[inv], pred_o[inv_o], parity.LOGIT_TOL, "xe predictions")
+    # SelectC is a HARD arg-max over alpha_c (editnet.py:410-416): a sample whose two largest copy weights are
+    # closer than rounding noise may legitimately pick the other memory row, so such samples are not compared
+    firm = np.ones(B, bool)
+    for st_ in xtr:
+        a = np.sort(st_["alpha_c"], 1)
+        if a.shape[1] > 1:
+            firm[:a.shape[0]] &= (a[:, -1] - a[:, -2]) > 1e-5
+    assert firm.mean() > 0.9
+    parity.assert_close(pred.cpu().numpy()[inv][firm[inv_o]], pred_o[inv_o][firm[inv_o]], parity.LOGIT_TOL,
+                        "xe predictions")
     # greedy: rows whose oracle margin is comfortable must match bit-exactly
     tr = []
     seq_o, logp_o = EN.greedy_decode(P, wm["<start>"], wm["<end>"], prev, plen, X, trace=tr)
