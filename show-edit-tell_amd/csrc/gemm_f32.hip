@@ -7,9 +7,9 @@
 // v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains, 157 TFLOP/s peak = 256 flop/clk/CU).
 //
 // Structure (one workgroup = 4 waves = one SIMD each):
-//   * tile BM x BN x 32; global -> registers (float4, whole 128-B rows) -> LDS with a 36-float
-//     row stride (conflict-free ds_write_b128 and ds_read_b128), two LDS buffers, one barrier
-//     per k-tile; the next k-tile's global loads are in flight during the MFMAs of this one.
+//   * tile BM x BN x 32; global -> registers (float4, whole 128-B rows) -> LDS (unpadded 128-B rows with
+//     XOR-swizzled 16-byte chunks: conflict-free ds_write_b128 and ds_read_b128), two LDS buffers, one
+//     barrier per k-tile; the global loads run two k-tiles ahead of the MFMAs.
 //   * K order inside an 8-wide block is permuted (lanes 0-31 take k0..3, lanes 32-63 k4..7) so one
 //     ds_read_b128 per operand row feeds four MFMAs; A and W use the same permutation.
 //   * several independent problems ride one launch (GemmLaunch holds up to 6 task descriptors)
