@@ -414,8 +414,11 @@ int set_editnet_greedy(const SetEditNetWeights* w, const SetEditNetDims* d, cons
         Slabs lg;
         SET_TRY(step_impl(w, d, X, B, W, W.it, 1, nullptr, 0, &lg, st));
         if (t == max_len) break;
-        SET_TRY(greedy_pick(lg, w->fc_b, d->V, t, max_len, end_idx,
-                            (long long*)seq, seq_logp, W.it, W.unfinished, W.alive, w->embed, W.emb, d->D, B, st));
+        // with the token table the step never reads relu(E[it]) (all its consumers gather the folded products),
+        // so the epilogue skips the embedding gather
+        const bool emb_needed = !(w->tok_table && (d->D % 64 == 0) && env_int("SET_NO_FUSED", 0) == 0);
+        SET_TRY(greedy_pick(lg, w->fc_b, d->V, t, max_len, end_idx, (long long*)seq, seq_logp, W.it, W.unfinished,
+                            W.alive, emb_needed ? w->embed : nullptr, W.emb, d->D, B, st));
     }
     return SET_OK;
 }

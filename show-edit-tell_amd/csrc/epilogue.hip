@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(256) greedy_pick_k(Slabs logits, const float* 
         s_tok = it;
     }
     __syncthreads();
-    if (emb_out) {
+    if (emb_out && table) {
         const long long tok = s_tok;
         for (int d = tid * 4; d < D; d += 1024) {
             f32x4 v = *reinterpret_cast<const f32x4*>(table + tok * D + d);

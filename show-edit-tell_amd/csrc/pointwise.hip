@@ -36,6 +36,17 @@ __device__ __forceinline__ void slab_accum(f32x4 (&acc)[Q], const Slabs& s, long
     if (s.n <= 0) return;
     const float* p = s.p + m * s.ld + col0;
     int i = 0;
+    for (; i + 4 <= s.n; i += 4) {                  // Q x 4 independent loads in flight
+        f32x4 v[4][Q];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < Q; ++q) v[u][q] = ld4(p + (long long)(i + u) * s.stride + q * colstep);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < Q; ++q) acc[q] += v[u][q];
+    }
     for (; i + 2 <= s.n; i += 2) {
         f32x4 v0[Q], v1[Q];
 #pragma unroll
@@ -70,6 +81,20 @@ __global__ void __launch_bounds__(256) lstm_pointwise_k(Slabs g0, Slabs g1, Slab
     if (idx >= (long long)M * per_row) return;
     const long long m = idx / per_row;
     const int j = (int)(idx - m * per_row) << 2;
+    // operands that do not depend on the slabs are requested first (the table row needs its token id): their
+    // latency overlaps the slab reads; the additions keep the order slabs, pre, table row, b0, b1
+    const float* trow = gt.tab ? gt.tab + gt.ids[m * gt.id_stride] * gt.ld + gt.col0 : nullptr;
+    const f32x4 c = ld4(c_in + m * D + j);
+    f32x4 xpre[4], xtab[4], xb0[4], xb1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = q * D + j;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        xpre[q] = pre ? ld4(pre + m * ldpre + n) : z;
+        xtab[q] = trow ? ld4(trow + n) : z;
+        xb0[q] = b0 ? ld4(b0 + n) : z;
+        xb1[q] = b1 ? ld4(b1 + n) : z;
+    }
     f32x4 g[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) g[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -78,13 +103,11 @@ __global__ void __launch_bounds__(256) lstm_pointwise_k(Slabs g0, Slabs g1, Slab
     slab_accum<4>(g, g2, m, j, D);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int n = q * D + j;
-        if (pre) g[q] += ld4(pre + m * ldpre + n);
-        if (gt.tab) g[q] += ld4(gt.tab + gt.ids[m * gt.id_stride] * gt.ld + gt.col0 + n);
-        if (b0) g[q] += ld4(b0 + n);
-        if (b1) g[q] += ld4(b1 + n);
+        if (pre) g[q] += xpre[q];
+        if (trow) g[q] += xtab[q];
+        if (b0) g[q] += xb0[q];
+        if (b1) g[q] += xb1[q];
     }
-    const f32x4 c = ld4(c_in + m * D + j);
     f32x4 cn, hn, og;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
