@@ -40,13 +40,46 @@ __global__ void __launch_bounds__(256) greedy_pick_k(Slabs logits, const float* 
         // slab 0 (+ bias), then the remaining K-slabs in index order; GP_MAXQ independent float4 loads
         // are in flight per pass
         const bool bias4 = bias && !(V & 3) && ((reinterpret_cast<uintptr_t>(bias) & 15u) == 0);
+        // the bias does not depend on the slabs: request it first (added last, as before)
+        f32x4 bq[GP_MAXQ];
+#pragma unroll
+        for (int q = 0; q < GP_MAXQ; ++q) {
+            const int v = (tid + 256 * q) * 4;
+            bq[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (v < V) {
+                if (bias4) {
+                    bq[q] = *reinterpret_cast<const f32x4*>(bias + v);
+                } else if (bias) {
+                    bq[q][0] = bias[v];
+                    if (v + 1 < V) bq[q][1] = bias[v + 1];
+                    if (v + 2 < V) bq[q][2] = bias[v + 2];
+                    if (v + 3 < V) bq[q][3] = bias[v + 3];
+                }
+            }
+        }
 #pragma unroll
         for (int q = 0; q < GP_MAXQ; ++q) {
             const int v = (tid + 256 * q) * 4;
             x[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (v < V) x[q] = *reinterpret_cast<const f32x4*>(row + v);
         }
-        for (int i = 1; i < logits.n; ++i) {
+        int i = 1;
+        for (; i + 2 <= logits.n; i += 2) {          // two slabs (2 x GP_MAXQ loads) in flight, added in slab order
+            f32x4 y[GP_MAXQ], z[GP_MAXQ];
+#pragma unroll
+            for (int q = 0; q < GP_MAXQ; ++q) {
+                const int v = (tid + 256 * q) * 4;
+                y[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                z[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (v < V) {
+                    y[q] = *reinterpret_cast<const f32x4*>(row + (long long)i * logits.stride + v);
+                    z[q] = *reinterpret_cast<const f32x4*>(row + (long long)(i + 1) * logits.stride + v);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < GP_MAXQ; ++q) { x[q] += y[q]; x[q] += z[q]; }
+        }
+        for (; i < logits.n; ++i) {
             f32x4 y[GP_MAXQ];
 #pragma unroll
             for (int q = 0; q < GP_MAXQ; ++q) {
@@ -60,16 +93,7 @@ __global__ void __launch_bounds__(256) greedy_pick_k(Slabs logits, const float* 
 #pragma unroll
         for (int q = 0; q < GP_MAXQ; ++q) {
             const int v = (tid + 256 * q) * 4;
-            if (v < V) {
-                if (bias4) {
-                    x[q] += *reinterpret_cast<const f32x4*>(bias + v);
-                } else if (bias) {
-                    x[q][0] += bias[v];
-                    if (v + 1 < V) x[q][1] += bias[v + 1];
-                    if (v + 2 < V) x[q][2] += bias[v + 2];
-                    if (v + 3 < V) x[q][3] += bias[v + 3];
-                }
-            }
+            if (bias) x[q] += bq[q];
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (v + e >= V) x[q][e] = -INFINITY;     // padding columns / rows past V
         }
