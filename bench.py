@@ -263,11 +263,12 @@ def main():
     }
     if prof is not None:
         by = {p["tag"]: p for p in prof}
-        g = by.get("gemm_nt_f32<128,64>")
+        gemm_tags = sorted((t for t in by if t.startswith("gemm_nt_f32")), key=lambda t: -by[t]["ms"])
+        g = by[gemm_tags[0]] if gemm_tags else None      # the dominant kernel = the GEMM tile variant with most time
         if g and g["ms"] > 0:
             tf = g["flops"] / (g["ms"] * 1e-3) / 1e12
             line["roofline"] = {
-                "kernel": "gemm_nt_f32<128,64,2,2> (v_mfma_f32_32x32x2_f32)", "bound": "mfma",
+                "kernel": gemm_tags[0].replace(">", ",2,2>") + " (v_mfma_f32_32x32x2_f32)", "bound": "mfma",
                 "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
                 "traffic": (lambda t: None if t is None else round(t["traffic_bytes_per_launch"] / 1e6, 2))(pmc_traffic()),
