@@ -468,7 +468,8 @@ void plan_ksplit(GemmProb* probs, int n, int cap_wgs) {
         if (ks > kts[i]) ks = kts[i];
         return ks < 1 ? 1 : ks;
     };
-    int kper = 4;
+    static const int min_kper = env_int("SET_GEMM_MIN_KPER", 4);
+    int kper = min_kper;
     for (; kper < max_kt; ++kper) {
         long long wgs = 0;
         for (int i = 0; i < n; ++i) wgs += (long long)tiles[i] * split_of(i, kper);

@@ -248,14 +248,16 @@ int gemm_gen(const float* A, long long lda, int a_kminor, const float* B, long l
     if ((!a_kminor || !b_kminor) && (K & 3)) return SET_ERR_UNSUPPORTED;
     if (a_kminor && ((M & 3) || M < 4)) return SET_ERR_UNSUPPORTED;
     if (b_kminor && ((N & 3) || N < 4)) return SET_ERR_UNSUPPORTED;
-    const int bm = M <= 64 ? 64 : 128, bn = 64;
+    static const int bm64_upto = env_int("SET_GEMM_GEN_BM64_UPTO", 128);    // same finding as the forward kernel
+    const int bm = M <= bm64_upto ? 64 : 128, bn = 64;
     const int tiles_m = cdiv(M, bm), tiles_n = cdiv(N, bn);
     const long long tiles = (long long)tiles_m * tiles_n;
     const int ktiles = cdiv(K, GEMM_BK);
     // split the contraction only when the output alone cannot fill the chip (512 workgroup slots)
     int ksplit = 1;
-    if (tiles < 384 && ktiles >= 8) {
-        ksplit = (int)(512 / tiles);
+    const int slots = bm == 64 ? 768 : 512;              // workgroups that are resident at once
+    if (tiles < slots * 3 / 4 && ktiles >= 8) {
+        ksplit = (int)(slots / tiles);
         if (ksplit > ktiles / 4) ksplit = ktiles / 4;
         if (ksplit > 64) ksplit = 64;
         const bool vec_ok = !(N & 3) && !(ldc & 3) && aligned16(C) && ws && aligned16(ws);
