@@ -35,6 +35,8 @@ typedef const f32x4 __attribute__((address_space(1)))* gptr4;
 // each) are then both bank-conflict-free, and a 128x64x32 stage pair is 48 KB -> three workgroups per CU.
 constexpr int LDS_STRIDE = 32;
 
+static int gemm_split_mode() { static int v = env_int("SET_GEMM_SPLIT", 0); return v; }
+
 struct GemmTask {
     const float* A[GEMM_MAX_SEG];
     const float* W[GEMM_MAX_SEG];
@@ -43,7 +45,7 @@ struct GemmTask {
     float* C;
     long long ldc, slab_stride;
     const float* bias;
-    int M, N, act, nseg, ktiles, ksplit, tiles_m, tiles_n, wg_begin;
+    int M, N, act, nseg, ktiles, ksplit, tiles_m, tiles_n, wg_begin, tm_stride;
 };
 struct GemmLaunch {
     GemmTask t[GEMM_MAX_TASKS];
@@ -77,10 +79,15 @@ __global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
     for (int i = 1; i < GEMM_MAX_TASKS; ++i)
         if (i < L.ntasks && (int)blockIdx.x >= L.t[i].wg_begin) ti = i;
     const GemmTask& T = L.t[ti];
+    // workgroup -> (row tile tm, column tile tn, k-slice ks).  Row tiles of the same (tn, ks) read the same
+    // weight block; their block ids differ by tm_stride, a multiple of 8, so they land on the SAME XCD (blocks
+    // go round-robin over the 8 XCDs) and the second reader finds the block in that XCD's L2.
     const int local = (int)blockIdx.x - T.wg_begin;
-    const int ks = local % T.ksplit;
-    const int tile = local / T.ksplit;
-    const int tn = tile % T.tiles_n, tm = tile / T.tiles_n;
+    const int tm = local / T.tm_stride;
+    const int rem = local - tm * T.tm_stride;
+    if (rem >= T.tiles_n * T.ksplit) return;          // padding slot
+    const int ks = rem % T.ksplit;
+    const int tn = rem / T.ksplit;
     const int m0 = tm * BM, n0 = tn * BN;
     const int kt0 = (int)(((long long)ks * T.ktiles) / T.ksplit);
     const int kt1 = (int)(((long long)(ks + 1) * T.ktiles) / T.ksplit);
@@ -270,10 +277,15 @@ __global__ void __launch_bounds__(256) gemm_nt_split_bf16(const GemmLaunch L) {
     for (int i = 1; i < GEMM_MAX_TASKS; ++i)
         if (i < L.ntasks && (int)blockIdx.x >= L.t[i].wg_begin) ti = i;
     const GemmTask& T = L.t[ti];
+    // workgroup -> (row tile tm, column tile tn, k-slice ks).  Row tiles of the same (tn, ks) read the same
+    // weight block; their block ids differ by tm_stride, a multiple of 8, so they land on the SAME XCD (blocks
+    // go round-robin over the 8 XCDs) and the second reader finds the block in that XCD's L2.
     const int local = (int)blockIdx.x - T.wg_begin;
-    const int ks = local % T.ksplit;
-    const int tile = local / T.ksplit;
-    const int tn = tile % T.tiles_n, tm = tile / T.tiles_n;
+    const int tm = local / T.tm_stride;
+    const int rem = local - tm * T.tm_stride;
+    if (rem >= T.tiles_n * T.ksplit) return;          // padding slot
+    const int ks = rem % T.ksplit;
+    const int tn = rem / T.ksplit;
     const int m0 = tm * BM, n0 = tn * BN;
     const int kt0 = (int)(((long long)ks * T.ktiles) / T.ksplit);
     const int kt1 = (int)(((long long)(ks + 1) * T.ktiles) / T.ksplit);
@@ -434,13 +446,13 @@ __global__ void __launch_bounds__(256) gemm_nt_split_bf16(const GemmLaunch L) {
     }
 }
 
-static int gemm_split_mode() { static int v = env_int("SET_GEMM_SPLIT", 0); return v; }
+
 
 int gemm_tile_m(int M) {
     // 64x64 tiles up to M = 128: at the decode batch two 64-row tiles per weight block (the second one hits the
     // same XCD's L2) halve the split-K factor -> half the slab bytes written here and re-read by the consumer,
     // and 32 KB workgroups pack three per CU.  Measured +4-5 % on the bench against the 128x64 tile.
-    static const int bm64_upto = env_int("SET_GEMM_BM64_UPTO", 128);
+    static const int bm64_upto = env_int("SET_GEMM_BM64_UPTO", gemm_split_mode() ? 64 : 128);   // the split kernel is 128x64 only
     return M <= 32 ? 32 : (M <= bm64_upto ? 64 : 128);
 }
 static int gemm_bn128() { static int v = env_int("SET_GEMM_BN128", 0); return v; }
@@ -511,7 +523,9 @@ int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag
         if (t.ksplit > 1 && (p.act != SET_ACT_NONE)) return SET_ERR_ARG;
         t.tiles_m = cdiv(p.M, bm); t.tiles_n = cdiv(p.N, bn);
         t.wg_begin = wg;
-        wg += t.tiles_m * t.tiles_n * t.ksplit;
+        static const int xcd_align = env_int("SET_GEMM_XCD_ALIGN", 1);
+        t.tm_stride = (t.tiles_m > 1 && xcd_align) ? (int)round_up((size_t)t.tiles_n * t.ksplit, 8) : t.tiles_n * t.ksplit;
+        wg += t.tiles_m * t.tm_stride;
     }
     for (int i = n; i < GEMM_MAX_TASKS; ++i) { L.t[i] = L.t[0]; L.t[i].wg_begin = 0x7fffffff; }
     double flops = 0.0, bytes = 0.0;
