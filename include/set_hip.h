@@ -342,6 +342,16 @@ int set_beam_gather_f32(float* s0, float* s1, float* s2, float* s3, const int32_
 int set_gemm_f32(const float* A, long long lda, int a_kminor, const float* B, long long ldb, int b_kminor,
                  float* C, long long ldc, int M, int N, int K, int accumulate, void* ws, size_t ws_bytes,
                  void* stream);
+/* Up to 6 independent problems of the same operand layout in one launch (the dX products of one module's
+ * backward share dY and are individually too small to fill the chip).  Outputs must not alias each other. */
+typedef struct SetGemmDesc {
+    const float* A; long long lda;
+    const float* B; long long ldb;
+    float* C; long long ldc;
+    int M, N, K, accumulate;
+} SetGemmDesc;
+int set_gemm_group_f32(const SetGemmDesc* descs, int n, int a_kminor, int b_kminor, void* ws, size_t ws_bytes,
+                       void* stream);
 
 #ifdef __cplusplus
 }

@@ -133,6 +133,12 @@ class DcnetWeights(C.Structure):
     _fields_ = [(f, C.c_void_p) for f, _ in DCNET_WEIGHT_FIELDS]
 
 
+class GemmDesc(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_longlong), ("B", C.c_void_p), ("ldb", C.c_longlong),
+                ("C", C.c_void_p), ("ldc", C.c_longlong), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("accumulate", C.c_int)]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _L = C.c_int64
@@ -198,6 +204,7 @@ PROTOTYPES = {
     "set_select_bwd_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "set_beam_pick_f32": (_I, [_P, _P, _L, _I, _I, _I, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "set_beam_gather_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "set_gemm_group_f32": (_I, [C.POINTER(GemmDesc), _I, _I, _I, _P, _Z, _P]),
     "set_gemm_f32": (_I, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, _I, _P, _Z, _P]),
     "set_caption_encoder_workspace_bytes": (_Z, [_I, _I, _I]),
     "set_caption_encoder_f32": (_I, [C.POINTER(EditNetWeights), _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),

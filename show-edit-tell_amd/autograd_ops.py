@@ -70,6 +70,39 @@ def gemm(a, a_kminor, b, b_kminor, M, N, K, out=None, accumulate=False):
     return out
 
 
+def gemm_group(items, a_kminor, b_kminor):
+    """items: [(a, b, M, N, K, out or None, accumulate)], all of one operand layout -> list of outputs, ONE launch
+    (set_gemm_group_f32; at most 6 problems, same row-tile class)."""
+    lib = _lib.load()
+    n = len(items)
+    descs = (_lib.GemmDesc * n)()
+    keep, outs = [], []
+    dev = items[0][0].device
+    for i, (a, b, M, N, K, out, acc) in enumerate(items):
+        a, lda = _mat(a)
+        b, ldb = _mat(b)
+        if out is None:
+            out, acc = torch.empty(M, N, dtype=torch.float32, device=dev), False
+        keep += [a, b]
+        outs.append(out)
+        descs[i] = _lib.GemmDesc(ptr(a), lda, ptr(b), ldb, ptr(out), out.stride(0), M, N, K, int(acc))
+    ws = _scratch(dev)
+    check(lib.set_gemm_group_f32(descs, n, int(a_kminor), int(b_kminor), ptr(ws), ws.numel(), stream_of(dev)),
+          "set_gemm_group_f32")
+    return outs
+
+
+def _dgrad_group(pairs):
+    """[(dy, w, out or None)] -> [dX (+)= dy . w], grouped into one launch when the kernel can take them all"""
+    ok = all(_native_ok(dy, w) and not (dy.shape[1] & 3) and not (w.shape[1] & 3) and w.shape[1] >= 4 and
+             (out is None or out.is_contiguous()) for dy, w, out in pairs)
+    same_class = len({dy.shape[0] <= 128 for dy, _, _ in pairs}) == 1
+    if not ok or not same_class or len(pairs) > 6:
+        return [_dgrad(dy, w, out) for dy, w, out in pairs]
+    return gemm_group([(dy, w, dy.shape[0], w.shape[1], dy.shape[1], out, out is not None) for dy, w, out in pairs],
+                      False, True)
+
+
 def _native_ok(*ts):
     return _NATIVE_GEMM and all(t.is_cuda and t.dtype == torch.float32 for t in ts)
 
@@ -276,8 +309,8 @@ class _LstmCell(torch.autograd.Function):
                                         ptr(gates), ptr(c), ptr(c_new), ptr(dg), ptr(dcp), M, D,
                                         stream_of(h.device)), "set_lstm_cell_bwd_f32")
         p_ih, p_hh, pb_ih, pb_hh = ctx.params
-        return (_dgrad(dg, w_ih), _dgrad(dg, w_hh), dcp, _wgrad(p_ih, dg, x), _wgrad(p_hh, dg, h), _bgrad(pb_ih, dg),
-                _bgrad(pb_hh, dg))
+        dx, dhp = _dgrad_group([(dg, w_ih, None), (dg, w_hh, None)])
+        return (dx, dhp, dcp, _wgrad(p_ih, dg, x), _wgrad(p_hh, dg, h), _bgrad(pb_ih, dg), _bgrad(pb_hh, dg))
 
 
 def lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh):
@@ -342,9 +375,10 @@ class _CaptionAttention(torch.autograd.Function):
         dz, ds, dt = (torch.empty(M, D, dtype=torch.float32, device=dev) for _ in range(3))
         check(lib.set_context_gate_bwd_f32(ptr(_c(dgated)), ptr(zt), ptr(s), ptr(t), ptr(dz), ptr(ds), ptr(dt), M, D,
                                            stream_of(dev)), "set_context_gate_bwd_f32")
-        dctx = _dgrad(ds, sc_w, out=_dgrad(dz, gate_w[:, 2 * D:]))
-        dword = _dgrad(dt, tc_w[:, :D], out=_dgrad(dz, gate_w[:, :D]))
-        dh1 = _dgrad(dt, tc_w[:, D:], out=_dgrad(dz, gate_w[:, D:2 * D]))
+        # six products in two launches: the three column blocks of the context gate, then the += terms
+        dctx, dword, dh1 = _dgrad_group([(dz, gate_w[:, 2 * D:], None), (dz, gate_w[:, :D], None),
+                                         (dz, gate_w[:, D:2 * D], None)])
+        _dgrad_group([(ds, sc_w, dctx), (dt, tc_w[:, :D], dword), (dt, tc_w[:, D:], dh1)])
         p_dec_w, p_dec_b, p_gate_w, p_gate_b, p_sc_w, p_sc_b, p_tc_w, p_tc_b = ctx.params
         wh = torch.cat([word, h1], 1)
         d_gate_w = _wgrad(p_gate_w, dz, torch.cat([wh, cx], 1))
@@ -508,14 +542,14 @@ class _CopyLstm(torch.autograd.Function):
         check(lib.set_copy_gate_bwd_f32(ptr(None if dh is None else _c(dh)), ptr(None if dadp is None else _c(dadp)),
                                         ptr(ogate), ptr(adp), ptr(cg), ptr(cmem), ptr(c_new), ptr(du), ptr(dcm), ptr(dcn),
                                         ptr(dop), M, D, st), "set_copy_gate_bwd_f32")
-        _dgrad(du, cnew_w, out=dcn)
-        _dgrad(du, cmem_w, out=dcm)
+        _dgrad_group([(du, cnew_w, dcn), (du, cmem_w, dcm)])
         dgw = torch.empty_like(gates)
         dc2 = torch.empty_like(c2)
         check(lib.set_lstm_gates_bwd_f32(ptr(dcn), ptr(dop), ptr(gates), ptr(c2), ptr(dgw), ptr(dc2), M, D, st),
               "set_lstm_gates_bwd_f32")
         p = ctx.params
-        return (_dgrad(dgw, x2h_w), _dgrad(dgw, h2h_w), dc2, dcm, _wgrad(p[0], dgw, x), _bgrad(p[1], dgw), _wgrad(p[2], dgw, h2),
+        dx, dh2 = _dgrad_group([(dgw, x2h_w, None), (dgw, h2h_w, None)])
+        return (dx, dh2, dc2, dcm, _wgrad(p[0], dgw, x), _bgrad(p[1], dgw), _wgrad(p[2], dgw, h2),
                 _bgrad(p[3], dgw), _wgrad(p[4], du, c_new), _bgrad(p[5], du), _wgrad(p[6], du, cmem), _bgrad(p[7], du))
 
 

@@ -337,4 +337,9 @@ int set_gemm_f32(const float* A, long long lda, int a_kminor, const float* B, lo
                     (hipStream_t)stream);
 }
 
+int set_gemm_group_f32(const SetGemmDesc* descs, int n, int a_kminor, int b_kminor, void* ws, size_t ws_bytes,
+                       void* stream) {
+    return gemm_gen_group(descs, n, a_kminor, b_kminor, ws, ws_bytes, (hipStream_t)stream);
+}
+
 }  // extern "C"

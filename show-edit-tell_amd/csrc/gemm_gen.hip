@@ -22,24 +22,39 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const f32x4 __attribute__((address_space(1)))* gptr4;
 
+constexpr int GEN_MAX_TASKS = 6;
 struct GenTask {
     const float* A;
     const float* B;
     float* C;            // C itself (ksplit == 1) or the slab base
     long long lda, ldb, ldc, slab_stride;
-    int M, N, K, ktiles, ksplit, tiles_n, accumulate;
+    int M, N, K, ktiles, ksplit, tiles_n, accumulate, wg_begin;
+    // reduction pass (ksplit > 1): out (+)= sum of slabs
+    float* out;
+    long long ldo;
+    int red_begin;       // first 256-thread block of this task in the grouped reduction launch
+};
+struct GenLaunch {
+    GenTask t[GEN_MAX_TASKS];
+    int ntasks;
 };
 
 template <int BM, int BN, bool A_KMAJ, bool B_KMAJ>
-__global__ void __launch_bounds__(256) gemm_gen_f32(const GenTask T) {
+__global__ void __launch_bounds__(256) gemm_gen_f32(const GenLaunch L) {
     constexpr int TM = BM / 64, TN = BN / 64;            // 2x2 waves
     constexpr int LA = BM / 32, LB = BN / 32;            // float4 loads per thread per k-tile
     __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * 32];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
-    const int ks = (int)blockIdx.x % T.ksplit;
-    const int tile = (int)blockIdx.x / T.ksplit;
+    int ti = 0;
+#pragma unroll
+    for (int i = 1; i < GEN_MAX_TASKS; ++i)
+        if (i < L.ntasks && (int)blockIdx.x >= L.t[i].wg_begin) ti = i;
+    const GenTask& T = L.t[ti];
+    const int local = (int)blockIdx.x - T.wg_begin;
+    const int ks = local % T.ksplit;
+    const int tile = local / T.ksplit;
     const int tn = tile % T.tiles_n, tm = tile / T.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int kt0 = (int)(((long long)ks * T.ktiles) / T.ksplit);
@@ -209,19 +224,24 @@ __global__ void __launch_bounds__(256) gemm_gen_f32(const GenTask T) {
     }
 }
 
-// out[m, n] (+)= sum over slabs, slab 0 first
-__global__ void __launch_bounds__(256) slab_reduce_k(const float* slabs, long long slab_stride, int nslab, float* out,
-                                                     long long ldo, int M, int N, int accumulate) {
-    const int per_row = N >> 2;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)M * per_row) return;
+// out[m, n] (+)= sum over slabs, slab 0 first; one launch serves every split task of a group
+__global__ void __launch_bounds__(256) slab_reduce_k(const GenLaunch L) {
+    int ti = -1;
+#pragma unroll
+    for (int i = 0; i < GEN_MAX_TASKS; ++i)
+        if (i < L.ntasks && L.t[i].ksplit > 1 && (int)blockIdx.x >= L.t[i].red_begin) ti = i;
+    if (ti < 0) return;
+    const GenTask& T = L.t[ti];
+    const int per_row = T.N >> 2;
+    const long long idx = (long long)((int)blockIdx.x - T.red_begin) * blockDim.x + threadIdx.x;
+    if (idx >= (long long)T.M * per_row) return;
     const long long m = idx / per_row;
     const int j = (int)(idx - m * per_row) << 2;
-    const float* p = slabs + m * N + j;
+    const float* p = T.C + m * T.N + j;
     f32x4 v = *reinterpret_cast<const f32x4*>(p);
-    for (int s = 1; s < nslab; ++s) v += *reinterpret_cast<const f32x4*>(p + (long long)s * slab_stride);
-    float* o = out + m * ldo + j;
-    if (accumulate) {
+    for (int s = 1; s < T.ksplit; ++s) v += *reinterpret_cast<const f32x4*>(p + (long long)s * T.slab_stride);
+    float* o = T.out + m * T.ldo + j;
+    if (T.accumulate) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] += v[e];
     } else {
@@ -231,66 +251,105 @@ __global__ void __launch_bounds__(256) slab_reduce_k(const float* slabs, long lo
 }
 
 template <int BM, int BN>
-static void launch_gen(const GenTask& T, int a_kmaj, int b_kmaj, unsigned wgs, hipStream_t s) {
+static void launch_gen(const GenLaunch& L, int a_kmaj, int b_kmaj, unsigned wgs, hipStream_t s) {
     dim3 grid(wgs), block(256);
-    if (a_kmaj && b_kmaj) hipLaunchKernelGGL((gemm_gen_f32<BM, BN, true, true>), grid, block, 0, s, T);
-    else if (a_kmaj) hipLaunchKernelGGL((gemm_gen_f32<BM, BN, true, false>), grid, block, 0, s, T);
-    else if (b_kmaj) hipLaunchKernelGGL((gemm_gen_f32<BM, BN, false, true>), grid, block, 0, s, T);
-    else hipLaunchKernelGGL((gemm_gen_f32<BM, BN, false, false>), grid, block, 0, s, T);
+    if (a_kmaj && b_kmaj) hipLaunchKernelGGL((gemm_gen_f32<BM, BN, true, true>), grid, block, 0, s, L);
+    else if (a_kmaj) hipLaunchKernelGGL((gemm_gen_f32<BM, BN, true, false>), grid, block, 0, s, L);
+    else if (b_kmaj) hipLaunchKernelGGL((gemm_gen_f32<BM, BN, false, true>), grid, block, 0, s, L);
+    else hipLaunchKernelGGL((gemm_gen_f32<BM, BN, false, false>), grid, block, 0, s, L);
+}
+
+// n independent problems of the same operand layout in ONE launch (+ one reduction launch when any is split):
+// the Linear backward of a module computes several dX = dY.W products per timestep that are each too small to
+// fill the chip.  All problems must fall into the same row-tile class.
+int gemm_gen_group(const SetGemmDesc* d, int n, int a_kminor, int b_kminor, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (n <= 0) return SET_OK;
+    if (n > GEN_MAX_TASKS || !d) return SET_ERR_ARG;
+    static const int bm64_upto = env_int("SET_GEMM_GEN_BM64_UPTO", 128);    // same finding as the forward kernel
+    GenLaunch L;
+    L.ntasks = n;
+    int bm = 0;
+    long long tiles[GEN_MAX_TASKS], tiles_total = 0;
+    int max_kt = 1;
+    for (int i = 0; i < n; ++i) {
+        const SetGemmDesc& p = d[i];
+        if (p.M <= 0 || p.N <= 0 || p.K <= 0 || !p.A || !p.B || !p.C) return SET_ERR_ARG;
+        if (!aligned16(p.A) || !aligned16(p.B) || (p.lda & 3) || (p.ldb & 3)) return SET_ERR_ARG;
+        // k-major operands are read in float4 along k; k-minor ones in float4 along their own dimension
+        if ((!a_kminor || !b_kminor) && (p.K & 3)) return SET_ERR_UNSUPPORTED;
+        if (a_kminor && ((p.M & 3) || p.M < 4)) return SET_ERR_UNSUPPORTED;
+        if (b_kminor && ((p.N & 3) || p.N < 4)) return SET_ERR_UNSUPPORTED;
+        const int b = p.M <= bm64_upto ? 64 : 128;
+        if (bm && b != bm) return SET_ERR_ARG;
+        bm = b;
+        GenTask& T = L.t[i];
+        T.A = p.A; T.B = p.B; T.lda = p.lda; T.ldb = p.ldb;
+        T.M = p.M; T.N = p.N; T.K = p.K; T.ktiles = cdiv(p.K, GEMM_BK); T.tiles_n = cdiv(p.N, 64);
+        T.accumulate = p.accumulate; T.out = p.C; T.ldo = p.ldc;
+        tiles[i] = (long long)cdiv(p.M, bm) * T.tiles_n;
+        tiles_total += tiles[i];
+        if (T.ktiles > max_kt) max_kt = T.ktiles;
+    }
+    // split the contractions only when the outputs alone cannot fill the chip; every workgroup then runs about
+    // `kper` k-tiles (>= 4) and the whole group fits the resident slots in one round
+    const int slots = bm == 64 ? 768 : 512;
+    int kper = max_kt;                                    // = no split
+    if (tiles_total < slots * 3 / 4) {
+        for (kper = 4; kper < max_kt; ++kper) {
+            long long wgs = 0;
+            for (int i = 0; i < n; ++i) wgs += tiles[i] * cdiv(L.t[i].ktiles, kper);
+            if (wgs <= slots) break;
+        }
+    }
+    size_t ws_off = 0;
+    int wg = 0, red_blocks = 0;
+    double flops = 0.0, bytes = 0.0, red_bytes = 0.0;
+    for (int i = 0; i < n; ++i) {
+        GenTask& T = L.t[i];
+        int ksplit = cdiv(T.ktiles, kper);
+        if (ksplit > 64) ksplit = 64;
+        const bool vec_ok = !(T.N & 3) && !(T.ldo & 3) && aligned16(T.out) && ws && aligned16(ws);
+        const size_t slab = round_up((size_t)T.M * T.N * sizeof(float), 256);
+        if (!vec_ok || T.ktiles < 8) ksplit = 1;
+        else if (ws_off + (size_t)ksplit * slab > ws_bytes) ksplit = (int)((ws_bytes - ws_off) / slab);
+        if (ksplit < 2) ksplit = 1;
+        T.ksplit = ksplit;
+        T.red_begin = 0x7fffffff;
+        if (ksplit == 1) { T.C = T.out; T.ldc = T.ldo; T.slab_stride = 0; }
+        else {
+            T.C = (float*)((char*)ws + ws_off); T.ldc = T.N; T.slab_stride = (long long)(slab / sizeof(float));
+            ws_off += (size_t)ksplit * slab;
+            T.red_begin = red_blocks;
+            red_blocks += (int)(((long long)T.M * (T.N >> 2) + 255) / 256);
+            red_bytes += 4.0 * T.M * T.N * (ksplit + 1.0);
+        }
+        T.wg_begin = wg;
+        wg += (int)(tiles[i] * ksplit);
+        flops += 2.0 * T.M * T.N * (double)T.K;
+        bytes += 4.0 * ((double)T.M * T.K + (double)T.N * T.K + (double)T.M * T.N * ksplit);
+    }
+    for (int i = n; i < GEN_MAX_TASKS; ++i) { L.t[i] = L.t[0]; L.t[i].wg_begin = 0x7fffffff; L.t[i].ksplit = 1; }
+    {
+        const char* name = a_kminor ? (b_kminor ? "gemm_gen_f32<tn>" : "gemm_gen_f32<tt>")
+                                    : (b_kminor ? "gemm_gen_f32<nn>" : "gemm_gen_f32<nt>");
+        ProfScope ps(name, s, flops, bytes);
+        if (bm == 128) launch_gen<128, 64>(L, !a_kminor, !b_kminor, (unsigned)wg, s);
+        else launch_gen<64, 64>(L, !a_kminor, !b_kminor, (unsigned)wg, s);
+        SET_LAUNCH_CHECK();
+    }
+    if (red_blocks > 0) {
+        ProfScope ps("slab_reduce", s, 0.0, red_bytes);
+        hipLaunchKernelGGL(slab_reduce_k, dim3((unsigned)red_blocks), dim3(256), 0, s, L);
+        SET_LAUNCH_CHECK();
+    }
+    return SET_OK;
 }
 
 int gemm_gen(const float* A, long long lda, int a_kminor, const float* B, long long ldb, int b_kminor, float* C,
              long long ldc, int M, int N, int K, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
     if (M <= 0 || N <= 0) return SET_OK;
-    if (K <= 0 || !A || !B || !C) return SET_ERR_ARG;
-    if (!aligned16(A) || !aligned16(B) || (lda & 3) || (ldb & 3)) return SET_ERR_ARG;
-    // k-major operands are read in float4 along k; k-minor ones in float4 along their own dimension
-    if ((!a_kminor || !b_kminor) && (K & 3)) return SET_ERR_UNSUPPORTED;
-    if (a_kminor && ((M & 3) || M < 4)) return SET_ERR_UNSUPPORTED;
-    if (b_kminor && ((N & 3) || N < 4)) return SET_ERR_UNSUPPORTED;
-    static const int bm64_upto = env_int("SET_GEMM_GEN_BM64_UPTO", 128);    // same finding as the forward kernel
-    const int bm = M <= bm64_upto ? 64 : 128, bn = 64;
-    const int tiles_m = cdiv(M, bm), tiles_n = cdiv(N, bn);
-    const long long tiles = (long long)tiles_m * tiles_n;
-    const int ktiles = cdiv(K, GEMM_BK);
-    // split the contraction only when the output alone cannot fill the chip (512 workgroup slots)
-    int ksplit = 1;
-    const int slots = bm == 64 ? 768 : 512;              // workgroups that are resident at once
-    if (tiles < slots * 3 / 4 && ktiles >= 8) {
-        ksplit = (int)(slots / tiles);
-        if (ksplit > ktiles / 4) ksplit = ktiles / 4;
-        if (ksplit > 64) ksplit = 64;
-        const bool vec_ok = !(N & 3) && !(ldc & 3) && aligned16(C) && ws && aligned16(ws);
-        const size_t slab = (size_t)M * N * sizeof(float);
-        if (!vec_ok) ksplit = 1;
-        else if ((size_t)ksplit * slab > ws_bytes) ksplit = (int)(ws_bytes / slab);
-        if (ksplit < 2) ksplit = 1;
-    }
-    GenTask T;
-    T.A = A; T.B = B; T.lda = lda; T.ldb = ldb;
-    T.M = M; T.N = N; T.K = K; T.ktiles = ktiles; T.ksplit = ksplit; T.tiles_n = tiles_n;
-    T.accumulate = accumulate;
-    if (ksplit == 1) { T.C = C; T.ldc = ldc; T.slab_stride = 0; }
-    else { T.C = (float*)ws; T.ldc = N; T.slab_stride = (long long)M * N; }
-    const double flops = 2.0 * M * N * (double)K;
-    const double bytes = 4.0 * ((double)M * K + (double)N * K + (double)M * N * ksplit);
-    {
-        const char* name = a_kminor ? (b_kminor ? "gemm_gen_f32<tn>" : "gemm_gen_f32<tt>")
-                                    : (b_kminor ? "gemm_gen_f32<nn>" : "gemm_gen_f32<nt>");
-        ProfScope ps(name, s, flops, bytes);
-        const unsigned wgs = (unsigned)(tiles * ksplit);
-        if (bm == 128) launch_gen<128, 64>(T, !a_kminor, !b_kminor, wgs, s);
-        else launch_gen<64, 64>(T, !a_kminor, !b_kminor, wgs, s);
-        SET_LAUNCH_CHECK();
-    }
-    if (ksplit > 1) {
-        ProfScope ps("slab_reduce", s, 0.0, 4.0 * M * N * (ksplit + 1.0));
-        const long long n = (long long)M * (N >> 2);
-        hipLaunchKernelGGL(slab_reduce_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)ws,
-                           (long long)M * N, ksplit, C, ldc, M, N, accumulate);
-        SET_LAUNCH_CHECK();
-    }
-    return SET_OK;
+    SetGemmDesc d{A, lda, B, ldb, C, ldc, M, N, K, accumulate};
+    return gemm_gen_group(&d, 1, a_kminor, b_kminor, ws, ws_bytes, s);
 }
 
 }  // namespace set

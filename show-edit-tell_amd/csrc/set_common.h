@@ -82,6 +82,7 @@ int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag
 // gemm_gen.hip: C (+)= a . b^T with either operand stored k-major or k-minor (training backward)
 int gemm_gen(const float* A, long long lda, int a_kminor, const float* B, long long ldb, int b_kminor, float* C,
              long long ldc, int M, int N, int K, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
+int gemm_gen_group(const SetGemmDesc* d, int n, int a_kminor, int b_kminor, void* ws, size_t ws_bytes, hipStream_t s);
 int gemm_tile_m(int M);   // BM the launcher will pick for M rows
 
 // ---------------------------------------------------------------------------------------------

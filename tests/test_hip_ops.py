@@ -113,3 +113,25 @@ def test_gemm_general_layouts(a_kminor, b_kminor):
     got = gemm(dy, False, w[:, K:2 * K], True, M, K, N)
     ref = _np(dy).astype(np.float64) @ _np(w)[:, K:2 * K].astype(np.float64)
     assert np.abs(_np(got) - ref).max() <= 1e-3
+
+
+def test_gemm_group():
+    """set_gemm_group_f32: several dX = dY.W products (k-major x k-minor) in one launch, with split-K, column-slice
+    weights and in-place accumulation, against float64 numpy."""
+    from show_edit_tell_amd.autograd_ops import gemm_group
+    rng = np.random.default_rng(9)
+    M = 128
+    dy = to_dev(rng.standard_normal((M, 4096)).astype(np.float32))
+    w1 = to_dev(rng.standard_normal((4096, 5120)).astype(np.float32) * 0.05)
+    w2 = to_dev(rng.standard_normal((4096, 1024)).astype(np.float32) * 0.05)
+    dz = to_dev(rng.standard_normal((M, 1024)).astype(np.float32))
+    wg = to_dev(rng.standard_normal((1024, 3072)).astype(np.float32) * 0.05)
+    o1, o2 = gemm_group([(dy, w1, M, 5120, 4096, None, False), (dy, w2, M, 1024, 4096, None, False)], False, True)
+    assert np.abs(_np(o1) - _np(dy).astype(np.float64) @ _np(w1).astype(np.float64)).max() < 2e-4
+    assert np.abs(_np(o2) - _np(dy).astype(np.float64) @ _np(w2).astype(np.float64)).max() < 2e-4
+    base = rng.standard_normal((3, M, 1024)).astype(np.float32)
+    outs = [to_dev(base[i]) for i in range(3)]
+    gemm_group([(dz, wg[:, 1024 * i:1024 * (i + 1)], M, 1024, 1024, outs[i], True) for i in range(3)], False, True)
+    for i in range(3):
+        ref = base[i] + _np(dz).astype(np.float64) @ _np(wg)[:, 1024 * i:1024 * (i + 1)].astype(np.float64)
+        assert np.abs(_np(outs[i]) - ref).max() < 1e-4, i
