@@ -154,16 +154,38 @@ __global__ void __launch_bounds__(256) attention_bwd_k(const float* dctx, const 
     __shared__ float s_dot;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* dc = dctx + (long long)b * Dv;
-    // dalpha_l = <dctx, V_l>: one wave per row
-    for (int l = wave; l < L; l += 4) {
-        const float* vr = Vals + ((long long)b * L + l) * Dv;
-        float s = 0.f;
-        for (int d = lane * 4; d < Dv; d += 256) {
-            const f32x4 x = ldb4(vr + d), y = ldb4(dc + d);
-            s += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+    // dalpha_l = <dctx, V_l>: one wave per row; the wave's slice of dctx stays in registers and the loads of two
+    // rows (up to 16 float4 per lane) are in flight together
+    constexpr int NQ = 8;                                   // Dv <= 2048 on this path (host check)
+    f32x4 dcr[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int d = lane * 4 + 256 * q;
+        dcr[q] = d < Dv ? ldb4(dc + d) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int l0 = wave; l0 < L; l0 += 8) {
+        const int l1 = l0 + 4;
+        const float* v0 = Vals + ((long long)b * L + l0) * Dv;
+        const float* v1 = Vals + ((long long)b * L + (l1 < L ? l1 : l0)) * Dv;
+        f32x4 x0[NQ], x1[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int d = lane * 4 + 256 * q;
+            x0[q] = d < Dv ? ldb4(v0 + d) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            x1[q] = d < Dv ? ldb4(v1 + d) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        s = wsum(s);
-        if (lane == 0) s_da[l] = s + (dalpha_ext ? dalpha_ext[(long long)b * L + l] : 0.f);
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {                      // same accumulation order as a d-ascending loop
+            s0 += x0[q][0] * dcr[q][0] + x0[q][1] * dcr[q][1] + x0[q][2] * dcr[q][2] + x0[q][3] * dcr[q][3];
+            s1 += x1[q][0] * dcr[q][0] + x1[q][1] * dcr[q][1] + x1[q][2] * dcr[q][2] + x1[q][3] * dcr[q][3];
+        }
+        s0 = wsum(s0);
+        s1 = wsum(s1);
+        if (lane == 0) {
+            s_da[l0] = s0 + (dalpha_ext ? dalpha_ext[(long long)b * L + l0] : 0.f);
+            if (l1 < L) s_da[l1] = s1 + (dalpha_ext ? dalpha_ext[(long long)b * L + l1] : 0.f);
+        }
     }
     __syncthreads();
     if (tid < 64) {
@@ -184,20 +206,30 @@ __global__ void __launch_bounds__(256) attention_bwd_k(const float* dctx, const 
     for (int a = tid * 4; a < A; a += 1024) {
         const f32x4 w = ldb4(w_full + a), a2 = ldb4(att2 + (long long)b * A + a);
         f32x4 acc2 = {0.f, 0.f, 0.f, 0.f}, accw = {0.f, 0.f, 0.f, 0.f};
-        for (int l = 0; l < L; ++l) {
-            const f32x4 p = ldb4(att1 + ((long long)b * L + l) * A + a) + a2;
-            const float de = s_de[l];
-            f32x4 dp;
+        constexpr int LB = 6;                               // rows of att1 in flight per pass
+        for (int lb = 0; lb < L; lb += LB) {
+            f32x4 pr[LB];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float act, dact;
-                if (TANH) { act = tanhf(p[e]); dact = 1.f - act * act; }
-                else { act = p[e] > 0.f ? p[e] : 0.f; dact = p[e] > 0.f ? 1.f : 0.f; }
-                dp[e] = de * w[e] * dact;
-                accw[e] += de * act;
+            for (int u = 0; u < LB; ++u)
+                pr[u] = (lb + u < L) ? ldb4(att1 + ((long long)b * L + lb + u) * A + a) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < LB; ++u) {
+                const int l = lb + u;
+                if (l >= L) break;
+                const f32x4 p = pr[u] + a2;
+                const float de = s_de[l];
+                f32x4 dp;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float act, dact;
+                    if (TANH) { act = tanhf(p[e]); dact = 1.f - act * act; }
+                    else { act = p[e] > 0.f ? p[e] : 0.f; dact = p[e] > 0.f ? 1.f : 0.f; }
+                    dp[e] = de * w[e] * dact;
+                    accw[e] += de * act;
+                }
+                acc2 += dp;
+                stb4(datt1 + ((long long)b * L + l) * A + a, dp);
             }
-            acc2 += dp;
-            stb4(datt1 + ((long long)b * L + l) * A + a, dp);
         }
         stb4(datt2 + (long long)b * A + a, acc2);
         stb4(dwfull_part + (long long)b * A + a, accw);
@@ -310,7 +342,7 @@ int set_attention_bwd_f32(const float* dctx, const float* dalpha_ext, const floa
                           void* stream) {
     if (!dctx || !alpha || !values || !att1 || !att2 || !w_full || !datt1 || !datt2 || !dwfull_part || M <= 0)
         return SET_ERR_ARG;
-    if (L > ATTB_MAX || (A & 3) || (Dv & 3) || A > 1024) return SET_ERR_UNSUPPORTED;
+    if (L > ATTB_MAX || (A & 3) || (Dv & 3) || A > 1024 || Dv > 2048) return SET_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (use_tanh)
         hipLaunchKernelGGL(attention_bwd_k<true>, dim3(M), dim3(256), 0, st, dctx, dalpha_ext, alpha, values, att1, att2,
