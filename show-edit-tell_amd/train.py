@@ -77,6 +77,25 @@ def xe_train_step(decoder, optimizer, image_features, caps, caplens, previous_ca
     return float(loss.detach()) , n_tok
 
 
+def dcnet_xe_train_step(dae, optimizer, caps, caplens, previous_caption, prev_caplen, group=None):
+    """One step of dcnet.py:352-402 (the denoising auto-encoder has no image input) on this rank's shard; same
+    global-token-count normalisation and gradient all-reduce as `xe_train_step`."""
+    from .autograd_ops import deferred_param_grads
+    dae.train()
+    scores, caps_sorted, decode_lengths, _ = dae(caps, caplens, previous_caption, prev_caplen)
+    loss_sum, n_tok, _, _ = xe_loss_sum(scores, caps_sorted, decode_lengths)
+    n_glob = global_token_count(n_tok, caps.device, group)
+    loss = loss_sum / n_glob
+    optimizer.zero_grad()
+    with deferred_param_grads():
+        loss.backward()
+    params = [p for p in dae.parameters() if p.requires_grad]
+    allreduce_gradients(params, group)
+    torch.nn.utils.clip_grad_norm_(params, GRAD_CLIP)
+    optimizer.step()
+    return float(loss.detach()), n_tok
+
+
 def reward_loss_sum(sample_logprobs, seq, reward):
     """Numerator and mask count of RewardCriterion (editnet_rl.py:557-573): the mask keeps every
     sampled word plus the <end> position (shifted `seq > 0`)."""
