@@ -398,7 +398,7 @@ __global__ void __launch_bounds__(256) gemm_nt_split_bf16(const GemmLaunch L) {
         SPL_MFMA(fA1, fW1);                                                                             \
         _Pragma("unroll") for (int q_ = 0; q_ < 24; ++q_) {                                             \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          \
-            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                                          \
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);                                          \
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                          \
         }                                                                                               \
         SPL_STAGE((KT) + 3, RA, RW);                                                                \
