@@ -58,7 +58,6 @@ def pmc_traffic():
 
 def cpu_baseline(seconds_budget=20.0):
     """Oracle (numpy port of the reference CPU path) on the host cores, bounded sample."""
-    import numpy as np
     from oracle import editnet_np as EN
     from show_edit_tell_amd import synth
     threads = int(os.environ.get("SET_CPU_THREADS", "0")) or min(os.cpu_count() or 1, 32)

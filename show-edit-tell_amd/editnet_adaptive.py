@@ -7,8 +7,6 @@ returns `gd_final_hidden` (caption encoder run on the ground-truth captions) and
 """
 from __future__ import annotations
 
-import torch
-
 from .editnet import (CaptionAttentionC, CaptionEncoderC, CopyLSTMCellC, EmbeddingC, LSTMCellC,  # noqa: F401
                       SelectC)
 from .editnet import DecoderC as _DecoderXE

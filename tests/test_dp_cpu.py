@@ -3,7 +3,6 @@
 reproduce single-process big-batch gradients exactly."""
 import os
 
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp

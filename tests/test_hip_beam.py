@@ -2,9 +2,8 @@
 against the oracle's hand-stated numpy beam search."""
 import numpy as np
 import pytest
-import torch
 
-from hip_adapter import editnet_modules, load_numpy_state, to_dev
+from hip_adapter import load_numpy_state, to_dev
 from oracle import beam_np, cases, dcnet_np as DN, editnet_np as EN
 
 pytestmark = pytest.mark.gpu

@@ -3,7 +3,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from show_edit_tell_amd import dcnet, dcnet_rl, editnet, editnet_rl, synth
+from show_edit_tell_amd import dcnet, dcnet_rl, editnet_rl, synth
 V, T = 10000, 20
 wm = synth.word_map(V)
 dev = torch.device("cuda:0")

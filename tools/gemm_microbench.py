@@ -5,12 +5,10 @@
 """
 import os
 import sys
-import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from show_edit_tell_amd import _lib
 from show_edit_tell_amd.editnet import _HipLinear
 
 SHAPES = [(128, 4096, 3072), (128, 4096, 1024), (128, 1024, 1024), (128, 10000, 1024), (128, 4096, 6144),
