@@ -136,7 +136,9 @@ _deferred = None
 
 
 @contextlib.contextmanager
-def deferred_param_grads():
+def deferred_param_grads(on_ready=None):
+    """`on_ready(param)` is called as soon as a parameter's gradient is final (used by the data-parallel step to
+    start the all-reduce of a bucket while the remaining weight-gradient contractions still run)."""
     global _deferred
     if _deferred is not None or not _FUSED_WGRAD:
         yield
@@ -168,6 +170,8 @@ def deferred_param_grads():
                     param.grad = _wgrad_mm(dy, x)
                 else:
                     _wgrad_mm(dy, x, out=param.grad)
+            if on_ready is not None:
+                on_ready(param)
     finally:
         _deferred = None
 

@@ -25,27 +25,64 @@ def xe_loss_sum(scores, caps_sorted, decode_lengths):
     return F.cross_entropy(sc, tg, reduction="sum"), sc.shape[0], sc, tg
 
 
-def allreduce_gradients(params, group=None, bucket_bytes=BUCKET_BYTES):
-    """SUM all-reduce of .grad over the process group in flat buckets (no-op without a group)."""
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return 0
-    grads = [p.grad for p in params if p.grad is not None]
-    n_buckets, i = 0, 0
-    while i < len(grads):
-        bucket, size = [], 0
-        while i < len(grads) and (not bucket or size + grads[i].numel() * grads[i].element_size() <= bucket_bytes):
-            bucket.append(grads[i])
-            size += grads[i].numel() * grads[i].element_size()
-            i += 1
-        flat = torch.cat([g.reshape(-1) for g in bucket])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        off = 0
-        for g in bucket:
-            g.copy_(flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
-        n_buckets += 1
-    return n_buckets
+class BucketedAllReduce:
+    """SUM all-reduce of gradients in flat buckets, started asynchronously as buckets fill (RCCL runs them on its own
+    stream while the remaining backward kernels keep the compute stream busy) and copied back in `finish()`.
+    xGMI rings are per-link bound, so buckets are few and large (64 MB)."""
+
+    def __init__(self, group=None, bucket_bytes=BUCKET_BYTES):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.bucket_bytes = bucket_bytes
+        self.bucket, self.size, self.pending, self.seen = [], 0, [], set()
+        self.n_buckets = 0
+
+    def add(self, grad):
+        """queue one final gradient tensor (each tensor once)"""
+        if not self.active or grad is None or id(grad) in self.seen:
+            return
+        self.seen.add(id(grad))
+        nbytes = grad.numel() * grad.element_size()
+        if self.bucket and self.size + nbytes > self.bucket_bytes:
+            self._launch()
+        self.bucket.append(grad)
+        self.size += nbytes
+        if self.size >= self.bucket_bytes:
+            self._launch()
+
+    def _launch(self):
+        if not self.bucket:
+            return
+        flat = torch.cat([g.reshape(-1) for g in self.bucket])
+        work = self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.pending.append((work, flat, self.bucket))
+        self.bucket, self.size = [], 0
+        self.n_buckets += 1
+
+    def finish(self):
+        """launch the last partial bucket, wait for every collective and scatter the sums back; returns #buckets"""
+        if not self.active:
+            return 0
+        self._launch()
+        for work, flat, bucket in self.pending:
+            work.wait()
+            off = 0
+            for g in bucket:
+                g.copy_(flat[off:off + g.numel()].view_as(g))
+                off += g.numel()
+        self.pending = []
+        return self.n_buckets
+
+
+def allreduce_gradients(params, group=None, bucket_bytes=BUCKET_BYTES, reducer=None):
+    """SUM all-reduce of .grad over the process group in flat buckets (no-op without a group).  With a `reducer`
+    that already received some gradients during backward, only the remaining ones are added."""
+    r = reducer if reducer is not None else BucketedAllReduce(group, bucket_bytes)
+    for p in params:
+        r.add(p.grad)
+    return r.finish()
 
 
 def global_token_count(n_local, device, group=None):
@@ -68,10 +105,13 @@ def xe_train_step(decoder, optimizer, image_features, caps, caplens, previous_ca
     loss = loss_sum / n_glob
     optimizer.zero_grad()
     from .autograd_ops import deferred_param_grads
-    with deferred_param_grads():          # one weight-gradient contraction per parameter over all timesteps
+    reducer = BucketedAllReduce(group)
+    # one weight-gradient contraction per parameter over all timesteps; every finished gradient goes straight
+    # into an all-reduce bucket, so the collectives overlap the remaining contractions
+    with deferred_param_grads(on_ready=lambda p: reducer.add(p.grad)):
         loss.backward()
     params = [p for p in decoder.parameters() if p.requires_grad]
-    allreduce_gradients(params, group)
+    allreduce_gradients(params, group, reducer=reducer)
     torch.nn.utils.clip_grad_norm_(params, GRAD_CLIP)
     optimizer.step()
     return float(loss.detach()) , n_tok
@@ -87,10 +127,11 @@ def dcnet_xe_train_step(dae, optimizer, caps, caplens, previous_caption, prev_ca
     n_glob = global_token_count(n_tok, caps.device, group)
     loss = loss_sum / n_glob
     optimizer.zero_grad()
-    with deferred_param_grads():
+    reducer = BucketedAllReduce(group)
+    with deferred_param_grads(on_ready=lambda p: reducer.add(p.grad)):
         loss.backward()
     params = [p for p in dae.parameters() if p.requires_grad]
-    allreduce_gradients(params, group)
+    allreduce_gradients(params, group, reducer=reducer)
     torch.nn.utils.clip_grad_norm_(params, GRAD_CLIP)
     optimizer.step()
     return float(loss.detach()), n_tok
@@ -124,7 +165,8 @@ def scst_train_step(decoder, optimizer, word_map, image_features, previous_capti
     # the n_samples rollouts of one image are independent rows (own dropout masks, own multinomial draws):
     # run them as ONE rollout over a batch of n_samples * B rows -- bigger GEMM tiles, one loop
     rep = lambda t: t if n_samples == 1 else t.repeat(n_samples, *([1] * (t.dim() - 1)))
-    with deferred_param_grads():
+    reducer = BucketedAllReduce(group)
+    with deferred_param_grads(on_ready=lambda p: reducer.add(p.grad)):
         seq, logp = decoder(word_map, rep(previous_caption), rep(prev_caplen), rep(image_features),
                             sample_max=False, sample_rl=True)
         rewards = ciderd.self_critical_reward(scorer, seq, rep(greedy), list(ground_truth) * n_samples, cider_weight)
@@ -134,7 +176,7 @@ def scst_train_step(decoder, optimizer, word_map, image_features, previous_capti
         loss.backward()
     reward_mean, loss_val = float(rewards[:, 0].mean()), float(loss.detach())
     params = [p for p in decoder.parameters() if p.requires_grad]
-    allreduce_gradients(params, group)
+    allreduce_gradients(params, group, reducer=reducer)
     torch.nn.utils.clip_grad_norm_(params, GRAD_CLIP)
     optimizer.step()
     return reward_mean, loss_val

@@ -32,6 +32,17 @@ def _worker(rank, world, port, ret):
     nb = allreduce_gradients(params, bucket_bytes=256)        # tiny buckets -> several collectives
     assert nb >= 2
     err = max(float((p.grad - r).abs().max()) for p, r in zip(params, ref))
+    # overlapped variant: gradients handed to the reducer one by one (as the backward finishes them), the rest
+    # at the end; same sums, each tensor reduced exactly once
+    from show_edit_tell_amd.train import BucketedAllReduce
+    for p in params:
+        p.grad = None
+    (torch.nn.functional.cross_entropy(lin(emb(ids[sl])), tgt[sl], reduction="sum") / n_glob).backward()
+    red = BucketedAllReduce(bucket_bytes=256)
+    red.add(params[0].grad)
+    red.add(params[0].grad)                                    # a repeated hand-over must not double count
+    assert allreduce_gradients(params, reducer=red) >= 2
+    err = max(err, max(float((p.grad - r).abs().max()) for p, r in zip(params, ref)))
     ret[rank] = err
     dist.destroy_process_group()
 
