@@ -87,3 +87,26 @@ def test_batched_beam_matches_per_image_beam():
         ref = evaluate.beam_search_editnet_batched_torch(xe, X, prev, plen, wm, k)
         for b in range(c["B"]):
             assert fused[b][:4] == ref[b][:4] and (len(fused[b]) == 18 or fused[b] == ref[b]), (k, b, fused[b], ref[b])
+
+
+def test_batched_beam_full_size_vs_oracle():
+    """Full-size model (D=1024, V=10000, 36x2048 regions): the fused batched beam search against the oracle's
+    numpy beam search, image by image."""
+    from show_edit_tell_amd import editnet, evaluate
+    d = cases.build_editnet("editnet_full_b4")
+    c, wm = d["case"], d["wm"]
+    sd = _boosted(d["sd"], c["V"], 4.0)
+    xe = load_numpy_state(editnet.DecoderC(wm, c["D"], c["D"], c["D"], c["A"], c["F"]), sd)
+    P = EN.cast_params(sd)
+    X, prev, plen = to_dev(d["X"]), to_dev(d["prev"]), to_dev(d["plen"])
+    got = evaluate.beam_search_editnet_batched(xe, X, prev, plen, wm, 3)
+    checked = 0
+    for b in range(c["B"]):
+        seq_o, sc_o, margin = beam_np.beam_editnet(P, d["X"][b:b + 1], d["prev"][b:b + 1], d["plen"][b:b + 1],
+                                                   wm["<start>"], wm["<end>"], 3)
+        if margin is None:
+            assert len(got[b]) == 18 and got[b][:4] == seq_o[:4]
+        elif margin > 1e-3:
+            assert got[b] == seq_o, (b, got[b], seq_o)
+            checked += 1
+    assert checked >= 1
