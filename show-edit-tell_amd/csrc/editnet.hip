@@ -285,7 +285,10 @@ static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const 
                            w->ca_dec_b, w->ca_full_w, w->ca_full_b, ws.mask, ws.H, ws.Mem, ws.ctx_cap, ws.sel,
                            ws.alpha_c, T, D, A, bt, st));
     // ---- C (+ context gating): fused small-tile kernel when D allows, else grouped GEMM + pointwise
-    const bool fused = fusedk;
+    // small batches (measured: up to 64 rows): the 32-row tiles leave the fused kernels with <= 64 workgroups; the grouped GEMM (split-K
+    // over the whole chip) + pointwise is faster there
+    static const int fused_min_rows = env_int("SET_FUSED_MIN_ROWS", 65);
+    const bool fused = fusedk && bt >= fused_min_rows;
     GemmProb c[3];
     if (fused) {
         SET_TRY(fused_context_gate(ws.ctx_cap, w->ca_gate_w + 2 * D, 3 * D, w->ca_sc_w, slabs_of(b[3]), slabs_of(b[2]),
@@ -300,7 +303,8 @@ static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const 
         plan_ksplit(c, 3, tgt);
         SET_TRY(gemm_group(c, 3, st, "gemm:C cg_ctx,sc,cmem"));
         SET_TRY(context_gate_pointwise(slabs_of(b[3]), slabs_of(c[0]), w->ca_gate_b, slabs_of(c[1]), w->ca_sc_b,
-                                       slabs_of(b[2]), w->ca_tc_b, ws.attend_cap, bt, D, st));
+                                       slabs_of(b[2]), w->ca_tc_b, ws.attend_cap, bt, D, st, nullptr, nullptr, nullptr,
+                                       g_cg, g_tc));
     }
     // ---- D
     GemmProb dd = slab_prob(ws.sD0, bt, 4 * D, B);

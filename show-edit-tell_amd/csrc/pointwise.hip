@@ -147,17 +147,20 @@ int lstm_pointwise(Slabs g0, Slabs g1, Slabs g2, const float* pre, long long ldp
 __global__ void __launch_bounds__(256) context_gate_k(Slabs cg_a, Slabs cg_b, const float* cg_bias, Slabs sc,
                                                       const float* sc_bias, Slabs tc, const float* tc_bias,
                                                       float* out, int M, int D, float* zt_out, float* s_out,
-                                                      float* t_out) {
+                                                      float* t_out, RowGather gz, RowGather gt) {
     const int per_row = D >> 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)M * per_row) return;
     const long long m = idx / per_row;
     const int j = (int)(idx - m * per_row) << 2;
     f32x4 z = slab_sum4(cg_a, m, j);
+    if (gz.tab) z += ld4(gz.tab + gz.ids[m * gz.id_stride] * gz.ld + gz.col0 + j);     // token-table part of [word,h1]
     z += slab_sum4(cg_b, m, j);
     z += ld4(cg_bias + j);
     f32x4 s = slab_sum4(sc, m, j) + ld4(sc_bias + j);
-    f32x4 t = slab_sum4(tc, m, j) + ld4(tc_bias + j);
+    f32x4 t = slab_sum4(tc, m, j);
+    if (gt.tab) t += ld4(gt.tab + gt.ids[m * gt.id_stride] * gt.ld + gt.col0 + j);
+    t += ld4(tc_bias + j);
     f32x4 o, zs, ss, ts;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -171,12 +174,12 @@ __global__ void __launch_bounds__(256) context_gate_k(Slabs cg_a, Slabs cg_b, co
 
 int context_gate_pointwise(Slabs cg_a, Slabs cg_b, const float* cg_bias, Slabs sc, const float* sc_bias,
                            Slabs tc, const float* tc_bias, float* out, int M, int D, hipStream_t s, float* zt_out,
-                           float* s_out, float* t_out) {
+                           float* s_out, float* t_out, RowGather gz, RowGather gt) {
     if (D & 3) return SET_ERR_UNSUPPORTED;
     const long long n = (long long)M * (D >> 2);
     ProfScope ps("context_gate", s, 0.0, 4.0 * M * D * (cg_a.n + cg_b.n + sc.n + tc.n + 1.0));
     hipLaunchKernelGGL(context_gate_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cg_a, cg_b, cg_bias,
-                       sc, sc_bias, tc, tc_bias, out, M, D, zt_out, s_out, t_out);
+                       sc, sc_bias, tc, tc_bias, out, M, D, zt_out, s_out, t_out, gz, gt);
     SET_LAUNCH_CHECK();
     return SET_OK;
 }

@@ -127,7 +127,8 @@ int lstm_pointwise(Slabs g0, Slabs g1, Slabs g2, const float* pre, long long ldp
                    int M, int D, hipStream_t s, RowGather gt = RowGather(), float* gates_out = nullptr);
 int context_gate_pointwise(Slabs cg_a, Slabs cg_b, const float* cg_bias, Slabs sc, const float* sc_bias,
                            Slabs tc, const float* tc_bias, float* out, int M, int D, hipStream_t s,
-                           float* zt_out = nullptr, float* s_out = nullptr, float* t_out = nullptr);
+                           float* zt_out = nullptr, float* s_out = nullptr, float* t_out = nullptr,
+                           RowGather gz = RowGather(), RowGather gt = RowGather());
 int copy_gate_pointwise(Slabs gn, const float* bn, Slabs gm, const float* bm, const float* c_new,
                         const float* sel, const float* ogate, float* c_out, float* h_out, int M, int D,
                         hipStream_t s, float* cg_out = nullptr);
