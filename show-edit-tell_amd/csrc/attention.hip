@@ -69,6 +69,7 @@ struct VisAttArgs {
     const float* att1; Slabs att2; const float* dec_bias; const float* w_full; const float* b_full;
     const float* X; const float* rmask; float* ctx; float* alpha_out;
     int R, F, A, fcols, fsn;
+    int prefetch;
 };
 
 __device__ __forceinline__ void caption_attention_body(const CapAttArgs& P, int b, float* sc, int* s_arg_p) {
@@ -199,7 +200,18 @@ __device__ __forceinline__ void visual_attention_body(const VisAttArgs& P, int b
         }
     }
     const float bf = b_full[0];
-    constexpr int RB = 5;
+    // the first context batch (12 regions of this thread's feature columns) does not depend on the scores:
+    // request it now so its HBM latency overlaps the scoring phase
+    constexpr int CB = 12;
+    const int f_first = fs * fcols + tid * 4;
+    const bool pre_ok = P.prefetch && f_first < fs * fcols + fcols && f_first < F && R >= CB;
+    f32x4 xpre[CB];
+    if (pre_ok) {
+        const float* xp0 = X + (long long)b * R * F + f_first;
+#pragma unroll
+        for (int u = 0; u < CB; ++u) xpre[u] = ld4a(xp0 + (long long)u * F);
+    }
+    constexpr int RB = 9;                                 // R = 36 regions -> one batch per wave
     for (int r0 = wave; r0 < R; r0 += 4 * RB) {
         f32x4 v[RB][2];
 #pragma unroll
@@ -240,6 +252,11 @@ __device__ __forceinline__ void visual_attention_body(const VisAttArgs& P, int b
         const float* xp = X + (long long)b * R * F + f;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         int r = 0;
+        if (pre_ok && f == f_first) {                     // the batch requested before the scoring phase
+#pragma unroll
+            for (int u = 0; u < CB; ++u) acc += xpre[u] * sc[u];
+            r = CB;
+        }
         for (; r + 12 <= R; r += 12) {                    // 12 regions in flight; accumulation stays in r order
             f32x4 v[12];
 #pragma unroll
@@ -272,8 +289,10 @@ __global__ void __launch_bounds__(256) step_attention_k(const VisAttArgs V, cons
 
 static int vis_fsn(int M, int F) {
     // enough workgroups to cover the chip: split the feature axis while slices stay >= 1024 columns
+    // measured at B=128: one slice per sample (128 + 128 workgroups) beats 2 or 4 slices (each slice recomputes the scores)
+    static const int min_cols = env_int("SET_ATT_MIN_COLS", 2048);
     int fsn = 1;
-    while (M * fsn < 512 && F / (fsn * 2) >= 1024 && (F % (fsn * 2 * 4)) == 0) fsn *= 2;
+    while (M * fsn < 512 && F / (fsn * 2) >= min_cols && (F % (fsn * 2 * 4)) == 0) fsn *= 2;
     return fsn;
 }
 
@@ -285,7 +304,8 @@ int step_attention(const float* att1, Slabs att2, const float* v_dec_bias, const
     if (R > ATT_MAX_ROWS || T > ATT_MAX_ROWS || A > 512 || (A & 3) || (F & 3) || (Dh & 3)) return SET_ERR_UNSUPPORTED;
     if (M <= 0) return SET_OK;
     const int fsn = vis_fsn(M, F);
-    VisAttArgs V{att1, att2, v_dec_bias, v_w_full, v_b_full, X, rmask, v_ctx, v_alpha, R, F, A, F / fsn, fsn};
+    static const int prefetch = env_int("SET_ATT_PREFETCH", 1);
+    VisAttArgs V{att1, att2, v_dec_bias, v_w_full, v_b_full, X, rmask, v_ctx, v_alpha, R, F, A, F / fsn, fsn, prefetch};
     CapAttArgs C{att1_c, att2_c, c_dec_bias, c_w_full, c_b_full, mask, H, Mem, c_ctx, sel, c_alpha, T, Dh, A};
     ProfScope ps("step_attention", s, 0.0,
                  4.0 * M * ((double)R * A * fsn + (double)R * F + F + (double)T * A + (double)T * Dh + 3.0 * Dh));
@@ -300,7 +320,7 @@ int visual_attention(const float* att1, Slabs att2, const float* dec_bias, const
     if (R > ATT_MAX_ROWS || A > 512 || (A & 3) || (F & 3)) return SET_ERR_UNSUPPORTED;
     if (M <= 0) return SET_OK;
     const int fsn = vis_fsn(M, F);
-    VisAttArgs P{att1, att2, dec_bias, w_full, b_full, X, rmask, ctx, alpha_out, R, F, A, F / fsn, fsn};
+    VisAttArgs P{att1, att2, dec_bias, w_full, b_full, X, rmask, ctx, alpha_out, R, F, A, F / fsn, fsn, 1};
     ProfScope ps("visual_attention", s, 0.0, 4.0 * M * ((double)R * A + (double)R * F + F + att2.n * A));
     hipLaunchKernelGGL(visual_attention_k, dim3(M * fsn), dim3(256), 0, s, P);
     SET_LAUNCH_CHECK();
