@@ -265,7 +265,7 @@ static void launch_gen(const GenLaunch& L, int a_kmaj, int b_kmaj, unsigned wgs,
 int gemm_gen_group(const SetGemmDesc* d, int n, int a_kminor, int b_kminor, void* ws, size_t ws_bytes, hipStream_t s) {
     if (n <= 0) return SET_OK;
     if (n > GEN_MAX_TASKS || !d) return SET_ERR_ARG;
-    static const int bm64_upto = env_int("SET_GEMM_GEN_BM64_UPTO", 128);    // same finding as the forward kernel
+    static const int bm64_upto = env_int("SET_GEMM_GEN_BM64_UPTO", 512);    // same finding as the forward kernel
     GenLaunch L;
     L.ntasks = n;
     int bm = 0;
