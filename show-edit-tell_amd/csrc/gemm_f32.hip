@@ -454,10 +454,11 @@ int gemm_tile_m(int M) {
     // same XCD's L2) halve the split-K factor -> half the slab bytes written here and re-read by the consumer,
     // and 32 KB workgroups pack three per CU.  Measured +4-5 % on the bench against the 128x64 tile.
     static const int bm64_upto = env_int("SET_GEMM_BM64_UPTO", gemm_split_mode() ? 64 : 512);   // the split kernel is 128x64 only
-    return M <= 32 ? 32 : (M <= bm64_upto ? 64 : 128);
+    static const int bm32_upto = env_int("SET_GEMM_BM32_UPTO", 32);
+    return M <= bm32_upto ? 32 : (M <= bm64_upto ? 64 : 128);
 }
 static int gemm_bn128() { static int v = env_int("SET_GEMM_BN128", 0); return v; }
-static int gemm_tile_n(int M) { return (M <= 32 || (M > 64 && gemm_bn128())) ? 128 : 64; }
+static int gemm_tile_n(int M) { const int bm = gemm_tile_m(M); return (bm == 32 || (bm == 128 && gemm_bn128())) ? 128 : 64; }
 
 // Split-K plan for one grouped launch: every workgroup should run about the same number of k-tiles
 // (`kper`) and the whole launch should fit the chip in ONE round: 256 CUs x 2 resident workgroups =
