@@ -4,6 +4,10 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-launches itself under
+`torch.distributed.run` with N ranks (one per GPU, RCCL); under torchrun the flag is informational and
+the ranks come from RANK / LOCAL_RANK / WORLD_SIZE.
+
 One bench "step" = one pass of the hot path over one batch: the free-running greedy decode of
 the reference's `editnet_rl.py:485-549` for a batch of 128 images — the per-sequence prologue
 (caption encoder + hoisted projections) plus 19 decode timesteps — entirely on the GPU through
@@ -13,25 +17,29 @@ Inputs and weights are synthetic (seeded generator, random-init weights of the r
 architecture, V = 10 000) and are resident in HBM before the timed region.  Multi-GPU: the path
 shards by batch with replicated weights and no data-path collective: each rank
 decodes its own 128-image batch (weak scaling); timing is barrier / sync bracketed, max over ranks.
-Each decode is a strictly sequential chain of ~190 small kernels over 128 rows, so by default
+Each decode is a strictly sequential chain of small kernels over 128 rows, so by default
 `--streams 3` independent B=128 batches are kept in flight per GPU, each on its own HIP stream and
 workspace (the K timed steps are still K complete B=128 decodes; nothing is skipped or shared);
-`config.single_stream_*` reports the one-batch-at-a-time figure measured in the same run.
+`single_stream_*` (top level) is the one-batch-at-a-time figure measured in the same run.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel = the fp32-MFMA grouped GEMM `gemm_nt_f32<128,64>` (six launches per
-                timestep); achieved = algorithmic FLOPs of its launches / their summed duration,
-                measured with HIP events on the launch stream in a second, identical, profiled pass
-                (`value` comes from the un-instrumented pass; both ms_per_step are reported)
+  roofline      dominant kernel = the fp32-MFMA grouped GEMM `gemm_nt_f32`; achieved = algorithmic FLOPs of its
+                launches / their summed duration, measured with HIP events on the launch stream in a second,
+                identical, profiled pass (`value` comes from the un-instrumented pass)
   kernels       the same event timing for every kernel family (ms per bench step)
-  cpu_baseline  the numpy oracle (oracle/editnet_np.py, a port of the reference's CPU path) timed
-                on this box's host cores for a bounded sample of the same workload
+  repeat        the timed region repeated (median / min / max decode-steps/sec over the windows)
+  train         the path's one exchange step: EditNet XE training step at B=128 per GPU (editnet.py:558-581,
+                train mode) with the bucketed gradient all-reduce; ms per step with and without the collectives
+  cpu_baseline  the as-written torch-CPU restatement of the reference loop (oracle/editnet_torch.py) and the numpy
+                port (oracle/editnet_np.py) timed on this box's host cores, bounded samples
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -43,82 +51,166 @@ MAX_LEN = 18
 STEPS_PER_DECODE = MAX_LEN + 1          # editnet_rl.py:503 runs max_len + 1 timesteps
 PEAK_FP32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0
+PMC_FILES = ("r02_pmc_bench_traffic.json", "r01_pmc_bench_traffic.json")
 
 
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (tools/pmc_bench.sh -> tools/pmc_traffic.py); counters cannot be read from inside this process."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_bench_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f)
-    except OSError:
-        return None
+    for name in PMC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+                d["file"] = "profiles/" + name
+                return d
+        except OSError:
+            continue
+    return None
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """Oracle (numpy port of the reference CPU path) on the host cores, bounded sample."""
+# ------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1 only): the oracle is test infrastructure; here it is the thing timed
+# BESIDE the product, never inside it.
+# ------------------------------------------------------------------------------------------------
+def _median(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
+
+
+def _time_decodes(fn, budget_s, min_n=3, max_n=10, warm=1):
+    for _ in range(warm):
+        fn()
+    ts, t_begin = [], time.perf_counter()
+    while len(ts) < max_n and (len(ts) < min_n or time.perf_counter() - t_begin < budget_s):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return ts
+
+
+def cpu_baseline(budget_s=float(os.environ.get("SET_CPU_BASELINE_BUDGET", "12"))):
+    """decode-steps/sec of the reference's greedy loop on the host cores.
+
+    `value` = the as-written torch-CPU restatement (oracle/editnet_torch.py: the op stream of
+    editnet_rl.py:503-547, nothing hoisted, torch's CPU BLAS) at B=128 on all physical cores, median over the
+    decodes that fit the budget (>= 3, <= 10).  `variants` adds 8 threads (comparable with the SURVEY §6 probe),
+    B=4 (BASELINE.json configs[0]) and the numpy/OpenBLAS port with hoisted invariants (oracle/editnet_np.py)."""
+    import numpy as np
+    import torch
     from oracle import editnet_np as EN
+    from oracle import editnet_torch as ET
     from show_edit_tell_amd import synth
-    threads = int(os.environ.get("SET_CPU_THREADS", "0")) or min(os.cpu_count() or 1, 32)
+    logical = os.cpu_count() or 1
     try:
-        from threadpoolctl import threadpool_limits
-        limiter = threadpool_limits(limits=threads)
+        import psutil
+        physical = psutil.cpu_count(logical=False) or logical
     except Exception:
-        limiter, threads = None, os.cpu_count()
+        physical = logical
     sd = synth.editnet_state(14, V, D, A, F, emb_scale=3.0, fc_scale=8.0, gain=3.0)
-    P = EN.cast_params(sd)
+    wm = synth.word_map(V)
     X = synth.features(25, B, R, F)
     prev, plen = synth.prev_captions(25, B, T, V, 5)
-    wm = synth.word_map(V)
-    EN.greedy_decode(P, wm["<start>"], wm["<end>"], prev[:8], plen[:8], X[:8])     # warm BLAS threads
-    n, t0 = 0, time.time()
-    while True:
-        EN.greedy_decode(P, wm["<start>"], wm["<end>"], prev, plen, X)
-        n += 1
-        el = time.time() - t0
-        if el > seconds_budget or n >= 10:
-            break
+    P_t = ET.params_from_numpy(sd)
+    Xt, prevt, plent = torch.from_numpy(X), torch.from_numpy(prev), torch.from_numpy(plen)
+    variants = []
+
+    def run_torch(nthreads, bs, budget):
+        torch.set_num_threads(nthreads)
+        fn = lambda: ET.greedy_decode(P_t, wm["<start>"], wm["<end>"], prevt[:bs], plent[:bs], Xt[:bs])
+        ts = _time_decodes(fn, budget)
+        return dict(impl="torch-cpu as written (oracle/editnet_torch.py)", batch=bs, threads=nthreads, decodes=len(ts),
+                    median_s_per_decode=round(_median(ts), 4),
+                    decode_steps_per_sec=round(STEPS_PER_DECODE / _median(ts), 3))
+
+    saved = torch.get_num_threads()
+    main_v = run_torch(physical, B, budget_s)
+    variants.append(main_v)
+    if physical != 8:
+        variants.append(run_torch(min(8, logical), B, budget_s))
+    variants.append(run_torch(physical, 4, budget_s / 4))
+    variants.append(run_torch(min(8, logical), 4, budget_s / 4))
+    torch.set_num_threads(saved)
+    # numpy port (loop invariants hoisted = the GPU path's algorithm on the CPU)
+    threads_np = min(logical, 32)
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=threads_np)
+    except Exception:
+        limiter, threads_np = None, logical
+    P_n = EN.cast_params(sd)
+    ts = _time_decodes(lambda: EN.greedy_decode(P_n, wm["<start>"], wm["<end>"], prev, plen, X), budget_s, max_n=6)
     if limiter is not None:
         limiter.restore_original_limits()
-    return dict(value=round(n * STEPS_PER_DECODE / el, 3), unit="decode-steps/sec", cores=threads,
-                kind="port", sample="%d full greedy decodes (prologue + 19 timesteps) of the B=128 workload, numpy fp32 "
-                "(OpenBLAS, %d threads of %d host cpus), %.1f s" % (n, threads, os.cpu_count(), el))
+    variants.append(dict(impl="numpy port, invariants hoisted (oracle/editnet_np.py)", batch=B, threads=threads_np,
+                         decodes=len(ts), median_s_per_decode=round(_median(ts), 4),
+                         decode_steps_per_sec=round(STEPS_PER_DECODE / _median(ts), 3)))
+    blas = "mkl" if torch.backends.mkl.is_available() else "non-mkl"
+    return dict(value=main_v["decode_steps_per_sec"], unit="decode-steps/sec", cores=physical, kind="port",
+                sample="median of %d full greedy decodes (encoder + 19 timesteps) of the B=128 workload, as-written torch "
+                       "fp32 restatement of editnet_rl.py:485-549 (torch %s, %s BLAS, %d threads = physical cores of %d "
+                       "logical cpus; numpy %s for the port variant)" % (main_v["decodes"], torch.__version__, blas,
+                                                                        physical, logical, np.__version__),
+                variants=variants)
 
 
 def experimental_split(args):
-    """Secondary, NOT the headline: the same bench with SET_GEMM_SPLIT=1 (csrc/gemm_f32.hip, gemm_nt_split_bf16:
-    every fp32 operand split exactly into 3 bf16, 6 partial products, fp32 accumulation -- fp32-level accuracy,
-    all parity tests pass with it) in a child process, because the switch is read once per process."""
-    import subprocess
+    """Secondary, NOT the headline, opt-in (--experimental): the same bench with SET_GEMM_SPLIT=1 (fp32 operands
+    split exactly into 3 bf16, 6 partial products, fp32 accumulation) in a child process."""
     env = dict(os.environ, SET_GEMM_SPLIT="1")
     cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--streams", str(args.streams), "--no-cpu-baseline", "--no-profile", "--no-experimental"]
+           "--streams", str(args.streams), "--no-cpu-baseline", "--no-profile", "--no-train", "--repeat", "1"]
     try:
         out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
         d = json.loads(out.stdout.strip().splitlines()[-1])
         return {"split_bf16x3_gemm": {"decode_steps_per_sec": d["value"],
-                                      "single_stream_decode_steps_per_sec": d["config"]["single_stream_decode_steps_per_sec"],
-                                      "switch": "SET_GEMM_SPLIT=1 (off by default)",
-                                      "arithmetic": "fp32 operands split exactly into 3 bf16 (8+8+8 significand bits), "
-                                                    "6 of 9 partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulate; "
-                                                    "dropped terms <= 2^-24 relative; parity suite green"}}
+                                      "single_stream_decode_steps_per_sec": d["single_stream_decode_steps_per_sec"],
+                                      "switch": "SET_GEMM_SPLIT=1 (off by default)"}}
     except Exception as e:          # never let the experiment break the bench line
         return {"split_bf16x3_gemm": {"error": repr(e)[:200]}}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without torchrun: re-launch under torch.distributed.run, one rank per GPU."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < n and not os.environ.get("SET_BENCH_ONE_DEVICE"):
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (set SET_BENCH_ONE_DEVICE=1 SET_BENCH_BACKEND=gloo "
+                         "to exercise the multi-rank path on one device)" % (n, have))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=300, help="timed bench steps (complete B=128 decodes); default gives a ~1 s region")
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--repeat", type=int, default=5, help="extra repetitions of the timed region (median reported under 'repeat')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--no-experimental", action="store_true",
-                    help="skip the opt-in split-precision (bf16x3) GEMM figure reported under 'experimental'")
+    ap.add_argument("--no-train", action="store_true", help="skip the XE training-step leg ('train' object)")
+    ap.add_argument("--train-steps", type=int, default=6)
+    ap.add_argument("--experimental", action="store_true",
+                    help="also report the opt-in split-precision (bf16x3) GEMM figure under 'experimental'")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("SET_BENCH_STREAMS", "3")),
                     help="independent batches in flight per GPU (each on its own HIP stream + workspace)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -142,7 +234,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    from show_edit_tell_amd import _lib, editnet_rl, synth
+    from show_edit_tell_amd import _lib, editnet, editnet_rl, synth
     wm = synth.word_map(V)
     dec = editnet_rl.DecoderC(wm, D, D, D, A, F)
     sd = synth.editnet_state(14, V, D, A, F, emb_scale=3.0, fc_scale=8.0, gain=3.0)
@@ -178,22 +270,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    with torch.no_grad():
-        run(args.warmup)
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed_region():
         barrier()
         t0 = time.perf_counter()
-        seq, _ = run(args.steps)
+        out = run(args.steps)
         barrier()
-        elapsed = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        return max_over_ranks(time.perf_counter() - t0), out
+
+    with torch.no_grad():
+        run(args.warmup)
+        elapsed, (seq, _) = timed_region()                 # the K timed steps `value` is computed from
+        windows = [timed_region()[0] for _ in range(max(0, args.repeat - 1))]
 
         single = None
         if streams is not None and rank == 0:
             torch.cuda.synchronize(dev)
             keep, streams = streams, None
+            run(min(args.warmup, 3))
+            torch.cuda.synchronize(dev)
             ts = time.perf_counter()
             run(args.steps)
             torch.cuda.synchronize(dev)
@@ -201,16 +302,15 @@ def main():
             streams = keep
         # secondary figure: teacher-forced XE forward (editnet.py:479-548, eval mode), same batch, 19 timesteps
         xe_rate = None
+        caps_np, clen_np = synth.captions(seed, B, V, 20, 20)
+        caps, clen = torch.from_numpy(caps_np).to(dev), torch.from_numpy(clen_np).to(dev)
         if rank == 0:
-            from show_edit_tell_amd import editnet
-            caps_np, clen_np = synth.captions(seed, B, V, 20, 20)
-            caps, clen = torch.from_numpy(caps_np).to(dev), torch.from_numpy(clen_np).to(dev)
             xe_fwd = lambda: editnet.DecoderC.forward(dec, X, caps, clen, prev, plen, False, 0.0)
             for _ in range(2):
                 xe_fwd()
             torch.cuda.synchronize(dev)
             tx = time.perf_counter()
-            nx = max(3, args.steps // 4)
+            nx = max(3, args.steps // 8)
             for _ in range(nx):
                 xe_fwd()
             torch.cuda.synchronize(dev)
@@ -222,12 +322,17 @@ def main():
             lib.set_profile_enable(1)
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
-            run(args.steps)
+            nprof = min(args.steps, 40)
+            run(nprof)
             torch.cuda.synchronize(dev)
             prof_elapsed = time.perf_counter() - t1
             prof = _lib.profile_report()
             lib.set_profile_enable(0)
             streams = keep
+
+    train = None
+    if not args.no_train:
+        train = train_leg(args, dec, wm, X, caps, clen, prev, plen, dev, dist, rank, world, barrier, max_over_ranks)
 
     if rank != 0:
         if dist is not None:
@@ -236,6 +341,7 @@ def main():
 
     n_gpus = world
     total_steps = n_gpus * args.steps * STEPS_PER_DECODE
+    rates = sorted(total_steps / e for e in [elapsed] + windows)
     line = {
         "metric": "decode-steps/sec (B=128, 36x2048 feats, seqlen=20)",
         "value": round(total_steps / elapsed, 2),
@@ -249,14 +355,16 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
+        "single_stream_decode_steps_per_sec": None if single is None else round(args.steps * STEPS_PER_DECODE / single, 2),
+        "single_stream_ms_per_step": None if single is None else round(1e3 * single / args.steps, 4),
+        "batches_in_flight_per_gpu": max(1, args.streams),
+        "repeat": {"windows": len(rates), "steps_per_window": args.steps, "median": round(_median(rates), 2),
+                   "min": round(rates[0], 2), "max": round(rates[-1], 2), "timed_region_s": round(elapsed, 4)},
         "config": {"workload": "EditNet greedy decode (editnet_rl.py:485-549): prologue + 19 timesteps per bench step",
                    "batch_per_gpu": B, "regions": R, "feat_dim": F, "prev_caption_len": T, "vocab": V,
-                   "decoder_dim": D, "attention_dim": A, "timesteps_per_bench_step": STEPS_PER_DECODE, "batches_in_flight_per_gpu": max(1, args.streams),
+                   "decoder_dim": D, "attention_dim": A, "timesteps_per_bench_step": STEPS_PER_DECODE,
                    "mode": "eval (loop-invariant projections hoisted)", "parallelism": "dp%d (no collective)" % n_gpus,
                    "us_per_timestep_incl_prologue": round(1e6 * elapsed / (args.steps * STEPS_PER_DECODE), 2),
-                   "single_stream_decode_steps_per_sec": (None if single is None else
-                                                          round(args.steps * STEPS_PER_DECODE / single, 2)),
-                   "single_stream_ms_per_step": None if single is None else round(1e3 * single / args.steps, 4),
                    "xe_forward_single_stream_decode_steps_per_sec": None if xe_rate is None else round(xe_rate, 2),
                    "distinct_tokens_in_last_batch": int(torch.unique(seq).numel())},
     }
@@ -266,33 +374,76 @@ def main():
         g = by[gemm_tags[0]] if gemm_tags else None      # the dominant kernel = the GEMM tile variant with most time
         if g and g["ms"] > 0:
             tf = g["flops"] / (g["ms"] * 1e-3) / 1e12
+            tr = pmc_traffic()
             line["roofline"] = {
                 "kernel": gemm_tags[0].replace(">", ",2,2>") + " (v_mfma_f32_32x32x2_f32)", "bound": "mfma",
                 "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                "traffic": (lambda t: None if t is None else round(t["traffic_bytes_per_launch"] / 1e6, 2))(pmc_traffic()),
-                "traffic_unit": "MB HBM per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_bench_traffic.json)",
+                "traffic": None if tr is None else round(tr["traffic_bytes_per_launch"] / 1e6, 2),
+                "traffic_unit": "MB HBM per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, %s)" % (tr or {}).get("file"),
                 "algorithmic_MB_per_launch": round(g["bytes"] / g["launches"] / 1e6, 2),
                 "launches": g["launches"], "avg_us_per_launch": round(1e3 * g["ms"] / g["launches"], 2),
                 "algorithmic_gflop_per_launch": round(g["flops"] / g["launches"] / 1e9, 4),
                 "algorithmic_GBs": round(g["bytes"] / (g["ms"] * 1e-3) / 1e9, 1),
-                "timing": "HIP events on the launch stream, second identical pass (profiled ms_per_step %.3f)"
-                          % (1e3 * prof_elapsed / args.steps)}
-        line["kernels"] = {p["tag"]: {"launches_per_step": round(p["launches"] / args.steps, 2),
-                                      "ms_per_step": round(p["ms"] / args.steps, 4),
+                "timing": "HIP events on the launch stream, second identical pass of %d steps (profiled ms_per_step %.3f)"
+                          % (nprof, 1e3 * prof_elapsed / nprof)}
+        line["kernels"] = {p["tag"]: {"launches_per_step": round(p["launches"] / nprof, 2),
+                                      "ms_per_step": round(p["ms"] / nprof, 4),
                                       "GBs": round(p["bytes"] / max(p["ms"], 1e-9) / 1e6, 1),
                                       "TFLOPs": round(p["flops"] / max(p["ms"], 1e-9) / 1e9, 2)} for p in prof}
+    if train is not None:
+        line["train"] = train
     split_env = os.environ.get("SET_GEMM_SPLIT", "0") not in ("", "0")
     if split_env:      # opt-in experimental kernel: say so in the line, never pass it off as the fp32-MFMA figure
         line["dtype"] = "f32 emulated as bf16x3 (6 partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulate)"
         line.pop("roofline", None)
-    if n_gpus == 1 and not args.no_experimental and not split_env:
+    if n_gpus == 1 and args.experimental and not split_env:
         line["experimental"] = experimental_split(args)
     if not args.no_cpu_baseline and n_gpus == 1:
         line["cpu_baseline"] = cpu_baseline()
     print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def train_leg(args, dec, wm, X, caps, clen, prev, plen, dev, dist, rank, world, barrier, max_over_ranks):
+    """BASELINE.json configs[1]/[2]: EditNet XE training step (editnet.py:558-581) at B=128 per GPU, train mode
+    (dropout on, nothing hoisted), forward + backward + bucketed gradient all-reduce (RCCL) + clip 0.25 + Adam.
+    Every rank runs the same number of steps; timing is barrier bracketed, max over ranks."""
+    import torch
+    from show_edit_tell_amd import editnet
+    from show_edit_tell_amd.train import xe_train_step
+    xe = editnet.DecoderC(wm, D, D, D, A, F)
+    xe.load_state_dict(dec.state_dict())
+    xe = xe.to(dev)
+    opt = torch.optim.Adam(xe.parameters(), lr=5e-4)                     # editnet.py:749
+    K = max(2, args.train_steps)
+
+    def timed(reduce):
+        for _ in range(2):
+            xe_train_step(xe, opt, X, caps, clen, prev, plen, False, 0.0, reduce=reduce)
+        barrier()
+        t0 = time.perf_counter()
+        losses = [xe_train_step(xe, opt, X, caps, clen, prev, plen, False, 0.0, reduce=reduce)[0] for _ in range(K)]
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0), losses
+
+    t_dp, losses = timed(True)
+    out = {"workload": "EditNet XE training step (editnet.py:558-581): train mode, B=128 per GPU, 19 timesteps, "
+                       "fwd + bwd + gradient all-reduce + clip 0.25 + Adam",
+           "n_gpus": world, "steps": K, "ms_per_train_step": round(1e3 * t_dp / K, 3),
+           "train_decode_steps_per_sec": round(world * K * STEPS_PER_DECODE / t_dp, 2),
+           "gradient_MB": round(sum(p.numel() for p in xe.parameters()) * 4 / 1e6, 1),
+           "loss_first": round(losses[0], 4), "loss_last": round(losses[-1], 4)}
+    if world > 1:
+        t_local, _ = timed(False)
+        out.update(ms_per_train_step_no_allreduce=round(1e3 * t_local / K, 3),
+                   allreduce_exposed_ms=round(1e3 * (t_dp - t_local) / K, 3),
+                   allreduce="bucketed SUM all-reduce, 64 MB flat buckets, launched as the deferred weight-gradient "
+                             "contractions finish (train.BucketedAllReduce)")
+    del opt, xe
+    torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == "__main__":

@@ -1,8 +1,8 @@
 """ORACLE (test infrastructure): numpy restatement of the reference's beam search
 (`editnet.py:595-718`, ensemble `eval/eval xe/eval_full.py:88-218`) over the oracle's step functions.
-The reference's own `evaluate()` cannot run on torch >= 1.5 (`top_k_words / vocab_size`,
-SURVEY.md §8c.3), so there is no captured golden for it: parity of the beam is pinned through the
-per-step vectors (tests/golden) plus this hand-stated search.  Only tests/ import this module."""
+Pinned: tests/test_beam_golden.py checks it against tests/golden/beam_*.npz, which hold the outputs of the
+reference's OWN per-image loops (AST-sliced with the single `top_k_words / vocab_size` -> `//` patch that
+torch >= 1.5 needs, oracle/ref_beam.py + oracle/make_beam_golden.py).  Only tests/ import this module."""
 import numpy as np
 
 from . import dcnet_np as DN
@@ -73,6 +73,11 @@ def beam_loop(states, combine, start, end, V, k, max_steps=50):
 def beam_editnet(P, X1, prev1, plen1, start, end, k=3):
     V = P["fc.weight"].shape[0]
     return beam_loop([EditNetBeam(P, X1, prev1, plen1, k)], lambda ls: EN._log_softmax(ls[0], 1), start, end, V, k)
+
+
+def beam_dcnet(Pd, prev1, plen1, start, end, k=3):
+    V = Pd["fc.weight"].shape[0]
+    return beam_loop([DcnetBeam(Pd, prev1, plen1, k)], lambda ls: EN._log_softmax(ls[0], 1), start, end, V, k)
 
 
 def beam_ensemble(Pe, Pd, X1, prev1, plen1, start, end, k=3):

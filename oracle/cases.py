@@ -126,3 +126,34 @@ def build_dcnet(name):
 # which logit columns the full-size fixtures keep verbatim
 def logit_slice_cols(V):
     return (np.arange(64) * 149 + 7) % V
+
+
+# ---- beam-search parity cases (oracle/make_beam_golden.py runs the reference's own evaluate() loop on them)
+# <end> is boosted so that hypotheses finish at different steps (k shrinks mid-search) while some images still
+# run into the reference's 50-step limit.
+BEAM_CASES = {
+    "beam_small_e3": dict(editnet="editnet_small", dcnet="dcnet_small", end_boost=3.0, beams=(1, 3, 5)),
+    "beam_small_e5": dict(editnet="editnet_small", dcnet="dcnet_small", end_boost=5.0, beams=(3,)),
+    "beam_full_b4": dict(editnet="editnet_full_b4", dcnet="dcnet_full_b4", end_boost=4.0, beams=(3,)),
+}
+
+
+def build_beam(name):
+    """EditNet + DCNet weights (fc.bias[<end>] boosted) and the EditNet case's inputs; both models share the
+    vocabulary (the ensemble averages their word distributions, eval_full.py:151-153)."""
+    bc = BEAM_CASES[name]
+    e = build_editnet(bc["editnet"])
+    dc = dict(DCNET_CASES[bc["dcnet"]])
+    assert dc["V"] == e["case"]["V"]
+    sd_d = synth.dcnet_state(dc["wseed"], dc["V"], dc["D"], dc["A"], dc["C"], dc["E"], dc["emb_scale"], dc["fc_scale"],
+                             dc["gain"])
+    V = e["case"]["V"]
+
+    def boosted(sd):
+        sd = dict(sd)
+        sd["fc.bias"] = sd["fc.bias"].copy()
+        sd["fc.bias"][V - 1] += np.float32(bc["end_boost"])
+        return sd
+
+    return dict(case=e["case"], dcase=dc, wm=e["wm"], X=e["X"], prev=e["prev"], plen=e["plen"],
+                sd_e=boosted(e["sd"]), sd_d=boosted(sd_d), beams=bc["beams"])

@@ -142,7 +142,8 @@ def make_editnet(name, adaptive=False):
         tg = pack_padded_sequence(caps_s[:, 1:], dl, batch_first=True).data
         out["xe_loss"] = np.float64(torch.nn.CrossEntropyLoss()(sc.double(), tg).item())
     # ---- a13: gradients of the XE loss (eval-mode dropout so they are deterministic), reference autograd
-    if not big and (not adaptive or small):
+    # (big-batch cases keep norms + 64-element slices only: config 1's backward at B=128)
+    if not adaptive or small:
         from torch.nn.utils.rnn import pack_padded_sequence as _pps
         dec_xe.zero_grad()
         if adaptive:     # the adaptive train() adds MSE(decoder_last_hidden, gd_final_hidden) (editnet_adaptive.py:594-596)
@@ -250,6 +251,24 @@ def make_dcnet(name):
             out.update({"xe_pred_" + k: v.reshape(pred.shape[0], pred.shape[1], -1).squeeze(-1)
                         if v.ndim == 1 else v.reshape(pred.shape[0], pred.shape[1], -1)
                         for k, v in _summ_logits(flat, c["V"]).items()})
+    # ---- a13 for DCNet: gradients of the XE loss (dcnet.py:353-402: CrossEntropyLoss over the packed rows),
+    # eval-mode dropout so they are deterministic, reference autograd
+    from torch.nn.utils.rnn import pack_padded_sequence as _pps
+    dae_xe.zero_grad()
+    predg, caps_g, dlg, _ = dae_xe(caps, clen, prev, plen)
+    lossg = torch.nn.CrossEntropyLoss()(_pps(predg, dlg, batch_first=True).data,
+                                        _pps(caps_g[:, 1:], dlg, batch_first=True).data)
+    lossg.backward()
+    out["grad_loss"] = np.float64(lossg.item())
+    for k_, p_ in dae_xe.named_parameters():
+        g_ = _np(p_.grad)
+        out["gradnorm." + k_] = np.float64(np.sqrt((g_.astype(np.float64) ** 2).sum()))
+        if small:
+            out["grad." + k_] = g_
+        else:
+            out["gradslice." + k_] = g_.reshape(-1)[:: max(1, g_.size // 64)][:64].copy()
+    dae_xe.zero_grad()
+    with torch.no_grad():
         seq, logp = dae_rl(wm, prev, plen, True, False)
         out.update(greedy_seq=_np(seq), greedy_logp=_np(logp))
         steps = _trace_greedy_dcnet(dae_rl, wm, prev, plen)

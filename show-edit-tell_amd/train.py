@@ -25,19 +25,36 @@ def xe_loss_sum(scores, caps_sorted, decode_lengths):
     return F.cross_entropy(sc, tg, reduction="sum"), sc.shape[0], sc, tg
 
 
+def _all_reduce_sum(dist, t, group=None, async_op=False):
+    """SUM all-reduce of `t` in place.  RCCL ("nccl") reduces device tensors directly; with the gloo
+    backend (CPU tests, two ranks sharing one GPU) device tensors are staged through host memory here so the
+    same code path runs on any backend build."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
 class BucketedAllReduce:
-    """SUM all-reduce of gradients in flat buckets, started asynchronously as buckets fill (RCCL runs them on its own
-    stream while the remaining backward kernels keep the compute stream busy) and copied back in `finish()`.
+    """SUM all-reduce of gradients in flat buckets.  A bucket's collective is started asynchronously as soon as
+    the bucket is full (RCCL runs it on its own stream) and the sums are copied back in `finish()`.  Gradients
+    arrive through `add()`: inside `deferred_param_grads(on_ready=...)` every parameter is handed over the moment its
+    time-batched weight-gradient contraction has been enqueued, so a bucket's collective overlaps the contractions of
+    the parameters that follow (NOT the activation backward, which has finished by then).
     xGMI rings are per-link bound, so buckets are few and large (64 MB)."""
 
-    def __init__(self, group=None, bucket_bytes=BUCKET_BYTES):
+    def __init__(self, group=None, bucket_bytes=None, enabled=True):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-        self.bucket_bytes = bucket_bytes
+        self.active = (enabled and dist.is_available() and dist.is_initialized()
+                       and dist.get_world_size(group) > 1)
+        self.bucket_bytes = bucket_bytes or BUCKET_BYTES
         self.bucket, self.size, self.pending, self.seen = [], 0, [], set()
         self.n_buckets = 0
+        self.bytes = 0
 
     def add(self, grad):
         """queue one final gradient tensor (each tensor once)"""
@@ -56,8 +73,9 @@ class BucketedAllReduce:
         if not self.bucket:
             return
         flat = torch.cat([g.reshape(-1) for g in self.bucket])
-        work = self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        work = _all_reduce_sum(self.dist, flat, self.group, async_op=True)
         self.pending.append((work, flat, self.bucket))
+        self.bytes += flat.numel() * flat.element_size()
         self.bucket, self.size = [], 0
         self.n_buckets += 1
 
@@ -67,7 +85,8 @@ class BucketedAllReduce:
             return 0
         self._launch()
         for work, flat, bucket in self.pending:
-            work.wait()
+            if work is not None:
+                work.wait()
             off = 0
             for g in bucket:
                 g.copy_(flat[off:off + g.numel()].view_as(g))
@@ -76,7 +95,7 @@ class BucketedAllReduce:
         return self.n_buckets
 
 
-def allreduce_gradients(params, group=None, bucket_bytes=BUCKET_BYTES, reducer=None):
+def allreduce_gradients(params, group=None, bucket_bytes=None, reducer=None):
     """SUM all-reduce of .grad over the process group in flat buckets (no-op without a group).  With a `reducer`
     that already received some gradients during backward, only the remaining ones are added."""
     r = reducer if reducer is not None else BucketedAllReduce(group, bucket_bytes)
@@ -85,56 +104,101 @@ def allreduce_gradients(params, group=None, bucket_bytes=BUCKET_BYTES, reducer=N
     return r.finish()
 
 
-def global_token_count(n_local, device, group=None):
+def _dist_active(group=None):
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+def global_token_count(n_local, device, group=None):
+    """Sum of the ranks' token counts (the CE normaliser of the concatenated batch, editnet.py:577)."""
+    import torch.distributed as dist
+    if not _dist_active(group):
         return n_local
-    t = torch.tensor([float(n_local)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    t = torch.tensor([float(n_local)], dtype=torch.float64, device="cpu" if dist.get_backend(group) == "gloo" else device)
+    _all_reduce_sum(dist, t, group)
     return int(t.item())
 
 
-def xe_train_step(decoder, optimizer, image_features, caps, caplens, previous_caption, prev_caplen, use_ss=False,
-                  ss_prob=0.0, group=None):
-    """One step of editnet.py:558-581 on this rank's shard.  Returns (global mean loss, local tokens)."""
-    decoder.train()
-    scores, caps_sorted, decode_lengths, _ = decoder(image_features, caps, caplens, previous_caption, prev_caplen,
-                                                     use_ss, ss_prob)
-    loss_sum, n_tok, _, _ = xe_loss_sum(scores, caps_sorted, decode_lengths)
-    n_glob = global_token_count(n_tok, image_features.device, group)
-    loss = loss_sum / n_glob
-    optimizer.zero_grad()
+def _global_loss(loss_sum_local, n_glob, group=None):
+    """Global mean loss = (sum over ranks of the local summed loss) / global count: the same number on every rank."""
+    import torch.distributed as dist
+    t = loss_sum_local.detach().double().reshape(1).clone()
+    if _dist_active(group):
+        _all_reduce_sum(dist, t, group)
+    return float(t.item()) / max(n_glob, 1)
+
+
+def xe_backward(decoder, image_features, caps, caplens, previous_caption, prev_caplen, use_ss=False, ss_prob=0.0,
+                group=None, reduce=True, image_mean=None):
+    """Forward + backward + gradient exchange of editnet.py:558-579 on this rank's shard; leaves the SUM-reduced
+    gradients of the GLOBAL mean loss in `.grad`.  Returns (global mean loss, local tokens, reducer).
+    `reduce=False` skips every collective (single-rank timing of the same step)."""
     from .autograd_ops import deferred_param_grads
-    reducer = BucketedAllReduce(group)
+    grp_on = reduce and _dist_active(group)
+    # the token count only depends on the caption lengths: exchange it BEFORE the forward is enqueued so the
+    # host never waits on the device between forward and backward
+    n_tok = int((caplens.reshape(-1) - 1).sum().item())
+    n_glob = global_token_count(n_tok, image_features.device, group) if grp_on else n_tok
+    out = decoder(image_features, caps, caplens, previous_caption, prev_caplen, use_ss, ss_prob) if image_mean is None \
+        else decoder(image_features, caps, caplens, previous_caption, prev_caplen, use_ss, ss_prob, image_mean)
+    scores, caps_sorted, decode_lengths = out[0], out[1], out[2]
+    loss_sum, n_chk, _, _ = xe_loss_sum(scores, caps_sorted, decode_lengths)
+    assert n_chk == n_tok, (n_chk, n_tok)
+    loss = loss_sum / n_glob
+    for p in decoder.parameters():
+        p.grad = None
+    reducer = BucketedAllReduce(group, enabled=grp_on)
     # one weight-gradient contraction per parameter over all timesteps; every finished gradient goes straight
     # into an all-reduce bucket, so the collectives overlap the remaining contractions
     with deferred_param_grads(on_ready=lambda p: reducer.add(p.grad)):
         loss.backward()
     params = [p for p in decoder.parameters() if p.requires_grad]
     allreduce_gradients(params, group, reducer=reducer)
+    return (_global_loss(loss_sum, n_glob, group) if grp_on else float(loss_sum.detach()) / max(n_glob, 1)), n_tok, reducer
+
+
+def xe_train_step(decoder, optimizer, image_features, caps, caplens, previous_caption, prev_caplen, use_ss=False,
+                  ss_prob=0.0, group=None, reduce=True):
+    """One step of editnet.py:558-581 on this rank's shard.  Returns (GLOBAL mean loss — identical on every
+    rank —, local tokens)."""
+    decoder.train()
+    loss, n_tok, _ = xe_backward(decoder, image_features, caps, caplens, previous_caption, prev_caplen, use_ss, ss_prob,
+                                 group, reduce)
+    params = [p for p in decoder.parameters() if p.requires_grad]
     torch.nn.utils.clip_grad_norm_(params, GRAD_CLIP)
     optimizer.step()
-    return float(loss.detach()) , n_tok
+    return loss, n_tok
 
 
-def dcnet_xe_train_step(dae, optimizer, caps, caplens, previous_caption, prev_caplen, group=None):
-    """One step of dcnet.py:352-402 (the denoising auto-encoder has no image input) on this rank's shard; same
-    global-token-count normalisation and gradient all-reduce as `xe_train_step`."""
+def dcnet_xe_backward(dae, caps, caplens, previous_caption, prev_caplen, group=None, reduce=True):
+    """DCNet twin of `xe_backward` (dcnet.py:352-400): the denoising auto-encoder has no image input."""
     from .autograd_ops import deferred_param_grads
-    dae.train()
+    grp_on = reduce and _dist_active(group)
+    n_tok = int((caplens.reshape(-1) - 1).sum().item())
+    n_glob = global_token_count(n_tok, caps.device, group) if grp_on else n_tok
     scores, caps_sorted, decode_lengths, _ = dae(caps, caplens, previous_caption, prev_caplen)
-    loss_sum, n_tok, _, _ = xe_loss_sum(scores, caps_sorted, decode_lengths)
-    n_glob = global_token_count(n_tok, caps.device, group)
+    loss_sum, n_chk, _, _ = xe_loss_sum(scores, caps_sorted, decode_lengths)
+    assert n_chk == n_tok, (n_chk, n_tok)
     loss = loss_sum / n_glob
-    optimizer.zero_grad()
-    reducer = BucketedAllReduce(group)
+    for p in dae.parameters():
+        p.grad = None
+    reducer = BucketedAllReduce(group, enabled=grp_on)
     with deferred_param_grads(on_ready=lambda p: reducer.add(p.grad)):
         loss.backward()
     params = [p for p in dae.parameters() if p.requires_grad]
     allreduce_gradients(params, group, reducer=reducer)
+    return (_global_loss(loss_sum, n_glob, group) if grp_on else float(loss_sum.detach()) / max(n_glob, 1)), n_tok, reducer
+
+
+def dcnet_xe_train_step(dae, optimizer, caps, caplens, previous_caption, prev_caplen, group=None, reduce=True):
+    """One step of dcnet.py:352-402 on this rank's shard; same global-token-count normalisation and gradient
+    all-reduce as `xe_train_step`.  Returns (GLOBAL mean loss, local tokens)."""
+    dae.train()
+    loss, n_tok, _ = dcnet_xe_backward(dae, caps, caplens, previous_caption, prev_caplen, group, reduce)
+    params = [p for p in dae.parameters() if p.requires_grad]
     torch.nn.utils.clip_grad_norm_(params, GRAD_CLIP)
     optimizer.step()
-    return float(loss.detach()), n_tok
+    return loss, n_tok
 
 
 def reward_loss_sum(sample_logprobs, seq, reward):
@@ -153,7 +217,7 @@ def scst_train_step(decoder, optimizer, word_map, image_features, previous_capti
     RewardCriterion, backward, gradient all-reduce, clip, optimizer.  The reference draws one sample per
     image; BASELINE.json config 5 asks for 5: all samples enter one RewardCriterion over n_samples * B rows.  As in the XE step the
     loss is normalised by the GLOBAL mask count so that N ranks reproduce one big batch.
-    Returns (mean reward of the samples on this rank, loss value)."""
+    Returns (mean reward of the samples on this rank, GLOBAL loss value)."""
     from . import ciderd
     from .autograd_ops import deferred_param_grads
     dev = image_features.device
@@ -174,7 +238,7 @@ def scst_train_step(decoder, optimizer, word_map, image_features, previous_capti
         n_glob = global_token_count(int(cnt.item()), dev, group)
         loss = num / n_glob
         loss.backward()
-    reward_mean, loss_val = float(rewards[:, 0].mean()), float(loss.detach())
+    reward_mean, loss_val = float(rewards[:, 0].mean()), _global_loss(num, n_glob, group)
     params = [p for p in decoder.parameters() if p.requires_grad]
     allreduce_gradients(params, group, reducer=reducer)
     torch.nn.utils.clip_grad_norm_(params, GRAD_CLIP)

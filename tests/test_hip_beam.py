@@ -1,112 +1,101 @@
-"""GPU: the beam-search callers (evaluate() / evaluate_full() mirrors) over the HIP operator API
-against the oracle's hand-stated numpy beam search."""
+"""GPU: beam search (row f2 / a8-beam) against the REFERENCE's own results (tests/golden/beam_*.npz: the
+per-image loops of editnet.py:603-713, dcnet.py:413-514 and eval_full.py:96-210 run on the reference's
+classes, oracle/make_beam_golden.py):
+  * the product's batched on-device search (show_edit_tell_amd/evaluate.py), many images at once and one
+    image per call;
+  * a search that drives the decoder through its sub-module attributes the way the reference's evaluate()
+    does (tests/beam_via_modules.py) — the boundary check for those attributes."""
 import numpy as np
 import pytest
 
+import beam_parity
+import beam_via_modules as BM
 from hip_adapter import load_numpy_state, to_dev
-from oracle import beam_np, cases, dcnet_np as DN, editnet_np as EN
+from oracle import cases
 
 pytestmark = pytest.mark.gpu
 
 
-def _boosted(sd, V, boost):
-    sd = dict(sd)
-    sd["fc.bias"] = sd["fc.bias"].copy()
-    sd["fc.bias"][V - 1] += np.float32(boost)
-    return sd
+def _models(d):
+    from show_edit_tell_amd import dcnet, editnet
+    c, dc, wm = d["case"], d["dcase"], d["wm"]
+    xe = load_numpy_state(editnet.DecoderC(wm, c["D"], c["D"], c["D"], c["A"], c["F"]), d["sd_e"])
+    dae = load_numpy_state(dcnet.DAE(wm, None, dc["D"], dc["A"], dc["C"], dc["E"]), d["sd_d"])
+    return xe, dae
 
 
-def test_beam_search_editnet_and_ensemble():
-    from show_edit_tell_amd import dcnet, editnet, evaluate
-    d = cases.build_editnet("editnet_small")
-    c, wm = d["case"], d["wm"]
-    # <end> boosted so that some hypotheses finish early and others run to the step limit
-    sd_e = _boosted(d["sd"], c["V"], 3.0)
-    sd_d = _boosted(cases.synth.dcnet_state(17, c["V"], c["D"], c["A"], c["D"] // 2, c["D"], 3.0, 8.0, 3.0), c["V"], 3.0)
-    xe = load_numpy_state(editnet.DecoderC(wm, c["D"], c["D"], c["D"], c["A"], c["F"]), sd_e)
-    dae = load_numpy_state(dcnet.DAE(wm, None, c["D"], c["A"], c["D"] // 2, c["D"]), sd_d)
-    Pe, Pd = EN.cast_params(sd_e), DN.cast_params(sd_d)
-    finished = 0
-    for b in range(c["B"]):
-        X1, prev1, plen1 = d["X"][b:b + 1], d["prev"][b:b + 1], d["plen"][b:b + 1]
-        for ens in (False, True):
-            if ens:
-                seq_o, sc_o, margin = beam_np.beam_ensemble(Pe, Pd, X1, prev1, plen1, wm["<start>"], wm["<end>"], 3)
-                seq, sc = evaluate.beam_search_ensemble(xe, dae, to_dev(X1), to_dev(prev1), to_dev(plen1), wm, 3)
-            else:
-                seq_o, sc_o, margin = beam_np.beam_editnet(Pe, X1, prev1, plen1, wm["<start>"], wm["<end>"], 3)
-                seq, sc = evaluate.beam_search_editnet(xe, to_dev(X1), to_dev(prev1), to_dev(plen1), wm, 3)
-            if margin is None:                  # ran into the step limit (editnet.py:702-704,711)
-                assert np.isnan(sc) and len(seq) == 18 and seq[:4] == seq_o[:4], (b, ens, seq, seq_o)
-            else:
-                assert abs(sc - sc_o) < 1e-3, (b, ens, sc, sc_o)
-                if margin > 1e-3:
-                    assert seq == seq_o, (b, ens, seq, seq_o)
-                    finished += 1
-            assert evaluate.sentence(seq, wm) == " ".join("w%d" % w for w in seq if 0 < w < c["V"] - 3)
-    assert finished >= 2
-
-
-def _same_search(batched_b, seq, sc, what):
-    if np.isnan(sc):                       # step-limit path: the 50-step trajectory is chaotic, compare the head
-        assert len(batched_b) == 18 and batched_b[:4] == seq[:4], (what, batched_b, seq)
-        return 0
-    assert batched_b == seq, (what, batched_b, seq)
-    return 1
-
-
-def test_batched_beam_matches_per_image_beam():
-    """Row f2: all images of a batch searched at once, entirely on the device (fused step + set_beam_pick_f32 +
-    set_beam_gather_f32) == the reference-style one-image-at-a-time search; EditNet, DCNet and the ensemble."""
-    from show_edit_tell_amd import dcnet, editnet, evaluate
-    d = cases.build_editnet("editnet_small")
-    c, wm = d["case"], d["wm"]
-    for boost in (3.0, 5.0):
-        xe = load_numpy_state(editnet.DecoderC(wm, c["D"], c["D"], c["D"], c["A"], c["F"]), _boosted(d["sd"], c["V"], boost))
-        sd_d = _boosted(cases.synth.dcnet_state(17, c["V"], c["D"], c["A"], c["D"] // 2, c["D"], 3.0, 8.0, 3.0), c["V"], boost)
-        dae = load_numpy_state(dcnet.DAE(wm, None, c["D"], c["A"], c["D"] // 2, c["D"]), sd_d)
-        X, prev, plen = to_dev(d["X"]), to_dev(d["prev"]), to_dev(d["plen"])
-        fused_e = evaluate.beam_search_editnet_batched(xe, X, prev, plen, wm, 3)
-        torch_e = evaluate.beam_search_editnet_batched_torch(xe, X, prev, plen, wm, 3)
-        fused_d = evaluate.beam_search_dcnet_batched(dae, prev, plen, wm, 3)
-        fused_x = evaluate.beam_search_ensemble_batched(xe, dae, X, prev, plen, wm, 3)
-        agree = 0
-        for b in range(c["B"]):
-            one = (X[b:b + 1], prev[b:b + 1], plen[b:b + 1])
-            seq, sc = evaluate.beam_search_editnet(xe, *one, wm, 3)
-            agree += _same_search(fused_e[b], seq, sc, ("editnet", boost, b))
-            _same_search(torch_e[b], seq, sc, ("editnet-torch", boost, b))
-            seq, sc = evaluate.beam_search_dcnet(dae, one[1], one[2], wm, 3)
-            agree += _same_search(fused_d[b], seq, sc, ("dcnet", boost, b))
-            seq, sc = evaluate.beam_search_ensemble(xe, dae, *one, wm, 3)
-            agree += _same_search(fused_x[b], seq, sc, ("ensemble", boost, b))
-        assert agree >= 6
-    # wider beams than the reference's 3 (k <= 8 in the kernel)
-    for k in (1, 5, 8):
-        fused = evaluate.beam_search_editnet_batched(xe, X, prev, plen, wm, k)
-        ref = evaluate.beam_search_editnet_batched_torch(xe, X, prev, plen, wm, k)
-        for b in range(c["B"]):
-            assert fused[b][:4] == ref[b][:4] and (len(fused[b]) == 18 or fused[b] == ref[b]), (k, b, fused[b], ref[b])
-
-
-def test_batched_beam_full_size_vs_oracle():
-    """Full-size model (D=1024, V=10000, 36x2048 regions): the fused batched beam search against the oracle's
-    numpy beam search, image by image."""
-    from show_edit_tell_amd import editnet, evaluate
-    d = cases.build_editnet("editnet_full_b4")
-    c, wm = d["case"], d["wm"]
-    sd = _boosted(d["sd"], c["V"], 4.0)
-    xe = load_numpy_state(editnet.DecoderC(wm, c["D"], c["D"], c["D"], c["A"], c["F"]), sd)
-    P = EN.cast_params(sd)
+@pytest.mark.parametrize("name", ["beam_small_e3", "beam_small_e5", "beam_full_b4"])
+def test_batched_beam_vs_reference_beam(name):
+    """All images of the batch searched at once on the device == the reference's one-image-at-a-time search."""
+    from show_edit_tell_amd import evaluate
+    d = cases.build_beam(name)
+    g = beam_parity.load(name)
+    wm, B = d["wm"], d["case"]["B"]
+    xe, dae = _models(d)
     X, prev, plen = to_dev(d["X"]), to_dev(d["prev"]), to_dev(d["plen"])
-    got = evaluate.beam_search_editnet_batched(xe, X, prev, plen, wm, 3)
-    checked = 0
+    firm = 0
+    for k in d["beams"]:
+        res = {"editnet": evaluate.beam_search_editnet_batched(xe, X, prev, plen, wm, k, return_scores=True),
+               "dcnet": evaluate.beam_search_dcnet_batched(dae, prev, plen, wm, k, return_scores=True),
+               "ensemble": evaluate.beam_search_ensemble_batched(xe, dae, X, prev, plen, wm, k, return_scores=True)}
+        for model, (seqs, scores) in res.items():
+            assert len(seqs) == B
+            for b in range(B):
+                firm += beam_parity.check_one(g, k, model, b, seqs[b], scores[b])
+    assert firm >= (6 if name != "beam_full_b4" else 4)
+
+
+def test_per_image_entry_points_vs_reference_beam():
+    """The reference's calling convention (one image per call) + sentence construction (editnet.py:715-716)."""
+    from show_edit_tell_amd import evaluate
+    d = cases.build_beam("beam_small_e5")
+    g = beam_parity.load("beam_small_e5")
+    wm, c = d["wm"], d["case"]
+    xe, dae = _models(d)
+    firm = 0
     for b in range(c["B"]):
-        seq_o, sc_o, margin = beam_np.beam_editnet(P, d["X"][b:b + 1], d["prev"][b:b + 1], d["plen"][b:b + 1],
-                                                   wm["<start>"], wm["<end>"], 3)
-        if margin is None:
-            assert len(got[b]) == 18 and got[b][:4] == seq_o[:4]
-        elif margin > 1e-3:
-            assert got[b] == seq_o, (b, got[b], seq_o)
-            checked += 1
-    assert checked >= 1
+        one = (to_dev(d["X"][b:b + 1]), to_dev(d["prev"][b:b + 1]), to_dev(d["plen"][b:b + 1]))
+        seq, sc = evaluate.beam_search_editnet(xe, *one, wm, 3)
+        firm += beam_parity.check_one(g, 3, "editnet", b, seq, sc)
+        assert evaluate.sentence(seq, wm) == " ".join("w%d" % w for w in seq if 0 < w < c["V"] - 3)
+        seq, sc = evaluate.beam_search_dcnet(dae, one[1], one[2], wm, 3)
+        firm += beam_parity.check_one(g, 3, "dcnet", b, seq, sc)
+        seq, sc = evaluate.beam_search_ensemble(xe, dae, *one, wm, 3)
+        firm += beam_parity.check_one(g, 3, "ensemble", b, seq, sc)
+    assert firm >= 9
+
+
+@pytest.mark.parametrize("name", ["beam_small_e3", "beam_small_e5"])
+def test_module_attribute_beam_vs_reference_beam(name):
+    """evaluate()-style use of the sub-module attributes (each call one HIP operator) reproduces the reference."""
+    d = cases.build_beam(name)
+    g = beam_parity.load(name)
+    wm, B = d["wm"], d["case"]["B"]
+    xe, dae = _models(d)
+    firm = 0
+    for b in range(B):
+        one = (to_dev(d["X"][b:b + 1]), to_dev(d["prev"][b:b + 1]), to_dev(d["plen"][b:b + 1]))
+        firm += beam_parity.check_one(g, 3, "editnet", b, *BM.beam_editnet(xe, *one, wm, 3))
+        firm += beam_parity.check_one(g, 3, "dcnet", b, *BM.beam_dcnet(dae, one[1], one[2], wm, 3))
+        firm += beam_parity.check_one(g, 3, "ensemble", b, *BM.beam_ensemble(xe, dae, *one, wm, 3))
+    assert firm >= 6
+
+
+def test_wide_beams_fused_vs_module_attribute_search():
+    """k up to 8 (the kernel's limit; the reference uses 3): the fused search equals the module-attribute search."""
+    from show_edit_tell_amd import evaluate
+    d = cases.build_beam("beam_small_e5")
+    wm, B = d["wm"], d["case"]["B"]
+    xe, _ = _models(d)
+    X, prev, plen = to_dev(d["X"]), to_dev(d["prev"]), to_dev(d["plen"])
+    agree = 0
+    for k in (2, 8):
+        seqs, scores = evaluate.beam_search_editnet_batched(xe, X, prev, plen, wm, k, return_scores=True)
+        for b in range(B):
+            seq, sc = BM.beam_editnet(xe, X[b:b + 1], prev[b:b + 1], plen[b:b + 1], wm, k)
+            if np.isnan(sc):
+                assert len(seqs[b]) == 18 and seqs[b][:4] == seq[:4]
+            else:
+                assert abs(scores[b] - sc) < beam_parity.SCORE_TOL, (k, b, scores[b], sc)
+                agree += int(seqs[b] == seq)
+    assert agree >= B

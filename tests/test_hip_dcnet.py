@@ -32,6 +32,32 @@ def test_dcnet_vs_golden(name):
     parity.check_greedy(_np(seq), _np(logp), g)
 
 
+def test_dcnet_lstm_cells_per_operator_vs_golden():
+    """Rows a2 / a6' for DCNet as stand-alone operators: `attention_lstm` (nn.LSTMCell(3072->D), dcnet.py:286,340)
+    and `language_lstm` (nn.LSTMCell(2048->D), dcnet.py:287,346) called through the module attributes on the
+    reference's own per-step inputs (greedy trace of the reduced model) must reproduce its per-step outputs."""
+    d, xe, rl = dcnet_modules("dcnet_small")
+    g = parity.load("dcnet_small")
+    wm = d["wm"]
+    S = int(g["greedy_nsteps"])
+    assert S >= 3
+    with torch.no_grad():
+        enc, fh, mask = xe.caption_encoder(to_dev(d["prev"]), to_dev(d["plen"]))
+        for t in range(1, S):
+            tok = to_dev(g["greedy_seq"][:, t - 1])
+            emb = xe.embed(tok)
+            h1p, c1p, h2p, c2p = (to_dev(g["greedy_" + k][t - 1]) for k in ("h1", "c1", "h2", "c2"))
+            h1, c1 = xe.attention_lstm(torch.cat([emb, fh, h2p], 1), (h1p, c1p))
+            parity.assert_close(_np(h1), g["greedy_h1"][t], parity.STATE_TOL * 5, "attention_lstm h1 step %d" % t)
+            parity.assert_close(_np(c1), g["greedy_c1"][t], parity.STATE_TOL * 5, "attention_lstm c1 step %d" % t)
+            ac = to_dev(g["greedy_attend_cap"][t])
+            h2, c2 = xe.language_lstm(torch.cat([to_dev(g["greedy_h1"][t]), ac], 1), (h2p, c2p))
+            parity.assert_close(_np(h2), g["greedy_h2"][t], parity.STATE_TOL * 5, "language_lstm h2 step %d" % t)
+            parity.assert_close(_np(c2), g["greedy_c2"][t], parity.STATE_TOL * 5, "language_lstm c2 step %d" % t)
+            logits = xe.fc(h2)
+            parity.assert_close(_np(logits), g["greedy_logits"][t], parity.LOGIT_TOL, "fc step %d" % t)
+
+
 def test_dcnet_grad_path_matches_fused_path():
     """The grad-enabled DCNet path (autograd-wrapped HIP operators) reproduces the fused no-grad path
     (which is pinned to the reference goldens above), produces finite gradients for every parameter,

@@ -53,12 +53,13 @@ def test_fused_paths_vs_oracle(B, T, R, D, A, F, V):
     assert firm.mean() > 0.9
     parity.assert_close(pred.cpu().numpy()[inv][firm[inv_o]], pred_o[inv_o][firm[inv_o]], parity.LOGIT_TOL,
                         "xe predictions")
-    # greedy: rows whose oracle margin is comfortable must match bit-exactly
+    # greedy: rows whose oracle margin is comfortable must match bit-exactly; near-tie rows must match up to the
+    # tie and pick one of the oracle's two best candidates there (parity.check_greedy_rows)
     tr = []
     seq_o, logp_o = EN.greedy_decode(P, wm["<start>"], wm["<end>"], prev, plen, X, trace=tr)
     lg = np.stack([s["logits"] for s in tr[:-1]]) if len(tr) > 1 else np.stack([s["logits"] for s in tr])
     srt = np.sort(lg, 2)
-    ok = ((srt[:, :, -1] - srt[:, :, -2]) > 1e-3).all(0) if V > 1 else np.ones(B, bool)
-    assert ok.mean() > 0.8
-    assert np.array_equal(seq.cpu().numpy()[ok], seq_o[ok])
-    parity.assert_close(logp.cpu().numpy()[ok], logp_o[ok], parity.LOGIT_TOL, "greedy logprobs")
+    margins = (srt[:, :, -1] - srt[:, :, -2]) if V > 1 else np.ones(lg.shape[:2], np.float32)
+    top2 = np.argsort(-lg.astype(np.float64), axis=2, kind="stable")[:, :, :2]
+    assert ((margins > 1e-3).all(0)).mean() > 0.8
+    parity.check_greedy_rows(seq.cpu().numpy(), logp.cpu().numpy(), seq_o, logp_o, margins, top2, wm["<end>"], 1e-3)

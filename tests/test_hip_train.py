@@ -31,6 +31,47 @@ def test_xe_gradients_vs_reference_autograd(name, deferred):
     _check_grads(xe, g, name)
 
 
+def test_xe_gradients_b128_vs_reference_autograd():
+    """BASELINE.json config 1 (EditNet XE forward+backward, batch=128, 36x2048, prev-caption len 20): loss, every
+    parameter's gradient norm and a 64-element strided slice of every gradient against the reference's autograd."""
+    from show_edit_tell_amd.autograd_ops import deferred_param_grads
+    from show_edit_tell_amd.train import xe_loss_sum
+    name = "editnet_full_b128"
+    d, xe, rl = editnet_modules(name)
+    g = parity.load(name)
+    xe.eval()
+    pred, caps_s, dl, sort_ind = xe(to_dev(d["X"]), to_dev(d["caps"]), to_dev(d["clen"]), to_dev(d["prev"]),
+                                    to_dev(d["plen"]), False, 0.0)
+    loss_sum, n_tok, _, _ = xe_loss_sum(pred, caps_s, dl)
+    loss = loss_sum / n_tok
+    assert abs(float(loss.detach()) - float(g["grad_loss"])) < 1e-4
+    with deferred_param_grads():
+        loss.backward()
+    _check_grads(xe, g, name)
+
+
+@pytest.mark.parametrize("name", ["dcnet_small", "dcnet_full_b4"])
+def test_dcnet_xe_gradients_vs_reference_autograd(name):
+    """DCNet (dcnet.py:353-402): all parameter gradients of the XE loss against the reference's autograd — through
+    the packed BiLSTM encoder, the additive attention and both LSTM cells; immediate and time-batched weight gradients."""
+    import contextlib
+    from hip_adapter import dcnet_modules
+    from show_edit_tell_amd.autograd_ops import deferred_param_grads
+    from show_edit_tell_amd.train import xe_loss_sum
+    g = parity.load(name)
+    for deferred in (False, True):
+        d, dae, _ = dcnet_modules(name)
+        dae.eval()
+        pred, caps_s, dl, _ = dae(to_dev(d["caps"]), to_dev(d["clen"]), to_dev(d["prev"]), to_dev(d["plen"]))
+        assert pred.requires_grad
+        loss_sum, n_tok, _, _ = xe_loss_sum(pred, caps_s, dl)
+        loss = loss_sum / n_tok
+        assert abs(float(loss.detach()) - float(g["grad_loss"])) < 1e-4
+        with (deferred_param_grads() if deferred else contextlib.nullcontext()):
+            loss.backward()
+        _check_grads(dae, g, name)
+
+
 def _check_grads(xe, g, name):
     # absolute floor: gradients that are mathematically zero (softmax shift invariance makes
     # d/d full_att.bias == 0) are pure rounding noise in both implementations

@@ -81,6 +81,20 @@ def test_editnet_greedy(name):
             parity.assert_close(full.astype(np.float64).sum(2), g["greedy_" + k + "_sum"], parity.SUM_TOL, "greedy sum " + k)
 
 
+@pytest.mark.parametrize("name", ["editnet_small", "editnet_small_end", "editnet_full_b4"])
+def test_editnet_torch_restatement_greedy(name):
+    """oracle/editnet_torch.py (the as-written torch-CPU restatement timed by bench.py's cpu_baseline)
+    against the reference's own greedy decode: ids bit-exact, log-probs within 1e-4."""
+    import torch
+    from oracle import editnet_torch as ET
+    d = cases.build_editnet(name)
+    g = parity.load(name)
+    wm = d["wm"]
+    seq, logp = ET.greedy_decode(ET.params_from_numpy(d["sd"]), wm["<start>"], wm["<end>"], torch.from_numpy(d["prev"]),
+                                 torch.from_numpy(d["plen"]), torch.from_numpy(d["X"]))
+    parity.check_greedy(seq.numpy(), logp.numpy(), g)
+
+
 def test_editnet_b128_greedy_and_xe():
     """BASELINE.json metric shape (B=128, 36x2048, prev-caption len 20)."""
     d, c, P, g = _editnet_inputs("editnet_full_b128")
