@@ -156,6 +156,15 @@ int set_editnet_greedy(const SetEditNetWeights* w, const SetEditNetDims* d, cons
                        int64_t start_idx, int64_t end_idx, int max_len, int64_t* seq,
                        float* seq_logp, void* ws, size_t ws_bytes, void* stream);
 
+/* The same loop with multinomial sampling (editnet_rl.py:521-528, sample_rl=True, eval mode, no gradients):
+ * it ~ Categorical(softmax(logits)) drawn on the device with Philox4x32-10 (counter = (row, timestep, offset),
+ * key = seed): reproducible for a given (seed, offset), independent streams for different offsets.
+ * seq_logp holds log_softmax(logits)[it].  No host synchronisation. */
+int set_editnet_sample(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X,
+                       const float* image_mean, const int64_t* prev, const int64_t* prevlen,
+                       int64_t start_idx, int64_t end_idx, int max_len, uint64_t seed, uint64_t offset,
+                       int64_t* seq, float* seq_logp, void* ws, size_t ws_bytes, void* stream);
+
 /* Teacher-forced XE forward (editnet.py:479-548, eval mode, use_ss=False) on a batch already
  * sorted by decreasing caption length.  caps (B,Lc) int64 sorted; host_decode_lengths[B] on the
  * HOST, non-increasing; predictions (B,maxT,V) is fully overwritten (zeros where not decoded). */
@@ -212,6 +221,10 @@ int set_dcnet_greedy_pick(const SetDcnetWeights* w, const SetDcnetDims* d, const
 int set_dcnet_greedy(const SetDcnetWeights* w, const SetDcnetDims* d, const int64_t* prev,
                      const int64_t* prevlen, int64_t start_idx, int64_t end_idx, int max_len,
                      int64_t* seq, float* seq_logp, void* ws, size_t ws_bytes, void* stream);
+/* multinomial twin of set_dcnet_greedy (dcnet_rl.py:320-327); see set_editnet_sample */
+int set_dcnet_sample(const SetDcnetWeights* w, const SetDcnetDims* d, const int64_t* prev,
+                     const int64_t* prevlen, int64_t start_idx, int64_t end_idx, int max_len, uint64_t seed,
+                     uint64_t offset, int64_t* seq, float* seq_logp, void* ws, size_t ws_bytes, void* stream);
 int set_dcnet_xe_forward(const SetDcnetWeights* w, const SetDcnetDims* d, const int64_t* caps,
                          int64_t caps_stride, const int* host_decode_lengths, const int64_t* prev,
                          const int64_t* prevlen, float* predictions, void* ws, size_t ws_bytes,
@@ -315,6 +328,25 @@ int set_attention_bwd_f32(const float* dctx, const float* dalpha_ext, const floa
                           int L, int Dv, int A, int use_tanh, void* stream);
 int set_select_bwd_f32(const float* dsel, const float* Mem, const float* alpha, float* dM, float* dalpha,
                        int M, int T, int D, void* stream);
+
+/* Multinomial sampling epilogue of one free-running step as an operator (the grad-enabled SCST rollout,
+ * editnet_rl.py:521-543 / dcnet_rl.py:320-340): replaces exp -> torch.multinomial -> gather -> <end> rewrite ->
+ * `unfinished` latch -> seq store -> `unfinished.sum() == 0` host check.  logits (B,V) include the bias.
+ * State owned by the caller across the steps of one rollout: it (B) int64, unfinished (B) int32,
+ * alive (max_len+2) int32 (all initialised here at t == 0); call with t = 0,1,2,... in order.
+ * Outputs of the step: seq[:,t] (seq (B,max_len) pre-zeroed), it = next input token, raw_ids (B) = the sampled
+ * word before the <end> rewrite or -1 once every row had finished at an earlier step (the reference's `break`),
+ * lse (B) = logsumexp(logits), step_logp (B) = log_softmax(logits)[raw_id] (0 after the break).
+ * RNG: Philox4x32-10, counter (row, t, offset), key seed. */
+int set_sample_pick_f32(const float* logits, int64_t ld_logits, int B, int V, int t, int max_len, int64_t end_idx,
+                        uint64_t seed, uint64_t offset, int64_t* seq, int64_t* it, int32_t* unfinished,
+                        int32_t* alive, int64_t* raw_ids, float* lse, float* step_logp, void* stream);
+/* backward of step_logp w.r.t. logits: dlogits[b,v] = g[b] (1[v == raw_id_b] - exp(logits[b,v] - lse[b])); rows
+ * with raw_id < 0 get zeros */
+int set_sample_logp_bwd_f32(const float* logits, int64_t ld_logits, const float* lse, const int64_t* raw_ids,
+                            const float* g, float* dlogits, int64_t ld_dlogits, int B, int V, void* stream);
+/* the device RNG itself (tests: known-answer vectors): out (n,4) uint32 = Philox4x32-10(counter (i,0,offset), key seed) */
+int set_philox4x32(uint32_t* out, int n, uint64_t seed, uint64_t offset, void* stream);
 
 /* Beam-search step epilogue for NI images x k hypotheses (rows i*k+j), replacing the host bookkeeping of
  * editnet.py:654-699 / dcnet.py:450-500 / eval_full.py:150-200: log_softmax (or, with logits2, the ensemble

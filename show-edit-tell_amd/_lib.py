@@ -143,6 +143,7 @@ _P = C.c_void_p
 _I = C.c_int
 _L = C.c_int64
 _Z = C.c_size_t
+_U = C.c_uint64
 
 # name -> (restype, argtypes); mirrors include/set_hip.h one to one
 PROTOTYPES = {
@@ -163,6 +164,8 @@ PROTOTYPES = {
                                      _P, _Z, _P]),
     "set_editnet_greedy": (_I, [C.POINTER(EditNetWeights), C.POINTER(EditNetDims), _P, _P, _P, _P, _L, _L, _I, _P, _P,
                                 _P, _Z, _P]),
+    "set_editnet_sample": (_I, [C.POINTER(EditNetWeights), C.POINTER(EditNetDims), _P, _P, _P, _P, _L, _L, _I, _U, _U, _P,
+                                _P, _P, _Z, _P]),
     "set_editnet_xe_forward": (_I, [C.POINTER(EditNetWeights), C.POINTER(EditNetDims), _P, _P, _P, _L,
                                     C.POINTER(C.c_int), _P, _P, _P, _P, _Z, _P]),
     "set_editnet_ws_tensor": (_P, [C.POINTER(EditNetDims), _P, C.c_char_p]),
@@ -172,6 +175,8 @@ PROTOTYPES = {
     "set_dcnet_greedy_pick": (_I, [C.POINTER(DcnetWeights), C.POINTER(DcnetDims), _P, _L, _I, _L, _P, _P, _I, _P, _Z,
                                    _P]),
     "set_dcnet_greedy": (_I, [C.POINTER(DcnetWeights), C.POINTER(DcnetDims), _P, _P, _L, _L, _I, _P, _P, _P, _Z, _P]),
+    "set_dcnet_sample": (_I, [C.POINTER(DcnetWeights), C.POINTER(DcnetDims), _P, _P, _L, _L, _I, _U, _U, _P, _P, _P, _Z,
+                              _P]),
     "set_dcnet_xe_forward": (_I, [C.POINTER(DcnetWeights), C.POINTER(DcnetDims), _P, _L, C.POINTER(C.c_int), _P, _P,
                                   _P, _P, _Z, _P]),
     "set_dcnet_ws_tensor": (_P, [C.POINTER(DcnetDims), _P, C.c_char_p]),
@@ -202,6 +207,9 @@ PROTOTYPES = {
     "set_context_gate_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "set_attention_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "set_select_bwd_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "set_sample_pick_f32": (_I, [_P, _L, _I, _I, _I, _I, _L, _U, _U, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "set_sample_logp_bwd_f32": (_I, [_P, _L, _P, _P, _P, _P, _L, _I, _I, _P]),
+    "set_philox4x32": (_I, [_P, _I, _U, _U, _P]),
     "set_beam_pick_f32": (_I, [_P, _P, _L, _I, _I, _I, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "set_beam_gather_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "set_gemm_group_f32": (_I, [C.POINTER(GemmDesc), _I, _I, _I, _P, _Z, _P]),

@@ -559,3 +559,58 @@ class _CopyLstm(torch.autograd.Function):
 
 def copy_lstm(x, h2, c2, cmem, x2h_w, x2h_b, h2h_w, h2h_b, cnew_w, cnew_b, cmem_w, cmem_b):
     return _CopyLstm.apply(x, h2, c2, cmem, x2h_w, x2h_b, h2h_w, h2h_b, cnew_w, cnew_b, cmem_w, cmem_b)
+
+
+# ------------------------------------------------------------------------------------------------
+# Multinomial sampling epilogue of a free-running step (editnet_rl.py:521-543, dcnet_rl.py:320-340)
+# ------------------------------------------------------------------------------------------------
+class SampleState:
+    """Device-side bookkeeping of one sampled rollout: seq (B,max_len), the token fed to every step (row t of
+    `tokens`), the `unfinished` latch and the per-step alive counters that emulate the reference's early `break`
+    without a host synchronisation.  Seed / offset select the Philox stream (seed drawn from torch's CPU generator,
+    so torch.manual_seed makes rollouts reproducible)."""
+
+    def __init__(self, B, max_len, start_idx, end_idx, device, seed=None, offset=0):
+        self.B, self.max_len, self.end_idx = B, max_len, int(end_idx)
+        self.seq = torch.zeros(B, max_len, dtype=torch.long, device=device)
+        self.tokens = torch.zeros(max_len + 2, B, dtype=torch.long, device=device)
+        self.tokens[0].fill_(int(start_idx))
+        self.unfinished = torch.empty(B, dtype=torch.int32, device=device)
+        self.alive = torch.empty(max_len + 2, dtype=torch.int32, device=device)
+        self.seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)
+        self.offset = int(offset)
+
+
+class _SamplePick(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, state, t):
+        lib = _lib.load()
+        logits = _c(logits)
+        B, V = logits.shape
+        dev = logits.device
+        raw = torch.empty(B, dtype=torch.long, device=dev)
+        lse = torch.empty(B, dtype=torch.float32, device=dev)
+        logp = torch.empty(B, dtype=torch.float32, device=dev)
+        check(lib.set_sample_pick_f32(ptr(logits), logits.stride(0), B, V, t, state.max_len, state.end_idx, state.seed,
+                                      state.offset, ptr(state.seq), ptr(state.tokens[t + 1]), ptr(state.unfinished),
+                                      ptr(state.alive), ptr(raw), ptr(lse), ptr(logp), stream_of(dev)),
+              "set_sample_pick_f32")
+        ctx.save_for_backward(logits, lse, raw)
+        return logp
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, lse, raw = ctx.saved_tensors
+        lib = _lib.load()
+        B, V = logits.shape
+        d = torch.empty_like(logits)
+        check(lib.set_sample_logp_bwd_f32(ptr(logits), logits.stride(0), ptr(lse), ptr(raw), ptr(_c(g)), ptr(d),
+                                          d.stride(0), B, V, stream_of(logits.device)), "set_sample_logp_bwd_f32")
+        return d, None, None
+
+
+def sample_pick(logits, state, t):
+    """One sampled step: draws it ~ softmax(logits) on the device (Philox), applies the <end> / unfinished / break
+    bookkeeping into `state` (seq[:, t], tokens[t + 1]) and returns log_softmax(logits)[it] (B), differentiable
+    w.r.t. logits.  No host synchronisation."""
+    return _SamplePick.apply(logits, state, t)

@@ -251,9 +251,10 @@ int set_dcnet_greedy_pick(const SetDcnetWeights* w, const SetDcnetDims* d, const
                        w->embed, W.emb, d->E, d->B, st);
 }
 
-int set_dcnet_greedy(const SetDcnetWeights* w, const SetDcnetDims* d, const int64_t* prev, const int64_t* prevlen,
-                     int64_t start_idx, int64_t end_idx, int max_len, int64_t* seq, float* seq_logp, void* ws,
-                     size_t ws_bytes, void* stream) {
+// free-running decode (dcnet_rl.py:286-346): sample == 0 greedy, 1 multinomial
+static int dcnet_rollout(const SetDcnetWeights* w, const SetDcnetDims* d, const int64_t* prev, const int64_t* prevlen,
+                         int64_t start_idx, int64_t end_idx, int max_len, int sample, uint64_t seed, uint64_t offset,
+                         int64_t* seq, float* seq_logp, void* ws, size_t ws_bytes, void* stream) {
     if (!w || !prev || !prevlen || !seq || !seq_logp || max_len <= 0) return SET_ERR_ARG;
     DcnetWs W;
     SET_TRY(prep(d, ws, ws_bytes, &W));
@@ -269,10 +270,27 @@ int set_dcnet_greedy(const SetDcnetWeights* w, const SetDcnetDims* d, const int6
         Slabs lg;
         SET_TRY(step_impl(w, d, B, W, nullptr, 0, &lg, st));
         if (t == max_len) break;
-        SET_TRY(greedy_pick(lg, w->fc_b, d->V, t, max_len, end_idx, (long long*)seq, seq_logp, W.it, W.unfinished,
-                            W.alive, w->embed, W.emb, d->E, B, st));
+        if (sample)
+            SET_TRY(sample_pick(lg, w->fc_b, d->V, t, max_len, end_idx, (long long*)seq, seq_logp, W.it, W.unfinished,
+                                W.alive, w->embed, W.emb, d->E, B, seed, offset, nullptr, nullptr, nullptr, st));
+        else
+            SET_TRY(greedy_pick(lg, w->fc_b, d->V, t, max_len, end_idx, (long long*)seq, seq_logp, W.it, W.unfinished,
+                                W.alive, w->embed, W.emb, d->E, B, st));
     }
     return SET_OK;
+}
+
+int set_dcnet_greedy(const SetDcnetWeights* w, const SetDcnetDims* d, const int64_t* prev, const int64_t* prevlen,
+                     int64_t start_idx, int64_t end_idx, int max_len, int64_t* seq, float* seq_logp, void* ws,
+                     size_t ws_bytes, void* stream) {
+    return dcnet_rollout(w, d, prev, prevlen, start_idx, end_idx, max_len, 0, 0, 0, seq, seq_logp, ws, ws_bytes, stream);
+}
+
+int set_dcnet_sample(const SetDcnetWeights* w, const SetDcnetDims* d, const int64_t* prev, const int64_t* prevlen,
+                     int64_t start_idx, int64_t end_idx, int max_len, uint64_t seed, uint64_t offset, int64_t* seq,
+                     float* seq_logp, void* ws, size_t ws_bytes, void* stream) {
+    return dcnet_rollout(w, d, prev, prevlen, start_idx, end_idx, max_len, 1, seed, offset, seq, seq_logp, ws, ws_bytes,
+                         stream);
 }
 
 int set_dcnet_xe_forward(const SetDcnetWeights* w, const SetDcnetDims* d, const int64_t* caps, int64_t caps_stride,

@@ -399,9 +399,11 @@ int set_editnet_greedy_pick(const SetEditNetWeights* w, const SetEditNetDims* d,
                        w->embed, W.emb, d->D, d->B, st);
 }
 
-int set_editnet_greedy(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X, const float* image_mean,
-                       const int64_t* prev, const int64_t* prevlen, int64_t start_idx, int64_t end_idx, int max_len,
-                       int64_t* seq, float* seq_logp, void* ws, size_t ws_bytes, void* stream) {
+// free-running decode (editnet_rl.py:485-549): sample == 0 greedy (sample_max), 1 multinomial (sample_rl)
+static int rollout(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X, const float* image_mean,
+                   const int64_t* prev, const int64_t* prevlen, int64_t start_idx, int64_t end_idx, int max_len,
+                   int sample, uint64_t seed, uint64_t offset, int64_t* seq, float* seq_logp, void* ws, size_t ws_bytes,
+                   void* stream) {
     if (!w || !X || !prev || !prevlen || !seq || !seq_logp || max_len <= 0) return SET_ERR_ARG;
     EditNetWs W;
     SET_TRY(prep(d, ws, ws_bytes, &W));
@@ -413,18 +415,38 @@ int set_editnet_greedy(const SetEditNetWeights* w, const SetEditNetDims* d, cons
     SET_HIP_TRY(hipMemsetAsync(seq_logp, 0, sizeof(float) * B * max_len, st));
     SET_TRY(set_tokens(W.it, start_idx, W.unfinished, W.alive, d->maxT + 2, B, st));
     SET_TRY(embed_relu(w->embed, (const int64_t*)W.it, 1, W.emb, d->D, B, d->D, d->V, st));
+    // with the token table the step never reads relu(E[it]) (all its consumers gather the folded products),
+    // so the epilogue skips the embedding gather
+    const bool emb_needed = !(w->tok_table && (d->D % 64 == 0) && env_int("SET_NO_FUSED", 0) == 0);
     // the reference runs max_len + 1 timesteps and discards the last one (editnet_rl.py:503,517-518)
     for (int t = 0; t <= max_len; ++t) {
         Slabs lg;
         SET_TRY(step_impl(w, d, X, B, W, W.it, 1, nullptr, 0, &lg, st));
         if (t == max_len) break;
-        // with the token table the step never reads relu(E[it]) (all its consumers gather the folded products),
-        // so the epilogue skips the embedding gather
-        const bool emb_needed = !(w->tok_table && (d->D % 64 == 0) && env_int("SET_NO_FUSED", 0) == 0);
-        SET_TRY(greedy_pick(lg, w->fc_b, d->V, t, max_len, end_idx, (long long*)seq, seq_logp, W.it, W.unfinished,
-                            W.alive, emb_needed ? w->embed : nullptr, W.emb, d->D, B, st));
+        if (sample)
+            SET_TRY(sample_pick(lg, w->fc_b, d->V, t, max_len, end_idx, (long long*)seq, seq_logp, W.it, W.unfinished,
+                                W.alive, emb_needed ? w->embed : nullptr, W.emb, d->D, B, seed, offset, nullptr, nullptr,
+                                nullptr, st));
+        else
+            SET_TRY(greedy_pick(lg, w->fc_b, d->V, t, max_len, end_idx, (long long*)seq, seq_logp, W.it, W.unfinished,
+                                W.alive, emb_needed ? w->embed : nullptr, W.emb, d->D, B, st));
     }
     return SET_OK;
+}
+
+int set_editnet_greedy(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X, const float* image_mean,
+                       const int64_t* prev, const int64_t* prevlen, int64_t start_idx, int64_t end_idx, int max_len,
+                       int64_t* seq, float* seq_logp, void* ws, size_t ws_bytes, void* stream) {
+    return rollout(w, d, X, image_mean, prev, prevlen, start_idx, end_idx, max_len, 0, 0, 0, seq, seq_logp, ws, ws_bytes,
+                   stream);
+}
+
+int set_editnet_sample(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X, const float* image_mean,
+                       const int64_t* prev, const int64_t* prevlen, int64_t start_idx, int64_t end_idx, int max_len,
+                       uint64_t seed, uint64_t offset, int64_t* seq, float* seq_logp, void* ws, size_t ws_bytes,
+                       void* stream) {
+    return rollout(w, d, X, image_mean, prev, prevlen, start_idx, end_idx, max_len, 1, seed, offset, seq, seq_logp, ws,
+                   ws_bytes, stream);
 }
 
 int set_editnet_xe_forward(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X,

@@ -179,6 +179,261 @@ int greedy_pick(Slabs logits, const float* bias, int V, int t, int max_len, long
     return SET_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Multinomial sampling epilogue (editnet_rl.py:521-543, dcnet_rl.py:320-340): the sampling twin of
+// greedy_pick_k.  prob = exp(log_softmax(logits)); it ~ Categorical(prob); seqLogprobs = logprobs[it];
+// then the same <end> -> 0 / `unfinished` latch / early-break bookkeeping and next-embedding gather.
+//
+// Device RNG: Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11), counter
+// = (row, timestep, offset_lo, offset_hi), key = (seed_lo, seed_hi): one independent 24-bit uniform per
+// (seed, offset, row, timestep), reproducible and independent of launch geometry.
+// Draw: inverse CDF over a FIXED enumeration of the vocabulary (thread-major: thread tid owns the words
+// (tid + 256 q) * 4 + e, q = 0.., e = 0..3, in that order; any fixed enumeration samples the same categorical
+// distribution).  One block-wide inclusive scan of the per-thread probability mass locates the owning
+// thread, which then walks its <= 48 words.  u = (r >> 8) * 2^-24 lies in [0, 1 - 2^-24], so u * total
+// rounds strictly below total and exactly one thread owns the target.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ float sample_uniform(unsigned long long seed, unsigned long long offset, int row, int t) {
+    uint32_t c[4] = {(uint32_t)row, (uint32_t)t, (uint32_t)offset, (uint32_t)(offset >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return (float)(c[0] >> 8) * (1.0f / 16777216.0f);
+}
+
+__global__ void __launch_bounds__(64) philox_fill_k(uint32_t* out, int n, unsigned long long seed,
+                                                    unsigned long long offset) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // element i -> counter (i, 0, offset): 4 words each
+    if (i >= n) return;
+    uint32_t c[4] = {(uint32_t)i, 0u, (uint32_t)offset, (uint32_t)(offset >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    out[4 * i] = c[0]; out[4 * i + 1] = c[1]; out[4 * i + 2] = c[2]; out[4 * i + 3] = c[3];
+}
+
+int philox_fill(uint32_t* out, int n, unsigned long long seed, unsigned long long offset, hipStream_t s) {
+    if (n <= 0) return SET_OK;
+    hipLaunchKernelGGL(philox_fill_k, dim3(cdiv(n, 64)), dim3(64), 0, s, out, n, seed, offset);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+struct SampleOut {
+    long long* raw_ids;   // (B) sampled word BEFORE the <end> -> 0 rewriting; -1 once the loop has been left
+    float* lse;           // (B) log-sum-exp of the row (for the backward of the gathered log-prob)
+    float* step_logp;     // (B) this step's log-prob (0 once the loop has been left)
+};
+
+template <bool REG>
+__global__ void __launch_bounds__(256) sample_pick_k(Slabs logits, const float* bias, int V, int t, int max_len,
+                                                     long long end_idx, long long* seq, float* seq_logp,
+                                                     long long* it_buf, int* unfinished, int* alive,
+                                                     const float* table, float* emb_out, int D,
+                                                     unsigned long long seed, unsigned long long offset,
+                                                     SampleOut so) {
+    __shared__ float s_red[4];
+    __shared__ float s_scan[4];
+    __shared__ float s_max;
+    __shared__ long long s_tok;
+    __shared__ int s_pick;
+    __shared__ float s_pick_x;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    f32x4 x[GP_MAXQ];
+    float best = -INFINITY;
+    if (REG) {
+        const float* row = logits.p + (long long)b * logits.ld;
+#pragma unroll
+        for (int q = 0; q < GP_MAXQ; ++q) {
+            const int v = (tid + 256 * q) * 4;
+            x[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (v < V) x[q] = *reinterpret_cast<const f32x4*>(row + v);
+        }
+        for (int i = 1; i < logits.n; ++i) {             // K-slabs in index order, as greedy_pick_k
+            f32x4 y[GP_MAXQ];
+#pragma unroll
+            for (int q = 0; q < GP_MAXQ; ++q) {
+                const int v = (tid + 256 * q) * 4;
+                y[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (v < V) y[q] = *reinterpret_cast<const f32x4*>(row + (long long)i * logits.stride + v);
+            }
+#pragma unroll
+            for (int q = 0; q < GP_MAXQ; ++q) x[q] += y[q];
+        }
+#pragma unroll
+        for (int q = 0; q < GP_MAXQ; ++q) {
+            const int v = (tid + 256 * q) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (v + e < V) { if (bias) x[q][e] += bias[v + e]; }
+                else x[q][e] = -INFINITY;
+                best = fmaxf(best, x[q][e]);
+            }
+        }
+    } else {
+        for (int v = tid; v < V; v += 256) best = fmaxf(best, logit_at(logits, bias, b, v));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o));
+    if (lane == 0) s_red[wave] = best;
+    if (tid == 0) s_pick = -1;
+    __syncthreads();
+    best = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    // per-thread probability mass (unnormalised), then inclusive scan over the threads
+    float mass = 0.f;
+    if (REG) {
+#pragma unroll
+        for (int q = 0; q < GP_MAXQ; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mass += expf(x[q][e] - best);                  // exp(-inf) == 0
+    } else {
+        for (int v = tid; v < V; v += 256) mass += expf(logit_at(logits, bias, b, v) - best);
+    }
+    float incl = mass;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) s_scan[wave] = incl;
+    __syncthreads();
+    float wave_base = 0.f;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) if (w < wave) wave_base += s_scan[w];
+    incl += wave_base;
+    const float total = ((s_scan[0] + s_scan[1]) + s_scan[2]) + s_scan[3];
+    const float target = sample_uniform(seed, offset, b, t) * total;
+    // the owner is the first thread whose inclusive mass exceeds the target (monotone scan; `excl` of a thread
+    // is recomputed from its own incl, so neighbours may disagree by an ulp: ownership is decided on incl only)
+    float prev_incl = __shfl_up(incl, 1);
+    if (lane == 0) prev_incl = wave_base;
+    const bool owner = (target < incl) && !(target < prev_incl);
+    if (owner) {
+        float c = prev_incl;
+        int pick = -1;
+        float pick_x = 0.f;
+        if (REG) {
+#pragma unroll
+            for (int q = 0; q < GP_MAXQ; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pe = expf(x[q][e] - best);
+                    c += pe;
+                    if (pick < 0 && pe > 0.f && target < c) { pick = (tid + 256 * q) * 4 + e; pick_x = x[q][e]; }
+                }
+            if (pick < 0) {                      // rounding left the target at the very end of this thread's span
+#pragma unroll
+                for (int q = 0; q < GP_MAXQ; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (x[q][e] > -INFINITY && expf(x[q][e] - best) > 0.f) { pick = (tid + 256 * q) * 4 + e; pick_x = x[q][e]; }
+            }
+        } else {
+            int last = -1;
+            float last_x = 0.f;
+            for (int v = tid; v < V; v += 256) {
+                const float xv = logit_at(logits, bias, b, v);
+                const float pe = expf(xv - best);
+                if (pe > 0.f) { last = v; last_x = xv; }
+                c += pe;
+                if (pe > 0.f && target < c) { pick = v; pick_x = xv; break; }
+            }
+            if (pick < 0) { pick = last; pick_x = last_x; }
+        }
+        s_pick = pick;
+        s_pick_x = pick_x;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int pick = s_pick;
+        float px = s_pick_x;
+        if (pick < 0) {                          // cannot happen for finite logits; keep the row well defined
+            pick = 0;
+            px = REG ? best : logit_at(logits, bias, b, 0);
+        }
+        const float lse = best + logf(total);
+        const float logp = (px - best) - logf(total);
+        long long it = pick;
+        if (it == end_idx) it = 0;
+        int unf = (t == 0) ? (it > 0) : (unfinished[b] && it > 0);
+        it = unf ? it : 0;
+        const bool broken = (t > 0) && (alive[t - 1] == 0);
+        if (t < max_len && !broken) {
+            seq[(long long)b * max_len + t] = it;
+            if (seq_logp) seq_logp[(long long)b * max_len + t] = logp;
+        }
+        if (so.raw_ids) so.raw_ids[b] = broken ? -1 : (long long)pick;
+        if (so.lse) so.lse[b] = lse;
+        if (so.step_logp) so.step_logp[b] = broken ? 0.f : logp;
+        unfinished[b] = unf;
+        if (unf) atomicAdd(&alive[t], 1);
+        it_buf[b] = it;
+        s_tok = it;
+    }
+    __syncthreads();
+    if (emb_out && table) {
+        const long long tok = s_tok;
+        for (int d = tid * 4; d < D; d += 1024) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(table + tok * D + d);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            *reinterpret_cast<f32x4*>(emb_out + (long long)b * D + d) = v;
+        }
+    }
+}
+
+int sample_pick(Slabs logits, const float* bias, int V, int t, int max_len, long long end_idx, long long* seq,
+                float* seq_logp, long long* it, int* unfinished, int* alive, const float* table, float* emb_out, int D,
+                int B, unsigned long long seed, unsigned long long offset, long long* raw_ids, float* lse,
+                float* step_logp, hipStream_t s) {
+    if (B <= 0) return SET_OK;
+    if (D & 3) return SET_ERR_UNSUPPORTED;
+    ProfScope ps("sample_pick", s, 0.0, 4.0 * B * (1.0 * V * logits.n + 2.0 * D));
+    const bool reg = V <= 4 * 256 * GP_MAXQ && !(logits.ld & 3) && !(logits.stride & 3) && aligned16(logits.p);
+    SampleOut so{raw_ids, lse, step_logp};
+    if (reg)
+        hipLaunchKernelGGL(sample_pick_k<true>, dim3(B), dim3(256), 0, s, logits, bias, V, t, max_len, end_idx, seq,
+                           seq_logp, it, unfinished, alive, table, emb_out, D, seed, offset, so);
+    else
+        hipLaunchKernelGGL(sample_pick_k<false>, dim3(B), dim3(256), 0, s, logits, bias, V, t, max_len, end_idx, seq,
+                           seq_logp, it, unfinished, alive, table, emb_out, D, seed, offset, so);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+// d logits[b, v] = g[b] * (1[v == id_b] - softmax(logits[b])[v])   (gradient of the gathered log-softmax;
+// rows with id < 0 — steps after the loop was left — get zeros)
+__global__ void __launch_bounds__(256) sample_logp_bwd_k(const float* logits, long long ld, const float* lse,
+                                                         const long long* ids, const float* g, float* dlogits,
+                                                         long long ldd, int V) {
+    const int b = blockIdx.x;
+    const long long id = ids[b];
+    const float gb = g[b], l = lse[b];
+    for (int v = threadIdx.x; v < V; v += 256) {
+        float d = 0.f;
+        if (id >= 0) d = gb * ((v == id ? 1.f : 0.f) - expf(logits[(long long)b * ld + v] - l));
+        dlogits[(long long)b * ldd + v] = d;
+    }
+}
+
+int sample_logp_bwd(const float* logits, long long ld, const float* lse, const long long* ids, const float* g,
+                    float* dlogits, long long ldd, int B, int V, hipStream_t s) {
+    if (B <= 0) return SET_OK;
+    hipLaunchKernelGGL(sample_logp_bwd_k, dim3(B), dim3(256), 0, s, logits, ld, lse, ids, g, dlogits, ldd, V);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
 // it[:] = value; unfinished[:] = 1; alive[0..n_alive) = 0
 __global__ void __launch_bounds__(256) set_tokens_k(long long* it, long long value, int* unfinished, int* alive,
                                                     int n_alive, int B) {

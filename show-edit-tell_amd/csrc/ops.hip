@@ -302,4 +302,29 @@ int set_caption_encoder_f32(const SetEditNetWeights* w, const int64_t* seq, cons
                            s_aff, (hipStream_t)stream);
 }
 
+// ---- multinomial sampling epilogue as an operator (editnet_rl.py:521-543 / dcnet_rl.py:320-340)
+int set_sample_pick_f32(const float* logits, int64_t ld_logits, int B, int V, int t, int max_len, int64_t end_idx,
+                        uint64_t seed, uint64_t offset, int64_t* seq, int64_t* it, int32_t* unfinished, int32_t* alive,
+                        int64_t* raw_ids, float* lse, float* step_logp, void* stream) {
+    if (!logits || !seq || !it || !unfinished || !alive || B <= 0 || V <= 0 || t < 0 || max_len <= 0 || ld_logits < V)
+        return SET_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (t == 0) SET_TRY(set_tokens((long long*)it, 0, unfinished, alive, max_len + 2, B, st));
+    Slabs lg{logits, 0, ld_logits, 1};
+    return sample_pick(lg, nullptr, V, t, max_len, end_idx, (long long*)seq, nullptr, (long long*)it, unfinished, alive,
+                       nullptr, nullptr, 4, B, seed, offset, (long long*)raw_ids, lse, step_logp, st);
+}
+
+int set_sample_logp_bwd_f32(const float* logits, int64_t ld_logits, const float* lse, const int64_t* raw_ids,
+                            const float* g, float* dlogits, int64_t ld_dlogits, int B, int V, void* stream) {
+    if (!logits || !lse || !raw_ids || !g || !dlogits || B <= 0 || V <= 0) return SET_ERR_ARG;
+    return sample_logp_bwd(logits, ld_logits, lse, (const long long*)raw_ids, g, dlogits, ld_dlogits, B, V,
+                           (hipStream_t)stream);
+}
+
+int set_philox4x32(uint32_t* out, int n, uint64_t seed, uint64_t offset, void* stream) {
+    if (!out || n < 0) return SET_ERR_ARG;
+    return philox_fill(out, n, seed, offset, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -175,6 +175,13 @@ int fused_encoder_step(const float* h_in, float* h_out, float* c, const float* w
 int greedy_pick(Slabs logits, const float* bias, int V, int t, int max_len, long long end_idx,
                 long long* seq, float* seq_logp, long long* it, int* unfinished, int* alive,
                 const float* table, float* emb_out, int D, int B, hipStream_t s);
+int sample_pick(Slabs logits, const float* bias, int V, int t, int max_len, long long end_idx, long long* seq,
+                float* seq_logp, long long* it, int* unfinished, int* alive, const float* table, float* emb_out, int D,
+                int B, unsigned long long seed, unsigned long long offset, long long* raw_ids, float* lse,
+                float* step_logp, hipStream_t s);
+int sample_logp_bwd(const float* logits, long long ld, const float* lse, const long long* ids, const float* g,
+                    float* dlogits, long long ldd, int B, int V, hipStream_t s);
+int philox_fill(uint32_t* out, int n, unsigned long long seed, unsigned long long offset, hipStream_t s);
 int iota_i64(long long* p, int n, hipStream_t s);
 int set_tokens(long long* it, long long value, int* unfinished, int* alive, int n_alive, int B,
                hipStream_t s);

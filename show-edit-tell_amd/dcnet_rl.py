@@ -20,8 +20,7 @@ class DAE(_DAE_XE):
 
     def forward(self, word_map, encoded_previous_captions, previous_cap_length, sample_max=True, sample_rl=False):
         _require_cuda(encoded_previous_captions, "previous captions")
-        if (sample_rl or self.training
-                or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))):
+        if (self.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))):
             return self._rollout_autograd(word_map, encoded_previous_captions, previous_cap_length, sample_max, sample_rl)
         lib = _lib.load()
         dev = encoded_previous_captions.device
@@ -33,6 +32,12 @@ class DAE(_DAE_XE):
         w = self._weights()
         seq = torch.empty(B, max_len, dtype=torch.long, device=dev)
         seq_logp = torch.empty(B, max_len, dtype=torch.float32, device=dev)
+        if sample_rl:        # multinomial sampling, eval mode, no gradients: fused device loop, Philox epilogue
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            check(lib.set_dcnet_sample(C.byref(w), C.byref(dims), ptr(prev), ptr(plen), int(word_map['<start>']),
+                                       int(word_map['<end>']), max_len, seed, 0, ptr(seq), ptr(seq_logp), ptr(ws),
+                                       ws.numel(), stream_of(dev)), "set_dcnet_sample")
+            return seq, seq_logp
         check(lib.set_dcnet_greedy(C.byref(w), C.byref(dims), ptr(prev), ptr(plen), int(word_map['<start>']),
                                    int(word_map['<end>']), max_len, ptr(seq), ptr(seq_logp), ptr(ws), ws.numel(),
                                    stream_of(dev)), "set_dcnet_greedy")
@@ -54,18 +59,19 @@ def _dae_rollout(self, word_map, encoded_previous_captions, previous_cap_length,
     ca = self.caption_attention
     att1_c = A.linear(enc, ca.cap_features_att.weight, ca.cap_features_att.bias)
     unfinished = None
+    state = A.SampleState(B, max_len, word_map['<start>'], word_map['<end>'], dev) if sample_rl else None
     for t in range(max_len + 1):
+        if sample_rl:
+            it = state.tokens[t]
         emb = self.embed.dropout(A.embed_relu(it, self.embed.embedding.weight))
         h1, c1, h2, c2 = self._step_autograd(emb, final_hidden, enc, mask, h1, c1, h2, c2, att1_c)
-        logprobs = F.log_softmax(A.linear(self.dropout(h2), self.fc.weight, self.fc.bias), dim=1)
+        logits = A.linear(self.dropout(h2), self.fc.weight, self.fc.bias)
         if t == max_len:
             break
-        if sample_max:
-            sample_logp, it = torch.max(logprobs, 1)
-        if sample_rl:
-            it = torch.multinomial(torch.exp(logprobs.detach()), 1)
-            sample_logp = logprobs.gather(1, it).view(-1)
-            it = it.view(-1)
+        if sample_rl:                    # dcnet_rl.py:320-340 on the device (Philox draw), no host sync
+            logps.append(A.sample_pick(logits, state, t))
+            continue
+        sample_logp, it = torch.max(F.log_softmax(logits, dim=1), 1)
         it = it.clone()
         it[it == int(word_map['<end>'])] = 0
         unfinished = (it > 0) if t == 0 else unfinished * (it > 0)
@@ -74,6 +80,8 @@ def _dae_rollout(self, word_map, encoded_previous_captions, previous_cap_length,
         logps.append(sample_logp.view(-1))
         if unfinished.sum() == 0:
             break
+    if sample_rl:
+        seq = state.seq
     seq_logp = torch.stack(logps, 1)
     if seq_logp.shape[1] < max_len:
         seq_logp = torch.cat([seq_logp, seq_logp.new_zeros(B, max_len - seq_logp.shape[1])], 1)

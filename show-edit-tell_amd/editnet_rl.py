@@ -29,8 +29,7 @@ class DecoderC(_DecoderXE):
     def forward(self, word_map, encoded_previous_captions, previous_cap_length, image_features, sample_max=True,
                 sample_rl=False, image_mean=None):
         _require_cuda(image_features, "image features")
-        if (sample_rl or self.training
-                or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))):
+        if (self.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))):
             return self._rollout_autograd(word_map, encoded_previous_captions, previous_cap_length, image_features,
                                           sample_max, sample_rl, image_mean)
         lib = _lib.load()
@@ -46,6 +45,12 @@ class DecoderC(_DecoderXE):
         w = self._weights(dims)
         seq = torch.empty(B, max_len, dtype=torch.long, device=dev)
         seq_logp = torch.empty(B, max_len, dtype=torch.float32, device=dev)
+        if sample_rl:        # multinomial sampling, eval mode, no gradients: fused device loop with the Philox epilogue
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())          # torch.manual_seed() makes it reproducible
+            check(lib.set_editnet_sample(C.byref(w), C.byref(dims), ptr(X), ptr(mean), ptr(prev), ptr(plen),
+                                         int(word_map['<start>']), int(word_map['<end>']), max_len, seed, 0, ptr(seq),
+                                         ptr(seq_logp), ptr(ws), ws.numel(), stream_of(dev)), "set_editnet_sample")
+            return seq, seq_logp
         check(lib.set_editnet_greedy(C.byref(w), C.byref(dims), ptr(X), ptr(mean), ptr(prev), ptr(plen),
                                      int(word_map['<start>']), int(word_map['<end>']), max_len, ptr(seq),
                                      ptr(seq_logp), ptr(ws), ws.numel(), stream_of(dev)), "set_editnet_greedy")
@@ -55,7 +60,9 @@ class DecoderC(_DecoderXE):
                           sample_rl, image_mean=None):
         """The reference loop editnet_rl.py:485-549 over autograd-wrapped HIP operators: used for the
         sampled SCST rollout (train mode, dropout active, gradients flow through seqLogprobs) and for
-        multinomial sampling in general.  Sampling uses torch.multinomial on the device."""
+        the grad-enabled greedy decode.  Sampling runs in the HIP epilogue `set_sample_pick_f32` (Philox draw,
+        log-prob gather, <end> / unfinished / break bookkeeping on the device): the sampled loop never synchronises
+        with the host (the reference does every step, editnet_rl.py:546)."""
         from . import autograd_ops as A
         if self._adaptive:
             raise NotImplementedError("rollout with adaptive features is not built yet")
@@ -77,7 +84,10 @@ class DecoderC(_DecoderXE):
             att1_eval = A.linear(A.linear(X, va.att_embed[0].weight, va.att_embed[0].bias, _lib.ACT_RELU),
                                  va.features_att.weight, va.features_att.bias)
         unfinished = None
+        state = A.SampleState(B, max_len, word_map['<start>'], word_map['<end>'], dev) if sample_rl else None
         for t in range(max_len + 1):
+            if sample_rl:
+                it = state.tokens[t]
             emb = self.embed.dropout(A.embed_relu(it, E))
             h1, c1 = A.lstm_cell(torch.cat([emb, final_hidden, h2, mean], 1), h1, c1, al.weight_ih, al.weight_hh,
                                  al.bias_ih, al.bias_hh)
@@ -97,15 +107,14 @@ class DecoderC(_DecoderXE):
             h2, c2 = A.copy_lstm(torch.cat([h1, attend_cap, attend_img], 1), h2, c2, sel, cl.x2h.weight, cl.x2h.bias,
                                  cl.h2h.weight, cl.h2h.bias, cl.gate_cnew.weight, cl.gate_cnew.bias,
                                  cl.gate_cmem.weight, cl.gate_cmem.bias)
-            logprobs = F.log_softmax(A.linear(self.dropout(h2), self.fc.weight, self.fc.bias), dim=1)
+            logits = A.linear(self.dropout(h2), self.fc.weight, self.fc.bias)
             if t == max_len:
                 break
-            if sample_max:
-                sample_logp, it = torch.max(logprobs, 1)
-            if sample_rl:
-                it = torch.multinomial(torch.exp(logprobs.detach()), 1)
-                sample_logp = logprobs.gather(1, it).view(-1)
-                it = it.view(-1)
+            if sample_rl:                # editnet_rl.py:521-543 on the device, no host sync
+                logps.append(A.sample_pick(logits, state, t))
+                continue
+            logprobs = F.log_softmax(logits, dim=1)
+            sample_logp, it = torch.max(logprobs, 1)
             it = it.clone()
             it[it == int(word_map['<end>'])] = 0
             unfinished = (it > 0) if t == 0 else unfinished * (it > 0)
@@ -114,6 +123,8 @@ class DecoderC(_DecoderXE):
             logps.append(sample_logp.view(-1))
             if unfinished.sum() == 0:
                 break
+        if sample_rl:
+            seq = state.seq
         seq_logp = torch.stack(logps, 1)
         if seq_logp.shape[1] < max_len:
             seq_logp = torch.cat([seq_logp, seq_logp.new_zeros(B, max_len - seq_logp.shape[1])], 1)

@@ -55,10 +55,13 @@ def _worker(rank, world, port, backend, one_device, name, bucket_bytes, ret):
     loss, n_tok, reducer = train.xe_backward(xe, *shard)
     got = _grads_of(xe)
     assert set(got) == set(ref)
+    # absolute floor: gradients that are mathematically zero (softmax shift invariance makes d/d full_att.bias == 0)
+    # are pure rounding noise in both runs
+    floor = 1e-6 * max(float(np.sqrt((r ** 2).sum())) for r in ref.values())
     worst = 0.0
     for k in ref:
         scale = max(np.abs(ref[k]).max(), 1e-6)
-        worst = max(worst, float(np.abs(got[k] - ref[k]).max() / scale))
+        worst = max(worst, float(max(np.abs(got[k] - ref[k]).max() - floor, 0.0) / scale))
     ret[rank] = dict(worst=worst, loss=loss, loss_ref=loss_ref, n_tok=n_tok, n_ref=n_ref,
                      buckets=reducer.n_buckets, bytes=reducer.bytes)
     dist.barrier()
