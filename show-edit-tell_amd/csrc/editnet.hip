@@ -161,7 +161,7 @@ int editnet_encoder(const SetEditNetWeights* w, const int64_t* seq, const int64_
         if (fused) {
             if (tab)
                 SET_TRY(fused_encoder_step(h_cur, h_nxt, enc_c, w->enc_h2h_w, w->tok_table + 6 * D, 10LL * D, 0,
-                                           w->enc_h2h_b, lens, t, 0, H, Mem, (long long)T * D, D, 0, B, D, st, seq, T));
+                                           w->enc_h2h_b, lens, t, 0, H, Mem, (long long)T * D, D, 0, B, D, st, seq, T, V));
             else
                 SET_TRY(fused_encoder_step(h_cur, h_nxt, enc_c, w->enc_h2h_w, xg, (long long)T * 4 * D, 4 * D,
                                            w->enc_h2h_b, lens, t, 0, H, Mem, (long long)T * D, D, 0, B, D, st));
@@ -248,9 +248,9 @@ static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const 
     const bool tab = w->tok_table != nullptr && tok_ids != nullptr && fusedk;
     RowGather g_gates, g_tc, g_cg;
     if (tab) {
-        g_gates = RowGather{w->tok_table, tok_ids, tok_stride, 10LL * D, 0};
-        g_tc = RowGather{w->tok_table, tok_ids, tok_stride, 10LL * D, 4 * D};
-        g_cg = RowGather{w->tok_table, tok_ids, tok_stride, 10LL * D, 5 * D};
+        g_gates = RowGather{w->tok_table, tok_ids, tok_stride, 10LL * D, 0, V};
+        g_tc = RowGather{w->tok_table, tok_ids, tok_stride, 10LL * D, 4 * D, V};
+        g_cg = RowGather{w->tok_table, tok_ids, tok_stride, 10LL * D, 5 * D, V};
     }
     GemmProb a[2];
     a[0] = slab_prob(ws.sA0, bt, 4 * D, B);

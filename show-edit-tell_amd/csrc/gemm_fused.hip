@@ -36,7 +36,7 @@ struct FusedArgs {
     long long ld_xg_row, ld_xg_t, ld_out_b, ld_out_t;
     int t, reverse, out_col0;
     RowGather g0, g1;                   // CTXGATE: token-table addends of z and of the tc_affine term
-    const int64_t* seq; int seq_T;      // ENCLSTM with a token table: xg row = e0 + seq[m*seq_T + pos] * ld_xg_row
+    const int64_t* seq; int seq_T, seq_V; // ENCLSTM with a token table: xg row = e0 + seq[m*seq_T + pos] * ld_xg_row (V rows)
 };
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
@@ -129,8 +129,8 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
         if (erow_ok && n0 + ec4 < P.N) {                 // N % 4 == 0 (host check)
             for (int i = 0; i < P.s0.n; ++i) pre0 += *(gptr4)(P.s0.p + (long long)i * P.s0.stride + em * P.s0.ld + n0 + ec4);
             for (int i = 0; i < P.s1.n; ++i) pre1 += *(gptr4)(P.s1.p + (long long)i * P.s1.stride + em * P.s1.ld + n0 + ec4);
-            if (P.g0.tab) pre0 += *(gptr4)(P.g0.tab + P.g0.ids[em * P.g0.id_stride] * P.g0.ld + P.g0.col0 + n0 + ec4);
-            if (P.g1.tab) pre1 += *(gptr4)(P.g1.tab + P.g1.ids[em * P.g1.id_stride] * P.g1.ld + P.g1.col0 + n0 + ec4);
+            if (P.g0.tab) pre0 += *(gptr4)(P.g0.row(em) + n0 + ec4);
+            if (P.g1.tab) pre1 += *(gptr4)(P.g1.row(em) + n0 + ec4);
         }
     } else if (EPI == EPI_COPYGATE) {
         if (erow_ok && n0 + ec4 < P.N) {
@@ -145,7 +145,9 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
             ehin = P.e1[em * P.N + unit];
             if (P.t < elen) {
                 epos = P.reverse ? (elen - 1 - P.t) : P.t;
-                const float* xr = P.seq ? P.e0 + P.seq[em * P.seq_T + epos] * P.ld_xg_row
+                long long tok = P.seq ? P.seq[em * P.seq_T + epos] : 0;
+                tok = tok < 0 ? 0 : (tok >= P.seq_V ? P.seq_V - 1 : tok);       // same clamp as embed_relu_k
+                const float* xr = P.seq ? P.e0 + tok * P.ld_xg_row
                                         : P.e0 + em * P.ld_xg_row + (long long)epos * P.ld_xg_t;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -314,14 +316,14 @@ int fused_copy_gate(const float* c_new, const float* sel, const float* ogate, co
 int fused_encoder_step(const float* h_in, float* h_out, float* c, const float* w_hh, const float* xg,
                        long long ld_xg_row, long long ld_xg_t, const float* b_extra, const int64_t* lens, int t,
                        int reverse, float* H, float* Mem, long long ld_out_b, long long ld_out_t, int out_col0, int B,
-                       int D, hipStream_t s, const int64_t* seq, int seq_T) {
+                       int D, hipStream_t s, const int64_t* seq, int seq_T, int seq_V) {
     if (D % 128) return SET_ERR_UNSUPPORTED;
     FusedArgs P{};
     P.A[0] = h_in; P.lda[0] = D; P.W[0] = w_hh; P.ldw[0] = D;
     P.K = D; P.M = B; P.N = D; P.gate_stride = D;
     P.b0 = b_extra; P.e0 = xg; P.e1 = h_in; P.o0 = h_out; P.o1 = c; P.o2 = H; P.o3 = Mem; P.lens = lens;
     P.ld_xg_row = ld_xg_row; P.ld_xg_t = ld_xg_t; P.ld_out_b = ld_out_b; P.ld_out_t = ld_out_t;
-    P.t = t; P.reverse = reverse; P.out_col0 = out_col0; P.seq = seq; P.seq_T = seq_T;
+    P.t = t; P.reverse = reverse; P.out_col0 = out_col0; P.seq = seq; P.seq_T = seq_T; P.seq_V = seq_V > 0 ? seq_V : 1;
     const int grid = cdiv(B, 32) * cdiv(D, 8);
     ProfScope ps("fused_encoder_step", s, 8.0 * B * D * D, 4.0 * (4.0 * D * D + 8.0 * B * D));
     return launch_fused<1, true, 128, EPI_ENCLSTM>(P, grid, s);

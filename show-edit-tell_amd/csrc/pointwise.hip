@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256) lstm_pointwise_k(Slabs g0, Slabs g1, Slab
     const int j = (int)(idx - m * per_row) << 2;
     // operands that do not depend on the slabs are requested first (the table row needs its token id): their
     // latency overlaps the slab reads; the additions keep the order slabs, pre, table row, b0, b1
-    const float* trow = gt.tab ? gt.tab + gt.ids[m * gt.id_stride] * gt.ld + gt.col0 : nullptr;
+    const float* trow = gt.tab ? gt.row(m) : nullptr;
     const f32x4 c = ld4(c_in + m * D + j);
     f32x4 xpre[4], xtab[4], xb0[4], xb1[4];
 #pragma unroll
@@ -154,12 +154,12 @@ __global__ void __launch_bounds__(256) context_gate_k(Slabs cg_a, Slabs cg_b, co
     const long long m = idx / per_row;
     const int j = (int)(idx - m * per_row) << 2;
     f32x4 z = slab_sum4(cg_a, m, j);
-    if (gz.tab) z += ld4(gz.tab + gz.ids[m * gz.id_stride] * gz.ld + gz.col0 + j);     // token-table part of [word,h1]
+    if (gz.tab) z += ld4(gz.row(m) + j);     // token-table part of [word,h1]
     z += slab_sum4(cg_b, m, j);
     z += ld4(cg_bias + j);
     f32x4 s = slab_sum4(sc, m, j) + ld4(sc_bias + j);
     f32x4 t = slab_sum4(tc, m, j);
-    if (gt.tab) t += ld4(gt.tab + gt.ids[m * gt.id_stride] * gt.ld + gt.col0 + j);
+    if (gt.tab) t += ld4(gt.row(m) + j);
     t += ld4(tc_bias + j);
     f32x4 o, zs, ss, ts;
 #pragma unroll

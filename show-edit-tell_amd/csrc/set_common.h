@@ -119,6 +119,12 @@ struct RowGather {
     const long long* ids = nullptr;
     long long id_stride = 1, ld = 0;
     int col0 = 0;
+    int nrows = 1;          // table rows (V): ids are clamped to [0, nrows) like embed_relu_k does (no OOB read)
+    __host__ __device__ const float* row(long long m) const {
+        long long id = ids[m * id_stride];
+        id = id < 0 ? 0 : (id >= nrows ? nrows - 1 : id);
+        return tab + id * ld + col0;
+    }
 };
 
 // pointwise.hip
@@ -169,7 +175,7 @@ int fused_copy_gate(const float* c_new, const float* sel, const float* ogate, co
 int fused_encoder_step(const float* h_in, float* h_out, float* c, const float* w_hh, const float* xg,
                        long long ld_xg_row, long long ld_xg_t, const float* b_extra, const int64_t* lens, int t,
                        int reverse, float* H, float* Mem, long long ld_out_b, long long ld_out_t, int out_col0, int B,
-                       int D, hipStream_t s, const int64_t* seq = nullptr, int seq_T = 0);
+                       int D, hipStream_t s, const int64_t* seq = nullptr, int seq_T = 0, int seq_V = 0);
 
 // epilogue.hip
 int greedy_pick(Slabs logits, const float* bias, int V, int t, int max_len, long long end_idx,

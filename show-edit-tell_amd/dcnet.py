@@ -2,7 +2,7 @@
 
 Mirrors `/root/reference/dcnet.py:147-350`: `Embedding`, `CaptionEncoder`, `CaptionAttention`,
 `DAE` with the same constructor signatures, attribute names and `state_dict` keys.  DCNet is
-text-only (no image features, `dcnet.py:303`).  Eval-mode forward only for now.
+text-only (no image features, `dcnet.py:303`).
 """
 from __future__ import annotations
 
@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import DcnetDims, DcnetWeights, DCNET_WEIGHT_FIELDS, EditNetWeights, check, ptr, stream_of
-from .editnet import _HipLinear, _HipLSTMCell, _f32c, _i64c, _no_train, _require_cuda
+from .editnet import _HipLinear, _HipLSTMCell, _f32c, _i64c, _require_cuda, _wants_grad
 
 
 class Embedding(nn.Module):
@@ -32,8 +32,10 @@ class Embedding(nn.Module):
         self.dropout = nn.Dropout(0.5)
 
     def forward(self, x):
-        _no_train(self, "Embedding")
         _require_cuda(x, "token ids")
+        if self.training or _wants_grad(self):
+            from . import autograd_ops as A
+            return self.dropout(A.embed_relu(_i64c(x), self.embedding.weight))      # dcnet.py:203-205
         lib = _lib.load()
         ids = _i64c(x)
         n, D = ids.numel(), self.emb_dim
@@ -57,10 +59,16 @@ class CaptionEncoder(nn.Module):
         self.concat = nn.Linear(enc_hid_dim * 2, concat_output_dim)
         self._owner = None      # set by DAE (plain attribute, not a sub-module)
 
+    def __getstate__(self):          # the owner link is a weakref (not picklable); DAE.__setstate__ restores it
+        state = dict(self.__dict__)
+        state["_owner"] = None
+        return state
+
     def forward(self, src, src_len):
-        _no_train(self, "CaptionEncoder")
         if self._owner is None:
             raise _lib.SetError("CaptionEncoder must be owned by a DAE (it runs through the DAE workspace)")
+        if self.training or _wants_grad(self):
+            return self._owner()._encoder_autograd(src, src_len)
         return self._owner()._encode(src, src_len)
 
 
@@ -75,6 +83,12 @@ class CaptionAttention(nn.Module):
 
     def forward(self, caption_features, decoder_hidden, prev_caption_mask):
         _require_cuda(caption_features, "caption features")
+        if _wants_grad(self, caption_features, decoder_hidden):
+            from . import autograd_ops as A
+            return A.dcnet_caption_attention(_f32c(caption_features), _f32c(decoder_hidden), _f32c(prev_caption_mask),
+                                             self.cap_features_att.weight, self.cap_features_att.bias,
+                                             self.cap_decoder_att.weight, self.cap_decoder_att.bias,
+                                             self.cap_full_att.weight, self.cap_full_att.bias)
         lib = _lib.load()
         H, h1, mask = _f32c(caption_features), _f32c(decoder_hidden), _f32c(prev_caption_mask)
         M, T, Dh = H.shape
@@ -113,6 +127,21 @@ class DAE(nn.Module):
         self._dims_cfg = (decoder_dim, attention_dim, caption_features_dim, emb_dim)
         self._ws = None
         self._ws_key = None
+
+    # the reference checkpoints pickle the whole module (dcnet.py:131-138): GPU workspaces must not travel
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_ws"] = state["_ws_key"] = None
+        return state
+
+    def __setstate__(self, state):
+        import weakref
+        super().__setstate__(state)
+        self.caption_encoder._owner = weakref.ref(self)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._ws = self._ws_key = None
+        return super()._apply(fn, *args, **kwargs)
 
     def init_hidden_state(self, batch_size):
         dev = self.fc.weight.device

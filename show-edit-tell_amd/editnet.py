@@ -40,10 +40,14 @@ def _require_cuda(t, what):
         raise _lib.SetError("%s must live on the GPU: the decode path has no CPU fallback" % what)
 
 
-def _no_train(mod, what):
-    if mod.training:
-        raise NotImplementedError(
-            "%s: train mode (dropout + backward) is not built yet; call .eval()" % what)
+def _wants_grad(mod, *tensors):
+    """True when a direct sub-module call has to be differentiable (the reference's sub-modules always are:
+    evaluate()-style callers may use them under autograd) or runs in train mode (dropout sites): the call then
+    goes through the autograd-wrapped HIP operators of autograd_ops.py instead of the plain forward kernels."""
+    if not torch.is_grad_enabled():
+        return False
+    return (any(p.requires_grad for p in mod.parameters())
+            or any(torch.is_tensor(t) and t.requires_grad for t in tensors))
 
 
 class LSTMCellC(nn.Module):
@@ -66,6 +70,10 @@ class LSTMCellC(nn.Module):
     def forward(self, x, states):
         ht, ct = states
         _require_cuda(x, "LSTMCellC input")
+        if _wants_grad(self, x, ht, ct):
+            from . import autograd_ops as A
+            return A.lstm_cell(_f32c(x), _f32c(ht), _f32c(ct), self.x2h.weight, self.h2h.weight, self.x2h.bias,
+                               self.h2h.bias)
         lib = _lib.load()
         x, ht, ct = _f32c(x), _f32c(ht), _f32c(ct)
         M, K, D = x.shape[0], x.shape[1], self.hidden_size
@@ -99,6 +107,11 @@ class CopyLSTMCellC(nn.Module):
     def forward(self, x, states, c_memory):
         ht, ct = states
         _require_cuda(x, "CopyLSTMCellC input")
+        if _wants_grad(self, x, ht, ct, c_memory):
+            from . import autograd_ops as A
+            return A.copy_lstm(_f32c(x), _f32c(ht), _f32c(ct), _f32c(c_memory), self.x2h.weight, self.x2h.bias,
+                               self.h2h.weight, self.h2h.bias, self.gate_cnew.weight, self.gate_cnew.bias,
+                               self.gate_cmem.weight, self.gate_cmem.bias)
         lib = _lib.load()
         x, ht, ct, cm = _f32c(x), _f32c(ht), _f32c(ct), _f32c(c_memory)
         M, K, D = x.shape[0], x.shape[1], self.hidden_size
@@ -126,8 +139,10 @@ class EmbeddingC(nn.Module):
         self.dropout = nn.Dropout(0.5)
 
     def forward(self, x):
-        _no_train(self, "EmbeddingC")
         _require_cuda(x, "token ids")
+        if self.training or _wants_grad(self):
+            from . import autograd_ops as A
+            return self.dropout(A.embed_relu(_i64c(x), self.embedding.weight))      # editnet.py:301-303
         lib = _lib.load()
         ids = _i64c(x)
         n, D = ids.numel(), self.emb_dim
@@ -151,8 +166,9 @@ class CaptionEncoderC(nn.Module):
         self.tanh = nn.Tanh()
 
     def forward(self, seq, seq_len):
-        _no_train(self, "CaptionEncoderC")
         _require_cuda(seq, "previous captions")
+        if self.training or _wants_grad(self):
+            return _caption_encoder_autograd(self, seq, seq_len)
         lib = _lib.load()
         seq, lens = _i64c(seq), _i64c(seq_len.reshape(-1))
         B, T, D = seq.shape[0], seq.shape[1], self.enc_hid_dim
@@ -173,6 +189,30 @@ class CaptionEncoderC(nn.Module):
               "set_caption_encoder_f32")
         tmax = int(lens.max().item())            # the reference pads to max(len) (editnet.py:327)
         return H[:, :tmax], M[:, :tmax], fh, mask[:, :tmax]
+
+
+def _caption_encoder_autograd(enc, seq, seq_len):
+    """CaptionEncoderC.forward (editnet.py:319-348) over autograd ops; rows advance while t < len."""
+    from . import autograd_ops as A
+    cell = enc.lstm_encoder_cell
+    lens = seq_len.reshape(-1)
+    tmax = int(lens.max().item())
+    B, D = seq.shape[0], enc.enc_hid_dim
+    emb = enc.embed.dropout(A.embed_relu(seq[:, :tmax], enc.embed.embedding.weight))
+    h = torch.zeros(B, D, device=seq.device)
+    c = torch.zeros(B, D, device=seq.device)
+    Hs, Ms = [], []
+    for t in range(tmax):
+        m = (lens > t).float().unsqueeze(1)
+        hn, cn = A.lstm_cell(emb[:, t], h, c, cell.x2h.weight, cell.h2h.weight, cell.x2h.bias, cell.h2h.bias)
+        h = m * hn + (1 - m) * h
+        c = m * cn + (1 - m) * c
+        Hs.append(m * hn)
+        Ms.append(m * cn)
+    H, M = torch.stack(Hs, 1), torch.stack(Ms, 1)
+    mask = (M.sum(2) != 0).float()
+    final_hidden = A.linear(h, enc.affine_hn.weight, enc.affine_hn.bias, _lib.ACT_TANH)
+    return H, M, final_hidden, mask
 
 
 class CaptionAttentionC(nn.Module):
@@ -199,6 +239,14 @@ class CaptionAttentionC(nn.Module):
 
     def forward(self, caption_features, decoder_hidden, word, prev_caption_mask):
         _require_cuda(caption_features, "caption features")
+        if _wants_grad(self, caption_features, decoder_hidden, word):
+            from . import autograd_ops as A
+            return A.caption_attention(
+                _f32c(caption_features), _f32c(decoder_hidden), _f32c(word), _f32c(prev_caption_mask),
+                self.cap_features_att.weight, self.cap_features_att.bias, self.cap_decoder_att.weight,
+                self.cap_decoder_att.bias, self.cap_full_att.weight, self.cap_full_att.bias, self.context_gate.weight,
+                self.context_gate.bias, self.sc_affine.weight, self.sc_affine.bias, self.tc_affine.weight,
+                self.tc_affine.bias)
         lib = _lib.load()
         H, h1, word, mask = _f32c(caption_features), _f32c(decoder_hidden), _f32c(word), _f32c(prev_caption_mask)
         M, T, D = H.shape
@@ -223,6 +271,9 @@ class SelectC(nn.Module):
         if soft:
             raise NotImplementedError("soft selection is never used by the reference (soft=False always)")
         _require_cuda(previous_encoded_m, "encoder memory")
+        if _wants_grad(self, previous_encoded_m, sim_weights):
+            from . import autograd_ops as A
+            return A.select(_f32c(previous_encoded_m), _f32c(sim_weights))
         lib = _lib.load()
         Mem, alpha = _f32c(previous_encoded_m), _f32c(sim_weights)
         B, T, D = Mem.shape
@@ -253,8 +304,18 @@ class VisualAttentionC(nn.Module):
         return w
 
     def forward(self, image_features, decoder_hidden):
-        _no_train(self, "VisualAttentionC")
         _require_cuda(image_features, "image features")
+        if self.training or _wants_grad(self, decoder_hidden):
+            # editnet.py:441-446 as written: region embedding (+ its Dropout(0.5) in train mode) recomputed per call
+            from . import autograd_ops as A
+            if self.adaptive:
+                raise NotImplementedError("direct differentiable calls of the adaptive VisualAttentionC go through "
+                                          "DecoderC.forward (editnet_adaptive.py:438-457)")
+            X = _f32c(image_features)
+            fe = self.att_embed[2](A.linear(X, self.att_embed[0].weight, self.att_embed[0].bias, _lib.ACT_RELU))
+            att1 = A.linear(fe, self.features_att.weight, self.features_att.bias)
+            return A.visual_attention_from_att1(X, att1, _f32c(decoder_hidden), self.decoder_att.weight,
+                                                self.decoder_att.bias, self.full_att.weight, self.full_att.bias)
         lib = _lib.load()
         X, h1 = _f32c(image_features), _f32c(decoder_hidden)
         M, R, F = X.shape
@@ -280,6 +341,9 @@ class _HipLSTMCell(nn.LSTMCell):
             z = torch.zeros(M, D, dtype=torch.float32, device=x.device)
             states = (z, z)
         ht, ct = _f32c(states[0]), _f32c(states[1])
+        if _wants_grad(self, x, ht, ct):
+            from . import autograd_ops as A
+            return A.lstm_cell(x, ht, ct, self.weight_ih, self.weight_hh, self.bias_ih, self.bias_hh)
         h_new, c_new = torch.empty_like(ht), torch.empty_like(ct)
         ws = torch.empty(lib.set_lstm_cell_workspace_bytes(M, D, K), dtype=torch.uint8, device=x.device)
         check(lib.set_lstm_cell_f32(ptr(x), K, K, ptr(ht), ptr(ct), ptr(self.weight_ih), K, ptr(self.weight_hh),
@@ -293,6 +357,9 @@ class _HipLinear(nn.Linear):
 
     def forward(self, x):
         _require_cuda(x, "Linear input")
+        if _wants_grad(self, x):
+            from . import autograd_ops as A
+            return A.linear(_f32c(x), self.weight, self.bias)
         lib = _lib.load()
         x = _f32c(x)
         lead = x.shape[:-1]
@@ -333,6 +400,40 @@ class DecoderC(nn.Module):
         self._ws = None
         self._ws_key = None
 
+    # ---- runtime state is NOT part of the module's persistent state --------------------------------------
+    # The reference checkpoints pickle the whole module (editnet.py:168-175, `'decoder': decoder`) and callers may
+    # copy.deepcopy a decoder: GPU workspaces, the derived token table and the last autograd graph must not travel.
+    _RUNTIME_ATTRS = ("_ws", "_ws_key", "_ws_cache", "_tok_state", "_last_hidden")
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        for k in self._RUNTIME_ATTRS:
+            state.pop(k, None)
+        state["_ws"] = state["_ws_key"] = None
+        return state
+
+    def invalidate_token_table(self):
+        """Drop the derived inference-time token table (see _token_table).  It is rebuilt automatically after two
+        further no-grad calls.  Called on every train()/eval() switch, load_state_dict() and device / dtype move;
+        call it yourself after writing weights in a way autograd cannot see (`p.data.add_()`, `dist.broadcast(p.data)`,
+        raw-pointer updates): such writes do not bump `tensor._version`, which is all the cache can observe
+        without a device->host synchronisation (SET_TOKEN_TABLE_VERIFY=1 adds that check for debugging)."""
+        self.__dict__.pop("_tok_state", None)
+
+    def train(self, mode=True):
+        self.invalidate_token_table()
+        return super().train(mode)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.invalidate_token_table()
+        return super().load_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_token_table()
+        self.__dict__.pop("_ws_cache", None)
+        self._ws = self._ws_key = None
+        return super()._apply(fn, *args, **kwargs)
+
     # ---- reference API ---------------------------------------------------------------------
     def init_hidden_state(self, batch_size):
         dev = self.fc.weight.device          # the parameters' device (the reference uses a module global)
@@ -355,9 +456,13 @@ class DecoderC(nn.Module):
 
     # The three contractions of the step whose only input is the current token are folded into a
     # (V,10D) table (include/set_hip.h: tok_table).  The table is derived from six parameter tensors
-    # and is rebuilt whenever any of them changes (tensor._version / data_ptr); it is only built once
-    # the same weights have been seen on two consecutive no-grad calls, so SCST training (weights
-    # change every iteration) never pays for it.  SET_TOKEN_TABLE=0 disables, =1 forces.
+    # and is rebuilt whenever any of them changes (tensor._version / data_ptr), on every train()/eval()
+    # switch, load_state_dict() and device move (invalidate_token_table); it is only built once the same
+    # weights have been seen on two consecutive no-grad calls, so SCST training (weights change every
+    # iteration, and the loop toggles eval()/train()) never pays for it.  In-place writes through `.data`
+    # are invisible to `_version`: call invalidate_token_table() after them.
+    # SET_TOKEN_TABLE=0 disables, =1 forces, SET_TOKEN_TABLE_VERIFY=1 re-checks a checksum of the six
+    # source tensors on every use (one device->host sync per call; debugging aid).
     def _token_table(self, dims):
         import os
         mode = os.environ.get("SET_TOKEN_TABLE", "auto")
@@ -382,6 +487,12 @@ class DecoderC(nn.Module):
                                                     stream_of(dev)), "set_editnet_build_token_table")
             torch.cuda.current_stream(dev).synchronize()        # other streams may use the table next
             st["table"] = table
+            st["check"] = torch.stack([t.detach().double().sum() for t in src]).cpu()
+        if st["table"] is not None and os.environ.get("SET_TOKEN_TABLE_VERIFY") == "1":
+            now = torch.stack([t.detach().double().sum() for t in src]).cpu()
+            if not torch.equal(now, st["check"]):
+                raise _lib.SetError("token table is stale: a source weight changed without bumping tensor._version "
+                                    "(in-place .data write?); call decoder.invalidate_token_table()")
         return st["table"]
 
     def _dims(self, B, T, R, maxT):
@@ -452,27 +563,7 @@ class DecoderC(nn.Module):
 
     # ---- grad-enabled path -------------------------------------------------------------------
     def _encoder_autograd(self, seq, seq_len):
-        """CaptionEncoderC.forward (editnet.py:319-348) over autograd ops; rows advance while t < len."""
-        from . import autograd_ops as A
-        enc, cell = self.caption_encoder, self.caption_encoder.lstm_encoder_cell
-        lens = seq_len.reshape(-1)
-        tmax = int(lens.max().item())
-        B, D = seq.shape[0], enc.enc_hid_dim
-        emb = self.embed.dropout(A.embed_relu(seq[:, :tmax], self.embed.embedding.weight))
-        h = torch.zeros(B, D, device=seq.device)
-        c = torch.zeros(B, D, device=seq.device)
-        Hs, Ms = [], []
-        for t in range(tmax):
-            m = (lens > t).float().unsqueeze(1)
-            hn, cn = A.lstm_cell(emb[:, t], h, c, cell.x2h.weight, cell.h2h.weight, cell.x2h.bias, cell.h2h.bias)
-            h = m * hn + (1 - m) * h
-            c = m * cn + (1 - m) * c
-            Hs.append(m * hn)
-            Ms.append(m * cn)
-        H, M = torch.stack(Hs, 1), torch.stack(Ms, 1)
-        mask = (M.sum(2) != 0).float()
-        final_hidden = A.linear(h, enc.affine_hn.weight, enc.affine_hn.bias, _lib.ACT_TANH)
-        return H, M, final_hidden, mask
+        return _caption_encoder_autograd(self.caption_encoder, seq, seq_len)
 
     def _forward_autograd(self, image_features, encoded_captions, caption_lengths, encoded_previous_captions,
                           previous_cap_length, use_ss, ss_prob, image_mean=None):
@@ -559,7 +650,8 @@ class DecoderC(nn.Module):
             if bt < batch_size:
                 preds = torch.cat([preds, preds.new_zeros(batch_size - bt, preds.shape[1])], 0)
             preds_t.append(preds)
-        self._last_hidden = torch.cat(last_parts[::-1], 0)     # row order: the longest captions leave last
+        if self._adaptive:           # only the adaptive forward returns it (editnet_adaptive.py:560-562)
+            self._last_hidden = torch.cat(last_parts[::-1], 0)     # row order: the longest captions leave last
         if batch_fc:                     # (T, B, V) computed at once; returned as its (B, T, V) view
             predictions = A.linear(torch.stack(h2_t, 0), self.fc.weight, self.fc.bias).transpose(0, 1)
             return predictions, encoded_captions, decode_lengths, sort_ind

@@ -1,32 +1,159 @@
-"""Feature input pipeline: pinned-host staging + asynchronous H2D copies on a
-side HIP stream, so that the 37.7 MB `(128,36,2048)` feature batch of step i+1 crosses PCIe
-(≈0.6 ms at 63 GB/s) while step i decodes (≈3.4-5 ms).  The reference uses a synchronous
-`DataLoader(num_workers=0)` + `.to(device)` (`editnet.py:560-564,790-798`).
+"""Feature input pipeline: reader workers -> pinned staging ring -> asynchronous H2D
+copies on a side HIP stream, so that reading + transferring the features of step i+1 overlaps the decode of
+step i.  The reference reads synchronously in the training process (`DataLoader(num_workers=0)`,
+`collate_fn_train` of `adaptive_features/editnet_adaptive.py:58-80`: per image one `np.load` of
+`data/cocobu_att/<id>.npz['feat']` (n x 2048, n = 10..100) into a zero `(B,100,2048)` float64 array plus
+`data/cocobu_fc/<id>.npy` (2048), then `.to(device)` / `.float()` at `:573-574`).
 
-    for batch in DevicePrefetcher(loader, device):      # yields tuples of device tensors
-        seq, logp = decoder(word_map, batch[3], batch[4], batch[0], True, False)
+    reader = AdaptiveFeatureReader(att_dir, fc_dir, id_batches, extras=per_batch_tensors, workers=8)
+    for images, images_mean, *extras in DevicePrefetcher(reader, device):       # device tensors, fp32
+        scores, *_ = decoder(images, images_mean, caps, caplens, prev, prevlen)
+
+Stages
+  1. `AdaptiveFeatureReader`: a producer thread walks the id batches; the per-image loads of a batch are spread
+     over a thread pool (np.load / zlib / the f64->f32 conversion release the GIL) and write straight into one
+     slot of a ring of PINNED host buffers: rows >= n are zeroed, values are converted to fp32 once (the
+     reference converts the whole padded float64 batch on the device).
+  2. `DevicePrefetcher`: issues the H2D copies of up to `depth` batches ahead on its own stream, hands a batch to
+     the consumer after making the consumer's stream wait on the copy event (no host sync on the compute
+     stream), and returns the pinned slot to the reader once the copy has completed.
+The fixed 36-region features of `editnet.py:48-74` live in HDF5 files; h5py is not available in this image, so
+that reader is not built (any iterable of host tensors can be fed to DevicePrefetcher).
 """
 from __future__ import annotations
 
+import os
+import queue
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
 import torch
 
 
+class AdaptiveFeatureReader:
+    """Iterable of `(images (B,R,F) fp32, images_mean (B,F) fp32, *extras)` host batches in pinned memory.
+
+    att_dir / fc_dir : directories holding `<image_id>.npz` (array 'feat', (n,F), n <= R) and `<image_id>.npy` (F,)
+    id_batches       : sequence of sequences of image ids (one inner sequence per batch)
+    extras           : optional sequence (same length) of tuples of tensors passed through unchanged
+    """
+
+    def __init__(self, att_dir, fc_dir, id_batches, extras=None, max_regions=100, feat_dim=2048, workers=8, depth=4,
+                 pin=None):
+        self.att_dir, self.fc_dir = att_dir, fc_dir
+        self.id_batches = [[int(i) for i in b] for b in id_batches]
+        self.extras = extras
+        self.R, self.F = max_regions, feat_dim
+        self.workers, self.depth = max(1, workers), max(2, depth)
+        self.pin = torch.cuda.is_available() if pin is None else pin
+        self._slots = None
+        self._free = None
+
+    def __len__(self):
+        return len(self.id_batches)
+
+    def _alloc(self):
+        bmax = max(len(b) for b in self.id_batches)
+        mk = lambda *shape: (torch.empty(*shape, dtype=torch.float32).pin_memory() if self.pin
+                             else torch.empty(*shape, dtype=torch.float32))
+        self._slots = [(mk(bmax, self.R, self.F), mk(bmax, self.F)) for _ in range(self.depth)]
+        self._free = queue.Queue()
+        for i in range(self.depth):
+            self._free.put(i)
+
+    def _load_one(self, img_np, mean_np, row, image_id):
+        with np.load(os.path.join(self.att_dir, "%d.npz" % image_id)) as z:
+            feat = z["feat"]
+        n = feat.shape[0]
+        if n > self.R or feat.shape[1] != self.F:
+            raise ValueError("image %d: features %s do not fit (%d,%d)" % (image_id, feat.shape, self.R, self.F))
+        img_np[row, :n] = feat                       # converts to fp32 on the way (float64 files included)
+        img_np[row, n:] = 0.0                        # zero padding = the reference's np.zeros((B,100,2048))
+        mean_np[row] = np.load(os.path.join(self.fc_dir, "%d.npy" % image_id))
+
+    def release(self, slot):
+        """hand a pinned slot back (called by DevicePrefetcher once its H2D copy has completed)"""
+        if slot is not None and self._free is not None:
+            self._free.put(slot)
+
+    def __iter__(self):
+        self._alloc()
+        ready = queue.Queue(maxsize=self.depth)
+        stop = threading.Event()
+
+        def producer():
+            try:
+                with ThreadPoolExecutor(self.workers) as pool:
+                    for bi, ids in enumerate(self.id_batches):
+                        slot = None
+                        while slot is None and not stop.is_set():
+                            try:
+                                slot = self._free.get(timeout=0.1)
+                            except queue.Empty:
+                                pass
+                        if stop.is_set():
+                            return
+                        img, mean = self._slots[slot]
+                        img_np, mean_np = img.numpy(), mean.numpy()
+                        list(pool.map(lambda a: self._load_one(img_np, mean_np, *a), enumerate(ids)))
+                        ready.put((bi, slot, len(ids)))
+                ready.put(None)
+            except BaseException as e:            # surface reader errors in the consumer
+                ready.put(e)
+
+        th = threading.Thread(target=producer, daemon=True)
+        th.start()
+        try:
+            while True:
+                item = ready.get()
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                bi, slot, n = item
+                img, mean = self._slots[slot]
+                batch = HostBatch((img[:n], mean[:n]) + tuple(self.extras[bi] if self.extras is not None else ()))
+                batch.slot, batch.owner = slot, self
+                yield batch
+        finally:
+            stop.set()
+
+
+class HostBatch(tuple):
+    """a tuple of host tensors that remembers which pinned ring slot it lives in"""
+    slot = None
+    owner = None
+
+
 class DevicePrefetcher:
-    def __init__(self, iterable, device, depth: int = 2):
+    """Asynchronous H2D staging of an iterable of host batches (tuples of tensors) on a side stream.
+
+    `timeline` (when record_timing=True) collects, per batch, timing events around its H2D copy on the copy stream
+    (tests use them to show the copy of batch i+1 running while batch i is being decoded)."""
+
+    def __init__(self, iterable, device, depth: int = 2, record_timing: bool = False):
         self.it = iter(iterable)
         self.device = torch.device(device)
         self.stream = torch.cuda.Stream(self.device)
         self.depth = max(1, depth)
         self.queue = []
+        self.record_timing = record_timing
+        self.timeline = []
 
     def _stage(self):
         try:
             batch = next(self.it)
         except StopIteration:
             return False
+        slot, owner = getattr(batch, "slot", None), getattr(batch, "owner", None)
         if not isinstance(batch, (tuple, list)):
             batch = (batch,)
         with torch.cuda.stream(self.stream):
+            t0 = None
+            if self.record_timing:
+                t0 = torch.cuda.Event(enable_timing=True)
+                t0.record(self.stream)
             dev = []
             for t in batch:
                 if torch.is_tensor(t):
@@ -34,19 +161,25 @@ class DevicePrefetcher:
                         t = t.pin_memory()
                     t = t.to(self.device, non_blocking=True)
                 dev.append(t)
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=self.record_timing)
             ev.record(self.stream)
-        self.queue.append((tuple(dev), ev))
+            if self.record_timing:
+                self.timeline.append((t0, ev))
+        self.queue.append((tuple(dev), ev, slot, owner))
         return True
 
     def __iter__(self):
         while len(self.queue) < self.depth and self._stage():
             pass
         while self.queue:
-            batch, ev = self.queue.pop(0)
-            torch.cuda.current_stream(self.device).wait_event(ev)
+            batch, ev, slot, owner = self.queue.pop(0)
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)                         # device-side dependency only: the host does not block the compute stream
             for t in batch:
                 if torch.is_tensor(t):
-                    t.record_stream(torch.cuda.current_stream(self.device))
+                    t.record_stream(cur)
+            if owner is not None:                      # the pinned slot is reusable once its copy has finished
+                ev.synchronize()
+                owner.release(slot)
             self._stage()
             yield batch

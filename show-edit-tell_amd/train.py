@@ -209,38 +209,64 @@ def reward_loss_sum(sample_logprobs, seq, reward):
     return torch.sum(-sample_logprobs * reward * mask), mask.sum()
 
 
-def scst_train_step(decoder, optimizer, word_map, image_features, previous_caption, prev_caplen, ground_truth,
-                    scorer, n_samples=1, cider_weight=1.0, group=None):
-    """One self-critical step of editnet_rl.py:649-686 on this rank's shard: greedy baseline in eval mode
-    under no_grad (fused device loop), `n_samples` multinomial rollouts in train mode (autograd operators),
-    reward = CIDEr-D(sample) - CIDEr-D(greedy) from `scorer` (ciderd.CiderD; host work, per sample),
-    RewardCriterion, backward, gradient all-reduce, clip, optimizer.  The reference draws one sample per
-    image; BASELINE.json config 5 asks for 5: all samples enter one RewardCriterion over n_samples * B rows.  As in the XE step the
-    loss is normalised by the GLOBAL mask count so that N ranks reproduce one big batch.
-    Returns (mean reward of the samples on this rank, GLOBAL loss value)."""
+def _scst_step(model, optimizer, greedy_fn, sample_fn, rep, ground_truth, scorer, n_samples, cider_weight, dev, group):
+    """Shared body of the self-critical step (editnet_rl.py:649-686, dcnet_rl.py:451-493): greedy baseline in eval
+    mode under no_grad (fused device loop), `n_samples` multinomial rollouts in train mode (autograd operators, the
+    sampling epilogue runs on the device), reward = CIDEr-D(sample) - CIDEr-D(greedy) from `scorer` (host work, per
+    sample), RewardCriterion normalised by the GLOBAL mask count, backward, gradient all-reduce, clip, optimizer."""
     from . import ciderd
     from .autograd_ops import deferred_param_grads
-    dev = image_features.device
-    optimizer.zero_grad()
-    decoder.eval()
+    for p in model.parameters():
+        p.grad = None
+    model.eval()
     with torch.no_grad():
-        greedy, _ = decoder(word_map, previous_caption, prev_caplen, image_features, sample_max=True, sample_rl=False)
-    decoder.train()
-    # the n_samples rollouts of one image are independent rows (own dropout masks, own multinomial draws):
-    # run them as ONE rollout over a batch of n_samples * B rows -- bigger GEMM tiles, one loop
-    rep = lambda t: t if n_samples == 1 else t.repeat(n_samples, *([1] * (t.dim() - 1)))
+        greedy, _ = greedy_fn()
+    model.train()
     reducer = BucketedAllReduce(group)
     with deferred_param_grads(on_ready=lambda p: reducer.add(p.grad)):
-        seq, logp = decoder(word_map, rep(previous_caption), rep(prev_caplen), rep(image_features),
-                            sample_max=False, sample_rl=True)
+        seq, logp = sample_fn()
         rewards = ciderd.self_critical_reward(scorer, seq, rep(greedy), list(ground_truth) * n_samples, cider_weight)
         num, cnt = reward_loss_sum(logp, seq, torch.from_numpy(rewards).to(dev))
         n_glob = global_token_count(int(cnt.item()), dev, group)
         loss = num / n_glob
         loss.backward()
     reward_mean, loss_val = float(rewards[:, 0].mean()), _global_loss(num, n_glob, group)
-    params = [p for p in decoder.parameters() if p.requires_grad]
+    params = [p for p in model.parameters() if p.requires_grad]
     allreduce_gradients(params, group, reducer=reducer)
     torch.nn.utils.clip_grad_norm_(params, GRAD_CLIP)
     optimizer.step()
     return reward_mean, loss_val
+
+
+def _repeater(n_samples):
+    # the n_samples rollouts of one image are independent rows (own dropout masks, own draws): run them as ONE
+    # rollout over a batch of n_samples * B rows -- bigger GEMM tiles, one loop
+    return lambda t: t if n_samples == 1 else t.repeat(n_samples, *([1] * (t.dim() - 1)))
+
+
+def scst_train_step(decoder, optimizer, word_map, image_features, previous_caption, prev_caplen, ground_truth,
+                    scorer, n_samples=1, cider_weight=1.0, group=None):
+    """One self-critical step of editnet_rl.py:649-686 on this rank's shard.  The reference draws one sample per
+    image; BASELINE.json config 5 asks for 5: all samples enter one RewardCriterion over n_samples * B rows.  As in
+    the XE step the loss is normalised by the GLOBAL mask count so that N ranks reproduce one big batch.
+    Returns (mean reward of the samples on this rank, GLOBAL loss value)."""
+    rep = _repeater(n_samples)
+    return _scst_step(
+        decoder, optimizer,
+        lambda: decoder(word_map, previous_caption, prev_caplen, image_features, sample_max=True, sample_rl=False),
+        lambda: decoder(word_map, rep(previous_caption), rep(prev_caplen), rep(image_features), sample_max=False,
+                        sample_rl=True),
+        rep, ground_truth, scorer, n_samples, cider_weight, image_features.device, group)
+
+
+def dcnet_scst_train_step(dae, optimizer, word_map, previous_caption, prev_caplen, ground_truth, scorer, n_samples=1,
+                          cider_weight=1.0, group=None):
+    """The text-only twin (dcnet_rl.py:451-493): `dae` is a dcnet_rl.DAE or the DAEWithAR wrapper the reference
+    trains (its forward delegates to `.dae`; `affine_hidden` receives no gradient from this loss, as in the reference).
+    Returns (mean reward of the samples on this rank, GLOBAL loss value)."""
+    rep = _repeater(n_samples)
+    return _scst_step(
+        dae, optimizer,
+        lambda: dae(word_map, previous_caption, prev_caplen, sample_max=True, sample_rl=False),
+        lambda: dae(word_map, rep(previous_caption), rep(prev_caplen), sample_max=False, sample_rl=True),
+        rep, ground_truth, scorer, n_samples, cider_weight, previous_caption.device, group)

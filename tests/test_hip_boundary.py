@@ -1,0 +1,254 @@
+"""GPU: boundary behaviour around the decode path:
+input pipeline overlap, DCNet SCST step + DAEWithAR, module pickling / deepcopy without runtime caches,
+token-table invalidation, differentiable / train-mode direct sub-module calls, id clamping."""
+import copy
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import parity
+from hip_adapter import adaptive_module, dcnet_modules, editnet_modules, to_dev
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def test_input_pipeline_overlaps_h2d_with_decode(tmp_path):
+    """Reader workers -> pinned ring -> side-stream H2D -> adaptive decode: values equal the reference collate,
+    and the H2D copy of batch i+1 runs while batch i is being decoded (event timestamps)."""
+    from show_edit_tell_amd import pipeline
+    from test_pipeline_cpu import _reference_collate, _write_dataset
+    name = "editnet_adaptive_full_b4"
+    d, xe = adaptive_module(name)
+    c = d["case"]
+    R, F, B = c["R"], c["F"], 32
+    att, fc, feats = _write_dataset(str(tmp_path), 48, F, R, seed=3)
+    ids = sorted(feats)
+    rng = np.random.default_rng(0)
+    batches = [list(rng.choice(ids, B, replace=False)) for _ in range(6)]
+    from show_edit_tell_amd import synth
+    caps, clen = synth.captions(5, B, c["V"], L=20, min_len=20)
+    prev, plen = synth.prev_captions(5, B, c["T"], c["V"], 5)
+    caps, clen, prev, plen = to_dev(caps), to_dev(clen), to_dev(prev), to_dev(plen)
+    reader = pipeline.AdaptiveFeatureReader(att, fc, batches, max_regions=R, feat_dim=F, workers=8, depth=4)
+    pf = pipeline.DevicePrefetcher(reader, DEV, depth=2, record_timing=True)
+    base = torch.cuda.Event(enable_timing=True)
+    base.record()
+    spans = []
+    with torch.no_grad():
+        for k, (images, means) in enumerate(pf):
+            assert images.is_cuda and images.dtype == torch.float32
+            if k == 0:
+                want_i, want_m = _reference_collate(feats, batches[0], R, F)
+                assert np.array_equal(_np(images), want_i) and np.array_equal(_np(means), want_m)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            pred, *_ = xe(images, means, caps, clen, prev, plen, False, 0.0)
+            e.record()
+            spans.append((s, e))
+    torch.cuda.synchronize()
+    assert len(spans) == len(batches) == len(pf.timeline)
+    decode = [(base.elapsed_time(s), base.elapsed_time(e)) for s, e in spans]
+    copies = [(base.elapsed_time(s), base.elapsed_time(e)) for s, e in pf.timeline]
+    overlapped = 0
+    for i in range(len(batches) - 1):
+        for j in range(i + 1, len(batches)):             # a later batch's copy inside decode i
+            lo, hi = max(decode[i][0], copies[j][0]), min(decode[i][1], copies[j][1])
+            if hi > lo:
+                overlapped += 1
+                break
+    assert overlapped >= 2, (decode, copies)
+    assert torch.isfinite(pred).all()
+
+
+def test_dcnet_scst_step_and_dae_with_ar():
+    """dcnet_rl.py:348-361,451-493: DAEWithAR keeps the reference's state_dict layout (dae.*, affine_hidden.*), its
+    forward delegates to the DAE, and the text-only SCST step updates the DAE with finite numbers."""
+    from show_edit_tell_amd import ciderd
+    from show_edit_tell_amd.dcnet_rl import DAEWithAR
+    from show_edit_tell_amd.train import dcnet_scst_train_step
+    d, xe, rl = dcnet_modules("dcnet_small")
+    wm = d["wm"]
+    model = DAEWithAR(dae=rl).to(DEV)
+    keys = set(model.state_dict())
+    assert {"affine_hidden.weight", "affine_hidden.bias", "dae.fc.weight", "dae.attention_lstm.weight_ih",
+            "dae.language_lstm.weight_hh", "dae.caption_encoder.lstm_encoder.weight_ih_l0_reverse",
+            "dae.caption_encoder.concat.weight", "dae.caption_attention.cap_full_att.weight",
+            "dae.embed.embedding.weight"} <= keys
+    assert all(k.startswith(("dae.", "affine_hidden.")) for k in keys)
+    prev, plen = to_dev(d["prev"]), to_dev(d["plen"])
+    g = parity.load("dcnet_small")
+    model.eval()
+    with torch.no_grad():
+        seq, logp = model(wm, prev, plen, sample_max=True, sample_rl=False)
+    parity.check_greedy(_np(seq), _np(logp), g)
+    B, V = prev.shape[0], len(wm)
+    rng = np.random.default_rng(3)
+    allcaps = np.zeros((B, 5, 12), dtype=np.int64)
+    for b in range(B):
+        for j in range(5):
+            n = int(rng.integers(3, 9))
+            allcaps[b, j, 0] = wm["<start>"]
+            allcaps[b, j, 1:1 + n] = rng.integers(1, V - 4, n)
+            allcaps[b, j, 1 + n] = wm["<end>"]
+    gt = ciderd.ground_truth_lists(allcaps, wm)
+    df, docs = ciderd.document_frequency([[ciderd.tokens_to_str(c) for c in caps] for caps in gt])
+    scorer = ciderd.CiderD(df, max(docs, 2))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    torch.manual_seed(4)
+    for n_samples in (1, 5):
+        reward, loss = dcnet_scst_train_step(model, opt, wm, prev, plen, gt, scorer, n_samples=n_samples)
+        assert np.isfinite(reward) and np.isfinite(loss)
+    after = model.state_dict()
+    assert any(not torch.equal(before[k], after[k]) for k in before if k.startswith("dae."))
+    assert torch.equal(before["affine_hidden.weight"], after["affine_hidden.weight"])      # no gradient from this loss
+    assert all(torch.isfinite(v).all() for v in after.values())
+
+
+def test_modules_pickle_and_deepcopy_without_runtime_caches():
+    """The reference checkpoints pickle whole modules (editnet.py:168-175, dcnet.py:131-138): workspaces, the token
+    table and the last autograd graph must not travel; copies must decode identically."""
+    d, xe, rl = editnet_modules("editnet_small")
+    wm = d["wm"]
+    prev, plen, X = to_dev(d["prev"]), to_dev(d["plen"]), to_dev(d["X"])
+    with torch.no_grad():
+        for _ in range(3):                                # third call runs with the token table built
+            seq, logp = rl(wm, prev, plen, X, True, False)
+    assert rl.__dict__.get("_tok_state", {}).get("table") is not None and rl._ws is not None
+    pred, *_ = xe(X, to_dev(d["caps"]), to_dev(d["clen"]), prev, plen, False, 0.0)      # grad-enabled forward
+    assert pred.requires_grad
+    buf = io.BytesIO()
+    torch.save({"decoder": rl, "decoder_xe": xe}, buf)
+    assert buf.tell() < 3 * sum(p.numel() * 4 for p in rl.parameters()) + (1 << 20)
+    buf.seek(0)
+    back = torch.load(buf, weights_only=False)
+    rl2, rl3 = back["decoder"], copy.deepcopy(rl)
+    copy.deepcopy(xe)
+    for m in (rl2, rl3):
+        assert m._ws is None and "_tok_state" not in m.__dict__ and "_ws_cache" not in m.__dict__
+        with torch.no_grad():
+            s2, l2 = m(wm, prev, plen, X, True, False)
+        assert torch.equal(s2, seq) and torch.allclose(l2, logp, atol=1e-5)
+    dd, dxe, drl = dcnet_modules("dcnet_small")
+    with torch.no_grad():
+        sd, ld = drl(dd["wm"], to_dev(dd["prev"]), to_dev(dd["plen"]), True, False)
+    buf = io.BytesIO()
+    torch.save({"dae": drl}, buf)
+    buf.seek(0)
+    for m in (torch.load(buf, weights_only=False)["dae"], copy.deepcopy(drl)):
+        assert m._ws is None and m.caption_encoder._owner() is m
+        with torch.no_grad():
+            s2, _ = m(dd["wm"], to_dev(dd["prev"]), to_dev(dd["plen"]), True, False)
+        assert torch.equal(s2, sd)
+
+
+def test_token_table_invalidation():
+    """The folded token table must never serve stale weights: autograd-visible updates, train()/eval() switches,
+    load_state_dict and the documented invalidate_token_table() after `.data` writes."""
+    d, xe, rl = editnet_modules("editnet_small")
+    wm = d["wm"]
+    prev, plen, X = to_dev(d["prev"]), to_dev(d["plen"]), to_dev(d["X"])
+
+    def decode():
+        with torch.no_grad():
+            return rl(wm, prev, plen, X, True, False)
+
+    def table():
+        return rl.__dict__.get("_tok_state", {}).get("table")
+
+    for _ in range(3):
+        base_seq, base_logp = decode()
+    assert table() is not None
+    rl.train()
+    rl.eval()
+    assert table() is None                              # mode switch drops it
+    for _ in range(3):
+        decode()
+    assert table() is not None
+    # a .data write (invisible to tensor._version) + the documented call
+    with torch.no_grad():
+        rl.embed.embedding.weight.data.mul_(-1.0)
+    rl.invalidate_token_table()
+    s1, l1 = decode()
+    for _ in range(2):
+        s2, l2 = decode()                               # rebuilt table: must describe the NEW weights
+    assert torch.equal(s1, s2) and torch.allclose(l1, l2, atol=1e-5)
+    assert not torch.equal(s1, base_seq)
+    # SET_TOKEN_TABLE_VERIFY catches the undocumented case
+    with torch.no_grad():
+        rl.embed.embedding.weight.data.mul_(-1.0)
+    os.environ["SET_TOKEN_TABLE_VERIFY"] = "1"
+    try:
+        with pytest.raises(Exception, match="stale"):
+            decode()
+    finally:
+        os.environ.pop("SET_TOKEN_TABLE_VERIFY")
+    rl.load_state_dict(rl.state_dict())
+    assert table() is None
+    s3, _ = decode()
+    assert torch.equal(s3, base_seq)
+
+
+def test_direct_submodule_calls_are_differentiable_and_train_mode_works():
+    """evaluate()-style direct use of the sub-modules under autograd (the reference's modules are ordinary
+    differentiable nn.Modules) and in train mode (dropout sites) — formerly NotImplementedError."""
+    d, xe, rl = editnet_modules("editnet_small")
+    prev, plen, X = to_dev(d["prev"]), to_dev(d["plen"]), to_dev(d["X"])
+    B, D = X.shape[0], xe.decoder_dim
+    xe.eval()
+    with torch.no_grad():
+        H0, M0, fh0, mask0 = xe.caption_encoder(prev, plen)
+        emb0 = xe.embed(prev[:, 0])
+    H, M, fh, mask = xe.caption_encoder(prev, plen)            # grad enabled, eval mode
+    assert H.requires_grad and torch.allclose(H, H0, atol=2e-5) and torch.equal(mask, mask0)
+    emb = xe.embed(prev[:, 0])
+    assert emb.requires_grad and torch.equal(emb.detach(), emb0)
+    h1, c1 = xe.init_hidden_state(B)
+    h2, c2 = xe.init_hidden_state(B)
+    h1, c1 = xe.attention_lstm(torch.cat([emb, fh, h2, X.mean(1)], 1), (h1, c1))
+    cap, alpha = xe.caption_attention(H, h1, emb, mask)
+    img = xe.visual_attention(X, h1)
+    sel = xe.select(M, alpha)
+    h2, c2 = xe.copy_lstm(torch.cat([h1, cap, img], 1), (h2, c2), sel)
+    logits = xe.fc(h2)
+    assert logits.requires_grad
+    logits.logsumexp(1).sum().backward()
+    for k, p in xe.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    xe.train()                                                  # dropout active in embed / att_embed
+    e1, e2 = xe.embed(prev[:, 0]), xe.embed(prev[:, 0])
+    assert not torch.equal(e1, e2) and float((e1 == 0).float().mean()) > 0.4
+    v1 = xe.visual_attention(X, h1.detach())
+    assert torch.isfinite(v1).all()
+    Ht, *_ = xe.caption_encoder(prev, plen)
+    assert torch.isfinite(Ht).all()
+
+
+def test_out_of_range_token_ids_are_clamped_with_and_without_token_table():
+    """ADVICE: the table gathers must clamp ids exactly like the embedding gather does, so behaviour does not depend
+    on whether the token table is active (no out-of-bounds device read)."""
+    d, xe, rl = editnet_modules("editnet_small")
+    wm, V = d["wm"], d["case"]["V"]
+    prev, plen, X = to_dev(d["prev"]).clone(), to_dev(d["plen"]), to_dev(d["X"])
+    prev[0, 0] = V + 1000                                     # clamps to V-1
+    prev[1, 0] = -5 if int(plen[1]) > 0 else prev[1, 0]      # clamps to 0
+    outs = []
+    with torch.no_grad():
+        for _ in range(3):                                    # calls 1-2 gather embeddings, call 3 uses the table
+            outs.append(rl(wm, prev, plen, X, True, False))
+    assert rl.__dict__.get("_tok_state", {}).get("table") is not None
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.allclose(outs[0][1], outs[2][1], atol=1e-5)
+    ok = prev.clone()
+    ok[0, 0] = V - 1
+    ok[1, 0] = 0 if int(plen[1]) > 0 else ok[1, 0]
+    with torch.no_grad():
+        ref = rl(wm, ok, plen, X, True, False)
+    assert torch.equal(ref[0], outs[2][0])
