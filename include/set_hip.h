@@ -177,7 +177,9 @@ int set_editnet_xe_forward(const SetEditNetWeights* w, const SetEditNetDims* d, 
 /* Debug / module-API accessor: device pointer of a named workspace tensor (NULL if unknown).
  * names: "H" (B,T,D) "M" (B,T,D) "final_hidden" (B,D) "mask" (B,T) "att1" (B,R,A) "att1_c" (B,T,A)
  * "image_mean" (B,F) "h1" "c1" "h2" "c2" "emb" "ctx_cap" "attend_cap" "sel" (B,D) "attend_img" (B,F)
- * "alpha_c" (B,T) "alpha" (B,R) "logits" (B,V) "it" (B) int64 "unfinished" (B) int32 */
+ * "alpha_c" (B,T) "alpha" (B,R) "logits" (B,V) "it" (B) int64 "unfinished" (B) int32
+ * "cap_proj" (B,T,2D) = [context_gate.W[:,2D:3D] H | sc_affine.W H] and "mem_proj" (B,T,D) = gate_cmem.W M: the
+ * per-sequence hoisted projections the step reads instead of contracting the attention context / selected row */
 void* set_editnet_ws_tensor(const SetEditNetDims* d, void* ws, const char* name);
 
 /* ------------------------------------------------------------------------------------------

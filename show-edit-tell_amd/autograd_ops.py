@@ -33,9 +33,8 @@ import contextlib
 import os as _os
 
 _FUSED_WGRAD = _os.environ.get("SET_FUSED_WGRAD", "1") != "0"
-# 1 (default): the Linear-backward contractions run on this package's fp32 MFMA kernel (set_gemm_f32);
-# 0: on torch.mm (rocBLAS) -- kept only as an A/B switch for benchmarking, both are GPU paths.
-_NATIVE_GEMM = _os.environ.get("SET_NATIVE_BWD_GEMM", "1") != "0"
+# every Linear-backward contraction runs on this package's fp32 MFMA kernel (set_gemm_f32): there is no vendor-BLAS
+# route on the path
 _GEMM_WS_BYTES = 64 << 20
 _gemm_ws = {}
 
@@ -103,17 +102,39 @@ def _dgrad_group(pairs):
                       False, True)
 
 
+def _linear_nograd(x, w, b):
+    """y = x w^T + b through set_linear_f32 (no autograd node): recomputation of small forward products inside a
+    backward (the decoder-side attention projection att2 = decoder_att(h1), editnet.py:371,443)."""
+    lib = _lib.load()
+    x = _c(x)
+    M, K, N = x.shape[0], x.shape[1], w.shape[0]
+    y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    ws = _ws(lib.set_linear_workspace_bytes, M, N, K, device=x.device)
+    check(lib.set_linear_f32(ptr(x), K, ptr(w), K, ptr(b), ptr(y), N, M, N, K, _lib.ACT_NONE, ptr(ws), ws.numel(),
+                             stream_of(x.device)), "set_linear_f32")
+    return y
+
+
 def _native_ok(*ts):
-    return _NATIVE_GEMM and all(t.is_cuda and t.dtype == torch.float32 for t in ts)
+    return all(t.is_cuda and t.dtype == torch.float32 for t in ts)
+
+
+def _pad_cols4(t):
+    """(M, N) -> (M, N4) zero-padded copy with N4 = N rounded up to 4 (only for feature counts that are not a multiple
+    of 4, e.g. a vocabulary of 9490 words): the kernel reads 16-byte chunks along its unit-stride dimension."""
+    pad = (-t.shape[1]) % 4
+    return t if pad == 0 else torch.nn.functional.pad(t, (0, pad))
 
 
 def _dgrad(dy, w, out=None):
     """dX (+)= dy . w   (dy: (M, N), w: (N, K) possibly a column slice of a wider weight) -> (M, K);
-    accumulates into `out` (a tensor this backward owns) when given"""
+    accumulates into `out` (a tensor this backward owns) when given.  Always on the package's fp32 MFMA kernel."""
     M, N = dy.shape
     K = w.shape[1]
-    if not _native_ok(dy, w) or (N & 3) or (K & 3) or K < 4 or (out is not None and not out.is_contiguous()):
-        return dy.mm(w) if out is None else out.addmm_(dy, w)
+    if (K & 3) or K < 4 or (out is not None and not out.is_contiguous()):
+        raise _lib.SetError("dX = dY.W needs an input feature count that is a multiple of 4 (got %d)" % K)
+    if N & 3:             # contraction over a ragged feature count: zero-pad dy's columns; W rows >= N are never read
+        dy = _pad_cols4(dy)
     return gemm(dy, False, w, True, M, K, N, out=out, accumulate=out is not None)
 
 
@@ -121,10 +142,15 @@ def _wgrad_mm(dy, x, out=None):
     """dW (+)= dy^T . x   (dy: (M, N), x: (M, K)) -> (N, K); accumulates into `out` when given"""
     M, N = dy.shape
     K = x.shape[1]
-    if not _native_ok(dy, x) or (N & 3) or (K & 3) or N < 4 or K < 4 or (out is not None and not out.is_contiguous()):
+    if (K & 3) or K < 4:
+        raise _lib.SetError("dW = dY^T.X needs an input feature count that is a multiple of 4 (got %d)" % K)
+    if (N & 3) or N < 4 or (out is not None and not out.is_contiguous()):
+        # ragged output-feature count (e.g. V = 9490 rows of fc.weight): contract into a padded buffer, keep N rows
+        dyp = _pad_cols4(dy)
+        full = gemm(dyp, True, x, True, dyp.shape[1], K, M)
         if out is None:
-            return dy.t().mm(x)
-        return out.addmm_(dy.t(), x)
+            return full[:N].contiguous()
+        return out.add_(full[:N])
     return gemm(dy, True, x, True, N, K, M, out=out, accumulate=out is not None)
 
 
@@ -388,7 +414,7 @@ class _CaptionAttention(torch.autograd.Function):
         d_gate_w = _wgrad(p_gate_w, dz, torch.cat([wh, cx], 1))
         d_sc_w = _wgrad(p_sc_w, ds, cx)
         d_tc_w = _wgrad(p_tc_w, dt, wh)
-        att2 = torch.addmm(dec_b, h1, dec_w.t())
+        att2 = _linear_nograd(h1, dec_w, dec_b)
         datt1, datt2, dfull_w, dH, dfull_b = _attention_bwd(dctx, dalpha, alpha, H, att1_c, att2, full_w, True, True)
         dh1 = _dgrad(datt2, dec_w, out=dh1)
         return (dH, datt1, dh1, dword, None, _wgrad(p_dec_w, datt2, h1), _bgrad(p_dec_b, datt2), dfull_w, dfull_b,
@@ -429,7 +455,7 @@ class _DcnetCaptionAttention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dctx):
         feats, att1_c, h1, dec_w, dec_b, full_w, alpha = ctx.saved_tensors
-        att2 = torch.addmm(dec_b, h1, dec_w.t())
+        att2 = _linear_nograd(h1, dec_w, dec_b)
         datt1, datt2, dfull_w, dF, dfull_b = _attention_bwd(dctx, None, alpha, feats, att1_c, att2, full_w, True, True)
         return (dF, datt1, _dgrad(datt2, dec_w), None, _wgrad(ctx.params[0], datt2, h1), _bgrad(ctx.params[1], datt2), dfull_w,
                 dfull_b)
@@ -468,7 +494,7 @@ class _VisualAttention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dctx):
         X, att1, h1, dec_w, dec_b, full_w, alpha = ctx.saved_tensors
-        att2 = torch.addmm(dec_b, h1, dec_w.t())
+        att2 = _linear_nograd(h1, dec_w, dec_b)
         datt1, datt2, dfull_w, _, dfull_b = _attention_bwd(dctx, None, alpha, X, att1, att2, full_w, False, False)
         return (None, datt1, _dgrad(datt2, dec_w), _wgrad(ctx.params[0], datt2, h1), _bgrad(ctx.params[1], datt2), dfull_w,
                 dfull_b, None)

@@ -64,6 +64,13 @@ struct CapAttArgs {
     const float* att1_c; Slabs att2_c; const float* dec_bias; const float* w_full; const float* b_full;
     const float* mask; const float* H; const float* Mem; float* ctx; float* sel; float* alpha_out;
     int T, Dh, A;
+    // Hoisted-projection mode (P != NULL; EditNet eval step): the contractions of the context (editnet.py:378-379)
+    // are linear in ctx = sum_t alpha_t H_t, so P[b,t] = [context_gate.W[:, 2D:3D] H_t | sc_affine.W H_t] (B,T,2Dh) is
+    // computed once per sequence and this kernel accumulates sum_t alpha_t P[b,t] instead of ctx, then applies the
+    // context gate itself:  out = zt*tanh(s) + (1-zt)*tanh(tc),  zt = sig((cg_ab + zc) + b_gate),  s = sc + b_sc.
+    // Q[b,t] = gate_cmem.W Mem_t (B,T,Dh) likewise turns gate_cmem(sel) (editnet.py:281) into a row gather.
+    const float* P; const float* Q; float* cmem_out; float* gated_out;
+    Slabs cg_ab, tc; RowGather gz, gtc; const float *b_gate, *b_sc, *b_tc;
 };
 struct VisAttArgs {
     const float* att1; Slabs att2; const float* dec_bias; const float* w_full; const float* b_full;
@@ -135,6 +142,50 @@ __device__ __forceinline__ void caption_attention_body(const CapAttArgs& P, int 
     const int js = s_arg;
     const float aj = sc[js];
     const float wj = aj * 1.f + (1.f - aj);            // the reference's fp32 expression (editnet.py:417-418)
+    if (P.P) {
+        // ---- hoisted projections + fused context gate
+        for (int d = tid * 4; d < Dh; d += 1024) {
+            // operands that do not depend on the attention weights first: their latency overlaps the P stream
+            const long long m = b;
+            f32x4 pre0 = {0.f, 0.f, 0.f, 0.f}, pre1 = {0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < P.cg_ab.n; ++i) pre0 += ld4a(P.cg_ab.p + (long long)i * P.cg_ab.stride + m * P.cg_ab.ld + d);
+            for (int i = 0; i < P.tc.n; ++i) pre1 += ld4a(P.tc.p + (long long)i * P.tc.stride + m * P.tc.ld + d);
+            if (P.gz.tab) pre0 += ld4a(P.gz.row(m) + d);
+            if (P.gtc.tab) pre1 += ld4a(P.gtc.row(m) + d);
+            const f32x4 bg = ld4a(P.b_gate + d), bs = ld4a(P.b_sc + d), bt = ld4a(P.b_tc + d);
+            const f32x4 mrow = Mem ? ld4a(Mem + ((long long)b * T + js) * Dh + d) : pre0;
+            const f32x4 qrow = P.Q ? ld4a(P.Q + ((long long)b * T + js) * Dh + d) : pre0;
+            const float* pp = P.P + (long long)b * T * 2 * Dh + d;
+            f32x4 zc = {0.f, 0.f, 0.f, 0.f}, sv = {0.f, 0.f, 0.f, 0.f};
+            int t = 0;
+            for (; t + 4 <= T; t += 4) {                      // 8 loads in flight; accumulation stays in t order
+                f32x4 vz[4], vs[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    vz[u] = ld4a(pp + (long long)(t + u) * 2 * Dh);
+                    vs[u] = ld4a(pp + (long long)(t + u) * 2 * Dh + Dh);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { zc += vz[u] * sc[t + u]; sv += vs[u] * sc[t + u]; }
+            }
+            for (; t < T; ++t) {
+                zc += ld4a(pp + (long long)t * 2 * Dh) * sc[t];
+                sv += ld4a(pp + (long long)t * 2 * Dh + Dh) * sc[t];
+            }
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // reference: ONE Linear over cat([word, h1, ctx]): the [word,h1] part first, then the ctx part, then bias
+                const float z = (pre0[e] + zc[e]) + bg[e];
+                const float zt = 1.f / (1.f + expf(-z));
+                o[e] = zt * tanhf(sv[e] + bs[e]) + (1.f - zt) * tanhf(pre1[e] + bt[e]);
+            }
+            *reinterpret_cast<f32x4*>(P.gated_out + (long long)b * Dh + d) = o;
+            if (Mem) *reinterpret_cast<f32x4*>(sel + (long long)b * Dh + d) = mrow * wj;
+            if (P.Q) *reinterpret_cast<f32x4*>(P.cmem_out + (long long)b * Dh + d) = qrow * wj;
+        }
+        return;
+    }
     for (int d = tid * 4; d < Dh; d += 1024) {
         const float* hp = H + (long long)b * T * Dh + d;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -167,7 +218,9 @@ int caption_attention(const float* att1_c, Slabs att2_c, const float* dec_bias, 
     if (T > ATT_MAX_ROWS || A > 512 || (A & 3) || (Dh & 3)) return SET_ERR_UNSUPPORTED;
     if (M <= 0) return SET_OK;
     ProfScope ps("caption_attention", s, 0.0, 4.0 * M * ((double)T * A + (double)T * Dh + 3.0 * Dh + att2_c.n * A));
-    CapAttArgs P{att1_c, att2_c, dec_bias, w_full, b_full, mask, H, Mem, ctx, sel, alpha_out, T, Dh, A};
+    CapAttArgs P{};
+    P.att1_c = att1_c; P.att2_c = att2_c; P.dec_bias = dec_bias; P.w_full = w_full; P.b_full = b_full; P.mask = mask;
+    P.H = H; P.Mem = Mem; P.ctx = ctx; P.sel = sel; P.alpha_out = alpha_out; P.T = T; P.Dh = Dh; P.A = A;
     hipLaunchKernelGGL(caption_attention_k, dim3(M), dim3(256), 0, s, P);
     SET_LAUNCH_CHECK();
     return SET_OK;
@@ -300,15 +353,24 @@ int step_attention(const float* att1, Slabs att2, const float* v_dec_bias, const
                    const float* X, const float* rmask, float* v_ctx, float* v_alpha, int R, int F,
                    const float* att1_c, Slabs att2_c, const float* c_dec_bias, const float* c_w_full,
                    const float* c_b_full, const float* mask, const float* H, const float* Mem, float* c_ctx, float* sel,
-                   float* c_alpha, int T, int Dh, int A, int M, hipStream_t s) {
+                   float* c_alpha, int T, int Dh, int A, int M, hipStream_t s, const CapHoist* hoist) {
     if (R > ATT_MAX_ROWS || T > ATT_MAX_ROWS || A > 512 || (A & 3) || (F & 3) || (Dh & 3)) return SET_ERR_UNSUPPORTED;
     if (M <= 0) return SET_OK;
     const int fsn = vis_fsn(M, F);
     static const int prefetch = env_int("SET_ATT_PREFETCH", 1);
     VisAttArgs V{att1, att2, v_dec_bias, v_w_full, v_b_full, X, rmask, v_ctx, v_alpha, R, F, A, F / fsn, fsn, prefetch};
-    CapAttArgs C{att1_c, att2_c, c_dec_bias, c_w_full, c_b_full, mask, H, Mem, c_ctx, sel, c_alpha, T, Dh, A};
+    CapAttArgs C{};
+    C.att1_c = att1_c; C.att2_c = att2_c; C.dec_bias = c_dec_bias; C.w_full = c_w_full; C.b_full = c_b_full; C.mask = mask;
+    C.H = H; C.Mem = Mem; C.ctx = c_ctx; C.sel = sel; C.alpha_out = c_alpha; C.T = T; C.Dh = Dh; C.A = A;
+    if (hoist && hoist->P) {
+        C.P = hoist->P; C.Q = hoist->Q; C.cmem_out = hoist->cmem_out; C.gated_out = hoist->gated_out;
+        C.cg_ab = hoist->cg_ab; C.tc = hoist->tc; C.gz = hoist->gz; C.gtc = hoist->gtc;
+        C.b_gate = hoist->b_gate; C.b_sc = hoist->b_sc; C.b_tc = hoist->b_tc;
+    }
+    const double cap_rows = (hoist && hoist->P) ? 2.0 * T * Dh + (double)(hoist->cg_ab.n + hoist->tc.n + 6) * Dh
+                                                : (double)T * Dh + 3.0 * Dh;
     ProfScope ps("step_attention", s, 0.0,
-                 4.0 * M * ((double)R * A * fsn + (double)R * F + F + (double)T * A + (double)T * Dh + 3.0 * Dh));
+                 4.0 * M * ((double)R * A * fsn + (double)R * F + F + (double)T * A + cap_rows));
     hipLaunchKernelGGL(step_attention_k, dim3(M * fsn + M), dim3(256), 0, s, V, C, M * fsn);
     SET_LAUNCH_CHECK();
     return SET_OK;

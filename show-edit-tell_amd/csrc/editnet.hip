@@ -32,8 +32,9 @@ int gemm_target_wgs() {
 struct EditNetWs {
     // per-sequence invariants (prologue)
     float *H, *Mem, *final_hidden, *mask, *att1, *att1_c, *image_mean, *pre1, *rmask;
+    float *cap_proj, *mem_proj;       // hoisted [context_gate.W[:,2D:] H | sc_affine.W H] (B,T,2D) and gate_cmem.W Mem (B,T,D)
     // recurrent state + per-step activations
-    float *h1, *c1, *h2, *c2, *emb, *ctx_cap, *attend_cap, *attend_img, *sel, *c_new, *ogate, *alpha_c, *alpha;
+    float *h1, *c1, *h2, *c2, *emb, *ctx_cap, *attend_cap, *attend_img, *sel, *cmem_pre, *c_new, *ogate, *alpha_c, *alpha;
     float* logits;
     long long* it;
     int *unfinished, *alive;
@@ -68,6 +69,8 @@ static EditNetWs carve(const SetEditNetDims* d, void* base) {
     w.image_mean = c.take<float>(B * F);
     w.pre1 = c.take<float>(B * 4 * D);
     w.rmask = c.take<float>(B * R);
+    w.cap_proj = c.take<float>(B * T * 2 * D);
+    w.mem_proj = c.take<float>(B * T * D);
     w.h1 = c.take<float>(B * D);
     w.c1 = c.take<float>(B * D);
     w.h2 = c.take<float>(B * D);
@@ -77,6 +80,7 @@ static EditNetWs carve(const SetEditNetDims* d, void* base) {
     w.attend_cap = c.take<float>(B * D);
     w.attend_img = c.take<float>(B * F);
     w.sel = c.take<float>(B * D);
+    w.cmem_pre = c.take<float>(B * D);
     w.c_new = c.take<float>(B * D);
     w.ogate = c.take<float>(B * D);
     w.alpha_c = c.take<float>(B * T);
@@ -198,9 +202,20 @@ static int begin_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const
                             ws.enc_h, ws.enc_c, ws.s_enc, ws.s_aff, st));
     // ---- hoisted, loop-invariant projections (eval mode)
     {
-        GemmProb p = direct_prob(ws.att1_c, A, B * T, A, w->ca_feat_b, SET_ACT_NONE);     // editnet.py:370
-        p.add(ws.H, D, w->ca_feat_w, D, D);
-        SET_TRY(gemm_group(&p, 1, st));
+        // one grouped launch over the encoder outputs: att1_c (editnet.py:370) and the contractions that are linear in
+        // the attention context / the selected memory row, hoisted out of the timestep (see CapAttArgs in attention.hip):
+        //   cap_proj[b,t] = [context_gate.W[:, 2D:3D] H_t | sc_affine.W H_t]   (editnet.py:378-379, no bias here)
+        //   mem_proj[b,t] = gate_cmem.W Mem_t                                   (editnet.py:281)
+        GemmProb p[4];
+        p[0] = direct_prob(ws.att1_c, A, B * T, A, w->ca_feat_b, SET_ACT_NONE);
+        p[0].add(ws.H, D, w->ca_feat_w, D, D);
+        p[1] = direct_prob(ws.cap_proj, 2LL * D, B * T, D, nullptr, SET_ACT_NONE);
+        p[1].add(ws.H, D, w->ca_gate_w + 2 * D, 3LL * D, D);
+        p[2] = direct_prob(ws.cap_proj + D, 2LL * D, B * T, D, nullptr, SET_ACT_NONE);
+        p[2].add(ws.H, D, w->ca_sc_w, D, D);
+        p[3] = direct_prob(ws.mem_proj, D, B * T, D, nullptr, SET_ACT_NONE);
+        p[3].add(ws.Mem, D, w->cl_cmem_w, D, D);
+        SET_TRY(gemm_group(p, 4, st, "gemm:pro cap projections"));
     }
     {
         GemmProb p = direct_prob(ws.fe, D, B * R, D, w->va_emb_b, SET_ACT_RELU);          // editnet.py:441
@@ -280,32 +295,20 @@ static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const 
     b[4].add(ws.h1, D, w->cl_x2h_w, ld_x2h, D);
     plan_ksplit(b, 5, tgt);
     SET_TRY(gemm_group(b, 5, st, "gemm:B att2,tc,cg,x2h_h1"));
+    // the caption role also applies the context gate: its ctx-side contractions are hoisted (ws.cap_proj), the
+    // [word,h1]-side ones arrive as slabs b[3] / b[2] (+ token-table rows); gate_cmem(sel) becomes a row of ws.mem_proj
+    CapHoist hoist;
+    hoist.P = ws.cap_proj; hoist.Q = ws.mem_proj; hoist.cmem_out = ws.cmem_pre; hoist.gated_out = ws.attend_cap;
+    hoist.cg_ab = slabs_of(b[3]); hoist.tc = slabs_of(b[2]); hoist.gz = g_cg; hoist.gtc = g_tc;
+    hoist.b_gate = w->ca_gate_b; hoist.b_sc = w->ca_sc_b; hoist.b_tc = w->ca_tc_b;
     SET_TRY(step_attention(ws.att1, slabs_of(b[1]), w->va_dec_b, w->va_full_w, w->va_full_b, X,
                            d->adaptive ? ws.rmask : nullptr, ws.attend_img, ws.alpha, R, F, ws.att1_c, slabs_of(b[0]),
                            w->ca_dec_b, w->ca_full_w, w->ca_full_b, ws.mask, ws.H, ws.Mem, ws.ctx_cap, ws.sel,
-                           ws.alpha_c, T, D, A, bt, st));
-    // ---- C (+ context gating): fused small-tile kernel when D allows, else grouped GEMM + pointwise
-    // small batches (measured: up to 64 rows): the 32-row tiles leave the fused kernels with <= 64 workgroups; the grouped GEMM (split-K
-    // over the whole chip) + pointwise is faster there
+                           ws.alpha_c, T, D, A, bt, st, &hoist));
+    // small batches (measured: up to 64 rows): the 32-row tiles leave the fused E kernel with <= 64 workgroups; the
+    // grouped GEMM (split-K over the whole chip) + pointwise is faster there
     static const int fused_min_rows = env_int("SET_FUSED_MIN_ROWS", 65);
     const bool fused = fusedk && bt >= fused_min_rows;
-    GemmProb c[3];
-    if (fused) {
-        SET_TRY(fused_context_gate(ws.ctx_cap, w->ca_gate_w + 2 * D, 3 * D, w->ca_sc_w, slabs_of(b[3]), slabs_of(b[2]),
-                                   w->ca_gate_b, w->ca_sc_b, w->ca_tc_b, ws.attend_cap, bt, D, st, g_cg, g_tc));
-    } else {
-        c[0] = slab_prob(ws.sC0, bt, D, B);
-        c[0].add(ws.ctx_cap, D, w->ca_gate_w + 2 * D, 3 * D, D);
-        c[1] = slab_prob(ws.sC1, bt, D, B);
-        c[1].add(ws.ctx_cap, D, w->ca_sc_w, D, D);
-        c[2] = slab_prob(ws.sC2, bt, D, B);
-        c[2].add(ws.sel, D, w->cl_cmem_w, D, D);
-        plan_ksplit(c, 3, tgt);
-        SET_TRY(gemm_group(c, 3, st, "gemm:C cg_ctx,sc,cmem"));
-        SET_TRY(context_gate_pointwise(slabs_of(b[3]), slabs_of(c[0]), w->ca_gate_b, slabs_of(c[1]), w->ca_sc_b,
-                                       slabs_of(b[2]), w->ca_tc_b, ws.attend_cap, bt, D, st, nullptr, nullptr, nullptr,
-                                       g_cg, g_tc));
-    }
     // ---- D
     GemmProb dd = slab_prob(ws.sD0, bt, 4 * D, B);
     dd.add(ws.attend_cap, D, w->cl_x2h_w + D, ld_x2h, D);
@@ -314,17 +317,17 @@ static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const 
     SET_TRY(gemm_group(&dd, 1, st, "gemm:D x2h_ctx"));
     SET_TRY(lstm_pointwise(slabs_of(a[1]), slabs_of(b[4]), slabs_of(dd), nullptr, 0, w->cl_x2h_b, w->cl_h2h_b, ws.c2,
                            ws.c_new, nullptr, ws.ogate, bt, D, st));
-    // ---- E (+ copy gate)
+    // ---- E (+ copy gate): gate_cnew(c_new) is the only contraction left here
     if (fused) {
-        SET_TRY(fused_copy_gate(ws.c_new, ws.sel, ws.ogate, w->cl_cnew_w, w->cl_cmem_w, w->cl_cnew_b, w->cl_cmem_b, ws.c2,
-                                ws.h2, bt, D, st));
+        SET_TRY(fused_copy_gate_pre(ws.c_new, ws.sel, ws.cmem_pre, ws.ogate, w->cl_cnew_w, w->cl_cnew_b, w->cl_cmem_b,
+                                    ws.c2, ws.h2, bt, D, st));
     } else {
         GemmProb e = slab_prob(ws.sE0, bt, D, B);
         e.add(ws.c_new, D, w->cl_cnew_w, D, D);
         plan_ksplit(&e, 1, tgt);
         SET_TRY(gemm_group(&e, 1, st, "gemm:E cnew"));
-        SET_TRY(copy_gate_pointwise(slabs_of(e), w->cl_cnew_b, slabs_of(c[2]), w->cl_cmem_b, ws.c_new, ws.sel, ws.ogate,
-                                    ws.c2, ws.h2, bt, D, st));
+        SET_TRY(copy_gate_pointwise(slabs_of(e), w->cl_cnew_b, Slabs{ws.cmem_pre, 0, D, 1}, w->cl_cmem_b, ws.c_new,
+                                    ws.sel, ws.ogate, ws.c2, ws.h2, bt, D, st));
     }
     // ---- F
     const long long Vp = (long long)round_up((size_t)V, 64);
@@ -520,6 +523,7 @@ void* set_editnet_ws_tensor(const SetEditNetDims* d, void* ws, const char* name)
         {"c1", W.c1}, {"h2", W.h2}, {"c2", W.c2}, {"emb", W.emb}, {"ctx_cap", W.ctx_cap},
         {"attend_cap", W.attend_cap}, {"attend_img", W.attend_img}, {"sel", W.sel}, {"c_new", W.c_new},
         {"alpha_c", W.alpha_c}, {"alpha", W.alpha}, {"logits", W.logits}, {"it", W.it},
+        {"cap_proj", W.cap_proj}, {"mem_proj", W.mem_proj},
         {"unfinished", W.unfinished}, {"alive", W.alive}};
     for (auto& e : tab)
         if (!strcmp(e.n, name)) return e.p;

@@ -492,7 +492,26 @@ void plan_ksplit(GemmProb* probs, int n, int cap_wgs) {
         for (int i = 0; i < n; ++i) wgs += (long long)tiles[i] * split_of(i, kper);
         if (wgs <= cap_wgs) break;
     }
-    for (int i = 0; i < n; ++i) probs[i].ksplit = split_of(i, kper);
+    long long total = 0;
+    for (int i = 0; i < n; ++i) { probs[i].ksplit = split_of(i, kper); total += (long long)tiles[i] * probs[i].ksplit; }
+    // A common kper rarely lands on the slot count (e.g. the phase-B group: 224 tiles x 3 slices = 672 of 768 slots,
+    // so a third of the CUs run 2 workgroups and the rest 3).  Fill the spare slots: give one more K-slice to the
+    // problems that fit, smallest first (their workgroups get shorter, nobody's gets longer).
+    static const int fill = env_int("SET_GEMM_FILL_SLOTS", 1);
+    if (fill && n > 1) {
+        bool grew = true;
+        while (grew) {
+            grew = false;
+            int best = -1;
+            for (int i = 0; i < n; ++i) {
+                const int ks = probs[i].ksplit;
+                if (ks >= probs[i].max_ksplit || ks >= kts[i] || kts[i] / (ks + 1) < min_kper) continue;
+                if (total + tiles[i] > cap_wgs) continue;
+                if (best < 0 || tiles[i] < tiles[best]) best = i;
+            }
+            if (best >= 0) { probs[best].ksplit += 1; total += tiles[best]; grew = true; }
+        }
+    }
 }
 
 int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag) {

@@ -18,7 +18,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const f32x4 __attribute__((address_space(1)))* gptr4;
 
-enum { EPI_CTXGATE = 0, EPI_COPYGATE = 1, EPI_ENCLSTM = 2 };
+enum { EPI_CTXGATE = 0, EPI_COPYGATE = 1, EPI_ENCLSTM = 2, EPI_COPYGATE1 = 3 };
 
 struct FusedArgs {
     // accumulator a = A[a] (M,K) x W[a] (N rows, K)^T ; both accumulators share K
@@ -31,6 +31,7 @@ struct FusedArgs {
     Slabs s0, s1;         // CTXGATE: s0 = context_gate[word,h1] slabs, s1 = tc_affine slabs
     const float *b0, *b1, *b2;          // CTXGATE: b_gate, b_sc, b_tc ; COPYGATE: b_cnew, b_cmem ; ENCLSTM: b_extra
     const float *e0, *e1, *e2;          // COPYGATE: c_new, sel, ogate ; ENCLSTM: xg, h_in, (unused)
+    const float* e3;                    // COPYGATE1: the hoisted gate_cmem(sel) product (M,N), its GEMM is not run here
     float *o0, *o1, *o2, *o3;           // CTXGATE: out ; COPYGATE: c2, h2 ; ENCLSTM: h_out, c (in place), H, Mem
     const int64_t* lens;                // ENCLSTM
     long long ld_xg_row, ld_xg_t, ld_out_b, ld_out_t;
@@ -122,7 +123,7 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
     const int erow = tid >> 3, ec4 = (tid & 7) * 4, eu = tid & 7;
     const long long em = m0 + erow;
     const bool erow_ok = em < P.M;
-    f32x4 pre0 = {0.f, 0.f, 0.f, 0.f}, pre1 = {0.f, 0.f, 0.f, 0.f}, pre2 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 pre0 = {0.f, 0.f, 0.f, 0.f}, pre1 = {0.f, 0.f, 0.f, 0.f}, pre2 = {0.f, 0.f, 0.f, 0.f}, pre3 = {0.f, 0.f, 0.f, 0.f};
     float eg[4] = {0.f, 0.f, 0.f, 0.f}, ecp = 0.f, ehin = 0.f;
     int elen = 0, epos = 0;
     if (EPI == EPI_CTXGATE) {
@@ -132,11 +133,12 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
             if (P.g0.tab) pre0 += *(gptr4)(P.g0.row(em) + n0 + ec4);
             if (P.g1.tab) pre1 += *(gptr4)(P.g1.row(em) + n0 + ec4);
         }
-    } else if (EPI == EPI_COPYGATE) {
+    } else if (EPI == EPI_COPYGATE || EPI == EPI_COPYGATE1) {
         if (erow_ok && n0 + ec4 < P.N) {
             pre0 = *(gptr4)(P.e0 + em * P.N + n0 + ec4);
             pre1 = *(gptr4)(P.e1 + em * P.N + n0 + ec4);
             pre2 = *(gptr4)(P.e2 + em * P.N + n0 + ec4);
+            if (EPI == EPI_COPYGATE1) pre3 = *(gptr4)(P.e3 + em * P.N + n0 + ec4);
         }
     } else {
         const int unit = n0 + eu;
@@ -249,8 +251,9 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
             const float zt = sigm(z);
             out0[e] = zt * tanhf(sv) + (1.f - zt) * tanhf(tt);
         } else {
+            // reference order (editnet.py:281): (gate_cnew(c_new) + b) + (gate_cmem(c_memory) + b)
             const float a = rsum(0, erow, ec4 + e) + P.b0[n];
-            const float b = rsum(1, erow, ec4 + e) + P.b1[n];
+            const float b = (EPI == EPI_COPYGATE1 ? pre3[e] : rsum(NACC - 1, erow, ec4 + e)) + P.b1[n];
             const float cg = sigm(a + b);
             const float co = cg * pre1[e] + (1.f - cg) * pre0[e];
             out0[e] = co;
@@ -258,7 +261,7 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
         }
     }
     *reinterpret_cast<f32x4*>(P.o0 + em * P.N + n0 + ec4) = out0;
-    if (EPI == EPI_COPYGATE) *reinterpret_cast<f32x4*>(P.o1 + em * P.N + n0 + ec4) = out1;
+    if (EPI == EPI_COPYGATE || EPI == EPI_COPYGATE1) *reinterpret_cast<f32x4*>(P.o1 + em * P.N + n0 + ec4) = out1;
 }
 
 template <int NACC, bool SHARED_A, int BK>
@@ -310,6 +313,22 @@ int fused_copy_gate(const float* c_new, const float* sel, const float* ogate, co
     const int grid = cdiv(M, 32) * cdiv(D, 32);
     ProfScope ps("fused_copy_gate", s, 4.0 * M * D * D, 4.0 * (2.0 * D * D + 6.0 * M * D));
     return launch_fused<2, false, 64, EPI_COPYGATE>(P, grid, s);
+}
+
+// the same with gate_cmem(sel) supplied (hoisted to the prologue: row gather in the attention kernel): one accumulator
+int fused_copy_gate_pre(const float* c_new, const float* sel, const float* cmem_pre, const float* ogate,
+                        const float* w_cnew, const float* b_cnew, const float* b_cmem, float* c_out, float* h_out, int M,
+                        int D, hipStream_t s) {
+    if (D % 64) return SET_ERR_UNSUPPORTED;
+    FusedArgs P{};
+    P.A[0] = c_new; P.lda[0] = D; P.W[0] = w_cnew; P.ldw[0] = D;
+    P.K = D; P.M = M; P.N = D;
+    P.b0 = b_cnew; P.b1 = b_cmem; P.e0 = c_new; P.e1 = sel; P.e2 = ogate; P.e3 = cmem_pre; P.o0 = c_out; P.o1 = h_out;
+    const int grid = cdiv(M, 32) * cdiv(D, 32);
+    ProfScope ps("fused_copy_gate", s, 2.0 * M * D * D, 4.0 * (1.0 * D * D + 7.0 * M * D));
+    static const int bk128 = env_int("SET_COPYGATE_BK128", 1);
+    if (bk128 && D % 128 == 0) return launch_fused<1, true, 128, EPI_COPYGATE1>(P, grid, s);
+    return launch_fused<1, true, 64, EPI_COPYGATE1>(P, grid, s);
 }
 
 // one encoder timestep: gates = h_in W_hh^T + xg[b,pos] + b_extra -> (h_out, c, H[b,pos], Mem[b,pos])

@@ -158,11 +158,17 @@ int caption_attention(const float* att1_c, Slabs att2_c, const float* dec_bias, 
 int visual_attention(const float* att1, Slabs att2, const float* dec_bias, const float* w_full,
                      const float* b_full, const float* X, const float* rmask, float* ctx,
                      float* alpha_out, int M, int R, int F, int A, hipStream_t s);
+// hoisted-projection operands of the caption role (attention.hip CapAttArgs): P (B,T,2Dh), Q (B,T,Dh) or NULL
+struct CapHoist {
+    const float* P = nullptr; const float* Q = nullptr; float* cmem_out = nullptr; float* gated_out = nullptr;
+    Slabs cg_ab{nullptr, 0, 0, 0}, tc{nullptr, 0, 0, 0}; RowGather gz, gtc;
+    const float *b_gate = nullptr, *b_sc = nullptr, *b_tc = nullptr;
+};
 int step_attention(const float* att1, Slabs att2, const float* v_dec_bias, const float* v_w_full, const float* v_b_full,
                    const float* X, const float* rmask, float* v_ctx, float* v_alpha, int R, int F,
                    const float* att1_c, Slabs att2_c, const float* c_dec_bias, const float* c_w_full,
                    const float* c_b_full, const float* mask, const float* H, const float* Mem, float* c_ctx, float* sel,
-                   float* c_alpha, int T, int Dh, int A, int M, hipStream_t s);
+                   float* c_alpha, int T, int Dh, int A, int M, hipStream_t s, const CapHoist* hoist = nullptr);
 int region_masks(const float* X, const float* fe, float* rmask, int B, int R, int F, int D, hipStream_t s);
 int select_rows(const float* Mem, const float* alpha, float* sel, int M, int T, int D, hipStream_t s);
 
@@ -172,6 +178,9 @@ int fused_context_gate(const float* ctx, const float* w_gate_ctx, long long ld_g
                        hipStream_t s, RowGather gz = RowGather(), RowGather gtc = RowGather());
 int fused_copy_gate(const float* c_new, const float* sel, const float* ogate, const float* w_cnew, const float* w_cmem,
                     const float* b_cnew, const float* b_cmem, float* c_out, float* h_out, int M, int D, hipStream_t s);
+int fused_copy_gate_pre(const float* c_new, const float* sel, const float* cmem_pre, const float* ogate,
+                        const float* w_cnew, const float* b_cnew, const float* b_cmem, float* c_out, float* h_out, int M,
+                        int D, hipStream_t s);
 int fused_encoder_step(const float* h_in, float* h_out, float* c, const float* w_hh, const float* xg,
                        long long ld_xg_row, long long ld_xg_t, const float* b_extra, const int64_t* lens, int t,
                        int reverse, float* H, float* Mem, long long ld_out_b, long long ld_out_t, int out_col0, int B,

@@ -65,7 +65,7 @@ class _FusedEditNet(_FusedModel):
         self.dims = d_b = decoder._dims(B, T, R, max_steps + 1)
         self.ws = ws_b = torch.empty(lib.set_editnet_workspace_bytes(C.byref(d_b)), dtype=torch.uint8, device=dev)
         for name, shp in (("H", (T, D)), ("M", (T, D)), ("mask", (T,)), ("att1", (R, A)), ("att1_c", (T, A)),
-                          ("pre1", (4 * D,)), ("rmask", (R,))):
+                          ("pre1", (4 * D,)), ("rmask", (R,)), ("cap_proj", (T, 2 * D)), ("mem_proj", (T, D))):
             self._views(lib.set_editnet_ws_tensor, d_b, ws_b, name, (B,) + shp).copy_(
                 self._views(lib.set_editnet_ws_tensor, d_img, ws_img, name, (NI,) + shp).repeat_interleave(k, 0))
         self.Xk = X.repeat_interleave(k, 0).contiguous()

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("deferred", [False, True])
-@pytest.mark.parametrize("name", ["editnet_small", "editnet_full_b4"])
+@pytest.mark.parametrize("name", ["editnet_small", "editnet_full_b4", "editnet_full_v9490"])
 def test_xe_gradients_vs_reference_autograd(name, deferred):
     import contextlib
     from show_edit_tell_amd.autograd_ops import deferred_param_grads
