@@ -372,7 +372,8 @@ int set_beam_gather_f32(float* s0, float* s1, float* s2, float* s3, const int32_
  *     a(m,k) = a_kminor ? A[k*lda + m] : A[m*lda + k];   b(n,k) = b_kminor ? B[k*ldb + n] : B[n*ldb + k]
  * accumulate != 0 adds into C (in-place .grad accumulation).  `ws` is scratch for split-K slabs (may be
  * NULL: the contraction is then never split).  Leading dimensions are multiples of 4 floats; a k-minor
- * operand needs its own dimension (M or N) to be a multiple of 4, a k-major one needs K % 4 == 0. */
+ * operand needs its own dimension (M or N) to be a multiple of 4; a k-major one needs K % 4 == 0, or rows that
+ * are zero-padded by the caller up to the next multiple of 4 (leading dimension >= round_up(K,4)). */
 int set_gemm_f32(const float* A, long long lda, int a_kminor, const float* B, long long ldb, int b_kminor,
                  float* C, long long ldc, int M, int N, int K, int accumulate, void* ws, size_t ws_bytes,
                  void* stream);

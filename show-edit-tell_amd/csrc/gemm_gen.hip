@@ -275,8 +275,14 @@ int gemm_gen_group(const SetGemmDesc* d, int n, int a_kminor, int b_kminor, void
         const SetGemmDesc& p = d[i];
         if (p.M <= 0 || p.N <= 0 || p.K <= 0 || !p.A || !p.B || !p.C) return SET_ERR_ARG;
         if (!aligned16(p.A) || !aligned16(p.B) || (p.lda & 3) || (p.ldb & 3)) return SET_ERR_ARG;
-        // k-major operands are read in float4 along k; k-minor ones in float4 along their own dimension
-        if ((!a_kminor || !b_kminor) && (p.K & 3)) return SET_ERR_UNSUPPORTED;
+        // k-major operands are read in float4 along k; k-minor ones in float4 along their own dimension.  A ragged
+        // contraction length (K % 4 != 0, e.g. a 9490-word vocabulary) is accepted when every k-major operand's rows
+        // are readable AND ZERO up to the next multiple of 4 (ld >= round_up(K,4), zero padding supplied by the caller):
+        // rows k >= K of a k-minor operand are never read.
+        if (p.K & 3) {
+            const long long K4 = ((long long)p.K + 3) & ~3LL;
+            if ((!a_kminor && p.lda < K4) || (!b_kminor && p.ldb < K4)) return SET_ERR_UNSUPPORTED;
+        }
         if (a_kminor && ((p.M & 3) || p.M < 4)) return SET_ERR_UNSUPPORTED;
         if (b_kminor && ((p.N & 3) || p.N < 4)) return SET_ERR_UNSUPPORTED;
         const int b = p.M <= bm64_upto ? 64 : 128;
