@@ -38,7 +38,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src in sources():
         obj = os.path.join(CSRC, "build", os.path.basename(src) + ".o")
         objs.append(obj)
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-c", src, "-o", obj]
+        # SET_HIPCC_FLAGS: extra compile flags (A/B experiments with -D switches on the GPU box)
+        extra = os.environ.get("SET_HIPCC_FLAGS", "").split()
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-comment"] + extra + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

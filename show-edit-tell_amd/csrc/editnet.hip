@@ -42,6 +42,7 @@ struct EditNetWs {
     float *sA0, *sA1, *sB0, *sB1, *sB2, *sB3, *sB4, *sC0, *sC1, *sC2, *sD0, *sE0, *sF0;
     // prologue scratch
     float *enc_h, *enc_c, *xg, *emb_seq, *fe, *s_enc, *s_aff, *s_pre;
+    int* enc_order;                   // [perm (B) | nactive (T)] of the length-ordered encoder
     size_t bytes;
 };
 
@@ -111,6 +112,7 @@ static EditNetWs carve(const SetEditNetDims* d, void* base) {
     w.s_enc = c.take<float>(KS * B * 4 * D);
     w.s_aff = c.take<float>(KS * B * D);
     w.s_pre = c.take<float>(KS * B * 4 * D);
+    w.enc_order = c.take<int>(B + T);
     w.bytes = c.off;
     return w;
 }
@@ -144,7 +146,7 @@ GemmProb direct_prob(float* out, long long ldo, int M, int N, const float* bias,
 // t < len[b]; H / Mem rows beyond a caption's length stay zero; mask = (Mem.sum(2) != 0).
 int editnet_encoder(const SetEditNetWeights* w, const int64_t* seq, const int64_t* lens, float* H, float* Mem,
                     float* final_hidden, float* mask, int B, int T, int D, int V, float* emb_seq, float* xg,
-                    float* enc_h, float* enc_c, float* s_enc, float* s_aff, hipStream_t st) {
+                    float* enc_h, float* enc_c, float* s_enc, float* s_aff, hipStream_t st, int* order) {
     const int tgt = gemm_target_wgs();
     const bool fused = (D % 128 == 0) && env_int("SET_NO_FUSED", 0) == 0;
     // with the token table the hoisted input projection x W_xh^T + b_xh is a row gather done by the step kernel
@@ -161,14 +163,23 @@ int editnet_encoder(const SetEditNetWeights* w, const int64_t* seq, const int64_
     SET_TRY(zero_f32(enc_c, (size_t)B * D, st));
     float* h_cur = enc_h;
     float* h_nxt = s_enc;                         // (B,D) ping-pong partner (the slab region is free in the fused path)
+    // visit the rows longest first (device-side ranking, no host sync) so that tiles of finished rows are skipped:
+    // order = [perm (B) | nactive (T)]
+    static const int skip = env_int("SET_ENC_SKIP", 1);
+    int *perm = nullptr, *nactive = nullptr;
+    if (fused && order && skip && B <= 4096) {
+        perm = order; nactive = order + B;
+        SET_TRY(encoder_order(lens, B, T, perm, nactive, st));
+    }
     for (int t = 0; t < T; ++t) {
         if (fused) {
             if (tab)
                 SET_TRY(fused_encoder_step(h_cur, h_nxt, enc_c, w->enc_h2h_w, w->tok_table + 6 * D, 10LL * D, 0,
-                                           w->enc_h2h_b, lens, t, 0, H, Mem, (long long)T * D, D, 0, B, D, st, seq, T, V));
+                                           w->enc_h2h_b, lens, t, 0, H, Mem, (long long)T * D, D, 0, B, D, st, seq, T, V, perm, nactive));
             else
                 SET_TRY(fused_encoder_step(h_cur, h_nxt, enc_c, w->enc_h2h_w, xg, (long long)T * 4 * D, 4 * D,
-                                           w->enc_h2h_b, lens, t, 0, H, Mem, (long long)T * D, D, 0, B, D, st));
+                                           w->enc_h2h_b, lens, t, 0, H, Mem, (long long)T * D, D, 0, B, D, st, nullptr, 0, 0,
+                                           perm, nactive));
             float* tmp = h_cur; h_cur = h_nxt; h_nxt = tmp;
             continue;
         }
@@ -199,7 +210,7 @@ static int begin_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const
     const int tgt = gemm_target_wgs();
     // ---- caption encoder (editnet.py:319-348)
     SET_TRY(editnet_encoder(w, prev, prevlen, ws.H, ws.Mem, ws.final_hidden, ws.mask, B, T, D, d->V, ws.emb_seq, ws.xg,
-                            ws.enc_h, ws.enc_c, ws.s_enc, ws.s_aff, st));
+                            ws.enc_h, ws.enc_c, ws.s_enc, ws.s_aff, st, ws.enc_order));
     // ---- hoisted, loop-invariant projections (eval mode)
     {
         // one grouped launch over the encoder outputs: att1_c (editnet.py:370) and the contractions that are linear in
@@ -293,6 +304,8 @@ static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const 
     b[3].add(ws.h1, D, w->ca_gate_w + D, 3 * D, D);
     b[4] = slab_prob(ws.sB4, bt, 4 * D, B);
     b[4].add(ws.h1, D, w->cl_x2h_w, ld_x2h, D);
+    static const int b_bm = env_int("SET_GEMM_B_BM", 0);
+    if (bt > 64) b[0].bm_hint = b_bm;
     plan_ksplit(b, 5, tgt);
     SET_TRY(gemm_group(b, 5, st, "gemm:B att2,tc,cg,x2h_h1"));
     // the caption role also applies the context gate: its ctx-side contractions are hoisted (ws.cap_proj), the
@@ -335,6 +348,8 @@ static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const 
     f.ldc = Vp;
     f.slab_stride = (long long)B * Vp;
     f.add(ws.h2, D, w->fc_w, D, D);
+    static const int f_bm = env_int("SET_GEMM_F_BM", 0);
+    if (bt > 64) f.bm_hint = f_bm;
     plan_ksplit(&f, 1, tgt);
     if (dst && f.ksplit == 1) {
         f.C = dst; f.ldc = ld_dst; f.bias = w->fc_b; f.slab_stride = 0;

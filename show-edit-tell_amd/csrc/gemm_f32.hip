@@ -458,7 +458,8 @@ int gemm_tile_m(int M) {
     return M <= bm32_upto ? 32 : (M <= bm64_upto ? 64 : 128);
 }
 static int gemm_bn128() { static int v = env_int("SET_GEMM_BN128", 0); return v; }
-static int gemm_tile_n(int M) { const int bm = gemm_tile_m(M); return (bm == 32 || (bm == 128 && gemm_bn128())) ? 128 : 64; }
+static int tile_m_of(const GemmProb& p) { return (p.bm_hint == 64 || p.bm_hint == 128) ? p.bm_hint : gemm_tile_m(p.M); }
+static int tile_n_of(const GemmProb& p) { const int bm = tile_m_of(p); return (bm == 32 || (bm == 128 && gemm_bn128())) ? 128 : 64; }
 
 // Split-K plan for one grouped launch: every workgroup should run about the same number of k-tiles
 // (`kper`) and the whole launch should fit the chip in ONE round: 256 CUs x 2 resident workgroups =
@@ -469,12 +470,12 @@ void plan_ksplit(GemmProb* probs, int n, int cap_wgs) {
     // the cap is given for 128-row tiles (2 workgroups per CU); 64x64 workgroups are half as large: 3 per CU
     static const int pct64 = env_int("SET_GEMM_WGS64_PCT", 150);
     static const int pct32 = env_int("SET_GEMM_WGS32_PCT", 50);
-    if (n > 0 && gemm_tile_m(probs[0].M) == 64) cap_wgs = cap_wgs * pct64 / 100;
+    if (n > 0 && tile_m_of(probs[0]) == 64) cap_wgs = cap_wgs * pct64 / 100;
     // <= 32 rows: the launch only streams weights; fewer, longer workgroups halve the slab traffic (measured +5 %)
-    if (n > 0 && gemm_tile_m(probs[0].M) == 32) cap_wgs = cap_wgs * pct32 / 100;
+    if (n > 0 && tile_m_of(probs[0]) == 32) cap_wgs = cap_wgs * pct32 / 100;
     int tiles[GEMM_MAX_TASKS], kts[GEMM_MAX_TASKS], max_kt = 1;
     for (int i = 0; i < n; ++i) {
-        const int bm = gemm_tile_m(probs[i].M), bn = gemm_tile_n(probs[i].M);
+        const int bm = tile_m_of(probs[0]), bn = tile_n_of(probs[0]);
         tiles[i] = cdiv(probs[i].M, bm) * cdiv(probs[i].N, bn);
         kts[i] = probs[i].ktiles();
         if (kts[i] > max_kt) max_kt = kts[i];
@@ -520,12 +521,12 @@ int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag
     GemmLaunch L;
     L.ntasks = n;
     int wg = 0;
-    const int bm = gemm_tile_m(probs[0].M), bn = gemm_tile_n(probs[0].M);
+    const int bm = tile_m_of(probs[0]), bn = tile_n_of(probs[0]);
     for (int i = 0; i < n; ++i) {
         const GemmProb& p = probs[i];
         GemmTask& t = L.t[i];
         if (p.M <= 0 || p.N <= 0 || p.nseg <= 0 || p.nseg > GEMM_MAX_SEG || !p.C) return SET_ERR_ARG;
-        if (gemm_tile_m(p.M) != bm) return SET_ERR_ARG;   // one tile shape per launch
+        if (!probs[0].bm_hint && gemm_tile_m(p.M) != bm) return SET_ERR_ARG;   // one tile shape per launch
         int kt = 0;
         for (int s = 0; s < GEMM_MAX_SEG; ++s) {
             if (s < p.nseg) {

@@ -38,6 +38,10 @@ struct FusedArgs {
     int t, reverse, out_col0;
     RowGather g0, g1;                   // CTXGATE: token-table addends of z and of the tc_affine term
     const int64_t* seq; int seq_T, seq_V; // ENCLSTM with a token table: xg row = e0 + seq[m*seq_T + pos] * ld_xg_row (V rows)
+    // ENCLSTM, optional: rows visited in order of decreasing length (perm[sorted position] = row) so that whole 32-row
+    // tiles whose rows have all finished (sorted position >= nactive[t]) skip the contraction (the reference shrinks
+    // its length-sorted batch prefix the same way, editnet.py:333-335)
+    const int* perm; const int* nactive;
 };
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
@@ -70,6 +74,7 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
         for (int i = 0; i < LPT; ++i) {
             int r = m0 + srow + RPP * i;
             r = r < P.M ? r : P.M - 1;
+            if (EPI == EPI_ENCLSTM && P.perm) r = P.perm[r];
             pa[a][i] = (gptr4)(P.A[a] + (long long)r * P.lda[a] + scol);
         }
 #pragma unroll
@@ -121,8 +126,14 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
 
     // ---- epilogue operands do not depend on the contraction: fetch them now, under the k-loop
     const int erow = tid >> 3, ec4 = (tid & 7) * 4, eu = tid & 7;
-    const long long em = m0 + erow;
-    const bool erow_ok = em < P.M;
+    const bool erow_ok = m0 + erow < P.M;
+    const long long em = (EPI == EPI_ENCLSTM && P.perm) ? (long long)P.perm[erow_ok ? m0 + erow : P.M - 1] : (long long)(m0 + erow);
+    if (EPI == EPI_ENCLSTM && P.nactive && m0 >= P.nactive[P.t]) {
+        // every row of this tile has finished (rows are visited longest first): carry the state, skip the contraction
+        const int unit = n0 + eu;
+        if (erow_ok && unit < P.N) P.o0[em * P.N + unit] = P.e1[em * P.N + unit];
+        return;
+    }
     f32x4 pre0 = {0.f, 0.f, 0.f, 0.f}, pre1 = {0.f, 0.f, 0.f, 0.f}, pre2 = {0.f, 0.f, 0.f, 0.f}, pre3 = {0.f, 0.f, 0.f, 0.f};
     float eg[4] = {0.f, 0.f, 0.f, 0.f}, ecp = 0.f, ehin = 0.f;
     int elen = 0, epos = 0;
@@ -331,11 +342,35 @@ int fused_copy_gate_pre(const float* c_new, const float* sel, const float* cmem_
     return launch_fused<1, true, 64, EPI_COPYGATE1>(P, grid, s);
 }
 
+// perm[p] = row with the p-th longest sequence (stable: ties keep row order); nactive[t] = #rows with len > t
+__global__ void __launch_bounds__(1024) encoder_order_k(const int64_t* lens, int B, int T, int* perm, int* nactive) {
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const long long lb = lens[b];
+        int rank = 0;
+        for (int j = 0; j < B; ++j) {
+            const long long lj = lens[j];
+            rank += (lj > lb) || (lj == lb && j < b);
+        }
+        perm[rank] = b;
+    }
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        int n = 0;
+        for (int j = 0; j < B; ++j) n += lens[j] > t;
+        nactive[t] = n;
+    }
+}
+
+int encoder_order(const int64_t* lens, int B, int T, int* perm, int* nactive, hipStream_t s) {
+    hipLaunchKernelGGL(encoder_order_k, dim3(1), dim3(1024), 0, s, lens, B, T, perm, nactive);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
 // one encoder timestep: gates = h_in W_hh^T + xg[b,pos] + b_extra -> (h_out, c, H[b,pos], Mem[b,pos])
 int fused_encoder_step(const float* h_in, float* h_out, float* c, const float* w_hh, const float* xg,
                        long long ld_xg_row, long long ld_xg_t, const float* b_extra, const int64_t* lens, int t,
                        int reverse, float* H, float* Mem, long long ld_out_b, long long ld_out_t, int out_col0, int B,
-                       int D, hipStream_t s, const int64_t* seq, int seq_T, int seq_V) {
+                       int D, hipStream_t s, const int64_t* seq, int seq_T, int seq_V, const int* perm, const int* nactive) {
     if (D % 128) return SET_ERR_UNSUPPORTED;
     FusedArgs P{};
     P.A[0] = h_in; P.lda[0] = D; P.W[0] = w_hh; P.ldw[0] = D;
@@ -343,6 +378,7 @@ int fused_encoder_step(const float* h_in, float* h_out, float* c, const float* w
     P.b0 = b_extra; P.e0 = xg; P.e1 = h_in; P.o0 = h_out; P.o1 = c; P.o2 = H; P.o3 = Mem; P.lens = lens;
     P.ld_xg_row = ld_xg_row; P.ld_xg_t = ld_xg_t; P.ld_out_b = ld_out_b; P.ld_out_t = ld_out_t;
     P.t = t; P.reverse = reverse; P.out_col0 = out_col0; P.seq = seq; P.seq_T = seq_T; P.seq_V = seq_V > 0 ? seq_V : 1;
+    P.perm = perm; P.nactive = nactive;
     const int grid = cdiv(B, 32) * cdiv(D, 8);
     ProfScope ps("fused_encoder_step", s, 8.0 * B * D * D, 4.0 * (4.0 * D * D + 8.0 * B * D));
     return launch_fused<1, true, 128, EPI_ENCLSTM>(P, grid, s);

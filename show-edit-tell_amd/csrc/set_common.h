@@ -69,6 +69,7 @@ struct GemmProb {
     int act = SET_ACT_NONE;      // fused only when ksplit == 1
     int ksplit = 1;              // filled by plan_ksplit or by the caller
     int max_ksplit = GEMM_MAX_KSPLIT;
+    int bm_hint = 0;             // 0: row tile chosen from M (gemm_tile_m); 64 / 128: forced for the whole launch (probs[0] decides)
     void add(const float* A, long long lda, const float* W, long long ldw, int K) {
         seg[nseg++] = GemmSeg{A, W, lda, ldw, K};
     }
@@ -111,7 +112,7 @@ GemmProb slab_prob(float* slab, int M, int N, int Bmax);
 GemmProb direct_prob(float* out, long long ldo, int M, int N, const float* bias, int act);
 int editnet_encoder(const SetEditNetWeights* w, const int64_t* seq, const int64_t* lens, float* H, float* Mem,
                     float* final_hidden, float* mask, int B, int T, int D, int V, float* emb_seq, float* xg,
-                    float* enc_h, float* enc_c, float* s_enc, float* s_aff, hipStream_t st);
+                    float* enc_h, float* enc_c, float* s_enc, float* s_aff, hipStream_t st, int* order = nullptr);
 
 // a per-row gathered addend: value(m, n) = tab[ids[m*id_stride]*ld + col0 + n]   (tab == NULL: none)
 struct RowGather {
@@ -184,7 +185,9 @@ int fused_copy_gate_pre(const float* c_new, const float* sel, const float* cmem_
 int fused_encoder_step(const float* h_in, float* h_out, float* c, const float* w_hh, const float* xg,
                        long long ld_xg_row, long long ld_xg_t, const float* b_extra, const int64_t* lens, int t,
                        int reverse, float* H, float* Mem, long long ld_out_b, long long ld_out_t, int out_col0, int B,
-                       int D, hipStream_t s, const int64_t* seq = nullptr, int seq_T = 0, int seq_V = 0);
+                       int D, hipStream_t s, const int64_t* seq = nullptr, int seq_T = 0, int seq_V = 0, const int* perm = nullptr,
+                       const int* nactive = nullptr);
+int encoder_order(const int64_t* lens, int B, int T, int* perm, int* nactive, hipStream_t s);
 
 // epilogue.hip
 int greedy_pick(Slabs logits, const float* bias, int V, int t, int max_len, long long end_idx,
