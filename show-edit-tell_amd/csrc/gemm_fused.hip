@@ -344,18 +344,21 @@ int fused_copy_gate_pre(const float* c_new, const float* sel, const float* cmem_
 
 // perm[p] = row with the p-th longest sequence (stable: ties keep row order); nactive[t] = #rows with len > t
 __global__ void __launch_bounds__(1024) encoder_order_k(const int64_t* lens, int B, int T, int* perm, int* nactive) {
+    __shared__ int sl[4096];                              // B <= 4096 (host check): the lengths once, then LDS only
+    for (int b = threadIdx.x; b < B; b += blockDim.x) sl[b] = (int)lens[b];
+    __syncthreads();
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
-        const long long lb = lens[b];
+        const int lb = sl[b];
         int rank = 0;
         for (int j = 0; j < B; ++j) {
-            const long long lj = lens[j];
+            const int lj = sl[j];
             rank += (lj > lb) || (lj == lb && j < b);
         }
         perm[rank] = b;
     }
     for (int t = threadIdx.x; t < T; t += blockDim.x) {
         int n = 0;
-        for (int j = 0; j < B; ++j) n += lens[j] > t;
+        for (int j = 0; j < B; ++j) n += sl[j] > t;
         nactive[t] = n;
     }
 }
