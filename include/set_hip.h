@@ -388,6 +388,21 @@ typedef struct SetGemmDesc {
 int set_gemm_group_f32(const SetGemmDesc* descs, int n, int a_kminor, int b_kminor, void* ws, size_t ws_bytes,
                        void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Host-side CIDEr-D for the self-critical reward (HOST pointers, no stream: per-sample n-gram work that shards with
+ * the batch; the reference calls an external Python scorer at editnet_rl.py:636).  Sentences are int64 token ids.
+ * create: the document-frequency table of preprocess_rl.py:7-55 as n_entries n-grams (entry i = lens[i] <= 4 ids at
+ * tokens[4 i ..]) with their document counts df[i]; ref_len = number of documents; n = 4, sigma = 6 for CIDEr-D.
+ * score: hypothesis i = hyp_tokens[hyp_off[i] .. hyp_off[i+1]) against reference set set_of_hyp[i]; set s = references
+ * [ref_set_off[s], ref_set_off[s+1]); reference r = ref_tokens[ref_off[r] .. ref_off[r+1]).  scores: n_hyp doubles.
+ * ------------------------------------------------------------------------------------------ */
+void* set_ciderd_create(const int64_t* tokens, const int32_t* lens, const double* df, int64_t n_entries, double ref_len,
+                        int n, double sigma);
+void set_ciderd_destroy(void* scorer);
+int set_ciderd_score(void* scorer, const int64_t* hyp_tokens, const int64_t* hyp_off, int n_hyp,
+                     const int32_t* set_of_hyp, const int64_t* ref_tokens, const int64_t* ref_off,
+                     const int64_t* ref_set_off, int n_sets, double* scores);
+
 #ifdef __cplusplus
 }
 #endif

@@ -214,6 +214,9 @@ PROTOTYPES = {
     "set_beam_gather_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "set_gemm_group_f32": (_I, [C.POINTER(GemmDesc), _I, _I, _I, _P, _Z, _P]),
     "set_gemm_f32": (_I, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, _I, _P, _Z, _P]),
+    "set_ciderd_create": (_P, [_P, _P, _P, _L, C.c_double, _I, C.c_double]),
+    "set_ciderd_destroy": (None, [_P]),
+    "set_ciderd_score": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _P]),
     "set_caption_encoder_workspace_bytes": (_Z, [_I, _I, _I]),
     "set_caption_encoder_f32": (_I, [C.POINTER(EditNetWeights), _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P]),
 }

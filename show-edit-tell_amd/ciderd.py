@@ -14,6 +14,10 @@ frequency table has the format `preprocess_rl.py:7-55` writes: {n-gram tuple of 
 images whose reference set contains it} plus `ref_len` = number of images.
 
 Host-side, per-sample work (strings and dictionaries): it shards with the batch and never touches the GPU.
+`compute_score` runs on the native implementation in csrc/ciderd_host.hip (`set_ciderd_*`, host pointers): in Python
+the scorer was half of the SCST step's wall time at 5 samples per image.  The pure-Python `score` below is the
+readable statement of the metric and the cross-check of the native one (tests/test_ciderd.py); identical
+(reference set, caption) pairs of a batch — e.g. the greedy baseline repeated for every sample — are scored once.
 """
 from __future__ import annotations
 
@@ -51,9 +55,59 @@ class CiderD:
     def __init__(self, df, ref_len, n=4, sigma=6.0):
         """df: n-gram -> document count; ref_len: number of documents the table was built from"""
         self.df = df
+        self.ref_len = float(ref_len)
         self.log_ref_len = math.log(float(ref_len))
         self.n = n
         self.sigma = sigma
+        self._tok = {}           # token string -> int id (interned for the native scorer)
+        self._native = None
+
+    # ---- native scorer (csrc/ciderd_host.hip) -------------------------------------------------------------
+    def _ids(self, sentence):
+        tok = self._tok
+        return [tok.setdefault(w, len(tok)) for w in sentence.split()]
+
+    def _handle(self):
+        """Build the native df table once (None if the library is unavailable: pure-Python scoring then)."""
+        if self._native is None:
+            try:
+                from . import _lib
+                lib = _lib.load()
+                if "set_ciderd_create" in _lib.MISSING:
+                    raise _lib.SetError("library without CIDEr-D")
+            except Exception:
+                self._native = False
+                return None
+            grams = [g for g in self.df if 1 <= len(g) <= 4]
+            toks = np.zeros((max(1, len(grams)), 4), dtype=np.int64)
+            lens = np.zeros(max(1, len(grams)), dtype=np.int32)
+            cnt = np.zeros(max(1, len(grams)), dtype=np.float64)
+            tok = self._tok
+            for i, g in enumerate(grams):
+                lens[i] = len(g)
+                cnt[i] = self.df[g]
+                for j, w in enumerate(g):
+                    toks[i, j] = tok.setdefault(w, len(tok))
+            h = lib.set_ciderd_create(toks.ctypes.data, lens.ctypes.data, cnt.ctypes.data, len(grams), self.ref_len,
+                                      self.n, self.sigma)
+            if not h:
+                self._native = False
+                return None
+            self._native = (lib, h)
+        return self._native or None
+
+    def __del__(self):
+        if isinstance(getattr(self, "_native", None), tuple):
+            lib, h = self._native
+            try:
+                lib.set_ciderd_destroy(h)
+            except Exception:
+                pass
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_native"] = None
+        return st
 
     def _vector(self, counts):
         vec = [dict() for _ in range(self.n)]
@@ -95,12 +149,57 @@ class CiderD:
     def compute_score(self, gts, res):
         """Same call shape as the external scorer at editnet_rl.py:636: gts = {image_id: [ref strings]},
         res = [{'image_id': id, 'caption': [string]}].  Returns (mean score, per-entry scores)."""
+        nat = self._handle()
+        if nat is None:
+            return self._compute_score_py(gts, res)
+        lib, h = nat
+        # reference sets and (set, caption) pairs are de-duplicated by content
+        set_index, sets = {}, []
+        pair_index, pairs = {}, []
+        which = np.zeros(len(res), dtype=np.int64)
+        for i, r in enumerate(res):
+            refs = gts[r['image_id']]
+            key = tuple(refs)
+            si = set_index.get(key)
+            if si is None:
+                si = set_index[key] = len(sets)
+                sets.append(refs)
+            pk = (si, r['caption'][0])
+            pi = pair_index.get(pk)
+            if pi is None:
+                pi = pair_index[pk] = len(pairs)
+                pairs.append(pk)
+            which[i] = pi
+        ref_tok, ref_off, set_off = [], [0], [0]
+        for refs in sets:
+            for sref in refs:
+                ref_tok += self._ids(sref)
+                ref_off.append(len(ref_tok))
+            set_off.append(len(ref_off) - 1)
+        hyp_tok, hyp_off, set_of = [], [0], []
+        for si, cap in pairs:
+            hyp_tok += self._ids(cap)
+            hyp_off.append(len(hyp_tok))
+            set_of.append(si)
+        a = lambda x, dt: np.ascontiguousarray(np.asarray(x if len(x) else [0], dtype=dt))
+        ht, ho, so = a(hyp_tok, np.int64), a(hyp_off, np.int64), a(set_of, np.int32)
+        rt, ro, rs = a(ref_tok, np.int64), a(ref_off, np.int64), a(set_off, np.int64)
+        out = np.zeros(max(1, len(pairs)), dtype=np.float64)
+        rc = lib.set_ciderd_score(h, ht.ctypes.data, ho.ctypes.data, len(pairs), so.ctypes.data, rt.ctypes.data,
+                                  ro.ctypes.data, rs.ctypes.data, len(sets), out.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("set_ciderd_score failed with code %d" % rc)
+        scores = out[which] if len(res) else np.zeros(0)
+        return float(scores.mean()) if len(res) else 0.0, scores
+
+    def _compute_score_py(self, gts, res):
+        """pure-Python twin of compute_score (cross-check; also the fallback when the library is not built)"""
         cache = {}
         scores = np.zeros(len(res))
         for i, r in enumerate(res):
             key = r['image_id']
             refs = gts[key]
-            rk = id(refs)
+            rk = tuple(refs)
             if rk not in cache:
                 cache[rk] = [self._vector(ngram_counts(s, self.n)) for s in refs]
             hyp = self._vector(ngram_counts(r['caption'][0], self.n))
@@ -140,7 +239,15 @@ def self_critical_reward(scorer, sampled, greedy, ground_truth, cider_weight=1.0
     sampled = np.asarray(sampled.cpu() if hasattr(sampled, 'cpu') else sampled)
     greedy = np.asarray(greedy.cpu() if hasattr(greedy, 'cpu') else greedy)
     B = sampled.shape[0]
-    refs = [[tokens_to_str(c) for c in caps] for caps in ground_truth]
+    memo = {}                    # the same image's reference lists are repeated once per sample: stringify them once
+
+    def ref_strings(caps):
+        k = id(caps)
+        if k not in memo:
+            memo[k] = [tokens_to_str(c) for c in caps]
+        return memo[k]
+
+    refs = [ref_strings(caps) for caps in ground_truth]
     gts = {i: refs[i % B] for i in range(2 * B)}
     res = [{'image_id': i, 'caption': [tokens_to_str(sampled[i])]} for i in range(B)]
     res += [{'image_id': B + i, 'caption': [tokens_to_str(greedy[i])]} for i in range(B)]

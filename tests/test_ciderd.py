@@ -58,3 +58,33 @@ def test_reward_plumbing():
     r = ciderd.self_critical_reward(s, sampled, greedy, gt)
     assert r.shape == (2, 4) and r.dtype == np.float32
     assert np.allclose(r[0], 10.0) and np.allclose(r[1], -10.0)
+
+
+def test_native_scorer_matches_python_statement():
+    """csrc/ciderd_host.hip (set_ciderd_*) against the pure-Python statement of the metric on a random corpus:
+    ragged lengths, repeated words (count clipping), unseen n-grams, duplicated (image, caption) pairs."""
+    rng = np.random.default_rng(0)
+    V, NI = 40, 12
+    refs = [[" ".join(str(int(w)) for w in rng.integers(1, V, rng.integers(3, 12))) + " 0" for _ in range(5)] for _ in range(NI)]
+    df, docs = ciderd.document_frequency(refs)
+    s = ciderd.CiderD(df, docs)
+    res, gts = [], {}
+    for i in range(60):
+        img = int(rng.integers(0, NI))
+        gts[i] = refs[img]
+        if i % 7 == 0:
+            cap = refs[img][int(rng.integers(0, 5))]                       # an exact reference
+        elif i % 7 == 1 and res:
+            cap = res[-1]["caption"][0]                                   # duplicate of the previous caption
+            gts[i] = gts[i - 1]
+        else:
+            cap = " ".join(str(int(w)) for w in rng.integers(1, V + 5, rng.integers(0, 14))) + " 0"
+        res.append({"image_id": i, "caption": [cap]})
+    mean_n, per_n = s.compute_score(gts, res)
+    assert s._native, "the native scorer must be in use (libset_hip.so exports set_ciderd_*)"
+    mean_p, per_p = s._compute_score_py(gts, res)
+    assert np.allclose(per_n, per_p, rtol=0, atol=1e-10), float(np.abs(per_n - per_p).max())
+    assert abs(mean_n - mean_p) < 1e-10
+    for i in (0, 7, 14):
+        assert abs(per_n[i] - s.score(res[i]["caption"][0], gts[i])) < 1e-10
+    assert per_n[0] > 1.0

@@ -99,3 +99,23 @@ def test_dp_hip_model_full_size_two_ranks_one_device_gloo():
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
 def test_dp_nccl_two_devices():
     _run("nccl", False, "editnet_small", 64 << 10)
+
+
+def test_bench_gpus_flag_spawns_ranks():
+    """`python bench.py --gpus 2` (no torchrun around it) must launch two ranks and report n_gpus = 2 — the command the
+    driver uses for its scaling run.  On the one-GPU test box both ranks share cuda:0 over gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SET_BENCH_ONE_DEVICE="1", SET_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--repeat", "1", "--no-profile", "--no-cpu-baseline", "--train-steps", "2"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
+    assert line["value"] > 0 and line["config"]["parallelism"].startswith("dp2")
+    tr = line["train"]
+    assert tr["n_gpus"] == 2 and tr["ms_per_train_step"] > 0 and "allreduce_exposed_ms" in tr

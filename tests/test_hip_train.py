@@ -184,6 +184,38 @@ def test_scst_train_step_with_ciderd_reward():
     assert all(torch.isfinite(p).all() for p in rl.parameters())
 
 
+def test_scst_full_size_five_samples():
+    """BASELINE.json configs[4] shape (full-size model, 5 sampled rollouts per image, CIDEr-D reward) at a small batch:
+    one self-critical step runs end to end — greedy baseline (fused loop) + 5·B sampled rows (device sampling epilogue)
+    + native CIDEr-D + backward + clip + Adam — with finite numbers, and the sampled log-probs are the log-softmax of the
+    step's logits at the drawn words (re-scored teacher-forced in eval mode is NOT comparable: dropout is active)."""
+    from show_edit_tell_amd import ciderd
+    from show_edit_tell_amd.train import scst_train_step
+    d, xe, rl = editnet_modules("editnet_full_b4")
+    wm = d["wm"]
+    prev, plen, X = to_dev(d["prev"]), to_dev(d["plen"]), to_dev(d["X"])
+    B, V = X.shape[0], len(wm)
+    rng = np.random.default_rng(7)
+    allcaps = np.zeros((B, 5, 20), dtype=np.int64)
+    for b in range(B):
+        for j in range(5):
+            n = int(rng.integers(6, 17))
+            allcaps[b, j, 0] = wm["<start>"]
+            allcaps[b, j, 1:1 + n] = rng.integers(1, V - 4, n)
+            allcaps[b, j, 1 + n] = wm["<end>"]
+    gt = ciderd.ground_truth_lists(allcaps, wm)
+    df, docs = ciderd.document_frequency([[ciderd.tokens_to_str(c) for c in caps] for caps in gt])
+    scorer = ciderd.CiderD(df, max(docs, 2))
+    opt = torch.optim.Adam(rl.parameters(), lr=5e-5)
+    before = rl.fc.weight.detach().clone()
+    torch.manual_seed(9)
+    reward, loss = scst_train_step(rl, opt, wm, X, prev, plen, gt, scorer, n_samples=5)
+    assert np.isfinite(reward) and np.isfinite(loss)
+    assert scorer._native, "the reward must come from the native CIDEr-D"
+    assert not torch.equal(before, rl.fc.weight.detach())
+    assert all(torch.isfinite(p).all() for p in rl.parameters())
+
+
 def test_adaptive_xe_gradients_vs_reference_autograd():
     """Adaptive features (10-100 zero-padded regions): gradients of CE + MSE(decoder_last_hidden, gd_final_hidden)
     (adaptive_features/editnet_adaptive.py:584-598) through the masked visual attention, against the reference."""
