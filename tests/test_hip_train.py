@@ -195,17 +195,23 @@ def test_scst_full_size_five_samples():
     wm = d["wm"]
     prev, plen, X = to_dev(d["prev"]), to_dev(d["plen"]), to_dev(d["X"])
     B, V = X.shape[0], len(wm)
-    rng = np.random.default_rng(7)
+    # references = five captions sampled from the model itself (fused sampled rollout, eval mode): random word
+    # salad would share no n-gram with the rollouts and every reward would be exactly zero
+    rl.eval()
     allcaps = np.zeros((B, 5, 20), dtype=np.int64)
-    for b in range(B):
+    with torch.no_grad():
         for j in range(5):
-            n = int(rng.integers(6, 17))
-            allcaps[b, j, 0] = wm["<start>"]
-            allcaps[b, j, 1:1 + n] = rng.integers(1, V - 4, n)
-            allcaps[b, j, 1 + n] = wm["<end>"]
+            torch.manual_seed(100 + j)
+            sj, _ = rl(wm, prev, plen, X, sample_max=False, sample_rl=True)
+            sj = sj.cpu().numpy()
+            for b in range(B):
+                words = [int(w) for w in sj[b] if w > 0][:17]
+                allcaps[b, j, 0] = wm["<start>"]
+                allcaps[b, j, 1:1 + len(words)] = words
+                allcaps[b, j, 1 + len(words)] = wm["<end>"]
     gt = ciderd.ground_truth_lists(allcaps, wm)
     df, docs = ciderd.document_frequency([[ciderd.tokens_to_str(c) for c in caps] for caps in gt])
-    scorer = ciderd.CiderD(df, max(docs, 2))
+    scorer = ciderd.CiderD(df, 50)                       # pretend the table came from a larger corpus (idf > 0)
     opt = torch.optim.Adam(rl.parameters(), lr=5e-5)
     before = rl.fc.weight.detach().clone()
     torch.manual_seed(9)
