@@ -589,8 +589,14 @@ class DecoderC(nn.Module):
         # padded ones stay exactly zero; the score mask is re-derived from the embedded rows
         valid = (X.sum(2) != 0).float().unsqueeze(2) if self._adaptive else None
 
-        def embed_regions(Xb, vb):
-            fe = va.att_embed[2](A.linear(Xb, va.att_embed[0].weight, va.att_embed[0].bias, _lib.ACT_RELU))
+        # relu(att_embed.0(X)) (editnet.py:441, 19.3 GFLOP at B=128) does not depend on the timestep: only the Dropout(0.5)
+        # mask drawn on top of it does.  It is contracted ONCE per sequence — and so is its weight gradient, from the sum
+        # over the timesteps of the masked upstream gradients that autograd accumulates — instead of once per timestep
+        # as the reference writes it; values and gradients are those of the reference for the same masks.
+        Y = A.linear(X, va.att_embed[0].weight, va.att_embed[0].bias, _lib.ACT_RELU)
+
+        def embed_regions(Yb, vb):
+            fe = va.att_embed[2](Yb)                    # fresh dropout mask per call in train mode
             if vb is None:
                 return fe, None
             fe = fe * vb
@@ -598,7 +604,7 @@ class DecoderC(nn.Module):
 
         att1_eval = rmask_eval = None
         if not self.training:            # dropout inactive: features_att(att_embed(X)) is loop invariant
-            fe, rmask_eval = embed_regions(X, valid)
+            fe, rmask_eval = embed_regions(Y, valid)
             att1_eval = A.linear(fe, va.features_att.weight, va.features_att.bias)
         prev_scores = None
         last_parts = []                  # rows leaving the batch after this step, with their final h2 (adaptive :560)
@@ -631,7 +637,7 @@ class DecoderC(nn.Module):
             if att1_eval is not None:
                 att1, rmask = head(att1_eval, bt), (None if rmask_eval is None else head(rmask_eval, bt))
             else:                                                                     # fresh dropout mask per step
-                fe, rmask = embed_regions(head(X, bt), None if valid is None else head(valid, bt))
+                fe, rmask = embed_regions(head(Y, bt), None if valid is None else head(valid, bt))
                 att1 = A.linear(fe, va.features_att.weight, va.features_att.bias)
             attend_img = A.visual_attention_from_att1(head(X, bt), att1, h1, va.decoder_att.weight, va.decoder_att.bias,
                                                       va.full_att.weight, va.full_att.bias, rmask)

@@ -79,10 +79,11 @@ class DecoderC(_DecoderXE):
         ca, va, cl, al = self.caption_attention, self.visual_attention, self.copy_lstm, self.attention_lstm
         E = self.embed.embedding.weight
         att1_c_all = A.linear(H, ca.cap_features_att.weight, ca.cap_features_att.bias)
+        # relu(att_embed.0(X)) is loop invariant (only its dropout mask is per step): contracted once, see editnet.py
+        Y = A.linear(X, va.att_embed[0].weight, va.att_embed[0].bias, _lib.ACT_RELU)
         att1_eval = None
         if not self.training:
-            att1_eval = A.linear(A.linear(X, va.att_embed[0].weight, va.att_embed[0].bias, _lib.ACT_RELU),
-                                 va.features_att.weight, va.features_att.bias)
+            att1_eval = A.linear(Y, va.features_att.weight, va.features_att.bias)
         unfinished = None
         state = A.SampleState(B, max_len, word_map['<start>'], word_map['<end>'], dev) if sample_rl else None
         for t in range(max_len + 1):
@@ -99,8 +100,7 @@ class DecoderC(_DecoderXE):
             if att1_eval is not None:
                 att1 = att1_eval
             else:
-                fe = va.att_embed[2](A.linear(X, va.att_embed[0].weight, va.att_embed[0].bias, _lib.ACT_RELU))
-                att1 = A.linear(fe, va.features_att.weight, va.features_att.bias)
+                att1 = A.linear(va.att_embed[2](Y), va.features_att.weight, va.features_att.bias)
             attend_img = A.visual_attention_from_att1(X, att1, h1, va.decoder_att.weight, va.decoder_att.bias,
                                                       va.full_att.weight, va.full_att.bias)
             sel = A.select(M, alpha_c)
