@@ -417,7 +417,7 @@ def train_leg(args, dec, wm, X, caps, clen, prev, plen, dev, dist, rank, world, 
     xe = editnet.DecoderC(wm, D, D, D, A, F)
     xe.load_state_dict(dec.state_dict())
     xe = xe.to(dev)
-    opt = torch.optim.Adam(xe.parameters(), lr=5e-4)                     # editnet.py:749
+    opt = torch.optim.Adam(xe.parameters(), lr=5e-4, fused=True)         # editnet.py:749 (torch's single-kernel Adam)
     K = max(2, args.train_steps)
 
     def timed(reduce):
