@@ -261,12 +261,35 @@ static int begin_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const
 // One timestep for rows [0,bt).  ws.emb must already hold relu(E[token]).  The vocabulary
 // projection is left as split-K slabs (`*logits_out`, bias NOT yet added) unless `dst` is given,
 // in which case (bt,V) logits with bias are written to dst (leading stride ld_dst).
+// The phase-A problems of a timestep (unplanned): attention-LSTM gate product over [emb|h2|h1] (emb omitted with the
+// token table) and the copy-LSTM's h2h(h2).
+static void build_phase_a(const SetEditNetWeights* w, const SetEditNetDims* d, EditNetWs& ws, int bt, bool tab,
+                          GemmProb a[2]) {
+    const int B = d->B, D = d->D;
+    const long long ld_ih = 3LL * D + d->F;
+    a[0] = slab_prob(ws.sA0, bt, 4 * D, B);
+    if (!tab) a[0].add(ws.emb, D, w->al_wih, ld_ih, D);
+    a[0].add(ws.h2, D, w->al_wih + 2 * D, ld_ih, D);
+    a[0].add(ws.h1, D, w->al_whh, D, D);
+    a[1] = slab_prob(ws.sA1, bt, 4 * D, B);
+    a[1].add(ws.h2, D, w->cl_h2h_w, D, D);
+}
+
+// F/A merge: with the token table NOTHING in phase A of timestep t+1 depends on the token timestep t is about to pick
+// (the token only selects a table row that the LSTM pointwise adds), and h1 / h2 of timestep t are final before its
+// vocabulary projection starts.  The free-running loop therefore launches fc(h2_t) and the phase-A products of t+1 as ONE
+// grouped GEMM (5.8 GFLOP, 32 k-tiles per workgroup, fc unsplit with its bias fused) instead of two launches with
+// 16-k-tile workgroups: one launch ramp less per timestep, half the logit traffic into the pick.
+//   a_pre  != NULL: phase A of THIS timestep was launched by the previous one; these are its planned problems
+//   a_next != NULL: launch the NEXT timestep's phase A together with this timestep's fc and return its problems here
+//   *logits_biased: set when the returned logits already include fc.bias (unsplit fc)
 static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X, int bt, EditNetWs& ws,
                      const long long* tok_ids, long long tok_stride, float* dst,
-                     long long ld_dst, Slabs* logits_out, hipStream_t st) {
+                     long long ld_dst, Slabs* logits_out, hipStream_t st, const GemmProb* a_pre = nullptr,
+                     GemmProb* a_next = nullptr, bool* logits_biased = nullptr) {
     const int B = d->B, T = d->T, R = d->R, F = d->F, D = d->D, A = d->A, V = d->V;
     const int tgt = gemm_target_wgs();
-    const long long ld_ih = 3LL * D + F, ld_x2h = 2LL * D + F;
+    const long long ld_x2h = 2LL * D + F;
     // ---- A
     // token-only contractions folded into the (V,6D) table (inference): their K-segments disappear and the
     // consuming pointwise kernels add the gathered table row instead
@@ -279,14 +302,13 @@ static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const 
         g_cg = RowGather{w->tok_table, tok_ids, tok_stride, 10LL * D, 5 * D, V};
     }
     GemmProb a[2];
-    a[0] = slab_prob(ws.sA0, bt, 4 * D, B);
-    if (!tab) a[0].add(ws.emb, D, w->al_wih, ld_ih, D);
-    a[0].add(ws.h2, D, w->al_wih + 2 * D, ld_ih, D);
-    a[0].add(ws.h1, D, w->al_whh, D, D);
-    a[1] = slab_prob(ws.sA1, bt, 4 * D, B);
-    a[1].add(ws.h2, D, w->cl_h2h_w, D, D);
-    plan_ksplit(a, 2, tgt);
-    SET_TRY(gemm_group(a, 2, st, "gemm:A gates1+h2h"));
+    if (a_pre) {
+        a[0] = a_pre[0]; a[1] = a_pre[1];
+    } else {
+        build_phase_a(w, d, ws, bt, tab, a);
+        plan_ksplit(a, 2, tgt);
+        SET_TRY(gemm_group(a, 2, st, "gemm:A gates1+h2h"));
+    }
     const Slabs none{nullptr, 0, 0, 0};
     SET_TRY(lstm_pointwise(slabs_of(a[0]), none, none, ws.pre1, 4 * D, nullptr, nullptr, ws.c1, ws.c1, ws.h1, nullptr,
                            bt, D, st, g_gates));
@@ -350,6 +372,21 @@ static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const 
     f.add(ws.h2, D, w->fc_w, D, D);
     static const int f_bm = env_int("SET_GEMM_F_BM", 0);
     if (bt > 64) f.bm_hint = f_bm;
+    if (logits_biased) *logits_biased = false;
+    if (a_next && tab && !dst) {
+        GemmProb fa[3];
+        fa[0] = f;
+        build_phase_a(w, d, ws, bt, true, fa + 1);
+        plan_ksplit(fa, 3, tgt);
+        if (fa[0].ksplit == 1) {             // unsplit fc: write the logits once, bias fused
+            fa[0].C = ws.logits; fa[0].slab_stride = 0; fa[0].bias = w->fc_b;
+            if (logits_biased) *logits_biased = true;
+        }
+        SET_TRY(gemm_group(fa, 3, st, "gemm:F fc + next A"));
+        a_next[0] = fa[1]; a_next[1] = fa[2];
+        if (logits_out) *logits_out = slabs_of(fa[0]);
+        return SET_OK;
+    }
     plan_ksplit(&f, 1, tgt);
     if (dst && f.ksplit == 1) {
         f.C = dst; f.ldc = ld_dst; f.bias = w->fc_b; f.slab_stride = 0;
@@ -437,16 +474,26 @@ static int rollout(const SetEditNetWeights* w, const SetEditNetDims* d, const fl
     // so the epilogue skips the embedding gather
     const bool emb_needed = !(w->tok_table && (d->D % 64 == 0) && env_int("SET_NO_FUSED", 0) == 0);
     // the reference runs max_len + 1 timesteps and discards the last one (editnet_rl.py:503,517-518)
+    static const int fa_merge = env_int("SET_FA_MERGE", 1);
+    const bool merge = fa_merge && !emb_needed;      // the token table is active: phase A does not see the token
+    GemmProb a_cur[2], a_nxt[2];
+    bool have_a = false;
     for (int t = 0; t <= max_len; ++t) {
         Slabs lg;
-        SET_TRY(step_impl(w, d, X, B, W, W.it, 1, nullptr, 0, &lg, st));
+        bool biased = false;
+        const bool next_a = merge && t < max_len;     // there is a next timestep to pre-launch phase A for
+        SET_TRY(step_impl(w, d, X, B, W, W.it, 1, nullptr, 0, &lg, st, have_a ? a_cur : nullptr, next_a ? a_nxt : nullptr,
+                          &biased));
+        have_a = next_a;
+        if (next_a) { a_cur[0] = a_nxt[0]; a_cur[1] = a_nxt[1]; }
         if (t == max_len) break;
+        const float* pick_bias = biased ? nullptr : w->fc_b;
         if (sample)
-            SET_TRY(sample_pick(lg, w->fc_b, d->V, t, max_len, end_idx, (long long*)seq, seq_logp, W.it, W.unfinished,
+            SET_TRY(sample_pick(lg, pick_bias, d->V, t, max_len, end_idx, (long long*)seq, seq_logp, W.it, W.unfinished,
                                 W.alive, emb_needed ? w->embed : nullptr, W.emb, d->D, B, seed, offset, nullptr, nullptr,
                                 nullptr, st));
         else
-            SET_TRY(greedy_pick(lg, w->fc_b, d->V, t, max_len, end_idx, (long long*)seq, seq_logp, W.it, W.unfinished,
+            SET_TRY(greedy_pick(lg, pick_bias, d->V, t, max_len, end_idx, (long long*)seq, seq_logp, W.it, W.unfinished,
                                 W.alive, emb_needed ? w->embed : nullptr, W.emb, d->D, B, st));
     }
     return SET_OK;
