@@ -333,7 +333,10 @@ def main():
 
     train = None
     if not args.no_train:
-        train = train_leg(args, dec, wm, X, caps, clen, prev, plen, dev, dist, rank, world, barrier, max_over_ranks)
+        try:
+            train = train_leg(args, dec, wm, X, caps, clen, prev, plen, dev, dist, rank, world, barrier, max_over_ranks)
+        except Exception as e:          # the secondary leg must never take the headline line down with it
+            train = {"error": repr(e)[:300]}
 
     if rank != 0:
         if dist is not None:

@@ -158,21 +158,30 @@ def _wgrad_mm(dy, x, out=None):
 # Inside `deferred_param_grads()` the per-timestep weight/bias gradient contributions are only recorded;
 # on exit every parameter gets ONE contraction over all timesteps (dW += cat(dy)^T . cat(x): contraction
 # length 19 x B instead of 19 GEMMs of length B that each re-read and re-write the whole .grad).
-_deferred = None
+import threading as _threading
+
+_tls = _threading.local()          # the pending table is per thread (autograd runs a .backward() on the calling thread's
+                                   # device thread; two models training on two threads must not share it)
+
+
+def _pending():
+    return getattr(_tls, "deferred", None)
 
 
 @contextlib.contextmanager
 def deferred_param_grads(on_ready=None):
     """`on_ready(param)` is called as soon as a parameter's gradient is final (used by the data-parallel step to
-    start the all-reduce of a bucket while the remaining weight-gradient contractions still run)."""
-    global _deferred
-    if _deferred is not None or not _FUSED_WGRAD:
+    start the all-reduce of a bucket while the remaining weight-gradient contractions still run).
+    Only `loss.backward()` inside the context is supported: parameter gradients are written straight into `.grad`
+    (`torch.autograd.grad(loss, params)` and parameter hooks do not see them)."""
+    if _pending() is not None or not _FUSED_WGRAD:
         yield
         return
-    _deferred = {}
+    _tls.deferred = {}
+    _active[_threading.get_ident()] = _tls.deferred
     try:
         yield
-        pending, cat_cache = _deferred, {}
+        pending, cat_cache = _tls.deferred, {}
 
         def cat(ts):
             if len(ts) == 1:
@@ -199,7 +208,23 @@ def deferred_param_grads(on_ready=None):
             if on_ready is not None:
                 on_ready(param)
     finally:
-        _deferred = None
+        _active.pop(_threading.get_ident(), None)
+        _tls.deferred = None
+
+
+_active = {}        # thread id of the thread that opened a deferred context -> its table (autograd's backward may run on
+                    # a worker thread of the engine: it looks the table up through the single open context)
+
+
+def _deferred_table():
+    t = _pending()
+    if t is not None:
+        return t
+    # backward kernels are enqueued from the autograd engine's device thread, not from the thread that called
+    # loss.backward(): fall back to the one context that is open process-wide (None if there is none or several)
+    if len(_active) == 1:
+        return next(iter(_active.values()))
+    return None
 
 
 def _is_leaf_param(param):
@@ -213,8 +238,8 @@ def _wgrad(param, dy, x):
     skips its own accumulation.  Leaf parameters only; anything else gets the gradient returned."""
     if not _is_leaf_param(param):
         return _wgrad_mm(dy, x)
-    if _deferred is not None:
-        ent = _deferred.setdefault(id(param), (param, ([], [])))
+    if _deferred_table() is not None:
+        ent = _deferred_table().setdefault(id(param), (param, ([], [])))
         ent[1][0].append(dy)
         ent[1][1].append(x)
     elif param.grad is None:
@@ -227,8 +252,8 @@ def _wgrad(param, dy, x):
 def _bgrad(param, dy):
     if not _is_leaf_param(param):
         return dy.sum(0).reshape(param.shape)
-    if _deferred is not None:
-        ent = _deferred.setdefault(id(param), (param, ([], None)))
+    if _deferred_table() is not None:
+        ent = _deferred_table().setdefault(id(param), (param, ([], None)))
         ent[1][0].append(dy)
         return None
     g = dy.sum(0).reshape(param.shape)
