@@ -328,6 +328,23 @@ int set_attention_bwd_f32(const float* dctx, const float* dalpha_ext, const floa
                           const float* values, const float* att1, const float* att2, const float* w_full,
                           float* datt1, float* datt2, float* dwfull_part, float* dvalues, float* de, int M,
                           int L, int Dv, int A, int use_tanh, void* stream);
+/* Caption-encoder recurrence of the grad-enabled path (CaptionEncoderC editnet.py:333-338; the packed BiLSTM of
+ * dcnet.py:233), one step for all rows with the length handling inside the kernels: rows with t < lens[b] advance, the
+ * others carry (h, c) and emit zeros.  xg = hoisted input projection x W_x^T + b_x, element (b, t, :) at
+ * xg + b ld_xg_row + t ld_xg_t.  train: h_out / c_out (B,D) new state, H / Mem (Mem may be NULL) row (b, t) at
+ * b ld_out_b + t ld_out_t + out_col0, Hprev (same layout, may be NULL) receives h (the state the step started from, the
+ * operand of dW_hh), gates (B,4D) post-activations.  bwd: dH / dM (same layout as H / Mem, may be NULL) + dh / dc
+ * (B,D, may be NULL) -> dgates rows (b, :) at dgates + b ld_dg (pre-activation gradients = gradient of xg[b,t,:]),
+ * dc_prev (B,D) and dh_pass (B,D): the caller adds dgates W_hh to dh_pass to obtain dh of the previous step. */
+size_t set_encoder_cell_workspace_bytes(int B, int D);
+int set_encoder_cell_train_f32(const float* xg, int64_t ld_xg_row, int64_t ld_xg_t, const float* h, const float* c,
+                               const float* w_hh, const float* b_hh, const int64_t* lens, int t, float* h_out, float* c_out,
+                               float* H, float* Mem, float* Hprev, int64_t ld_out_b, int64_t ld_out_t, int out_col0,
+                               float* gates, int B, int D, void* ws, size_t ws_bytes, void* stream);
+int set_encoder_cell_bwd_f32(const float* dh, const float* dc, const float* dH, const float* dM, int64_t ld_d_b,
+                             int64_t ld_d_t, int d_col0, const int64_t* lens, int t, const float* gates,
+                             const float* c_prev, const float* c_new, float* dgates, int64_t ld_dg, float* dc_prev,
+                             float* dh_pass, int B, int D, void* stream);
 int set_select_bwd_f32(const float* dsel, const float* Mem, const float* alpha, float* dM, float* dalpha,
                        int M, int T, int D, void* stream);
 

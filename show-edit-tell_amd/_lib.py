@@ -206,6 +206,10 @@ PROTOTYPES = {
                                              _I, _I, _I, _I, _P, _Z, _P]),
     "set_context_gate_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "set_attention_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "set_encoder_cell_workspace_bytes": (_Z, [_I, _I]),
+    "set_encoder_cell_train_f32": (_I, [_P, _L, _L, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _L, _L, _I, _P, _I, _I, _P,
+                                        _Z, _P]),
+    "set_encoder_cell_bwd_f32": (_I, [_P, _P, _P, _P, _L, _L, _I, _P, _I, _P, _P, _P, _P, _L, _P, _P, _I, _I, _P]),
     "set_select_bwd_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "set_sample_pick_f32": (_I, [_P, _L, _I, _I, _I, _I, _L, _U, _U, _P, _P, _P, _P, _P, _P, _P, _P]),
     "set_sample_logp_bwd_f32": (_I, [_P, _L, _P, _P, _P, _P, _L, _I, _I, _P]),

@@ -373,6 +373,89 @@ def lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh):
 
 
 # ------------------------------------------------------------------------------------------------
+# The caption encoders' recurrence as ONE autograd node (CaptionEncoderC editnet.py:319-348; each direction of the
+# packed BiLSTM of dcnet.py:220-243).  The reference runs a length-sorted, prefix-shrinking batch; per row that is
+# "advance while t < len, then hold the state, outputs beyond the length stay zero", which the cell kernels implement
+# directly (set_encoder_cell_train_f32 / _bwd_f32).  Compared with a per-step chain of lstm_cell + masked torch
+# arithmetic this removes ~25 tiny kernels per step and direction in forward + backward, and the input projection
+# x W_x^T (and its two gradient contractions) runs ONCE over all (b, t) instead of once per step.
+# ------------------------------------------------------------------------------------------------
+class _EncoderLSTM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emb, lens, w_ih, b_ih, w_hh, b_hh, reverse, want_mem):
+        lib = _lib.load()
+        emb = _c(emb)
+        lens = _c(lens.reshape(-1).long())
+        B, T, E = emb.shape
+        D = w_hh.shape[1]
+        dev = emb.device
+        st = stream_of(dev)
+        xg = _linear_nograd(emb.reshape(B * T, E), w_ih, b_ih)                 # (B*T, 4D): hoisted x W_x^T + b_x
+        H = torch.empty(B, T, D, dtype=torch.float32, device=dev)
+        Mem = torch.empty(B, T, D, dtype=torch.float32, device=dev) if want_mem else None
+        Hprev = torch.empty(B, T, D, dtype=torch.float32, device=dev)
+        hs = torch.empty(T + 1, B, D, dtype=torch.float32, device=dev)
+        cs = torch.empty(T + 1, B, D, dtype=torch.float32, device=dev)
+        hs[0].zero_()
+        cs[0].zero_()
+        gates = torch.empty(T, B, 4 * D, dtype=torch.float32, device=dev)
+        ws = _ws(lib.set_encoder_cell_workspace_bytes, B, D, device=dev)
+        order = list(range(T - 1, -1, -1)) if reverse else list(range(T))
+        for k, t in enumerate(order):
+            check(lib.set_encoder_cell_train_f32(ptr(xg), T * 4 * D, 4 * D, ptr(hs[k]), ptr(cs[k]), ptr(w_hh), ptr(b_hh),
+                                                 ptr(lens), t, ptr(hs[k + 1]), ptr(cs[k + 1]), ptr(H), ptr(Mem), ptr(Hprev),
+                                                 T * D, D, 0, ptr(gates[k]), B, D, ptr(ws), ws.numel(), st),
+                  "set_encoder_cell_train_f32")
+        ctx.order = order
+        ctx.params = (w_ih, b_ih, w_hh, b_hh)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(emb, lens, w_ih, w_hh, cs, gates, Hprev)
+        h_last = hs[T]
+        if want_mem:
+            return H, Mem, h_last
+        return H, h_last
+
+    @staticmethod
+    def backward(ctx, dH, *rest):
+        emb, lens, w_ih, w_hh, cs, gates, Hprev = ctx.saved_tensors
+        if len(rest) == 2:
+            dM, dh_last = rest
+        else:
+            dM, dh_last = None, rest[0]
+        lib = _lib.load()
+        B, T, E = emb.shape
+        D = w_hh.shape[1]
+        dev = emb.device
+        st = stream_of(dev)
+        dH = None if dH is None else _c(dH)
+        dM = None if dM is None else _c(dM)
+        dG = torch.empty(B, T, 4 * D, dtype=torch.float32, device=dev)       # gradient of xg = pre-activation gate gradients
+        dh = None if dh_last is None else _c(dh_last)
+        dc = None
+        for k in range(T - 1, -1, -1):
+            t = ctx.order[k]
+            dc_prev = torch.empty(B, D, dtype=torch.float32, device=dev)
+            dh_pass = torch.empty(B, D, dtype=torch.float32, device=dev)
+            dg_t = dG[:, t]                                                     # (B, 4D) rows with stride T*4D
+            check(lib.set_encoder_cell_bwd_f32(ptr(dh), ptr(dc), ptr(dH), ptr(dM), T * D, D, 0, ptr(lens), t, ptr(gates[k]),
+                                               ptr(cs[k]), ptr(cs[k + 1]), ptr(dg_t), T * 4 * D, ptr(dc_prev), ptr(dh_pass),
+                                               B, D, st), "set_encoder_cell_bwd_f32")
+            dh = gemm(dg_t, False, w_hh, True, B, D, 4 * D, out=dh_pass, accumulate=True)    # dh_{k-1} = dh_pass + dgates W_hh
+            dc = dc_prev
+        p_ih, pb_ih, p_hh, pb_hh = ctx.params
+        dG2 = dG.reshape(B * T, 4 * D)
+        d_emb = _dgrad(dG2, w_ih).reshape(B, T, E) if ctx.needs_input_grad[0] else None
+        return (d_emb, None, _wgrad(p_ih, dG2, emb.reshape(B * T, E)), _bgrad(pb_ih, dG2),
+                _wgrad(p_hh, dG2, Hprev.reshape(B * T, D)), _bgrad(pb_hh, dG2), None, None)
+
+
+def encoder_lstm(emb, lens, w_ih, b_ih, w_hh, b_hh, reverse=False, want_mem=True):
+    """emb (B,T,E) [dropout already applied], lens (B,) -> (H (B,T,D), Mem (B,T,D), h_last (B,D)) — or (H, h_last) when
+    want_mem is False; rows are advanced while t < lens[b] (reverse: positions T-1 .. 0), padded outputs are zero."""
+    return _EncoderLSTM.apply(emb, lens, w_ih, b_ih, w_hh, b_hh, reverse, want_mem)
+
+
+# ------------------------------------------------------------------------------------------------
 # additive attention backward shared by the caption (tanh) and visual (relu) attentions
 # ------------------------------------------------------------------------------------------------
 def _attention_bwd(dctx, dalpha_ext, alpha, values, att1, att2, w_full, use_tanh, want_dvalues):

@@ -283,6 +283,108 @@ __global__ void __launch_bounds__(256) select_bwd_k(const float* dsel, const flo
         dalpha[(long long)b * T + t] = (t == js) ? ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) : 0.f;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Caption-encoder recurrence for the grad-enabled path (CaptionEncoderC editnet.py:333-338; the packed BiLSTM of
+// dcnet.py:233): one step for ALL rows with the reference's length handling inside the kernel — rows with
+// t < len[b] advance, the others carry their state and emit zeros — instead of ~12 masked elementwise torch kernels
+// per step (and as many again in the backward).  xg holds the hoisted input projection x W_x^T + b_x for every (b, t).
+//   forward : gates = hh slabs + xg[b,t] + b_hh ; (i,f,g,o) ; c' = f c + i g ; h' = o tanh(c')
+//             valid row : h_out = h', c_out = c', H[b,t] = h', Mem[b,t] = c', gates_out = post-activations
+//             else      : h_out = h,  c_out = c,  H[b,t] = 0,  Mem[b,t] = 0,  gates_out = 0
+//   backward: valid row : dh' = dh_out + dH[b,t], dc' = dc_out + dM[b,t] -> LSTM cell backward (dgates, dc_prev), dh_pass = 0
+//             else      : dgates = 0, dc_prev = dc_out, dh_pass = dh_out
+//             (the caller adds dgates W_hh to dh_pass: that is dh of the previous step)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) enc_cell_train_k(Slabs hh, const float* xg, long long ld_xg_row, long long ld_xg_t,
+                                                        const float* b_hh, const int64_t* lens, int t, const float* h_in,
+                                                        const float* c_in, float* h_out, float* c_out, float* H, float* Mem,
+                                                        float* Hprev, long long ld_out_b, long long ld_out_t, int out_col0,
+                                                        float* gates_out, int B, int D) {
+    const int per_row = D >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * per_row) return;
+    const long long b = idx / per_row;
+    const int j = (int)(idx - b * per_row) << 2;
+    const bool valid = t < (int)lens[b];
+    const f32x4 hp = ldb4(h_in + b * D + j), cp = ldb4(c_in + b * D + j);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    float* gr = gates_out + b * 4 * D + j;
+    const long long o = b * ld_out_b + (long long)t * ld_out_t + out_col0 + j;
+    if (Hprev) stb4(Hprev + b * (long long)(ld_out_b) + (long long)t * ld_out_t + out_col0 + j, hp);
+    if (!valid) {
+        stb4(h_out + b * D + j, hp); stb4(c_out + b * D + j, cp);
+        stb4(H + o, zero);
+        if (Mem) stb4(Mem + o, zero);
+        stb4(gr, zero); stb4(gr + D, zero); stb4(gr + 2 * D, zero); stb4(gr + 3 * D, zero);
+        return;
+    }
+    const float* xr = xg + b * ld_xg_row + (long long)t * ld_xg_t;
+    f32x4 g[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 v = zero;
+        for (int i = 0; i < hh.n; ++i) v += ldb4(hh.p + (long long)i * hh.stride + b * hh.ld + q * D + j);
+        v += ldb4(xr + q * D + j);
+        if (b_hh) v += ldb4(b_hh + q * D + j);
+        g[q] = v;
+    }
+    f32x4 ai, af, ag, ao, cn, hn;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        ai[e] = 1.f / (1.f + expf(-g[0][e])); af[e] = 1.f / (1.f + expf(-g[1][e]));
+        ag[e] = tanhf(g[2][e]); ao[e] = 1.f / (1.f + expf(-g[3][e]));
+        cn[e] = af[e] * cp[e] + ai[e] * ag[e];
+        hn[e] = ao[e] * tanhf(cn[e]);
+    }
+    stb4(h_out + b * D + j, hn); stb4(c_out + b * D + j, cn);
+    stb4(H + o, hn);
+    if (Mem) stb4(Mem + o, cn);
+    stb4(gr, ai); stb4(gr + D, af); stb4(gr + 2 * D, ag); stb4(gr + 3 * D, ao);
+}
+
+__global__ void __launch_bounds__(256) enc_cell_bwd_k(const float* dh_out, const float* dc_out, const float* dH, const float* dM,
+                                                      long long ld_d_b, long long ld_d_t, int d_col0, const int64_t* lens,
+                                                      int t, const float* gates, const float* c_prev, const float* c_new,
+                                                      float* dgates, long long ld_dg, float* dc_prev, float* dh_pass, int B,
+                                                      int D) {
+    const int per_row = D >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * per_row) return;
+    const long long b = idx / per_row;
+    const int j = (int)(idx - b * per_row) << 2;
+    const bool valid = t < (int)lens[b];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 dhv = dh_out ? ldb4(dh_out + b * D + j) : zero;
+    f32x4 dcv = dc_out ? ldb4(dc_out + b * D + j) : zero;
+    float* dr = dgates + b * ld_dg + j;
+    if (!valid) {
+        stb4(dr, zero); stb4(dr + D, zero); stb4(dr + 2 * D, zero); stb4(dr + 3 * D, zero);
+        stb4(dc_prev + b * D + j, dcv);
+        stb4(dh_pass + b * D + j, dhv);
+        return;
+    }
+    const long long o = b * ld_d_b + (long long)t * ld_d_t + d_col0 + j;
+    if (dH) dhv += ldb4(dH + o);
+    if (dM) dcv += ldb4(dM + o);
+    const float* gr = gates + b * 4 * D + j;
+    const f32x4 gi = ldb4(gr), gf = ldb4(gr + D), gg = ldb4(gr + 2 * D), go = ldb4(gr + 3 * D);
+    const f32x4 cp = ldb4(c_prev + b * D + j), cn = ldb4(c_new + b * D + j);
+    f32x4 di, df, dg, dou, dcp;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float tc = tanhf(cn[e]);
+        const float dct = dcv[e] + dhv[e] * go[e] * (1.f - tc * tc);
+        di[e] = dct * gg[e] * gi[e] * (1.f - gi[e]);
+        df[e] = dct * cp[e] * gf[e] * (1.f - gf[e]);
+        dg[e] = dct * gi[e] * (1.f - gg[e] * gg[e]);
+        dou[e] = dhv[e] * tc * go[e] * (1.f - go[e]);
+        dcp[e] = dct * gf[e];
+    }
+    stb4(dr, di); stb4(dr + D, df); stb4(dr + 2 * D, dg); stb4(dr + 3 * D, dou);
+    stb4(dc_prev + b * D + j, dcp);
+    stb4(dh_pass + b * D + j, zero);
+}
+
 }  // namespace set
 
 using namespace set;
@@ -372,6 +474,46 @@ int set_gemm_f32(const float* A, long long lda, int a_kminor, const float* B, lo
 int set_gemm_group_f32(const SetGemmDesc* descs, int n, int a_kminor, int b_kminor, void* ws, size_t ws_bytes,
                        void* stream) {
     return gemm_gen_group(descs, n, a_kminor, b_kminor, ws, ws_bytes, (hipStream_t)stream);
+}
+
+size_t set_encoder_cell_workspace_bytes(int B, int D) {
+    if (B <= 0 || D <= 0) return 0;
+    return round_up((size_t)GEMM_MAX_KSPLIT * B * 4 * D * sizeof(float), 256) + 256;
+}
+
+int set_encoder_cell_train_f32(const float* xg, int64_t ld_xg_row, int64_t ld_xg_t, const float* h, const float* c,
+                               const float* w_hh, const float* b_hh, const int64_t* lens, int t, float* h_out, float* c_out,
+                               float* H, float* Mem, float* Hprev, int64_t ld_out_b, int64_t ld_out_t, int out_col0,
+                               float* gates, int B, int D, void* ws, size_t ws_bytes, void* stream) {
+    if (!xg || !h || !c || !w_hh || !lens || !h_out || !c_out || !H || !gates || B <= 0 || D <= 0 || t < 0) return SET_ERR_ARG;
+    if ((D % GEMM_BK) || (ld_xg_row & 3) || (ld_xg_t & 3) || (ld_out_b & 3) || (ld_out_t & 3) || (out_col0 & 3))
+        return SET_ERR_UNSUPPORTED;
+    if (!ws || !aligned16(ws) || ws_bytes < set_encoder_cell_workspace_bytes(B, D) - 256) return SET_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    GemmProb p = slab_prob((float*)ws, B, 4 * D, B);
+    p.add(h, D, w_hh, D, D);
+    plan_ksplit(&p, 1, gemm_target_wgs());
+    SET_TRY(gemm_group(&p, 1, st, "gemm:enc h2h (train)"));
+    const long long n = (long long)B * (D >> 2);
+    ProfScope ps("enc_cell_train", st, 0.0, 4.0 * B * D * (4.0 * p.ksplit + 16.0));
+    hipLaunchKernelGGL(enc_cell_train_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slabs_of(p), xg, ld_xg_row,
+                       ld_xg_t, b_hh, lens, t, h, c, h_out, c_out, H, Mem, Hprev, ld_out_b, ld_out_t, out_col0, gates, B, D);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+int set_encoder_cell_bwd_f32(const float* dh, const float* dc, const float* dH, const float* dM, int64_t ld_d_b,
+                             int64_t ld_d_t, int d_col0, const int64_t* lens, int t, const float* gates,
+                             const float* c_prev, const float* c_new, float* dgates, int64_t ld_dg, float* dc_prev,
+                             float* dh_pass, int B, int D, void* stream) {
+    if (!lens || !gates || !c_prev || !c_new || !dgates || !dc_prev || !dh_pass || B <= 0 || D <= 0 || t < 0) return SET_ERR_ARG;
+    if ((D & 3) || (ld_d_b & 3) || (ld_d_t & 3) || (d_col0 & 3) || (ld_dg & 3)) return SET_ERR_UNSUPPORTED;
+    const long long n = (long long)B * (D >> 2);
+    ProfScope ps("enc_cell_bwd", (hipStream_t)stream, 0.0, 4.0 * B * D * 16.0);
+    hipLaunchKernelGGL(enc_cell_bwd_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dh, dc, dH, dM,
+                       ld_d_b, ld_d_t, d_col0, lens, t, gates, c_prev, c_new, dgates, ld_dg, dc_prev, dh_pass, B, D);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
 }
 
 }  // extern "C"

@@ -231,25 +231,15 @@ class DAE(nn.Module):
         tmax = int(lens.max().item())
         B, Cc = src.shape[0], enc.enc_hid_dim
         emb = self.embed.dropout(A.embed_relu(src[:, :tmax], self.embed.embedding.weight))
-        dev = src.device
-        outs = []
-        finals = []
-        for sfx, reverse in (("", False), ("_reverse", True)):
+        outs, finals = [], []
+        for sfx, reverse in (("", False), ("_reverse", True)):      # each direction = one autograd node
             w_ih, w_hh = getattr(lstm, "weight_ih_l0" + sfx), getattr(lstm, "weight_hh_l0" + sfx)
             b_ih, b_hh = getattr(lstm, "bias_ih_l0" + sfx), getattr(lstm, "bias_hh_l0" + sfx)
-            h = torch.zeros(B, Cc, device=dev)
-            c = torch.zeros(B, Cc, device=dev)
-            cols = [None] * tmax
-            for t in (range(tmax - 1, -1, -1) if reverse else range(tmax)):
-                m = (lens > t).float().unsqueeze(1)
-                hn, cn = A.lstm_cell(emb[:, t], h, c, w_ih, w_hh, b_ih, b_hh)
-                h = m * hn + (1 - m) * h
-                c = m * cn + (1 - m) * c
-                cols[t] = m * hn
-            outs.append(torch.stack(cols, 1))
-            finals.append(h)
+            Hd, h_last = A.encoder_lstm(emb, lens, w_ih, b_ih, w_hh, b_hh, reverse=reverse, want_mem=False)
+            outs.append(Hd)
+            finals.append(h_last)
         outputs = torch.cat(outs, 2)
-        mask = (outputs.sum(2) != 0).float()
+        mask = (outputs.detach().sum(2) != 0).float()
         final_hidden = A.linear(torch.cat(finals, 1), enc.concat.weight, enc.concat.bias, _lib.ACT_TANH)
         return outputs, final_hidden, mask
 

@@ -192,26 +192,16 @@ class CaptionEncoderC(nn.Module):
 
 
 def _caption_encoder_autograd(enc, seq, seq_len):
-    """CaptionEncoderC.forward (editnet.py:319-348) over autograd ops; rows advance while t < len."""
+    """CaptionEncoderC.forward (editnet.py:319-348), grad-enabled: embedding (+ its dropout) for all positions, then the
+    whole recurrence as one autograd node (autograd_ops.encoder_lstm: rows advance while t < len, padded outputs zero)."""
     from . import autograd_ops as A
     cell = enc.lstm_encoder_cell
     lens = seq_len.reshape(-1)
     tmax = int(lens.max().item())
-    B, D = seq.shape[0], enc.enc_hid_dim
     emb = enc.embed.dropout(A.embed_relu(seq[:, :tmax], enc.embed.embedding.weight))
-    h = torch.zeros(B, D, device=seq.device)
-    c = torch.zeros(B, D, device=seq.device)
-    Hs, Ms = [], []
-    for t in range(tmax):
-        m = (lens > t).float().unsqueeze(1)
-        hn, cn = A.lstm_cell(emb[:, t], h, c, cell.x2h.weight, cell.h2h.weight, cell.x2h.bias, cell.h2h.bias)
-        h = m * hn + (1 - m) * h
-        c = m * cn + (1 - m) * c
-        Hs.append(m * hn)
-        Ms.append(m * cn)
-    H, M = torch.stack(Hs, 1), torch.stack(Ms, 1)
-    mask = (M.sum(2) != 0).float()
-    final_hidden = A.linear(h, enc.affine_hn.weight, enc.affine_hn.bias, _lib.ACT_TANH)
+    H, M, h_last = A.encoder_lstm(emb, lens, cell.x2h.weight, cell.x2h.bias, cell.h2h.weight, cell.h2h.bias)
+    mask = (M.detach().sum(2) != 0).float()
+    final_hidden = A.linear(h_last, enc.affine_hn.weight, enc.affine_hn.bias, _lib.ACT_TANH)
     return H, M, final_hidden, mask
 
 
