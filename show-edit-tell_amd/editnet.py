@@ -404,14 +404,15 @@ class DecoderC(nn.Module):
 
     def invalidate_token_table(self):
         """Drop the derived inference-time token table (see _token_table).  It is rebuilt automatically after two
-        further no-grad calls.  Called on every train()/eval() switch, load_state_dict() and device / dtype move;
+        further no-grad calls.  Called on every train() <-> eval() switch, load_state_dict() and device / dtype move;
         call it yourself after writing weights in a way autograd cannot see (`p.data.add_()`, `dist.broadcast(p.data)`,
         raw-pointer updates): such writes do not bump `tensor._version`, which is all the cache can observe
         without a device->host synchronisation (SET_TOKEN_TABLE_VERIFY=1 adds that check for debugging)."""
         self.__dict__.pop("_tok_state", None)
 
     def train(self, mode=True):
-        self.invalidate_token_table()
+        if bool(mode) != self.training:          # an actual train <-> eval switch (eval() on an eval module keeps the table)
+            self.invalidate_token_table()
         return super().train(mode)
 
     def load_state_dict(self, *args, **kwargs):

@@ -129,7 +129,7 @@ def _global_loss(loss_sum_local, n_glob, group=None):
 
 
 def xe_backward(decoder, image_features, caps, caplens, previous_caption, prev_caplen, use_ss=False, ss_prob=0.0,
-                group=None, reduce=True, image_mean=None):
+                group=None, reduce=True):
     """Forward + backward + gradient exchange of editnet.py:558-579 on this rank's shard; leaves the SUM-reduced
     gradients of the GLOBAL mean loss in `.grad`.  Returns (global mean loss, local tokens, reducer).
     `reduce=False` skips every collective (single-rank timing of the same step)."""
@@ -139,9 +139,8 @@ def xe_backward(decoder, image_features, caps, caplens, previous_caption, prev_c
     # host never waits on the device between forward and backward
     n_tok = int((caplens.reshape(-1) - 1).sum().item())
     n_glob = global_token_count(n_tok, image_features.device, group) if grp_on else n_tok
-    out = decoder(image_features, caps, caplens, previous_caption, prev_caplen, use_ss, ss_prob) if image_mean is None \
-        else decoder(image_features, caps, caplens, previous_caption, prev_caplen, use_ss, ss_prob, image_mean)
-    scores, caps_sorted, decode_lengths = out[0], out[1], out[2]
+    scores, caps_sorted, decode_lengths, _ = decoder(image_features, caps, caplens, previous_caption, prev_caplen, use_ss,
+                                                     ss_prob)
     loss_sum, n_chk, _, _ = xe_loss_sum(scores, caps_sorted, decode_lengths)
     assert n_chk == n_tok, (n_chk, n_tok)
     loss = loss_sum / n_glob
