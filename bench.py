@@ -30,6 +30,8 @@ Extra objects on the JSON line:
   repeat        the timed region repeated (median / min / max decode-steps/sec over the windows)
   train         the path's one exchange step: EditNet XE training step at B=128 per GPU (editnet.py:558-581,
                 train mode) with the bucketed gradient all-reduce; ms per step with and without the collectives
+  secondary     (N = 1) the path's other callers, timed in the same run: SCST step (configs[4]), adaptive features
+                (configs[3]), DCNet / B=4 greedy decode (configs[0] shape), batched beam search (row f2); tools/secondary.py
   cpu_baseline  the as-written torch-CPU restatement of the reference loop (oracle/editnet_torch.py) and the numpy
                 port (oracle/editnet_np.py) timed on this box's host cores, bounded samples
 """
@@ -160,7 +162,7 @@ def experimental_split(args):
     split exactly into 3 bf16, 6 partial products, fp32 accumulation) in a child process."""
     env = dict(os.environ, SET_GEMM_SPLIT="1")
     cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--streams", str(args.streams), "--no-cpu-baseline", "--no-profile", "--no-train", "--repeat", "1"]
+           "--streams", str(args.streams), "--no-cpu-baseline", "--no-profile", "--no-train", "--no-secondary", "--repeat", "1"]
     try:
         out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
         d = json.loads(out.stdout.strip().splitlines()[-1])
@@ -203,6 +205,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the XE training-step leg ('train' object)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the 'secondary' object (SCST step, adaptive features, DCNet / B=4 greedy, batched beam search)")
     ap.add_argument("--train-steps", type=int, default=6)
     ap.add_argument("--experimental", action="store_true",
                     help="also report the opt-in split-precision (bf16x3) GEMM figure under 'experimental'")
@@ -403,6 +407,9 @@ def main():
         line.pop("roofline", None)
     if n_gpus == 1 and args.experimental and not split_env:
         line["experimental"] = experimental_split(args)
+    if not args.no_secondary and n_gpus == 1:
+        from tools import secondary
+        line["secondary"] = secondary.all_secondary(dev)
     if not args.no_cpu_baseline and n_gpus == 1:
         line["cpu_baseline"] = cpu_baseline()
     print(json.dumps(line))
@@ -423,19 +430,27 @@ def train_leg(args, dec, wm, X, caps, clen, prev, plen, dev, dist, rank, world, 
     opt = torch.optim.Adam(xe.parameters(), lr=5e-4, fused=True)         # editnet.py:749 (torch's single-kernel Adam)
     K = max(2, args.train_steps)
 
-    def timed(reduce):
-        for _ in range(2):
+    windows = []
+
+    def timed(reduce, n_windows=3):
+        """median of n_windows barrier-bracketed windows of K steps (the step is host-launch heavy, so a single short
+        window picks up host jitter: 26-37 ms seen for the same build on one box)"""
+        for _ in range(3):
             xe_train_step(xe, opt, X, caps, clen, prev, plen, False, 0.0, reduce=reduce)
-        barrier()
-        t0 = time.perf_counter()
-        losses = [xe_train_step(xe, opt, X, caps, clen, prev, plen, False, 0.0, reduce=reduce)[0] for _ in range(K)]
-        barrier()
-        return max_over_ranks(time.perf_counter() - t0), losses
+        ts, losses = [], []
+        for _ in range(n_windows):
+            barrier()
+            t0 = time.perf_counter()
+            losses += [xe_train_step(xe, opt, X, caps, clen, prev, plen, False, 0.0, reduce=reduce)[0] for _ in range(K)]
+            barrier()
+            ts.append(max_over_ranks(time.perf_counter() - t0))
+        windows.append([round(1e3 * t / K, 3) for t in ts])
+        return sorted(ts)[len(ts) // 2], losses
 
     t_dp, losses = timed(True)
     out = {"workload": "EditNet XE training step (editnet.py:558-581): train mode, B=128 per GPU, 19 timesteps, "
                        "fwd + bwd + gradient all-reduce + clip 0.25 + Adam",
-           "n_gpus": world, "steps": K, "ms_per_train_step": round(1e3 * t_dp / K, 3),
+           "n_gpus": world, "steps": K, "ms_per_train_step": round(1e3 * t_dp / K, 3), "windows_ms": windows[0],
            "train_decode_steps_per_sec": round(world * K * STEPS_PER_DECODE / t_dp, 2),
            "gradient_MB": round(sum(p.numel() for p in xe.parameters()) * 4 / 1e6, 1),
            "loss_first": round(losses[0], 4), "loss_last": round(losses[-1], 4)}

@@ -111,7 +111,7 @@ def test_bench_gpus_flag_spawns_ranks():
     env = dict(os.environ, SET_BENCH_ONE_DEVICE="1", SET_BENCH_BACKEND="gloo")
     env.pop("WORLD_SIZE", None)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                          "--repeat", "1", "--no-profile", "--no-cpu-baseline", "--train-steps", "2"],
+                          "--repeat", "1", "--no-profile", "--no-cpu-baseline", "--no-secondary", "--train-steps", "2"],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])

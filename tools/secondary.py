@@ -1,0 +1,149 @@
+"""Secondary measurements of the path's other callers, as functions so that bench.py
+can put them on its JSON line (`secondary` object, rank 0, N = 1) instead of leaving them builder-only numbers:
+  scst      BASELINE.json configs[4]: self-critical step, B=64, 5 sampled rollouts per image, CIDEr-D reward
+  adaptive  BASELINE.json configs[3]: adaptive features B=64, R=100 (10..100 valid): XE forward (eval) and training step
+  dcnet     BASELINE.json configs[0] shape: DCNet / EditNet greedy decode at B=4 (and DCNet at B=128)
+  beam      row f2: beam search k=3 over 128 images at once (EditNet, EditNet+DCNet ensemble)
+Synthetic inputs / random-init weights of the reference's architecture (show_edit_tell_amd.synth), GPU box only."""
+import time
+
+import numpy as np
+import torch
+
+R, F, T, V, D, A = 36, 2048, 20, 10000, 1024, 512
+
+
+def _timed(fn, n, warm):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(n):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / n, out
+
+
+def _editnet(cls, dev, wm, end_boost=0.0):
+    from show_edit_tell_amd import synth
+    sd = synth.editnet_state(14, V, D, A, F, emb_scale=3.0, fc_scale=8.0, gain=3.0)
+    if end_boost:
+        sd["fc.bias"] = sd["fc.bias"].copy()
+        sd["fc.bias"][wm["<end>"]] += end_boost
+    sd["caption_encoder.embed.embedding.weight"] = sd["embed.embedding.weight"]
+    m = cls(wm, D, D, D, A, F)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return m.to(dev)
+
+
+def _dcnet(cls, dev, wm, end_boost=0.0):
+    from show_edit_tell_amd import synth
+    sd = synth.dcnet_state(17, V, D, A, D // 2, D, 3.0, 8.0, 3.0)
+    if end_boost:
+        sd["fc.bias"] = sd["fc.bias"].copy()
+        sd["fc.bias"][wm["<end>"]] += end_boost
+    m = cls(wm, None, D, A, D // 2, D)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    return m.to(dev)
+
+
+def scst(dev, batch=64, samples=5, steps=3):
+    from show_edit_tell_amd import ciderd, editnet_rl, synth
+    from show_edit_tell_amd.train import scst_train_step
+    wm = synth.word_map(V)
+    dec = _editnet(editnet_rl.DecoderC, dev, wm)
+    opt = torch.optim.Adam(dec.parameters(), lr=5e-5, fused=True)
+    X = torch.from_numpy(synth.features(41, batch, R, F)).to(dev)
+    prev, plen = (torch.from_numpy(x).to(dev) for x in synth.prev_captions(41, batch, T, V, 5))
+    rng = np.random.default_rng(41)
+    allcaps = np.zeros((batch, 5, 20), dtype=np.int64)
+    for b in range(batch):
+        for j in range(5):
+            n = int(rng.integers(6, 17))
+            allcaps[b, j, 0] = wm["<start>"]
+            allcaps[b, j, 1:1 + n] = rng.integers(1, V - 4, n)
+            allcaps[b, j, 1 + n] = wm["<end>"]
+    gt = ciderd.ground_truth_lists(allcaps, wm)
+    df, docs = ciderd.document_frequency([[ciderd.tokens_to_str(c) for c in caps] for caps in gt])
+    scorer = ciderd.CiderD(df, docs)
+    t, _ = _timed(lambda: scst_train_step(dec, opt, wm, X, prev, plen, gt, scorer, n_samples=samples), steps, 1)
+    return {"workload": "SCST step (editnet_rl.py:649-686): B=%d, %d sampled rollouts per image + greedy baseline + CIDEr-D "
+                        "reward + backward + clip + Adam" % (batch, samples),
+            "ms_per_step": round(1e3 * t, 2), "decode_steps_per_sec": round(19 * (samples + 1) / t, 1),
+            "native_ciderd": bool(scorer._native)}
+
+
+def adaptive(dev, batch=64, regions=100):
+    from show_edit_tell_amd import editnet_adaptive, synth
+    from show_edit_tell_amd.autograd_ops import deferred_param_grads
+    from show_edit_tell_amd.train import xe_loss_sum
+    wm = synth.word_map(V)
+    dec = _editnet(editnet_adaptive.DecoderC, dev, wm)
+    Xn, mean_n, nvalid = synth.adaptive_features(33, batch, regions, F, 10)
+    X, mean = torch.from_numpy(Xn).to(dev), torch.from_numpy(mean_n).to(dev)
+    prev, plen = (torch.from_numpy(x).to(dev) for x in synth.prev_captions(33, batch, T, V, 5))
+    caps, clen = (torch.from_numpy(x).to(dev) for x in synth.captions(33, batch, V, 20, 20))
+    dec.eval()
+    with torch.no_grad():
+        t_fwd, _ = _timed(lambda: dec(X, mean, caps, clen, prev, plen, False, 0.0), 8, 3)
+    opt = torch.optim.Adam(dec.parameters(), lr=5e-4, fused=True)
+
+    def train_step():
+        dec.train()
+        opt.zero_grad()
+        pred, caps_s, dl, _, gd_fh, last_h = dec(X, mean, caps, clen, prev, plen, False, 0.0)
+        ls, n, _, _ = xe_loss_sum(pred, caps_s, dl)
+        loss = ls / n + torch.nn.functional.mse_loss(last_h, gd_fh)          # editnet_adaptive.py:594-596
+        with deferred_param_grads():
+            loss.backward()
+        torch.nn.utils.clip_grad_norm_(dec.parameters(), 0.25)
+        opt.step()
+
+    t_train, _ = _timed(train_step, 4, 2)
+    return {"workload": "adaptive features (editnet_adaptive.py), B=%d, R=%d (%d..%d valid regions)" % (
+                batch, regions, int(nvalid.min()), int(nvalid.max())),
+            "xe_forward_ms": round(1e3 * t_fwd, 3), "xe_forward_decode_steps_per_sec": round(19 / t_fwd, 1),
+            "train_step_ms": round(1e3 * t_train, 2)}
+
+
+def dcnet(dev):
+    from show_edit_tell_amd import dcnet_rl, editnet_rl, synth
+    wm = synth.word_map(V)
+    out = {"workload": "greedy decode, 19 timesteps (dcnet_rl.py:286-346 / editnet_rl.py:485-549)"}
+    with torch.no_grad():
+        dae = _dcnet(dcnet_rl.DAE, dev, wm).eval()
+        er = _editnet(editnet_rl.DecoderC, dev, wm).eval()
+        for B in (4, 128):
+            prev, plen = (torch.from_numpy(x).to(dev) for x in synth.prev_captions(3, B, T, V, 5))
+            X = torch.from_numpy(synth.features(3, B, R, F)).to(dev)
+            t, _ = _timed(lambda: dae(wm, prev, plen, True, False), 10, 3)
+            out["dcnet_greedy_b%d_ms" % B] = round(1e3 * t, 3)
+            if B == 4:
+                t, _ = _timed(lambda: er(wm, prev, plen, X, True, False), 10, 3)
+                out["editnet_greedy_b4_ms"] = round(1e3 * t, 3)
+    return out
+
+
+def beam(dev, images=128, k=3):
+    from show_edit_tell_amd import dcnet as dc, editnet, evaluate, synth
+    wm = synth.word_map(V)
+    dec = _editnet(editnet.DecoderC, dev, wm, end_boost=4.0).eval()      # captions end after ~10-20 words
+    dae = _dcnet(dc.DAE, dev, wm, end_boost=4.0).eval()
+    X = torch.from_numpy(synth.features(31, images, R, F)).to(dev)
+    prev, plen = (torch.from_numpy(x).to(dev) for x in synth.prev_captions(31, images, T, V, 5))
+    t_e, seqs = _timed(lambda: evaluate.beam_search_editnet_batched(dec, X, prev, plen, wm, k), 3, 1)
+    t_x, _ = _timed(lambda: evaluate.beam_search_ensemble_batched(dec, dae, X, prev, plen, wm, k), 3, 1)
+    return {"workload": "beam search k=%d over %d images at once (editnet.py:595-718, eval_full.py:88-218)" % (k, images),
+            "editnet_ms": round(1e3 * t_e, 2), "ensemble_ms": round(1e3 * t_x, 2),
+            "images_per_sec_editnet": round(images / t_e, 1), "mean_caption_len": round(float(np.mean([len(s) for s in seqs])), 2)}
+
+
+def all_secondary(dev):
+    out = {}
+    for name, fn in (("scst", scst), ("adaptive", adaptive), ("dcnet", dcnet), ("beam", beam)):
+        try:
+            out[name] = fn(dev)
+        except Exception as e:              # a secondary figure must never break the bench line
+            out[name] = {"error": repr(e)[:200]}
+        torch.cuda.empty_cache()
+    return out
