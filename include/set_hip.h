@@ -347,6 +347,30 @@ int set_encoder_cell_bwd_f32(const float* dh, const float* dc, const float* dH, 
                              float* dh_pass, int B, int D, void* stream);
 int set_select_bwd_f32(const float* dsel, const float* Mem, const float* alpha, float* dM, float* dalpha,
                        int M, int T, int D, void* stream);
+/* Accumulating forms used by the whole-sequence training node (xe_sequence.py): gradients of loop-invariant operands
+ * (H, Mem, cap_features_att(H), and features_att(att_embed(X)) in eval mode) are summed over the timesteps in place
+ * instead of by one tensor-sized add per timestep.  acc_* = 1: `out += contribution`, rows beyond M are not touched.
+ * select: with acc_dM only the selected row of dM changes (dalpha is always overwritten). */
+int set_attention_bwd_acc_f32(const float* dctx, const float* dalpha_ext, const float* alpha,
+                              const float* values, const float* att1, const float* att2, const float* w_full,
+                              float* datt1, float* datt2, float* dwfull_part, float* dvalues, float* de, int M,
+                              int L, int Dv, int A, int use_tanh, int acc_datt1, int acc_dvalues, void* stream);
+int set_select_bwd_acc_f32(const float* dsel, const float* Mem, const float* alpha, float* dM, float* dalpha,
+                           int M, int T, int D, int acc_dM, void* stream);
+/* nn.Dropout(p) in training mode (editnet.py:299-302, :441, :546) with the library's Philox4x32-10 generator:
+ * y[r, c] = x[r, c] / (1 - p) with probability 1 - p, else 0; one uniform per element from counter
+ * (r, c / 4, offset) and key seed, so a (seed, offset) pair reproduces the mask.  x == y (in place) is allowed.
+ * backward: dx (+)= dy * (y != 0 ? scale : 0) with y the forward OUTPUT (scale = 1 / (1 - p)); on the two sites that
+ * follow a ReLU this also applies the ReLU's derivative (scale = 1 in eval mode = plain ReLU backward).
+ * cols, all leading dimensions: multiples of 4; pointers 16-byte aligned. */
+int set_dropout_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int cols, float p, uint64_t seed,
+                    uint64_t offset, void* stream);
+int set_dropout_bwd_f32(const float* dy, int64_t lddy, const float* y, int64_t ldy, float* dx, int64_t ldx, int rows,
+                        int cols, float scale, int accumulate, void* stream);
+/* dst[:, :] (+)= [src0 | src1 | ...] column blocks (1..4 segments, cols[i] floats wide, row stride ld[i]): builds the
+ * concatenated LSTM input rows of editnet.py:523 / :541 inside the per-sequence operand logs (no torch.cat). */
+int set_pack_f32(float* dst, int64_t ldd, int rows, int nseg, const float* const* src, const int64_t* ld,
+                 const int* cols, int accumulate, void* stream);
 
 /* Multinomial sampling epilogue of one free-running step as an operator (the grad-enabled SCST rollout,
  * editnet_rl.py:521-543 / dcnet_rl.py:320-340): replaces exp -> torch.multinomial -> gather -> <end> rewrite ->

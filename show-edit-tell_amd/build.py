@@ -14,6 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libset_hip.so")
 ARCH = "gfx950"
+# per-file flags.  gemm_f32.hip: the six leading scalar kernel arguments (task count + first-workgroup table) are preloaded
+# into SGPRs by the command processor instead of being fetched from the kernarg segment by every workgroup
+FILE_FLAGS = {"gemm_f32.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=6"]}
 
 
 def sources():
@@ -40,7 +43,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         objs.append(obj)
         # SET_HIPCC_FLAGS: extra compile flags (A/B experiments with -D switches on the GPU box)
         extra = os.environ.get("SET_HIPCC_FLAGS", "").split()
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-comment"] + extra + ["-c", src, "-o", obj]
+        cmd = ([hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-comment"] + extra +
+               FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj])
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(256) attention_bwd_k(const float* dctx, const 
                                                        const float* Vals, const float* att1, const float* att2,
                                                        const float* w_full, float* datt1, float* datt2,
                                                        float* dwfull_part, float* dV, float* de_out, int L, int Dv,
-                                                       int A) {
+                                                       int A, int acc_datt1, int acc_dv) {
     __shared__ float s_da[ATTB_MAX];
     __shared__ float s_de[ATTB_MAX];
     __shared__ float s_dot;
@@ -228,7 +228,8 @@ __global__ void __launch_bounds__(256) attention_bwd_k(const float* dctx, const 
                     accw[e] += de * act;
                 }
                 acc2 += dp;
-                stb4(datt1 + ((long long)b * L + l) * A + a, dp);
+                float* o = datt1 + ((long long)b * L + l) * A + a;
+                stb4(o, acc_datt1 ? ldb4(o) + dp : dp);
             }
         }
         stb4(datt2 + (long long)b * A + a, acc2);
@@ -237,7 +238,11 @@ __global__ void __launch_bounds__(256) attention_bwd_k(const float* dctx, const 
     if (dV) {
         for (int d = tid * 4; d < Dv; d += 1024) {
             const f32x4 y = ldb4(dc + d);
-            for (int l = 0; l < L; ++l) stb4(dV + ((long long)b * L + l) * Dv + d, y * alpha[(long long)b * L + l]);
+            for (int l = 0; l < L; ++l) {
+                float* o = dV + ((long long)b * L + l) * Dv + d;
+                const f32x4 v = y * alpha[(long long)b * L + l];
+                stb4(o, acc_dv ? ldb4(o) + v : v);
+            }
         }
     }
 }
@@ -247,7 +252,7 @@ __global__ void __launch_bounds__(256) attention_bwd_k(const float* dctx, const 
 //   dM[b, j*] = w dsel ; dalpha[b, j*] = <dsel, M[b, j*]> ; zero elsewhere
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) select_bwd_k(const float* dsel, const float* Mem, const float* alpha, float* dM,
-                                                    float* dalpha, int T, int D) {
+                                                    float* dalpha, int T, int D, int acc_dm) {
     __shared__ int s_arg;
     __shared__ float s_val, s_red[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -274,7 +279,9 @@ __global__ void __launch_bounds__(256) select_bwd_k(const float* dsel, const flo
                 v = g * w;
                 dot += g[0] * m[0] + g[1] * m[1] + g[2] * m[2] + g[3] * m[3];
             }
-            stb4(dM + ((long long)b * T + t) * D + d, v);
+            float* o = dM + ((long long)b * T + t) * D + d;
+            if (!acc_dm) stb4(o, v);
+            else if (t == js) stb4(o, ldb4(o) + v);         // accumulate: only the selected row changes
         }
     dot = wsum(dot);
     if (lane == 0) s_red[wave] = dot;
@@ -438,31 +445,44 @@ int set_context_gate_bwd_f32(const float* dout, const float* zt, const float* s,
     return SET_OK;
 }
 
-int set_attention_bwd_f32(const float* dctx, const float* dalpha_ext, const float* alpha, const float* values,
-                          const float* att1, const float* att2, const float* w_full, float* datt1, float* datt2,
-                          float* dwfull_part, float* dvalues, float* de, int M, int L, int Dv, int A, int use_tanh,
-                          void* stream) {
+int set_attention_bwd_acc_f32(const float* dctx, const float* dalpha_ext, const float* alpha, const float* values,
+                              const float* att1, const float* att2, const float* w_full, float* datt1, float* datt2,
+                              float* dwfull_part, float* dvalues, float* de, int M, int L, int Dv, int A, int use_tanh,
+                              int acc_datt1, int acc_dvalues, void* stream) {
     if (!dctx || !alpha || !values || !att1 || !att2 || !w_full || !datt1 || !datt2 || !dwfull_part || M <= 0)
         return SET_ERR_ARG;
     if (L > ATTB_MAX || (A & 3) || (Dv & 3) || A > 1024 || Dv > 2048) return SET_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (use_tanh)
         hipLaunchKernelGGL(attention_bwd_k<true>, dim3(M), dim3(256), 0, st, dctx, dalpha_ext, alpha, values, att1, att2,
-                           w_full, datt1, datt2, dwfull_part, dvalues, de, L, Dv, A);
+                           w_full, datt1, datt2, dwfull_part, dvalues, de, L, Dv, A, acc_datt1, acc_dvalues);
     else
         hipLaunchKernelGGL(attention_bwd_k<false>, dim3(M), dim3(256), 0, st, dctx, dalpha_ext, alpha, values, att1, att2,
-                           w_full, datt1, datt2, dwfull_part, dvalues, de, L, Dv, A);
+                           w_full, datt1, datt2, dwfull_part, dvalues, de, L, Dv, A, acc_datt1, acc_dvalues);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+int set_attention_bwd_f32(const float* dctx, const float* dalpha_ext, const float* alpha, const float* values,
+                          const float* att1, const float* att2, const float* w_full, float* datt1, float* datt2,
+                          float* dwfull_part, float* dvalues, float* de, int M, int L, int Dv, int A, int use_tanh,
+                          void* stream) {
+    return set_attention_bwd_acc_f32(dctx, dalpha_ext, alpha, values, att1, att2, w_full, datt1, datt2, dwfull_part,
+                                     dvalues, de, M, L, Dv, A, use_tanh, 0, 0, stream);
+}
+
+int set_select_bwd_acc_f32(const float* dsel, const float* Mem, const float* alpha, float* dM, float* dalpha, int M,
+                           int T, int D, int acc_dM, void* stream) {
+    if (!dsel || !Mem || !alpha || !dM || !dalpha || M <= 0 || T <= 0 || D <= 0) return SET_ERR_ARG;
+    if (D & 3) return SET_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(select_bwd_k, dim3(M), dim3(256), 0, (hipStream_t)stream, dsel, Mem, alpha, dM, dalpha, T, D, acc_dM);
     SET_LAUNCH_CHECK();
     return SET_OK;
 }
 
 int set_select_bwd_f32(const float* dsel, const float* Mem, const float* alpha, float* dM, float* dalpha, int M, int T,
                        int D, void* stream) {
-    if (!dsel || !Mem || !alpha || !dM || !dalpha || M <= 0 || T <= 0 || D <= 0) return SET_ERR_ARG;
-    if (D & 3) return SET_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(select_bwd_k, dim3(M), dim3(256), 0, (hipStream_t)stream, dsel, Mem, alpha, dM, dalpha, T, D);
-    SET_LAUNCH_CHECK();
-    return SET_OK;
+    return set_select_bwd_acc_f32(dsel, Mem, alpha, dM, dalpha, M, T, D, 0, stream);
 }
 
 int set_gemm_f32(const float* A, long long lda, int a_kminor, const float* B, long long ldb, int b_kminor, float* C,

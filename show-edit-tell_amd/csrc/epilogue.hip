@@ -3,6 +3,7 @@
 //   `unfinished` latch, seq / seqLogprobs stores, early-break emulation, and the NEXT step's
 //   embedding gather relu(E[it]) (editnet.py:300-304) fused in so the loop needs no extra launch.
 #include "set_common.h"
+#include "philox.h"
 
 namespace set {
 
@@ -193,20 +194,6 @@ int greedy_pick(Slabs logits, const float* bias, int V, int t, int max_len, long
 // thread, which then walks its <= 48 words.  u = (r >> 8) * 2^-24 lies in [0, 1 - 2^-24], so u * total
 // rounds strictly below total and exactly one thread owns the target.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
-    const uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-}
-__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        philox_round(c, k0, k1);
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-}
 __device__ __forceinline__ float sample_uniform(unsigned long long seed, unsigned long long offset, int row, int t) {
     uint32_t c[4] = {(uint32_t)row, (uint32_t)t, (uint32_t)offset, (uint32_t)(offset >> 32)};
     philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));

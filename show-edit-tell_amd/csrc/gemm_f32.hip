@@ -71,16 +71,27 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+// KG = 1: four waves, each owns a (BM/WAVES_M) x (BN/WAVES_N) piece of the tile over the whole k-tile.
+// KG = 2: eight waves; waves 0-3 contract the first two 8-wide k-blocks of every k-tile, waves 4-7 the last two, and
+//         the two partial tiles are added through LDS after the loop (group 0 + group 1, fixed order).  Same tile, same
+//         LDS stages and slab plan as KG = 1, but six instead of three resident waves per SIMD at three workgroups per
+//         CU and half as many MFMAs between two barriers, which fills more of the matrix pipe's idle slots.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KG = 1>
+__global__ void __launch_bounds__(256 * KG) gemm_nt_f32(const int ntasks, const int wb1, const int wb2, const int wb3,
+                                                        const int wb4, const int wb5, const GemmLaunch L) {
+    // ntasks / wb1..wb5 repeat L.ntasks and L.t[1..5].wg_begin as leading scalar arguments: this file is compiled with
+    // -mllvm -amdgpu-kernarg-preload-count=6, so they arrive in SGPRs with the wave and the task lookup below needs no
+    // memory round trip before the task's own fields can be requested (about 0.5 us of every workgroup's start-up)
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per k-group");
+    static_assert(KG == 1 || KG == 2, "one or two k-groups");
     constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
-    constexpr int LA = BM / 32, LW = BN / 32;            // float4 loads per thread per k-tile
-    static_assert(TM >= 1 && TN >= 1, "wave tile is a multiple of 32x32");
+    constexpr int RP = 32 * KG;                          // rows staged per pass of the whole workgroup
+    constexpr int LA = BM / RP, LW = BN / RP;            // float4 loads per thread per k-tile
+    static_assert(TM >= 1 && TN >= 1 && LA >= 1 && LW >= 1, "wave tile is a multiple of 32x32");
     __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * LDS_STRIDE];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = (tid >> 6) & 3, kg = tid >> 8;
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
 #ifdef SET_EXP_STAMPS
     unsigned long long stamp_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -89,10 +100,16 @@ __global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
     SET_STAMP(0);
 
     // ---- which task / tile / k-slice is this workgroup
+    static_assert(GEMM_MAX_TASKS == 6, "five leading wg_begin arguments");
     int ti = 0;
-#pragma unroll
-    for (int i = 1; i < GEMM_MAX_TASKS; ++i)
-        if (i < L.ntasks && (int)blockIdx.x >= L.t[i].wg_begin) ti = i;
+    {
+        const int bid = (int)blockIdx.x;
+        if (1 < ntasks && bid >= wb1) ti = 1;
+        if (2 < ntasks && bid >= wb2) ti = 2;
+        if (3 < ntasks && bid >= wb3) ti = 3;
+        if (4 < ntasks && bid >= wb4) ti = 4;
+        if (5 < ntasks && bid >= wb5) ti = 5;
+    }
     const GemmTask& T = L.t[ti];
     // workgroup -> (row tile tm, column tile tn, k-slice ks).  Row tiles of the same (tn, ks) read the same
     // weight block; their block ids differ by tm_stride, a multiple of 8, so they land on the SAME XCD (blocks
@@ -107,16 +124,16 @@ __global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
     const int kt0 = (int)(((long long)ks * T.ktiles) / T.ksplit);
     const int kt1 = (int)(((long long)(ks + 1) * T.ktiles) / T.ksplit);
 
-    // ---- staging assignment: thread -> (row = tid/8 + 32*i, 16-byte column = tid%8)
+    // ---- staging assignment: thread -> (row = tid/8 + RP*i, 16-byte column = tid%8)
     const int srow = tid >> 3, scol = (tid & 7) * 4;
-    const int sswz = ((tid & 7) ^ ((srow >> 1) & 7)) * 4;          // swizzled chunk (rows srow+32i share (r>>1)&7)
+    const int sswz = ((tid & 7) ^ ((srow >> 1) & 7)) * 4;          // swizzled chunk (rows srow+RP*i share (r>>1)&7)
     int arow[LA], wrow[LW];
 #pragma unroll
-    for (int i = 0; i < LA; ++i) { int r = m0 + srow + 32 * i; arow[i] = r < T.M ? r : T.M - 1; }
+    for (int i = 0; i < LA; ++i) { int r = m0 + srow + RP * i; arow[i] = r < T.M ? r : T.M - 1; }
 #pragma unroll
-    for (int i = 0; i < LW; ++i) { int r = n0 + srow + 32 * i; wrow[i] = r < T.N ? r : T.N - 1; }
+    for (int i = 0; i < LW; ++i) { int r = n0 + srow + RP * i; wrow[i] = r < T.N ? r : T.N - 1; }
 #ifdef SET_EXP_SAMEW
-    for (int i = 0; i < LW; ++i) wrow[i] = srow + 32 * i;      // diagnostic: every workgroup streams the same weight rows (L2 hits)
+    for (int i = 0; i < LW; ++i) wrow[i] = srow + RP * i;      // diagnostic: every workgroup streams the same weight rows (L2 hits)
 #endif
 
     f32x4 ra0[LA], rw0[LW], ra1[LA], rw1[LW];      // two register stages: loads run two k-tiles ahead
@@ -151,9 +168,9 @@ __global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
         float* sA_ = lds[(BUF)];                                                                        \
         float* sW_ = lds[(BUF)] + BM * LDS_STRIDE;                                                      \
         _Pragma("unroll") for (int i = 0; i < LA; ++i)                                                  \
-            *reinterpret_cast<f32x4*>(sA_ + (srow + 32 * i) * LDS_STRIDE + sswz) = RA[i];              \
+            *reinterpret_cast<f32x4*>(sA_ + (srow + RP * i) * LDS_STRIDE + sswz) = RA[i];              \
         _Pragma("unroll") for (int i = 0; i < LW; ++i)                                                  \
-            *reinterpret_cast<f32x4*>(sW_ + (srow + 32 * i) * LDS_STRIDE + sswz) = RW[i];              \
+            *reinterpret_cast<f32x4*>(sW_ + (srow + RP * i) * LDS_STRIDE + sswz) = RW[i];              \
     }
 
     f32x16 acc[TM][TN];
@@ -163,11 +180,21 @@ __global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#ifdef SET_EXP_ACC2
+    f32x16 accB[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) accB[i][j][e] = 0.f;
+#endif
 
     const int frow = lane & 31;
-    int fo[4];                                                    // swizzled float offset of k-chunk 2*kk + (lane>>5)
+    constexpr int KB = 4 / KG;                                    // 8-wide k-blocks of a k-tile contracted by this wave
+    int fo[KB];                                                   // swizzled float offset of k-chunk 2*kk + (lane>>5)
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) fo[kk] = (((kk * 2 + (lane >> 5)) ^ ((frow >> 1) & 7)) * 4);
+    for (int kk = 0; kk < KB; ++kk) fo[kk] = ((((kg * KB + kk) * 2 + (lane >> 5)) ^ ((frow >> 1) & 7)) * 4);
     // Software pipeline (one barrier per k-tile, two LDS buffers, one register stage):
     //   iteration kt:  MFMAs of tile kt from lds[buf]   ||  ds_write tile kt+1 -> lds[buf^1]
     //                                                    ||  global loads of tile kt+2 -> registers
@@ -189,6 +216,20 @@ __global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].w, FB[j].w, acc[i][j], 0, 0, 0); \
             }                                                                                           \
     }
+#define SET_FRAG_MFMA2(FA, FB, GA, GB)                                                                  \
+    {                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                            \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].x, FB[j].x, acc[i][j], 0, 0, 0); \
+                accB[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(GA[i].x, GB[j].x, accB[i][j], 0, 0, 0); \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].y, FB[j].y, acc[i][j], 0, 0, 0); \
+                accB[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(GA[i].y, GB[j].y, accB[i][j], 0, 0, 0); \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].z, FB[j].z, acc[i][j], 0, 0, 0); \
+                accB[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(GA[i].z, GB[j].z, accB[i][j], 0, 0, 0); \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].w, FB[j].w, acc[i][j], 0, 0, 0); \
+                accB[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(GA[i].w, GB[j].w, accB[i][j], 0, 0, 0); \
+            }                                                                                           \
+    }
     // stage(kt): global loads of tile kt into a register set (no-op past the end of the slice)
 #ifdef SET_EXP_NOLOAD
 #define SET_STAGE(KT, RA, RW) if ((KT) < kt0 + 3 && (KT) < kt1) { if ((KT) == seg_end) SET_SEEK(KT); SET_GLOAD(RA, RW); }
@@ -201,6 +242,25 @@ __global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
 #endif
     // one k-tile: MFMAs from lds[BUF]; meanwhile registers (tile kt+1) -> lds[BUF^1], then reload them
     // with tile kt+3
+#ifdef SET_EXP_ACC2
+#define SET_ITER(KT, BUF, RA, RW)                                                                       \
+    {                                                                                                   \
+        const float* sA = lds[BUF] + (wm * TM * 32 + frow) * LDS_STRIDE;                                \
+        const float* sW = lds[BUF] + BM * LDS_STRIDE + (wn * TN * 32 + frow) * LDS_STRIDE;              \
+        f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN], fa2[TM], fb2[TN], fa3[TM], fb3[TN];                   \
+        SET_FRAG_LOAD(0, fa0, fb0);                                                                     \
+        SET_FRAG_LOAD(1, fa1, fb1);                                                                     \
+        SET_FRAG_LOAD(2, fa2, fb2);                                                                     \
+        SET_FRAG_LOAD(3, fa3, fb3);                                                                     \
+        SET_FRAG_MFMA2(fa0, fb0, fa1, fb1);                                                             \
+        if ((KT) + 1 < kt1) {                                                                           \
+            SET_LSTORE((BUF) ^ 1, RA, RW);                                                              \
+            SET_STAGE((KT) + 3, RA, RW);                                                                \
+        }                                                                                               \
+        SET_FRAG_MFMA2(fa2, fb2, fa3, fb3);                                                             \
+        __syncthreads();                                                                                \
+    }
+#else
 #define SET_ITER(KT, BUF, RA, RW)                                                                       \
     {                                                                                                   \
         const float* sA = lds[BUF] + (wm * TM * 32 + frow) * LDS_STRIDE;                                \
@@ -213,13 +273,16 @@ __global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
             SET_LSTORE((BUF) ^ 1, RA, RW);                                                              \
             SET_STAGE((KT) + 3, RA, RW);                                                                \
         }                                                                                               \
-        SET_FRAG_LOAD(2, fa0, fb0);                                                                     \
-        SET_FRAG_MFMA(fa1, fb1);                                                                        \
-        SET_FRAG_LOAD(3, fa1, fb1);                                                                     \
-        SET_FRAG_MFMA(fa0, fb0);                                                                        \
+        if constexpr (KG == 1) {                                                                        \
+            SET_FRAG_LOAD(2, fa0, fb0);                                                                 \
+            SET_FRAG_MFMA(fa1, fb1);                                                                    \
+            SET_FRAG_LOAD(3, fa1, fb1);                                                                 \
+            SET_FRAG_MFMA(fa0, fb0);                                                                    \
+        }                                                                                               \
         SET_FRAG_MFMA(fa1, fb1);                                                                        \
         __syncthreads();                                                                                \
     }
+#endif
     if (kt0 < kt1) {
         SET_SEEK(kt0);
         SET_STAMP(1);
@@ -250,11 +313,43 @@ __global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
 #undef SET_STAGE
 #undef SET_FRAG_LOAD
 #undef SET_FRAG_MFMA
+#undef SET_FRAG_MFMA2
+#ifdef SET_EXP_ACC2
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] += accB[i][j][e];
+#endif
 
     // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #ifdef SET_EXP_NOEPI
     if (T.M > 0) { if (acc[0][0][0] == 12345.678f) T.C[0] = 1.f; return; }
 #endif
+    if constexpr (KG == 2) {
+        // add the two k-groups' partial tiles: group 1 parks its accumulators in LDS (lane-major, conflict-free), group 0
+        // adds them to its own; only group 0 stores below
+        float* sR = &lds[1][0] + wave * (TM * TN * 1024) + lane;
+        if (kg == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sR[((i * TN + j) * 16 + r) * 64] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (kg == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += sR[((i * TN + j) * 16 + r) * 64];
+        }
+    }
+    const bool writer = (kg == 0);
     float* Cs = T.C + (long long)ks * T.slab_stride;
     const bool fused = (T.ksplit == 1);
     const int crow0 = m0 + wm * TM * 32 + 4 * (lane >> 5);
@@ -274,11 +369,13 @@ __global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 if (i + j) __syncthreads();                   // the previous sub-tile's reads are done
+                if (writer) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[i][j][r];
-                    if (fused) v = apply_act(v + bv, T.act);
-                    sT[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = v;
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[i][j][r];
+                        if (fused) v = apply_act(v + bv, T.act);
+                        sT[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = v;
+                    }
                 }
                 __syncthreads();
                 const int rbase = m0 + wm * TM * 32 + i * 32 + trow;
@@ -286,7 +383,7 @@ __global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 v4 = *reinterpret_cast<const f32x4*>(sT + q * 256 + lane * 4);
                     const int row = rbase + 8 * q;
-                    if (row < T.M && col < T.N)               // N % 4 == 0 on this path: a 4-column group is all in or all out
+                    if (writer && row < T.M && col < T.N)     // N % 4 == 0 on this path: a 4-column group is all in or all out
                         *reinterpret_cast<f32x4*>(Cs + (long long)row * T.ldc + col) = v4;
                 }
             }
@@ -302,7 +399,7 @@ __global__ void __launch_bounds__(256) gemm_nt_f32(const GemmLaunch L) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = crow0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                if (row < T.M) {
+                if (writer && row < T.M) {
                     float v = acc[i][j][r];
                     if (fused) v = apply_act(v + bv, T.act);
                     Cs[(long long)row * T.ldc + col] = v;
@@ -540,6 +637,7 @@ int gemm_tile_m(int M) {
     static const int bm32_upto = env_int("SET_GEMM_BM32_UPTO", 32);
     return M <= bm32_upto ? 32 : (M <= bm64_upto ? 64 : 128);
 }
+static int gemm_kgroups() { static int v = env_int("SET_GEMM_KGROUPS", 1); return v; }
 static int gemm_bn128() { static int v = env_int("SET_GEMM_BN128", 0); return v; }
 static int tile_m_of(const GemmProb& p) { return (p.bm_hint == 64 || p.bm_hint == 128) ? p.bm_hint : gemm_tile_m(p.M); }
 static int tile_n_of(const GemmProb& p) { const int bm = tile_m_of(p); return (bm == 32 || (bm == 128 && gemm_bn128())) ? 128 : 64; }
@@ -664,14 +762,20 @@ int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag
             attr_set = true;
         }
         hipLaunchKernelGGL(gemm_nt_split_bf16, grid, block, kLds, stream, L);
-    } else if (bm == 128 && bn == 128)
-        hipLaunchKernelGGL((gemm_nt_f32<128, 128, 2, 2>), grid, block, 0, stream, L);
-    else if (bm == 128)
-        hipLaunchKernelGGL((gemm_nt_f32<128, 64, 2, 2>), grid, block, 0, stream, L);
-    else if (bm == 64)
-        hipLaunchKernelGGL((gemm_nt_f32<64, 64, 2, 2>), grid, block, 0, stream, L);
-    else
-        hipLaunchKernelGGL((gemm_nt_f32<32, 128, 1, 4>), grid, block, 0, stream, L);
+    } else {
+        const int nt = L.ntasks, w1 = L.t[1].wg_begin, w2 = L.t[2].wg_begin, w3 = L.t[3].wg_begin, w4 = L.t[4].wg_begin,
+                  w5 = L.t[5].wg_begin;
+        if (bm == 128 && bn == 128)
+            hipLaunchKernelGGL((gemm_nt_f32<128, 128, 2, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, L);
+        else if (bm == 128)
+            hipLaunchKernelGGL((gemm_nt_f32<128, 64, 2, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, L);
+        else if (bm == 64 && gemm_kgroups() == 2)
+            hipLaunchKernelGGL((gemm_nt_f32<64, 64, 2, 2, 2>), grid, dim3(512), 0, stream, nt, w1, w2, w3, w4, w5, L);
+        else if (bm == 64)
+            hipLaunchKernelGGL((gemm_nt_f32<64, 64, 2, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, L);
+        else
+            hipLaunchKernelGGL((gemm_nt_f32<32, 128, 1, 4>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, L);
+    }
     SET_LAUNCH_CHECK();
     return SET_OK;
 }

@@ -1,0 +1,117 @@
+// Pointwise helpers of the whole-sequence training node (show-edit-tell_amd/xe_sequence.py): the reference's three
+// nn.Dropout sites (editnet.py:299-302 embedding, :441 region embedding, :546 before fc) and the row-block packing that
+// builds the LSTM input rows [emb | final_hidden | h2 | mean] / [h1 | attend_cap | attend_img] (editnet.py:523,541)
+// straight inside the per-sequence operand logs the time-batched weight-gradient contractions read.
+#include "set_common.h"
+#include "philox.h"
+
+namespace set {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// y = x * keep / (1 - p), keep ~ Bernoulli(1 - p): one Philox call -> four 24-bit uniforms -> four adjacent columns.
+// counter = (row, column group, offset_lo, offset_hi), key = seed: independent of the launch geometry.
+__global__ void __launch_bounds__(256) dropout_k(const float* x, long long ldx, float* y, long long ldy, int rows, int cols4,
+                                                 float p, float scale, unsigned long long seed, unsigned long long offset) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)rows * cols4) return;
+    const int r = (int)(i / cols4), c = (int)(i - (long long)r * cols4);
+    uint32_t k[4] = {(uint32_t)r, (uint32_t)c, (uint32_t)offset, (uint32_t)(offset >> 32)};
+    philox4x32_10(k, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + 4 * c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = ((float)(k[e] >> 8) * (1.0f / 16777216.0f) >= p) ? v[e] * scale : 0.f;
+    *reinterpret_cast<f32x4*>(y + r * ldy + 4 * c) = o;
+}
+
+// dx (+)= dy * (y != 0 ? scale : 0): y is the dropout OUTPUT.  y == 0 means "dropped" or "the input was exactly 0"; for
+// the two sites that follow a ReLU (embedding, region embedding) the second case carries no gradient anyway, so the
+// same kernel also applies the ReLU's derivative there (scale = 1, eval mode: plain ReLU backward).
+__global__ void __launch_bounds__(256) dropout_bwd_k(const float* dy, long long lddy, const float* y, long long ldy, float* dx,
+                                                     long long ldx, int rows, int cols4, float scale, int accumulate) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)rows * cols4) return;
+    const int r = (int)(i / cols4), c = (int)(i - (long long)r * cols4);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * lddy + 4 * c);
+    const f32x4 yy = *reinterpret_cast<const f32x4*>(y + r * ldy + 4 * c);
+    float* o = dx + r * ldx + 4 * c;
+    f32x4 v = accumulate ? *reinterpret_cast<const f32x4*>(o) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += yy[e] != 0.f ? g[e] * scale : 0.f;
+    *reinterpret_cast<f32x4*>(o) = v;
+}
+
+struct PackArgs {
+    const float* src[4];
+    long long ld[4];
+    int c4_end[4];       // cumulative column groups (of 4 floats)
+    int nseg;
+};
+__global__ void __launch_bounds__(256) pack_k(float* dst, long long ldd, int rows, int cols4, PackArgs a, int accumulate) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)rows * cols4) return;
+    const int r = (int)(i / cols4), c = (int)(i - (long long)r * cols4);
+    int s = 0, c0 = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (k + 1 < a.nseg && c >= a.c4_end[k]) { s = k + 1; c0 = a.c4_end[k]; }
+    const f32x4 v = *reinterpret_cast<const f32x4*>(a.src[s] + r * a.ld[s] + 4 * (c - c0));
+    float* o = dst + r * ldd + 4 * c;
+    *reinterpret_cast<f32x4*>(o) = accumulate ? *reinterpret_cast<const f32x4*>(o) + v : v;
+}
+
+}  // namespace set
+
+using namespace set;
+
+extern "C" {
+
+int set_dropout_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int cols, float p, uint64_t seed,
+                    uint64_t offset, void* stream) {
+    if (!x || !y || rows <= 0 || cols <= 0 || !(p >= 0.f) || !(p < 1.f)) return SET_ERR_ARG;
+    if ((cols & 3) || (ldx & 3) || (ldy & 3) || !aligned16(x) || !aligned16(y)) return SET_ERR_UNSUPPORTED;
+    const long long n = (long long)rows * (cols >> 2);
+    hipLaunchKernelGGL(dropout_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)ldx, y,
+                       (long long)ldy, rows, cols >> 2, p, 1.0f / (1.0f - p), (unsigned long long)seed,
+                       (unsigned long long)offset);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+int set_dropout_bwd_f32(const float* dy, int64_t lddy, const float* y, int64_t ldy, float* dx, int64_t ldx, int rows,
+                        int cols, float scale, int accumulate, void* stream) {
+    if (!dy || !y || !dx || rows <= 0 || cols <= 0) return SET_ERR_ARG;
+    if ((cols & 3) || (lddy & 3) || (ldy & 3) || (ldx & 3) || !aligned16(dy) || !aligned16(y) || !aligned16(dx))
+        return SET_ERR_UNSUPPORTED;
+    const long long n = (long long)rows * (cols >> 2);
+    hipLaunchKernelGGL(dropout_bwd_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy,
+                       (long long)lddy, y, (long long)ldy, dx, (long long)ldx, rows, cols >> 2, scale, accumulate);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+int set_pack_f32(float* dst, int64_t ldd, int rows, int nseg, const float* const* src, const int64_t* ld, const int* cols,
+                 int accumulate, void* stream) {
+    if (!dst || !src || !ld || !cols || rows <= 0 || nseg <= 0 || nseg > 4) return SET_ERR_ARG;
+    PackArgs a;
+    int c4 = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (i < nseg) {
+            if (!src[i] || cols[i] <= 0) return SET_ERR_ARG;
+            if ((cols[i] & 3) || (ld[i] & 3) || !aligned16(src[i])) return SET_ERR_UNSUPPORTED;
+            c4 += cols[i] >> 2;
+            a.src[i] = src[i]; a.ld[i] = ld[i];
+        } else { a.src[i] = nullptr; a.ld[i] = 0; }
+        a.c4_end[i] = c4;
+    }
+    a.nseg = nseg;
+    if ((ldd & 3) || !aligned16(dst)) return SET_ERR_UNSUPPORTED;
+    const long long n = (long long)rows * c4;
+    hipLaunchKernelGGL(pack_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, (long long)ldd, rows,
+                       c4, a, accumulate);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+}  // extern "C"

@@ -27,6 +27,11 @@ from . import _lib
 from ._lib import EditNetDims, EditNetWeights, EDITNET_WEIGHT_FIELDS, check, ptr, stream_of
 
 
+import os as _os
+
+_XE_SEQUENCE = _os.environ.get("SET_XE_SEQUENCE", "1") != "0"     # 0: keep the per-operator autograd loop everywhere
+
+
 def _f32c(t):
     return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
 
@@ -592,6 +597,16 @@ class DecoderC(nn.Module):
                 return fe, None
             fe = fe * vb
             return fe, (fe.detach().sum(2) != 0).float()
+
+        if _XE_SEQUENCE and not self._adaptive and not (use_ss and ss_prob > 0.0):
+            # the whole loop as ONE autograd node (xe_sequence.py): logs instead of cat / add / per-step bias sums
+            from . import xe_sequence as S
+            Yin = Y if self.training else A.linear(Y, va.features_att.weight, va.features_att.bias)
+            cfg = S.SeqConfig(decode_lengths, self.training, self.embed.dropout.p, va.att_embed[2].p, self.dropout.p,
+                              int(torch.randint(0, 2 ** 62, (1,)).item()))
+            predictions = S.xe_sequence(cfg, X, mean, H, M, final_hidden, mask, att1_c_all, Yin, encoded_captions,
+                                        S.decoder_params(self))
+            return predictions, encoded_captions, decode_lengths, sort_ind
 
         att1_eval = rmask_eval = None
         if not self.training:            # dropout inactive: features_att(att_embed(X)) is loop invariant

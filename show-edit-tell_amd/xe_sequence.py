@@ -1,0 +1,390 @@
+"""The teacher-forced EditNet decode loop (reference `editnet.py:479-548`) as ONE autograd node.
+
+`autograd_ops.py` wraps every module call of a timestep in its own autograd node; PyTorch then stitches the timesteps
+together with `cat`s of the LSTM inputs, tensor-sized `add`s wherever a state feeds several consumers, a `sum` per bias
+and timestep, its own dropout kernels ... (23 % of the training step's GPU time and ~1800 launches per step at B = 128).
+Here the whole loop is one `torch.autograd.Function`:
+
+* forward: the same HIP operators (`set_*_train_f32`), but every saved activation is written straight into a
+  per-sequence LOG of shape (T, B, .) — the concatenated LSTM input rows `[emb | final_hidden | h2 | mean]` and
+  `[h1 | attend_cap | attend_img]` are packed in place by `set_pack_f32`, the three `nn.Dropout` sites use the library's
+  Philox kernels (`set_dropout_f32`);
+* backward: back-propagation through time on raw buffers.  Every "+=" of the chain rule is the accumulate flag of the
+  fp32-MFMA GEMM (`set_gemm_group_f32`) or of the attention / select backward kernels (`set_*_bwd_acc_f32`): the running
+  dh1 / dh2 and the gradients of the loop-invariant operands (H, Mem, cap_features_att(H), final_hidden,
+  relu(att_embed(X))) are summed where they are produced; no tensor is added to another by a separate kernel;
+* parameter gradients: ONE contraction per parameter over all T x B log rows (`autograd_ops._wgrad` / `_bgrad`, which also
+  feed the data-parallel step's bucketed all-reduce through `deferred_param_grads(on_ready=...)`).
+
+Values and gradients equal the per-operator path's (same kernels, same contraction order inside a GEMM; the sums over
+timesteps are taken in reverse time order instead of autograd's engine order) — `tests/test_hip_train.py` checks both
+against the reference's own autograd gradients.  Scheduled sampling and the adaptive-feature model keep the per-operator
+path (`DecoderC._forward_autograd`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from . import autograd_ops as A
+from ._lib import EditNetWeights, check, ptr, stream_of
+
+PARAM_NAMES = (
+    "E", "al_wih", "al_whh", "al_bih", "al_bhh",
+    "ca_dec_w", "ca_dec_b", "ca_full_w", "ca_full_b", "ca_gate_w", "ca_gate_b", "ca_sc_w", "ca_sc_b", "ca_tc_w", "ca_tc_b",
+    "va_fa_w", "va_fa_b", "va_dec_w", "va_dec_b", "va_full_w", "va_full_b",
+    "cl_x2h_w", "cl_x2h_b", "cl_h2h_w", "cl_h2h_b", "cl_cnew_w", "cl_cnew_b", "cl_cmem_w", "cl_cmem_b",
+    "fc_w", "fc_b")
+
+
+def decoder_params(dec):
+    """the decoder's parameters in PARAM_NAMES order"""
+    ca, va, cl, al = dec.caption_attention, dec.visual_attention, dec.copy_lstm, dec.attention_lstm
+    return (dec.embed.embedding.weight, al.weight_ih, al.weight_hh, al.bias_ih, al.bias_hh,
+            ca.cap_decoder_att.weight, ca.cap_decoder_att.bias, ca.cap_full_att.weight, ca.cap_full_att.bias,
+            ca.context_gate.weight, ca.context_gate.bias, ca.sc_affine.weight, ca.sc_affine.bias,
+            ca.tc_affine.weight, ca.tc_affine.bias,
+            va.features_att.weight, va.features_att.bias, va.decoder_att.weight, va.decoder_att.bias,
+            va.full_att.weight, va.full_att.bias,
+            cl.x2h.weight, cl.x2h.bias, cl.h2h.weight, cl.h2h.bias, cl.gate_cnew.weight, cl.gate_cnew.bias,
+            cl.gate_cmem.weight, cl.gate_cmem.bias, dec.fc.weight, dec.fc.bias)
+
+
+class SeqConfig:
+    """non-tensor arguments of one sequence"""
+
+    def __init__(self, decode_lengths, train, p_embed, p_region, p_out, seed):
+        self.decode_lengths = [int(x) for x in decode_lengths]
+        self.train = bool(train)
+        self.p_embed, self.p_region, self.p_out = float(p_embed), float(p_region), float(p_out)
+        self.seed = int(seed)
+
+
+def _z(*shape, dev):
+    return torch.zeros(*shape, dtype=torch.float32, device=dev)
+
+
+def _e(*shape, dev):
+    return torch.empty(*shape, dtype=torch.float32, device=dev)
+
+
+class _Ops:
+    """thin, allocation-free callers of the C ABI for one (device, stream)"""
+
+    def __init__(self, dev):
+        self.lib = _lib.load()
+        self.dev = dev
+        self.st = stream_of(dev)
+        self._ws = {}
+
+    def ws(self, key, nbytes):
+        w = self._ws.get(key)
+        if w is None or w.numel() < nbytes:
+            w = self._ws[key] = torch.empty(max(16, nbytes), dtype=torch.uint8, device=self.dev)
+        return w
+
+    def pack(self, dst, rows, srcs, accumulate=False):
+        """dst[:rows, :sum(cols)] (+)= [src0 | src1 | ...]; srcs: 2-D views with unit inner stride"""
+        n = len(srcs)
+        ps = (C.c_void_p * n)(*[s.data_ptr() for s in srcs])
+        ls = (C.c_int64 * n)(*[s.stride(0) for s in srcs])
+        cs = (C.c_int * n)(*[s.shape[1] for s in srcs])
+        check(self.lib.set_pack_f32(dst.data_ptr(), dst.stride(0), rows, n, ps, ls, cs, int(accumulate), self.st), "set_pack_f32")
+
+    def dropout(self, x, y, rows, cols, p, seed, offset):
+        check(self.lib.set_dropout_f32(x.data_ptr(), x.stride(-2), y.data_ptr(), y.stride(-2), rows, cols, p, seed, offset,
+                                       self.st), "set_dropout_f32")
+
+    def dropout_bwd(self, dy, y, dx, rows, cols, scale, accumulate):
+        check(self.lib.set_dropout_bwd_f32(dy.data_ptr(), dy.stride(-2), y.data_ptr(), y.stride(-2), dx.data_ptr(),
+                                           dx.stride(-2), rows, cols, scale, int(accumulate), self.st), "set_dropout_bwd_f32")
+
+    def linear(self, x, w, b, y, M):
+        """y[:M] = x[:M] w^T + b   (x, y: 2-D views, unit inner stride)"""
+        K, N = w.shape[1], w.shape[0]
+        ws = self.ws("lin", self.lib.set_linear_workspace_bytes(M, N, K))
+        check(self.lib.set_linear_f32(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), ptr(b), y.data_ptr(), y.stride(0),
+                                      M, N, K, _lib.ACT_NONE, ws.data_ptr(), ws.numel(), self.st), "set_linear_f32")
+
+
+def _rows(t2d, n):
+    return t2d if t2d.shape[0] == n else t2d[:n]
+
+
+class _XESequence(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cfg, X, mean, H, Mem, final_hidden, mask, att1_c, Yin, caps, *params):
+        P = dict(zip(PARAM_NAMES, params))
+        dev = X.device
+        ops = _Ops(dev)
+        lib, st = ops.lib, ops.st
+        lens = cfg.decode_lengths
+        T, B = max(lens), X.shape[0]
+        bts = [sum(1 for l in lens if l > t) for t in range(T)]
+        R, F = X.shape[1], X.shape[2]
+        Tc, D = H.shape[1], H.shape[2]
+        Adim, V = P["ca_dec_w"].shape[0], P["fc_w"].shape[0]
+        K1, K2 = 3 * D + F, 2 * D + F
+        train = cfg.train
+        X, mean, H, Mem, final_hidden, mask, att1_c, Yin = (t.contiguous() for t in (X, mean, H, Mem, final_hidden, mask, att1_c, Yin))
+        caps = caps.contiguous()
+
+        L = {}                                                # the per-sequence logs
+        L["X1"] = _z(T, B, K1, dev=dev)
+        L["X1"][:, :, 3 * D:].copy_(mean.unsqueeze(0).expand(T, B, F))
+        L["EMB"] = _z(T, B, D, dev=dev)
+        L["H1"], L["C1"] = _z(T + 1, B, D, dev=dev), _z(T + 1, B, D, dev=dev)
+        L["H2"], L["C2"] = _z(T + 1, B, D, dev=dev), _z(T + 1, B, D, dev=dev)
+        L["G1"], L["G2"] = _z(T, B, 4 * D, dev=dev), _z(T, B, 4 * D, dev=dev)
+        L["WHC"] = _z(T, B, 3 * D, dev=dev)                   # [word | h1 | caption context]
+        L["ZT"], L["S"], L["TT"] = (_z(T, B, D, dev=dev) for _ in range(3))
+        L["ALPHAC"], L["ALPHAV"] = _z(T, B, Tc, dev=dev), _z(T, B, R, dev=dev)
+        L["SEL"], L["CNEW"], L["CG"] = (_z(T, B, D, dev=dev) for _ in range(3))
+        L["X2"] = _z(T, B, K2, dev=dev)
+        if train:                          # rows of sequences that have left the batch must be finite (they meet zero gradient rows)
+            alloc = _e if min(lens) == T else _z
+            L["FE"] = alloc(T, B, R, D, dev=dev)
+            L["ATT1"] = alloc(T, B, R, Adim, dev=dev)
+            L["H2D"] = _z(T, B, D, dev=dev)
+        gated, cx, aimg = _e(B, D, dev=dev), _e(B, D, dev=dev), _e(B, F, dev=dev)
+
+        w = EditNetWeights()
+        w.ca_dec_w, w.ca_dec_b = P["ca_dec_w"].data_ptr(), P["ca_dec_b"].data_ptr()
+        w.ca_full_w, w.ca_full_b = P["ca_full_w"].data_ptr(), P["ca_full_b"].data_ptr()
+        w.ca_gate_w, w.ca_gate_b = P["ca_gate_w"].data_ptr(), P["ca_gate_b"].data_ptr()
+        w.ca_sc_w, w.ca_sc_b, w.ca_tc_w, w.ca_tc_b = (P[k].data_ptr() for k in ("ca_sc_w", "ca_sc_b", "ca_tc_w", "ca_tc_b"))
+        w.va_dec_w, w.va_dec_b, w.va_full_w, w.va_full_b = (P[k].data_ptr() for k in ("va_dec_w", "va_dec_b", "va_full_w", "va_full_b"))
+        w.cl_x2h_w, w.cl_x2h_b, w.cl_h2h_w, w.cl_h2h_b = (P[k].data_ptr() for k in ("cl_x2h_w", "cl_x2h_b", "cl_h2h_w", "cl_h2h_b"))
+        w.cl_cnew_w, w.cl_cnew_b, w.cl_cmem_w, w.cl_cmem_b = (P[k].data_ptr() for k in ("cl_cnew_w", "cl_cnew_b", "cl_cmem_w", "cl_cmem_b"))
+        wref = C.byref(w)
+        ws_l = ops.ws("lstm", lib.set_lstm_cell_workspace_bytes(B, D, K1))
+        ws_c = ops.ws("cap", lib.set_caption_attention_workspace_bytes(B, Tc, D, Adim))
+        ws_v = ops.ws("vis", lib.set_visual_attention_workspace_bytes(B, R, F, D, Adim))
+        ws_k = ops.ws("copy", lib.set_copy_lstm_workspace_bytes(B, D, K2))
+        E = P["E"]
+        cap_stride = caps.stride(0)
+        scale_off = lambda site, t: (site << 40) | t
+
+        for t in range(T):
+            bt = bts[t]
+            emb = L["EMB"][t]
+            check(lib.set_embed_relu_f32(E.data_ptr(), caps[:, t].data_ptr(), cap_stride, emb.data_ptr(), D, bt, D, E.shape[0], st),
+                  "set_embed_relu_f32")
+            if train and cfg.p_embed > 0:
+                ops.dropout(emb, emb, bt, D, cfg.p_embed, cfg.seed, scale_off(1, t))
+            x1 = L["X1"][t]
+            ops.pack(x1, bt, [emb, final_hidden, L["H2"][t]])                 # columns [0, 3D); mean is prefilled
+            h1 = L["H1"][t + 1]
+            check(lib.set_lstm_cell_train_f32(x1.data_ptr(), K1, K1, L["H1"][t].data_ptr(), L["C1"][t].data_ptr(),
+                                              P["al_wih"].data_ptr(), K1, P["al_whh"].data_ptr(), P["al_bih"].data_ptr(),
+                                              P["al_bhh"].data_ptr(), h1.data_ptr(), L["C1"][t + 1].data_ptr(),
+                                              L["G1"][t].data_ptr(), bt, D, ws_l.data_ptr(), ws_l.numel(), st),
+                  "set_lstm_cell_train_f32")
+            check(lib.set_caption_attention_train_f32(wref, H.data_ptr(), att1_c.data_ptr(), h1.data_ptr(), emb.data_ptr(),
+                                                      mask.data_ptr(), gated.data_ptr(), L["ALPHAC"][t].data_ptr(), cx.data_ptr(),
+                                                      L["ZT"][t].data_ptr(), L["S"][t].data_ptr(), L["TT"][t].data_ptr(), bt, Tc,
+                                                      D, D, Adim, ws_c.data_ptr(), ws_c.numel(), st),
+                  "set_caption_attention_train_f32")
+            ops.pack(L["WHC"][t], bt, [emb, h1, cx])
+            if train:
+                fe = L["FE"][t]
+                ops.dropout(Yin.view(B * R, D), fe.view(B * R, D), bt * R, D, cfg.p_region, cfg.seed, scale_off(2, t))
+                att1 = L["ATT1"][t]
+                ops.linear(fe.view(B * R, D), P["va_fa_w"], P["va_fa_b"], att1.view(B * R, Adim), bt * R)
+            else:
+                att1 = Yin
+            check(lib.set_visual_attention_masked_f32(wref, X.data_ptr(), att1.data_ptr(), None, h1.data_ptr(), aimg.data_ptr(),
+                                                      L["ALPHAV"][t].data_ptr(), bt, R, F, D, Adim, ws_v.data_ptr(),
+                                                      ws_v.numel(), st), "set_visual_attention_masked_f32")
+            sel = L["SEL"][t]
+            check(lib.set_select_f32(Mem.data_ptr(), L["ALPHAC"][t].data_ptr(), sel.data_ptr(), bt, Tc, D, st), "set_select_f32")
+            x2 = L["X2"][t]
+            ops.pack(x2, bt, [h1, gated, aimg])
+            check(lib.set_copy_lstm_train_f32(wref, x2.data_ptr(), K2, K2, L["H2"][t].data_ptr(), L["C2"][t].data_ptr(),
+                                              sel.data_ptr(), L["H2"][t + 1].data_ptr(), L["C2"][t + 1].data_ptr(),
+                                              L["G2"][t].data_ptr(), L["CNEW"][t].data_ptr(), L["CG"][t].data_ptr(), bt, D,
+                                              ws_k.data_ptr(), ws_k.numel(), st), "set_copy_lstm_train_f32")
+            if train and cfg.p_out > 0:
+                ops.dropout(L["H2"][t + 1], L["H2D"][t], bt, D, cfg.p_out, cfg.seed, scale_off(3, t))
+        hout = L["H2D"] if (train and cfg.p_out > 0) else L["H2"][1:]
+        uniform = min(lens) == T
+        if uniform:                        # fc over all timesteps at once: (T, B, V), returned as its (B, T, V) view
+            pred_tb = _e(T, B, V, dev=dev)
+            ops.linear(hout.reshape(T * B, D), P["fc_w"], P["fc_b"], pred_tb.view(T * B, V), T * B)
+            out = pred_tb.transpose(0, 1)
+        else:                              # rows that left the batch keep zero scores (editnet.py:547)
+            out = _z(B, T, V, dev=dev)
+            for t in range(T):
+                ops.linear(hout[t], P["fc_w"], P["fc_b"], out[:, t], bts[t])
+        ctx.cfg, ctx.L, ctx.bts, ctx.uniform, ctx.hout = cfg, L, bts, uniform, hout
+        ctx.dims = (T, B, R, F, Tc, D, Adim, V)
+        ctx.save_for_backward(X, H, Mem, mask, att1_c, Yin, caps, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dpred):
+        X, H, Mem, mask, att1_c, Yin, caps = ctx.saved_tensors[:7]
+        params = ctx.saved_tensors[7:]
+        P = dict(zip(PARAM_NAMES, params))
+        cfg, L, bts = ctx.cfg, ctx.L, ctx.bts
+        T, B, R, F, Tc, D, Adim, V = ctx.dims
+        dev = X.device
+        ops = _Ops(dev)
+        lib, st = ops.lib, ops.st
+        train = cfg.train
+        K1, K2 = 3 * D + F, 2 * D + F
+
+        # ---- fc: dH2D for all timesteps in one contraction
+        if ctx.uniform:
+            dp = dpred.transpose(0, 1)
+            dp = dp if dp.is_contiguous() else dp.contiguous()
+            dp2 = dp.view(T * B, V)
+            dH2D = A._dgrad(dp2, P["fc_w"]).view(T, B, D)
+            g_fc_w = A._wgrad(params[PARAM_NAMES.index("fc_w")], dp2, ctx.hout.reshape(T * B, D))
+            g_fc_b = A._bgrad(params[PARAM_NAMES.index("fc_b")], dp2)
+        else:
+            dp = dpred.transpose(0, 1).contiguous()           # (T, B, V); rows beyond a step's batch carry zero gradient
+            for t in range(T):
+                if bts[t] < B:
+                    dp[t, bts[t]:].zero_()
+            dp2 = dp.view(T * B, V)
+            dH2D = A._dgrad(dp2, P["fc_w"]).view(T, B, D)
+            g_fc_w = A._wgrad(params[PARAM_NAMES.index("fc_w")], dp2, ctx.hout.reshape(T * B, D))
+            g_fc_b = A._bgrad(params[PARAM_NAMES.index("fc_b")], dp2)
+
+        # ---- gradient logs (zero rows where a sequence has left the batch) and running accumulators
+        DG1, DGW = _z(T, B, 4 * D, dev=dev), _z(T, B, 4 * D, dev=dev)
+        DU, DZ, DS, DT = (_z(T, B, D, dev=dev) for _ in range(4))
+        DATT2C, DATT2V, DWFC, DWFV = (_z(T, B, Adim, dev=dev) for _ in range(4))
+        DEC, DEV = _z(T, B, Tc, dev=dev), _z(T, B, R, dev=dev)
+        DEMBRAW = _z(T, B, D, dev=dev)
+        DATT1 = _z(T, B, R, Adim, dev=dev) if train else None
+        dH, dMem = torch.zeros_like(H), torch.zeros_like(Mem)
+        dFH, datt1c = _z(B, D, dev=dev), torch.zeros_like(att1_c)
+        dYin = torch.zeros_like(Yin)                           # train: d relu(att_embed(X)); eval: d features_att(.)
+        DH1, DH2 = _z(B, D, dev=dev), _z(B, D, dev=dev)
+        DC1 = [_z(B, D, dev=dev), _z(B, D, dev=dev)]
+        DC2 = [_z(B, D, dev=dev), _z(B, D, dev=dev)]
+        dcm, dcn, dop, og = (_e(B, D, dev=dev) for _ in range(4))
+        dgated, daimg = _e(B, D, dev=dev), _e(B, F, dev=dev)
+        dctx, demb, dalc = _e(B, D, dev=dev), _e(B, D, dev=dev), _e(B, Tc, dev=dev)
+        att2 = _e(B, Adim, dev=dev)
+        dfe = _e(B * R, D, dev=dev) if train else None
+        gate_w, tc_w, x2h_w, wih = P["ca_gate_w"], P["ca_tc_w"], P["cl_x2h_w"], P["al_wih"]
+        sc_out = 1.0 / (1.0 - cfg.p_out) if (train and cfg.p_out > 0) else 1.0
+        sc_emb = 1.0 / (1.0 - cfg.p_embed) if (train and cfg.p_embed > 0) else 1.0
+        sc_reg = 1.0 / (1.0 - cfg.p_region) if train else 1.0
+        va_full = P["va_full_w"].reshape(-1)
+        ca_full = P["ca_full_w"].reshape(-1)
+
+        def gg(items):
+            """[(dy, w_view, out, accumulate)] -> out (+)= dy . w, one grouped launch"""
+            A.gemm_group([(dy, wv, dy.shape[0], wv.shape[1], dy.shape[1], out, acc) for dy, wv, out, acc in items], False, True)
+
+        for t in range(T - 1, -1, -1):
+            bt = bts[t]
+            r = lambda x: _rows(x, bt)
+            h1 = L["H1"][t + 1]
+            # h2(t) -> fc (through the output dropout); the recurrent / next-step terms are already in DH2
+            if train and cfg.p_out > 0:
+                ops.dropout_bwd(dH2D[t], L["H2D"][t], DH2, bt, D, sc_out, True)
+            else:
+                ops.pack(DH2, bt, [dH2D[t]], accumulate=True)
+            # ---- CopyLSTMCellC backward (editnet.py:265-285)
+            ops.pack(og, bt, [L["G2"][t][:, 3 * D:]])
+            du, dgw = DU[t], DGW[t]
+            dc2_in, dc2_out = DC2[t & 1], DC2[(t & 1) ^ 1]
+            check(lib.set_copy_gate_bwd_f32(DH2.data_ptr(), dc2_in.data_ptr(), og.data_ptr(), L["C2"][t + 1].data_ptr(),
+                                            L["CG"][t].data_ptr(), L["SEL"][t].data_ptr(), L["CNEW"][t].data_ptr(), du.data_ptr(),
+                                            dcm.data_ptr(), dcn.data_ptr(), dop.data_ptr(), bt, D, st), "set_copy_gate_bwd_f32")
+            gg([(r(du), P["cl_cnew_w"], r(dcn), True), (r(du), P["cl_cmem_w"], r(dcm), True)])
+            check(lib.set_lstm_gates_bwd_f32(dcn.data_ptr(), dop.data_ptr(), L["G2"][t].data_ptr(), L["C2"][t].data_ptr(),
+                                             dgw.data_ptr(), dc2_out.data_ptr(), bt, D, st), "set_lstm_gates_bwd_f32")
+            gg([(r(dgw), x2h_w[:, :D], r(DH1), True), (r(dgw), x2h_w[:, D:2 * D], r(dgated), False),
+                (r(dgw), x2h_w[:, 2 * D:], r(daimg), False), (r(dgw), P["cl_h2h_w"], r(DH2), False)])
+            # ---- SelectC backward: dMem += ..., dalpha_c
+            check(lib.set_select_bwd_acc_f32(dcm.data_ptr(), Mem.data_ptr(), L["ALPHAC"][t].data_ptr(), dMem.data_ptr(),
+                                             dalc.data_ptr(), bt, Tc, D, 1, st), "set_select_bwd_acc_f32")
+            # ---- VisualAttentionC backward
+            ops.linear(h1, P["va_dec_w"], P["va_dec_b"], att2, bt)
+            att1 = L["ATT1"][t] if train else Yin
+            datt1 = DATT1[t] if train else dYin
+            check(lib.set_attention_bwd_acc_f32(daimg.data_ptr(), None, L["ALPHAV"][t].data_ptr(), X.data_ptr(), att1.data_ptr(),
+                                                att2.data_ptr(), va_full.data_ptr(), datt1.data_ptr(), DATT2V[t].data_ptr(),
+                                                DWFV[t].data_ptr(), None, DEV[t].data_ptr(), bt, R, F, Adim, 0,
+                                                0 if train else 1, 0, st), "set_attention_bwd_acc_f32")
+            gg([(r(DATT2V[t]), P["va_dec_w"], r(DH1), True)])
+            if train:
+                A.gemm(datt1.view(B * R, Adim)[:bt * R], False, P["va_fa_w"], True, bt * R, D, Adim, out=dfe[:bt * R])
+                ops.dropout_bwd(dfe, L["FE"][t].view(B * R, D), dYin.view(B * R, D), bt * R, D, sc_reg, True)
+            # ---- CaptionAttentionC backward
+            check(lib.set_context_gate_bwd_f32(dgated.data_ptr(), L["ZT"][t].data_ptr(), L["S"][t].data_ptr(),
+                                               L["TT"][t].data_ptr(), DZ[t].data_ptr(), DS[t].data_ptr(), DT[t].data_ptr(), bt, D, st),
+                  "set_context_gate_bwd_f32")
+            dz, ds, dt = r(DZ[t]), r(DS[t]), r(DT[t])
+            gg([(dz, gate_w[:, 2 * D:], r(dctx), False), (dz, gate_w[:, :D], r(demb), False), (dz, gate_w[:, D:2 * D], r(DH1), True)])
+            gg([(ds, P["ca_sc_w"], r(dctx), True), (dt, tc_w[:, :D], r(demb), True), (dt, tc_w[:, D:], r(DH1), True)])
+            ops.linear(h1, P["ca_dec_w"], P["ca_dec_b"], att2, bt)
+            check(lib.set_attention_bwd_acc_f32(dctx.data_ptr(), dalc.data_ptr(), L["ALPHAC"][t].data_ptr(), H.data_ptr(),
+                                                att1_c.data_ptr(), att2.data_ptr(), ca_full.data_ptr(), datt1c.data_ptr(),
+                                                DATT2C[t].data_ptr(), DWFC[t].data_ptr(), dH.data_ptr(), DEC[t].data_ptr(), bt, Tc,
+                                                D, Adim, 1, 1, 1, st), "set_attention_bwd_acc_f32")
+            gg([(r(DATT2C[t]), P["ca_dec_w"], r(DH1), True)])
+            # ---- attention LSTM backward
+            dc1_in, dc1_out = DC1[t & 1], DC1[(t & 1) ^ 1]
+            check(lib.set_lstm_cell_bwd_f32(DH1.data_ptr(), dc1_in.data_ptr(), L["G1"][t].data_ptr(), L["C1"][t].data_ptr(),
+                                            L["C1"][t + 1].data_ptr(), DG1[t].data_ptr(), dc1_out.data_ptr(), bt, D, st),
+                  "set_lstm_cell_bwd_f32")
+            dg1 = r(DG1[t])
+            gg([(dg1, wih[:, :D], r(demb), True), (dg1, wih[:, D:2 * D], r(dFH), True),
+                (dg1, wih[:, 2 * D:3 * D], r(DH2), True), (dg1, P["al_whh"], r(DH1), False)])
+            # ---- embedding: dropout + ReLU backward; the table rows are scattered once after the loop
+            ops.dropout_bwd(demb, L["EMB"][t], DEMBRAW[t], bt, D, sc_emb, False)
+
+        # ---- parameter gradients: one contraction per parameter over all (t, b) rows
+        pidx = {n: i for i, n in enumerate(PARAM_NAMES)}
+        g = [None] * len(PARAM_NAMES)
+        TB = T * B
+
+        def W(name, dy, x):
+            g[pidx[name]] = A._wgrad(params[pidx[name]], dy, x)
+
+        def Bg(name, dy):
+            g[pidx[name]] = A._bgrad(params[pidx[name]], dy)
+
+        g[pidx["fc_w"]], g[pidx["fc_b"]] = g_fc_w, g_fc_b
+        ids = caps[:, :T].t().reshape(-1)
+        dE = torch.zeros_like(P["E"])
+        dE.index_add_(0, ids, DEMBRAW.view(TB, D))
+        g[pidx["E"]] = dE
+        dg1 = DG1.view(TB, 4 * D)
+        W("al_wih", dg1, L["X1"].view(TB, K1)); W("al_whh", dg1, L["H1"][:T].reshape(TB, D))
+        Bg("al_bih", dg1); Bg("al_bhh", dg1)
+        dgw = DGW.view(TB, 4 * D)
+        W("cl_x2h_w", dgw, L["X2"].view(TB, K2)); W("cl_h2h_w", dgw, L["H2"][:T].reshape(TB, D))
+        Bg("cl_x2h_b", dgw); Bg("cl_h2h_b", dgw)
+        du = DU.view(TB, D)
+        W("cl_cnew_w", du, L["CNEW"].view(TB, D)); W("cl_cmem_w", du, L["SEL"].view(TB, D))
+        Bg("cl_cnew_b", du); Bg("cl_cmem_b", du)
+        whc = L["WHC"].view(TB, 3 * D)
+        W("ca_gate_w", DZ.view(TB, D), whc); Bg("ca_gate_b", DZ.view(TB, D))
+        W("ca_tc_w", DT.view(TB, D), whc[:, :2 * D]); Bg("ca_tc_b", DT.view(TB, D))
+        W("ca_sc_w", DS.view(TB, D), whc[:, 2 * D:]); Bg("ca_sc_b", DS.view(TB, D))
+        h1_all = L["H1"][1:].reshape(TB, D)
+        W("ca_dec_w", DATT2C.view(TB, Adim), h1_all); Bg("ca_dec_b", DATT2C.view(TB, Adim))
+        W("va_dec_w", DATT2V.view(TB, Adim), h1_all); Bg("va_dec_b", DATT2V.view(TB, Adim))
+        g[pidx["ca_full_w"]] = DWFC.view(TB, Adim).sum(0, keepdim=True)
+        g[pidx["ca_full_b"]] = DEC.sum().reshape(1)
+        g[pidx["va_full_w"]] = DWFV.view(TB, Adim).sum(0, keepdim=True)
+        g[pidx["va_full_b"]] = DEV.sum().reshape(1)
+        if train:
+            W("va_fa_w", DATT1.view(TB * R, Adim), L["FE"].view(TB * R, D)); Bg("va_fa_b", DATT1.view(TB * R, Adim))
+        ctx.L = None
+        # inputs: cfg, X, mean, H, Mem, final_hidden, mask, att1_c, Yin, caps
+        return (None, None, None, dH, dMem, dFH, None, datt1c, dYin, None) + tuple(g)
+
+
+def xe_sequence(cfg, X, mean, H, Mem, final_hidden, mask, att1_c, Yin, caps, params):
+    return _XESequence.apply(cfg, X, mean, H, Mem, final_hidden, mask, att1_c, Yin, caps, *params)

@@ -16,7 +16,12 @@ ProfScope::~ProfScope() {}
 }
 
 typedef float f32x16_ __attribute__((ext_vector_type(16)));
+// effective shader clock over a kernel: s_memtime (shader cycles) against s_memrealtime (100 MHz), block 0 / thread 0
+__device__ unsigned long long g_raw_clock[2];
+#define RAW_CLOCK_BEGIN() const unsigned long long cy0_ = clock64(), wl0_ = wall_clock64()
+#define RAW_CLOCK_END() if (blockIdx.x == 0 && threadIdx.x == 0) { g_raw_clock[0] = clock64() - cy0_; g_raw_clock[1] = wall_clock64() - wl0_; }
 __global__ void __launch_bounds__(256) raw_mfma_k(float* out, int iters, float a0, float b0) {
+    RAW_CLOCK_BEGIN();
     f32x16_ c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
     float a = a0 + threadIdx.x, b = b0;
     for (int it = 0; it < iters; ++it) {
@@ -34,6 +39,36 @@ __global__ void __launch_bounds__(256) raw_mfma_k(float* out, int iters, float a
 }
 
 __global__ void __launch_bounds__(256) empty_k(float* out, int flag) { if (flag) out[threadIdx.x] = 0.f; }
+
+// the same issue pattern on random operands (8 operand pairs per lane, rotated) instead of constants: what the matrix pipe
+// sustains when its inputs toggle like real weights / activations do
+__global__ void __launch_bounds__(256) raw_mfma_rand_k(float* out, const float* src, int iters) {
+    RAW_CLOCK_BEGIN();
+    f32x16_ c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+    float a[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = src[(threadIdx.x * 8 + i) % 4096]; b[i] = src[4096 + (threadIdx.x * 8 + i + blockIdx.x) % 4096]; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * r], b[2 * r], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * r + 1], b[2 * r + 1], c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * r + 1], b[2 * r], c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * r], b[2 * r + 1], c3, 0, 0, 0);
+        }
+    }
+    float s = 0;
+    for (int e = 0; e < 16; ++e) s += c0[e] + c1[e] + c2[e] + c3[e];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    RAW_CLOCK_END();
+}
+
+static void print_raw_clock(const char* what) {
+    unsigned long long h[2];
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_raw_clock), sizeof h);
+    printf("     %s: %.0f shader cycles in %.2f us -> effective shader clock %.3f GHz (%.1f cycles per MFMA per SIMD at 3 waves)\n", what,
+           (double)h[0], h[1] / 100.0, (double)h[0] / (h[1] * 10.0), (double)h[0] / (512.0 * 16 * 3));
+}
 
 static float* dev_rand(size_t n, unsigned seed) {
     std::vector<float> h(n);
@@ -99,6 +134,15 @@ int main(int argc, char** argv) {
         printf("%-28s %8.2f us/iter  %7.2f TFLOP/s  (%d launches/iter, %.2f us/launch)\n", name, 1e3 * ms / iters,
                fl / (ms / iters * 1e-3) / 1e12, n_launch, 1e3 * ms / iters / n_launch);
     };
+    if (getenv("ONLY_RAW")) {          // long raw-MFMA runs for clock / power sampling with rocm-smi
+        float* out; hipMalloc(&out, 768 * 256 * 4);
+        float* src = dev_rand(8192, 77);
+        if (atoi(getenv("ONLY_RAW")) == 1)
+            run("raw MFMA, random operands", [&] { hipLaunchKernelGGL(raw_mfma_rand_k, dim3(768), dim3(256), 0, st, out, src, 512); }, 768.0 * 4 * 512 * 16 * 4096.0, 1);
+        else
+            run("raw MFMA, constant operands", [&] { hipLaunchKernelGGL(raw_mfma_k, dim3(768), dim3(256), 0, st, out, 512, 1.f, 1.f); }, 768.0 * 4 * 512 * 16 * 4096.0, 1);
+        return 0;
+    }
     printf("F/A: %d WGs ksplit %d/%d/%d   B: %d WGs ksplit %d/%d/%d/%d/%d   D: %d WGs ksplit %d\n", wgs(fa, 3), fa[0].ksplit,
            fa[1].ksplit, fa[2].ksplit, wgs(b, 5), b[0].ksplit, b[1].ksplit, b[2].ksplit, b[3].ksplit, b[4].ksplit, wgs(&dd, 1), dd.ksplit);
 #ifdef SET_EXP_STAMPS
@@ -168,6 +212,11 @@ int main(int argc, char** argv) {
         const int inner = 512;      // 512 x 16 MFMAs per wave per launch = the F/A launch's MFMA count per wave x 16
         run("raw MFMA 768 WGs", [&] { hipLaunchKernelGGL(raw_mfma_k, dim3(768), dim3(256), 0, st, out, inner, 1.f, 1.f); },
             768.0 * 4 * inner * 16 * 4096.0, 1);
+        print_raw_clock("constant operands");
+        float* src = dev_rand(8192, 77);
+        run("raw MFMA, random operands", [&] { hipLaunchKernelGGL(raw_mfma_rand_k, dim3(768), dim3(256), 0, st, out, src, inner); },
+            768.0 * 4 * inner * 16 * 4096.0, 1);
+        print_raw_clock("random operands");
     }
     return 0;
 }
