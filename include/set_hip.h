@@ -355,6 +355,10 @@ int set_attention_bwd_acc_f32(const float* dctx, const float* dalpha_ext, const 
                               const float* values, const float* att1, const float* att2, const float* w_full,
                               float* datt1, float* datt2, float* dwfull_part, float* dvalues, float* de, int M,
                               int L, int Dv, int A, int use_tanh, int acc_datt1, int acc_dvalues, void* stream);
+/* dvalues[b, l, :] (+)= sum_t alpha[t, b, l] dctx[t, b, :] over per-sequence logs alpha (T,B,L), dctx (T,B,Dv), T <= 64:
+ * the attended rows' gradient of all timesteps in one pass. */
+int set_attention_dvalues_f32(const float* alpha, const float* dctx, float* dvalues, int T, int B, int L, int Dv,
+                              int accumulate, void* stream);
 int set_select_bwd_acc_f32(const float* dsel, const float* Mem, const float* alpha, float* dM, float* dalpha,
                            int M, int T, int D, int acc_dM, void* stream);
 /* nn.Dropout(p) in training mode (editnet.py:299-302, :441, :546) with the library's Philox4x32-10 generator:

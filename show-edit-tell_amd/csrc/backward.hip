@@ -445,6 +445,42 @@ int set_context_gate_bwd_f32(const float* dout, const float* zt, const float* s,
     return SET_OK;
 }
 
+// dvalues[b, l, :] (+)= sum_t alpha[t, b, l] * dctx[t, b, :]  — the attended rows' gradient of ALL timesteps of a sequence at
+// once (alpha (T,B,L), dctx (T,B,Dv) are per-sequence logs); replaces T read-modify-write passes over dvalues.
+__global__ void __launch_bounds__(256) attention_dvalues_k(const float* alpha, const float* dctx, float* dV, int T, int B, int L,
+                                                           int Dv, int accumulate) {
+    __shared__ float s_a[32 * 64];                          // alpha[:, b, :] (T <= 64 steps x L <= 32 rows per pass)
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int d = (blockIdx.y * 256 + tid) * 4;
+    for (int l0 = 0; l0 < L; l0 += 32) {
+        const int ln = L - l0 < 32 ? L - l0 : 32;
+        __syncthreads();
+        for (int i = tid; i < T * ln; i += 256) {
+            const int t = i / ln, l = i - t * ln;
+            s_a[t * 32 + l] = alpha[((long long)t * B + b) * L + l0 + l];
+        }
+        __syncthreads();
+        if (d < Dv) {
+            for (int l = 0; l < ln; ++l) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < T; ++t) acc += ldb4(dctx + ((long long)t * B + b) * Dv + d) * s_a[t * 32 + l];
+                float* o = dV + ((long long)b * L + l0 + l) * Dv + d;
+                stb4(o, accumulate ? ldb4(o) + acc : acc);
+            }
+        }
+    }
+}
+
+extern "C" int set_attention_dvalues_f32(const float* alpha, const float* dctx, float* dvalues, int T, int B, int L, int Dv,
+                                         int accumulate, void* stream) {
+    if (!alpha || !dctx || !dvalues || T <= 0 || B <= 0 || L <= 0 || Dv <= 0) return SET_ERR_ARG;
+    if (T > 64 || (Dv & 3)) return SET_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(attention_dvalues_k, dim3(B, cdiv(Dv, 1024)), dim3(256), 0, (hipStream_t)stream, alpha, dctx, dvalues, T,
+                       B, L, Dv, accumulate);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
 int set_attention_bwd_acc_f32(const float* dctx, const float* dalpha_ext, const float* alpha, const float* values,
                               const float* att1, const float* att2, const float* w_full, float* datt1, float* datt2,
                               float* dwfull_part, float* dvalues, float* de, int M, int L, int Dv, int A, int use_tanh,

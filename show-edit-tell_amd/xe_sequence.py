@@ -109,6 +109,17 @@ class _Ops:
                                       M, N, K, _lib.ACT_NONE, ws.data_ptr(), ws.numel(), self.st), "set_linear_f32")
 
 
+def _dvalues(alpha, dctx, ops):
+    """dH (B, Tc, D) = sum_t alpha[t, b, :] (outer) dctx[t, b, :] over the per-sequence logs (rows of finished sequences are
+    zero in both), one launch"""
+    T, B, Tc = alpha.shape
+    D = dctx.shape[2]
+    dH = torch.empty(B, Tc, D, dtype=torch.float32, device=alpha.device)
+    check(ops.lib.set_attention_dvalues_f32(alpha.data_ptr(), dctx.data_ptr(), dH.data_ptr(), T, B, Tc, D, 0, ops.st),
+          "set_attention_dvalues_f32")
+    return dH
+
+
 def _rows(t2d, n):
     return t2d if t2d.shape[0] == n else t2d[:n]
 
@@ -131,23 +142,29 @@ class _XESequence(torch.autograd.Function):
         X, mean, H, Mem, final_hidden, mask, att1_c, Yin = (t.contiguous() for t in (X, mean, H, Mem, final_hidden, mask, att1_c, Yin))
         caps = caps.contiguous()
 
-        L = {}                                                # the per-sequence logs
-        L["X1"] = _z(T, B, K1, dev=dev)
+        # the per-sequence logs.  Rows of sequences that have left the batch are never written: with ragged lengths the
+        # logs start as zeros (such rows meet zero gradient rows in the time-batched contractions and must be finite);
+        # with uniform lengths every row is written and only the initial states need zeros
+        uniform = min(lens) == T
+        _zl = _e if uniform else _z
+        L = {}
+        L["X1"] = _zl(T, B, K1, dev=dev)
         L["X1"][:, :, 3 * D:].copy_(mean.unsqueeze(0).expand(T, B, F))
-        L["EMB"] = _z(T, B, D, dev=dev)
-        L["H1"], L["C1"] = _z(T + 1, B, D, dev=dev), _z(T + 1, B, D, dev=dev)
-        L["H2"], L["C2"] = _z(T + 1, B, D, dev=dev), _z(T + 1, B, D, dev=dev)
-        L["G1"], L["G2"] = _z(T, B, 4 * D, dev=dev), _z(T, B, 4 * D, dev=dev)
-        L["WHC"] = _z(T, B, 3 * D, dev=dev)                   # [word | h1 | caption context]
-        L["ZT"], L["S"], L["TT"] = (_z(T, B, D, dev=dev) for _ in range(3))
-        L["ALPHAC"], L["ALPHAV"] = _z(T, B, Tc, dev=dev), _z(T, B, R, dev=dev)
-        L["SEL"], L["CNEW"], L["CG"] = (_z(T, B, D, dev=dev) for _ in range(3))
-        L["X2"] = _z(T, B, K2, dev=dev)
-        if train:                          # rows of sequences that have left the batch must be finite (they meet zero gradient rows)
-            alloc = _e if min(lens) == T else _z
-            L["FE"] = alloc(T, B, R, D, dev=dev)
-            L["ATT1"] = alloc(T, B, R, Adim, dev=dev)
-            L["H2D"] = _z(T, B, D, dev=dev)
+        L["EMB"] = _zl(T, B, D, dev=dev)
+        for k in ("H1", "C1", "H2", "C2"):                    # slot t = state BEFORE step t; slot 0 = the zero initial state
+            L[k] = _zl(T + 1, B, D, dev=dev)
+            if uniform:
+                L[k][0].zero_()
+        L["G1"], L["G2"] = _zl(T, B, 4 * D, dev=dev), _zl(T, B, 4 * D, dev=dev)
+        L["WHC"] = _zl(T, B, 3 * D, dev=dev)                  # [word | h1 | caption context]
+        L["ZT"], L["S"], L["TT"] = (_zl(T, B, D, dev=dev) for _ in range(3))
+        L["ALPHAC"], L["ALPHAV"] = _zl(T, B, Tc, dev=dev), _zl(T, B, R, dev=dev)
+        L["SEL"], L["CNEW"], L["CG"] = (_zl(T, B, D, dev=dev) for _ in range(3))
+        L["X2"] = _zl(T, B, K2, dev=dev)
+        if train:
+            L["FE"] = _zl(T, B, R, D, dev=dev)
+            L["ATT1"] = _zl(T, B, R, Adim, dev=dev)
+            L["H2D"] = _zl(T, B, D, dev=dev)
         gated, cx, aimg = _e(B, D, dev=dev), _e(B, D, dev=dev), _e(B, F, dev=dev)
 
         w = EditNetWeights()
@@ -209,7 +226,6 @@ class _XESequence(torch.autograd.Function):
             if train and cfg.p_out > 0:
                 ops.dropout(L["H2"][t + 1], L["H2D"][t], bt, D, cfg.p_out, cfg.seed, scale_off(3, t))
         hout = L["H2D"] if (train and cfg.p_out > 0) else L["H2"][1:]
-        uniform = min(lens) == T
         if uniform:                        # fc over all timesteps at once: (T, B, V), returned as its (B, T, V) view
             pred_tb = _e(T, B, V, dev=dev)
             ops.linear(hout.reshape(T * B, D), P["fc_w"], P["fc_b"], pred_tb.view(T * B, V), T * B)
@@ -255,13 +271,15 @@ class _XESequence(torch.autograd.Function):
             g_fc_b = A._bgrad(params[PARAM_NAMES.index("fc_b")], dp2)
 
         # ---- gradient logs (zero rows where a sequence has left the batch) and running accumulators
-        DG1, DGW = _z(T, B, 4 * D, dev=dev), _z(T, B, 4 * D, dev=dev)
-        DU, DZ, DS, DT = (_z(T, B, D, dev=dev) for _ in range(4))
-        DATT2C, DATT2V, DWFC, DWFV = (_z(T, B, Adim, dev=dev) for _ in range(4))
-        DEC, DEV = _z(T, B, Tc, dev=dev), _z(T, B, R, dev=dev)
-        DEMBRAW = _z(T, B, D, dev=dev)
-        DATT1 = _z(T, B, R, Adim, dev=dev) if train else None
-        dH, dMem = torch.zeros_like(H), torch.zeros_like(Mem)
+        _zl = _e if ctx.uniform else _z
+        DG1, DGW = _zl(T, B, 4 * D, dev=dev), _zl(T, B, 4 * D, dev=dev)
+        DU, DZ, DS, DT = (_zl(T, B, D, dev=dev) for _ in range(4))
+        DATT2C, DATT2V, DWFC, DWFV = (_zl(T, B, Adim, dev=dev) for _ in range(4))
+        DEC, DEV = _zl(T, B, Tc, dev=dev), _zl(T, B, R, dev=dev)
+        DEMBRAW = _zl(T, B, D, dev=dev)
+        DCTX = _zl(T, B, D, dev=dev)                           # d(caption context) per step: dH = sum_t alpha_t (x) dctx_t, once
+        DATT1 = _zl(T, B, R, Adim, dev=dev) if train else None
+        dMem = torch.zeros_like(Mem)
         dFH, datt1c = _z(B, D, dev=dev), torch.zeros_like(att1_c)
         dYin = torch.zeros_like(Yin)                           # train: d relu(att_embed(X)); eval: d features_att(.)
         DH1, DH2 = _z(B, D, dev=dev), _z(B, D, dev=dev)
@@ -269,7 +287,7 @@ class _XESequence(torch.autograd.Function):
         DC2 = [_z(B, D, dev=dev), _z(B, D, dev=dev)]
         dcm, dcn, dop, og = (_e(B, D, dev=dev) for _ in range(4))
         dgated, daimg = _e(B, D, dev=dev), _e(B, F, dev=dev)
-        dctx, demb, dalc = _e(B, D, dev=dev), _e(B, D, dev=dev), _e(B, Tc, dev=dev)
+        demb, dalc = _e(B, D, dev=dev), _e(B, Tc, dev=dev)
         att2 = _e(B, Adim, dev=dev)
         dfe = _e(B * R, D, dev=dev) if train else None
         gate_w, tc_w, x2h_w, wih = P["ca_gate_w"], P["ca_tc_w"], P["cl_x2h_w"], P["al_wih"]
@@ -324,13 +342,14 @@ class _XESequence(torch.autograd.Function):
                                                L["TT"][t].data_ptr(), DZ[t].data_ptr(), DS[t].data_ptr(), DT[t].data_ptr(), bt, D, st),
                   "set_context_gate_bwd_f32")
             dz, ds, dt = r(DZ[t]), r(DS[t]), r(DT[t])
+            dctx = DCTX[t]
             gg([(dz, gate_w[:, 2 * D:], r(dctx), False), (dz, gate_w[:, :D], r(demb), False), (dz, gate_w[:, D:2 * D], r(DH1), True)])
             gg([(ds, P["ca_sc_w"], r(dctx), True), (dt, tc_w[:, :D], r(demb), True), (dt, tc_w[:, D:], r(DH1), True)])
             ops.linear(h1, P["ca_dec_w"], P["ca_dec_b"], att2, bt)
             check(lib.set_attention_bwd_acc_f32(dctx.data_ptr(), dalc.data_ptr(), L["ALPHAC"][t].data_ptr(), H.data_ptr(),
                                                 att1_c.data_ptr(), att2.data_ptr(), ca_full.data_ptr(), datt1c.data_ptr(),
-                                                DATT2C[t].data_ptr(), DWFC[t].data_ptr(), dH.data_ptr(), DEC[t].data_ptr(), bt, Tc,
-                                                D, Adim, 1, 1, 1, st), "set_attention_bwd_acc_f32")
+                                                DATT2C[t].data_ptr(), DWFC[t].data_ptr(), None, DEC[t].data_ptr(), bt, Tc,
+                                                D, Adim, 1, 1, 0, st), "set_attention_bwd_acc_f32")
             gg([(r(DATT2C[t]), P["ca_dec_w"], r(DH1), True)])
             # ---- attention LSTM backward
             dc1_in, dc1_out = DC1[t & 1], DC1[(t & 1) ^ 1]
@@ -343,6 +362,9 @@ class _XESequence(torch.autograd.Function):
             # ---- embedding: dropout + ReLU backward; the table rows are scattered once after the loop
             ops.dropout_bwd(demb, L["EMB"][t], DEMBRAW[t], bt, D, sc_emb, False)
 
+        # dH[b, l, :] = sum_t alpha_c[t, b, l] dctx[t, b, :]: one batched (Tc x T)(T x D) product per sample over the logs
+        # instead of a read-modify-write of all of dH in every timestep
+        dH = _dvalues(L["ALPHAC"], DCTX, ops)
         # ---- parameter gradients: one contraction per parameter over all (t, b) rows
         pidx = {n: i for i, n in enumerate(PARAM_NAMES)}
         g = [None] * len(PARAM_NAMES)

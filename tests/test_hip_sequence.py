@@ -1,0 +1,199 @@
+"""GPU: the whole-sequence XE training node (show_edit_tell_amd/xe_sequence.py) and its helper kernels.
+Gradient parity against the REFERENCE's autograd runs in tests/test_hip_train.py (both routes); here: the node against
+the per-operator route on ragged / uniform batches, the Philox dropout kernels, the row packer, the accumulating
+backward kernels."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _build(V, D, A, F, seed=5):
+    from show_edit_tell_amd import editnet, synth
+    wm = synth.word_map(V)
+    sd = synth.editnet_state(seed, V, D, A, F)
+    sd["caption_encoder.embed.embedding.weight"] = sd["embed.embedding.weight"]
+    m = editnet.DecoderC(wm, D, D, D, A, F)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return m.to(_dev())
+
+
+def _inputs(B, R, F, T, V, min_len):
+    from show_edit_tell_amd import synth
+    dev = _dev()
+    X = torch.from_numpy(synth.features(3, B, R, F)).to(dev)
+    prev, plen = (torch.from_numpy(x).to(dev) for x in synth.prev_captions(3, B, T, V, 5))
+    caps, clen = (torch.from_numpy(x).to(dev) for x in synth.captions(3, B, V, T, min_len))
+    return X, caps, clen, prev, plen
+
+
+def _loss_and_grads(m, inputs, seq, deferred, monkeypatch):
+    import contextlib
+    from show_edit_tell_amd import editnet
+    from show_edit_tell_amd.autograd_ops import deferred_param_grads
+    from show_edit_tell_amd.train import xe_loss_sum
+    monkeypatch.setattr(editnet, "_XE_SEQUENCE", seq)
+    m.zero_grad(set_to_none=True)
+    X, caps, clen, prev, plen = inputs
+    pred, caps_s, dl, _ = m(X, caps, clen, prev, plen, False, 0.0)
+    ls, n, _, _ = xe_loss_sum(pred, caps_s, dl)
+    with (deferred_param_grads() if deferred else contextlib.nullcontext()):
+        (ls / n).backward()
+    return pred.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize("B,V,D,A,F,min_len,deferred", [(4, 203, 64, 32, 256, 8, False), (6, 203, 64, 32, 256, 20, True),
+                                                       (16, 1000, 256, 128, 2048, 6, True)])
+def test_sequence_node_equals_per_operator_route(B, V, D, A, F, min_len, deferred, monkeypatch):
+    """same kernels, two host schedules: identical scores; gradients equal up to the order of the sums over timesteps"""
+    m = _build(V, D, A, F).eval()
+    inputs = _inputs(B, 36, F, 20, V, min_len)
+    p0, g0 = _loss_and_grads(m, inputs, False, deferred, monkeypatch)
+    p1, g1 = _loss_and_grads(m, inputs, True, deferred, monkeypatch)
+    assert torch.equal(p0, p1)
+    assert set(g0) == set(g1)
+    gmax = max(float(g.abs().max()) for g in g0.values())
+    for k in g0:
+        if k.endswith("full_att.bias"):          # mathematically zero (softmax is shift invariant): rounding noise
+            assert float(g1[k].abs().max()) < 1e-4 * gmax
+            continue
+        err = float((g0[k] - g1[k]).abs().max()) / max(float(g0[k].abs().max()), 1e-6 * gmax)
+        assert err < 1e-3, (k, err)
+
+
+def test_sequence_node_train_mode_learns(monkeypatch):
+    """train(): the three dropout sites run on the library's Philox kernels; ragged lengths; the loss falls"""
+    from show_edit_tell_amd import editnet
+    from show_edit_tell_amd.autograd_ops import deferred_param_grads
+    from show_edit_tell_amd.train import xe_loss_sum
+    monkeypatch.setattr(editnet, "_XE_SEQUENCE", True)
+    torch.manual_seed(0)
+    m = _build(203, 64, 32, 256).train()
+    X, caps, clen, prev, plen = _inputs(8, 36, 256, 20, 203, 6)
+    opt = torch.optim.Adam(m.parameters(), lr=2e-3)
+    losses = []
+    for _ in range(12):
+        opt.zero_grad()
+        pred, caps_s, dl, _ = m(X, caps, clen, prev, plen, False, 0.0)
+        ls, n, _, _ = xe_loss_sum(pred, caps_s, dl)
+        with deferred_param_grads():
+            (ls / n).backward()
+        opt.step()
+        losses.append(float((ls / n).detach()))
+    assert all(np.isfinite(losses))
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+    assert np.mean(losses[-3:]) < np.mean(losses[:3]) - 0.2, losses
+    # two forwards draw different masks (the seed comes from torch's CPU generator)
+    a = m(X, caps, clen, prev, plen, False, 0.0)[0].detach()
+    b = m(X, caps, clen, prev, plen, False, 0.0)[0].detach()
+    assert not torch.equal(a, b)
+
+
+def test_dropout_kernels():
+    from show_edit_tell_amd import _lib
+    lib, dev = _lib.load(), _dev()
+    st = _lib.stream_of(dev)
+    rows, cols, p = 512, 1024, 0.5
+    x = torch.rand(rows, cols, device=dev) + 0.5
+    y = torch.empty_like(x)
+    _lib.check(lib.set_dropout_f32(x.data_ptr(), cols, y.data_ptr(), cols, rows, cols, p, 1234, 7, st), "set_dropout_f32")
+    keep = (y != 0)
+    frac = float(keep.float().mean())
+    assert abs(frac - (1 - p)) < 4 * np.sqrt(p * (1 - p) / (rows * cols))
+    assert torch.allclose(y[keep], x[keep] / (1 - p))
+    # per-row and per-column keep rates are unbiased too (no stripe pattern from the counter layout)
+    assert float((keep.float().mean(0) - (1 - p)).abs().max()) < 0.12
+    assert float((keep.float().mean(1) - (1 - p)).abs().max()) < 0.09
+    y2 = torch.empty_like(x)
+    _lib.check(lib.set_dropout_f32(x.data_ptr(), cols, y2.data_ptr(), cols, rows, cols, p, 1234, 7, st), "set_dropout_f32")
+    assert torch.equal(y, y2)                                  # (seed, offset) reproduces the mask
+    _lib.check(lib.set_dropout_f32(x.data_ptr(), cols, y2.data_ptr(), cols, rows, cols, p, 1234, 8, st), "set_dropout_f32")
+    assert float(((y2 != 0) == keep).float().mean()) < 0.55    # another offset: an independent mask
+    # p = 0.2, strided views
+    big = torch.zeros(rows, 2 * cols, device=dev)
+    _lib.check(lib.set_dropout_f32(x.data_ptr(), cols, big[:, cols:].data_ptr(), 2 * cols, rows, cols, 0.2, 5, 0, st),
+               "set_dropout_f32")
+    assert float(big[:, :cols].abs().max()) == 0.0
+    assert abs(float((big[:, cols:] != 0).float().mean()) - 0.8) < 0.01
+    # backward: dx (+)= dy * mask * scale
+    dy = torch.randn(rows, cols, device=dev)
+    dx = torch.ones(rows, cols, device=dev)
+    _lib.check(lib.set_dropout_bwd_f32(dy.data_ptr(), cols, y.data_ptr(), cols, dx.data_ptr(), cols, rows, cols, 2.0, 1, st),
+               "set_dropout_bwd_f32")
+    assert torch.allclose(dx, 1.0 + dy * keep * 2.0)
+    _lib.check(lib.set_dropout_bwd_f32(dy.data_ptr(), cols, y.data_ptr(), cols, dx.data_ptr(), cols, rows, cols, 2.0, 0, st),
+               "set_dropout_bwd_f32")
+    assert torch.allclose(dx, dy * keep * 2.0)
+    assert lib.set_dropout_f32(x.data_ptr(), cols, y.data_ptr(), cols, rows, cols, 1.0, 1, 0, st) == 1      # SET_ERR_ARG
+
+
+def test_pack_rows():
+    from show_edit_tell_amd import _lib
+    lib, dev = _lib.load(), _dev()
+    st = _lib.stream_of(dev)
+    a, b, c = torch.randn(37, 64, device=dev), torch.randn(40, 256, device=dev)[:, 128:], torch.randn(37, 8, device=dev)
+    dst = torch.full((40, 512), 9.0, device=dev)
+    srcs = [a, b, c]
+    n = len(srcs)
+    ps = (C.c_void_p * n)(*[s.data_ptr() for s in srcs])
+    ls = (C.c_int64 * n)(*[s.stride(0) for s in srcs])
+    cs = (C.c_int * n)(*[s.shape[1] for s in srcs])
+    _lib.check(lib.set_pack_f32(dst.data_ptr(), 512, 37, n, ps, ls, cs, 0, st), "set_pack_f32")
+    ref = torch.cat([a, b[:37], c], 1)
+    assert torch.equal(dst[:37, :200], ref)
+    assert float((dst[:37, 200:] - 9.0).abs().max()) == 0.0 and float((dst[37:] - 9.0).abs().max()) == 0.0
+    _lib.check(lib.set_pack_f32(dst.data_ptr(), 512, 37, n, ps, ls, cs, 1, st), "set_pack_f32")
+    assert torch.allclose(dst[:37, :200], 2 * ref)
+
+
+def test_accumulating_backward_kernels():
+    """set_attention_bwd_acc_f32 / set_select_bwd_acc_f32 with the flags set add exactly what the plain forms write;
+    set_attention_dvalues_f32 equals the sum over timesteps of the per-step dvalues"""
+    from show_edit_tell_amd import _lib
+    lib, dev = _lib.load(), _dev()
+    st = _lib.stream_of(dev)
+    M, L, Dv, A = 9, 20, 64, 32
+    g = torch.Generator(device="cpu").manual_seed(3)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    dctx, alpha = rnd(M, Dv), torch.softmax(rnd(M, L), 1)
+    vals, att1, att2, wf, dal = rnd(M, L, Dv), rnd(M, L, A), rnd(M, A), rnd(A), rnd(M, L)
+
+    def run(acc1, accv, datt1, dval):
+        datt2, dwf, de = torch.empty(M, A, device=dev), torch.empty(M, A, device=dev), torch.empty(M, L, device=dev)
+        _lib.check(lib.set_attention_bwd_acc_f32(dctx.data_ptr(), dal.data_ptr(), alpha.data_ptr(), vals.data_ptr(),
+                                                 att1.data_ptr(), att2.data_ptr(), wf.data_ptr(), datt1.data_ptr(),
+                                                 datt2.data_ptr(), dwf.data_ptr(), dval.data_ptr(), de.data_ptr(), M, L, Dv, A, 1,
+                                                 acc1, accv, st), "set_attention_bwd_acc_f32")
+        return datt2, dwf, de
+
+    d1, dv = torch.empty(M, L, A, device=dev), torch.empty(M, L, Dv, device=dev)
+    base = run(0, 0, d1, dv)
+    d1b, dvb = d1.clone() * 0 + 1.5, dv.clone() * 0 - 2.0
+    again = run(1, 1, d1b, dvb)
+    assert torch.allclose(d1b, d1 + 1.5) and torch.allclose(dvb, dv - 2.0)
+    for x, y in zip(base, again):
+        assert torch.equal(x, y)
+    # select
+    Mem, dsel = rnd(M, L, Dv), rnd(M, Dv)
+    dM, da = torch.empty(M, L, Dv, device=dev), torch.empty(M, L, device=dev)
+    _lib.check(lib.set_select_bwd_acc_f32(dsel.data_ptr(), Mem.data_ptr(), alpha.data_ptr(), dM.data_ptr(), da.data_ptr(), M, L,
+                                          Dv, 0, st), "set_select_bwd_acc_f32")
+    dM2, da2 = torch.full((M, L, Dv), 3.0, device=dev), torch.empty(M, L, device=dev)
+    _lib.check(lib.set_select_bwd_acc_f32(dsel.data_ptr(), Mem.data_ptr(), alpha.data_ptr(), dM2.data_ptr(), da2.data_ptr(), M,
+                                          L, Dv, 1, st), "set_select_bwd_acc_f32")
+    assert torch.allclose(dM2, dM + 3.0) and torch.equal(da, da2)
+    # batched dvalues over T steps
+    T = 7
+    al, dc = torch.softmax(rnd(T, M, L), 2), rnd(T, M, Dv)
+    out = torch.empty(M, L, Dv, device=dev)
+    _lib.check(lib.set_attention_dvalues_f32(al.data_ptr(), dc.data_ptr(), out.data_ptr(), T, M, L, Dv, 0, st),
+               "set_attention_dvalues_f32")
+    ref = torch.einsum("tbl,tbd->bld", al.double(), dc.double()).float()
+    assert torch.allclose(out, ref, atol=1e-5)

@@ -11,12 +11,17 @@ from hip_adapter import editnet_modules, to_dev
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("seq", [True, False], ids=["sequence-node", "per-operator"])
 @pytest.mark.parametrize("deferred", [False, True])
 @pytest.mark.parametrize("name", ["editnet_small", "editnet_full_b4", "editnet_full_v9490"])
-def test_xe_gradients_vs_reference_autograd(name, deferred):
+def test_xe_gradients_vs_reference_autograd(name, deferred, seq, monkeypatch):
+    """both grad-enabled routes of DecoderC.forward: the whole-sequence node (xe_sequence.py, the default) and the
+    per-operator autograd loop it replaces (still used with scheduled sampling / adaptive features)"""
     import contextlib
+    from show_edit_tell_amd import editnet
     from show_edit_tell_amd.autograd_ops import deferred_param_grads
     from show_edit_tell_amd.train import xe_loss_sum
+    monkeypatch.setattr(editnet, "_XE_SEQUENCE", seq)
     d, xe, rl = editnet_modules(name)
     g = parity.load(name)
     xe.eval()                                         # dropout off; parameters still require grad
