@@ -84,6 +84,18 @@ class DecoderC(_DecoderXE):
         att1_eval = None
         if not self.training:
             att1_eval = A.linear(Y, va.features_att.weight, va.features_att.bias)
+        from . import editnet as _editnet
+        if sample_rl and _editnet._XE_SEQUENCE:
+            # the sampled rollout as ONE autograd node (xe_sequence.py, rollout mode): the same kernels, logs instead of
+            # per-step autograd nodes; the final, unused step of the reference loop (t == max_len) is not run
+            from . import xe_sequence as S
+            sample_seed = int(torch.randint(0, 2 ** 62, (1,)).item())      # first draw, as A.SampleState does on the per-operator route
+            cfg = S.SeqConfig([], self.training, self.embed.dropout.p, va.att_embed[2].p, self.dropout.p,
+                              int(torch.randint(0, 2 ** 62, (1,)).item()),
+                              rollout=dict(max_len=max_len, start_idx=int(word_map['<start>']), end_idx=int(word_map['<end>']),
+                                           seed=sample_seed))
+            return S.xe_sequence(cfg, X, mean, H, M, final_hidden, mask, att1_c_all, Y if self.training else att1_eval,
+                                 torch.zeros(1, 1, dtype=torch.long, device=dev), S.decoder_params(self))
         unfinished = None
         state = A.SampleState(B, max_len, word_map['<start>'], word_map['<end>'], dev) if sample_rl else None
         for t in range(max_len + 1):

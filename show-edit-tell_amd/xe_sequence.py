@@ -55,11 +55,14 @@ def decoder_params(dec):
 class SeqConfig:
     """non-tensor arguments of one sequence"""
 
-    def __init__(self, decode_lengths, train, p_embed, p_region, p_out, seed):
+    def __init__(self, decode_lengths, train, p_embed, p_region, p_out, seed, rollout=None):
         self.decode_lengths = [int(x) for x in decode_lengths]
         self.train = bool(train)
         self.p_embed, self.p_region, self.p_out = float(p_embed), float(p_region), float(p_out)
         self.seed = int(seed)
+        # free-running sampled rollout (editnet_rl.py:485-549 with sample_rl): dict(max_len, start_idx, end_idx) — the token
+        # of step t is what the device sampling epilogue drew at step t-1, the node returns (seq, seq_logp)
+        self.rollout = rollout
 
 
 def _z(*shape, dev):
@@ -131,7 +134,8 @@ class _XESequence(torch.autograd.Function):
         dev = X.device
         ops = _Ops(dev)
         lib, st = ops.lib, ops.st
-        lens = cfg.decode_lengths
+        ro = cfg.rollout
+        lens = cfg.decode_lengths if ro is None else [int(ro["max_len"])] * X.shape[0]
         T, B = max(lens), X.shape[0]
         bts = [sum(1 for l in lens if l > t) for t in range(T)]
         R, F = X.shape[1], X.shape[2]
@@ -181,13 +185,20 @@ class _XESequence(torch.autograd.Function):
         ws_v = ops.ws("vis", lib.set_visual_attention_workspace_bytes(B, R, F, D, Adim))
         ws_k = ops.ws("copy", lib.set_copy_lstm_workspace_bytes(B, D, K2))
         E = P["E"]
-        cap_stride = caps.stride(0)
+        cap_stride = caps.stride(0) if ro is None else 1
+        state = None
+        if ro is not None:
+            state = A.SampleState(B, T, ro["start_idx"], ro["end_idx"], dev, seed=ro.get("seed"))
+            L["LOGITS"] = _e(T, B, V, dev=dev)
+            L["RAW"] = torch.empty(T, B, dtype=torch.long, device=dev)
+            L["LSE"], L["LOGP"] = _e(T, B, dev=dev), _e(T, B, dev=dev)
         scale_off = lambda site, t: (site << 40) | t
 
         for t in range(T):
             bt = bts[t]
             emb = L["EMB"][t]
-            check(lib.set_embed_relu_f32(E.data_ptr(), caps[:, t].data_ptr(), cap_stride, emb.data_ptr(), D, bt, D, E.shape[0], st),
+            tok = caps[:, t] if ro is None else state.tokens[t]
+            check(lib.set_embed_relu_f32(E.data_ptr(), tok.data_ptr(), cap_stride, emb.data_ptr(), D, bt, D, E.shape[0], st),
                   "set_embed_relu_f32")
             if train and cfg.p_embed > 0:
                 ops.dropout(emb, emb, bt, D, cfg.p_embed, cfg.seed, scale_off(1, t))
@@ -225,7 +236,21 @@ class _XESequence(torch.autograd.Function):
                                               ws_k.data_ptr(), ws_k.numel(), st), "set_copy_lstm_train_f32")
             if train and cfg.p_out > 0:
                 ops.dropout(L["H2"][t + 1], L["H2D"][t], bt, D, cfg.p_out, cfg.seed, scale_off(3, t))
+            if ro is not None:             # editnet_rl.py:514-547: scores of this step, then the device sampling epilogue
+                hz = L["H2D"][t] if (train and cfg.p_out > 0) else L["H2"][t + 1]
+                ops.linear(hz, P["fc_w"], P["fc_b"], L["LOGITS"][t], B)
+                check(lib.set_sample_pick_f32(L["LOGITS"][t].data_ptr(), V, B, V, t, T, state.end_idx, state.seed, state.offset,
+                                              state.seq.data_ptr(), state.tokens[t + 1].data_ptr(), state.unfinished.data_ptr(),
+                                              state.alive.data_ptr(), L["RAW"][t].data_ptr(), L["LSE"][t].data_ptr(),
+                                              L["LOGP"][t].data_ptr(), st), "set_sample_pick_f32")
         hout = L["H2D"] if (train and cfg.p_out > 0) else L["H2"][1:]
+        if ro is not None:
+            ctx.cfg, ctx.L, ctx.bts, ctx.uniform, ctx.hout = cfg, L, bts, True, hout
+            ctx.dims = (T, B, R, F, Tc, D, Adim, V)
+            ctx.tokens = state.tokens
+            ctx.save_for_backward(X, H, Mem, mask, att1_c, Yin, caps, *params)
+            ctx.mark_non_differentiable(state.seq)
+            return state.seq, L["LOGP"].t()
         if uniform:                        # fc over all timesteps at once: (T, B, V), returned as its (B, T, V) view
             pred_tb = _e(T, B, V, dev=dev)
             ops.linear(hout.reshape(T * B, D), P["fc_w"], P["fc_b"], pred_tb.view(T * B, V), T * B)
@@ -240,7 +265,7 @@ class _XESequence(torch.autograd.Function):
         return out
 
     @staticmethod
-    def backward(ctx, dpred):
+    def backward(ctx, dpred, dlogp=None):
         X, H, Mem, mask, att1_c, Yin, caps = ctx.saved_tensors[:7]
         params = ctx.saved_tensors[7:]
         P = dict(zip(PARAM_NAMES, params))
@@ -253,7 +278,18 @@ class _XESequence(torch.autograd.Function):
         K1, K2 = 3 * D + F, 2 * D + F
 
         # ---- fc: dH2D for all timesteps in one contraction
-        if ctx.uniform:
+        if cfg.rollout is not None:        # d seq_logp -> d scores of every step (sampling epilogue backward), then as below
+            dl = dlogp.t().contiguous()                            # (T, B)
+            dp = _e(T, B, V, dev=dev)
+            for t in range(T):
+                check(lib.set_sample_logp_bwd_f32(L["LOGITS"][t].data_ptr(), V, L["LSE"][t].data_ptr(), L["RAW"][t].data_ptr(),
+                                                  dl[t].data_ptr(), dp[t].data_ptr(), V, B, V, st), "set_sample_logp_bwd_f32")
+            L["LOGITS"] = None
+            dp2 = dp.view(T * B, V)
+            dH2D = A._dgrad(dp2, P["fc_w"]).view(T, B, D)
+            g_fc_w = A._wgrad(params[PARAM_NAMES.index("fc_w")], dp2, ctx.hout.reshape(T * B, D))
+            g_fc_b = A._bgrad(params[PARAM_NAMES.index("fc_b")], dp2)
+        elif ctx.uniform:
             dp = dpred.transpose(0, 1)
             dp = dp if dp.is_contiguous() else dp.contiguous()
             dp2 = dp.view(T * B, V)
@@ -377,7 +413,7 @@ class _XESequence(torch.autograd.Function):
             g[pidx[name]] = A._bgrad(params[pidx[name]], dy)
 
         g[pidx["fc_w"]], g[pidx["fc_b"]] = g_fc_w, g_fc_b
-        ids = caps[:, :T].t().reshape(-1)
+        ids = caps[:, :T].t().reshape(-1) if cfg.rollout is None else ctx.tokens[:T].reshape(-1)
         dE = torch.zeros_like(P["E"])
         dE.index_add_(0, ids, DEMBRAW.view(TB, D))
         g[pidx["E"]] = dE

@@ -197,3 +197,37 @@ def test_accumulating_backward_kernels():
                "set_attention_dvalues_f32")
     ref = torch.einsum("tbl,tbd->bld", al.double(), dc.double()).float()
     assert torch.allclose(out, ref, atol=1e-5)
+
+
+def test_rollout_node_equals_per_operator_rollout(monkeypatch):
+    """sampled SCST rollout (editnet_rl.py:485-549, sample_rl) in eval mode (no dropout): the node and the per-operator
+    route draw the same Philox stream from the same scores -> identical sequences and log-probs, equal gradients of a
+    weighted sum of the log-probs"""
+    from show_edit_tell_amd import editnet, editnet_rl, synth
+    V, D, A, F, B = 203, 64, 32, 256, 6
+    wm = synth.word_map(V)
+    sd = synth.editnet_state(9, V, D, A, F, emb_scale=3.0, fc_scale=4.0, gain=2.0)
+    sd["caption_encoder.embed.embedding.weight"] = sd["embed.embedding.weight"]
+    m = editnet_rl.DecoderC(wm, D, D, D, A, F)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m = m.to(_dev()).eval()
+    X, _, _, prev, plen = _inputs(B, 36, F, 20, V, 20)
+    wgt = torch.linspace(0.5, 1.5, B * m.max_len, device=_dev()).view(B, m.max_len)
+    out = []
+    for seq_node in (False, True):
+        monkeypatch.setattr(editnet, "_XE_SEQUENCE", seq_node)
+        m.zero_grad(set_to_none=True)
+        torch.manual_seed(11)
+        seq, logp = m(wm, prev, plen, X, sample_max=False, sample_rl=True)
+        assert logp.requires_grad and not seq.requires_grad
+        (logp * wgt).sum().backward()
+        out.append((seq.clone(), logp.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}))
+    (s0, l0, g0), (s1, l1, g1) = out
+    assert torch.equal(s0, s1) and int((s0 > 0).sum()) > B
+    assert torch.allclose(l0, l1, atol=1e-5)
+    gmax = max(float(g.abs().max()) for g in g0.values())
+    for k in g0:
+        if k.endswith("full_att.bias"):
+            continue
+        err = float((g0[k] - g1[k]).abs().max()) / max(float(g0[k].abs().max()), 1e-6 * gmax)
+        assert err < 1e-3, (k, err)
