@@ -371,6 +371,11 @@ int set_dropout_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int rows
                     uint64_t offset, void* stream);
 int set_dropout_bwd_f32(const float* dy, int64_t lddy, const float* y, int64_t ldy, float* dx, int64_t ldx, int rows,
                         int cols, float scale, int accumulate, void* stream);
+/* out[c] (+)= sum_r x[r, c] (bias gradients over all (t, b) rows): two deterministic passes through a workspace of
+ * set_colsum_workspace_bytes(cols); cols, ld multiples of 4. */
+size_t set_colsum_workspace_bytes(int cols);
+int set_colsum_f32(const float* x, int64_t ld, int rows, int cols, float* out, int accumulate, void* ws,
+                   size_t ws_bytes, void* stream);
 /* dst[:, :] (+)= [src0 | src1 | ...] column blocks (1..4 segments, cols[i] floats wide, row stride ld[i]): builds the
  * concatenated LSTM input rows of editnet.py:523 / :541 inside the per-sequence operand logs (no torch.cat). */
 int set_pack_f32(float* dst, int64_t ldd, int rows, int nseg, const float* const* src, const int64_t* ld,

@@ -194,11 +194,10 @@ def deferred_param_grads(on_ready=None):
         for param, (dys, xs) in pending.values():
             dy = cat(dys)
             if xs is None:
-                g = dy.sum(0).reshape(param.shape)
                 if param.grad is None:
-                    param.grad = g
+                    param.grad = _colsum(dy).reshape(param.shape)
                 else:
-                    param.grad.add_(g)
+                    _colsum(dy, out=param.grad)
             else:
                 x = cat(xs)
                 if param.grad is None:
@@ -249,18 +248,36 @@ def _wgrad(param, dy, x):
     return None
 
 
+def _colsum(dy, out=None):
+    """sum over the rows of a 2-D fp32 matrix on the library's two-pass kernel (set_colsum_f32); out (+)= when given"""
+    if not (dy.is_cuda and dy.dtype == torch.float32 and dy.dim() == 2 and dy.shape[1] % 4 == 0 and dy.shape[0] >= 64):
+        g = dy.sum(0)
+        return g if out is None else out.add_(g.reshape(out.shape))
+    lib = _lib.load()
+    dy, ld = _mat(dy)
+    rows, cols = dy.shape
+    acc = out is not None
+    if out is None:
+        out = torch.empty(cols, dtype=torch.float32, device=dy.device)
+    if not out.is_contiguous() or out.data_ptr() % 16:
+        return out.add_(dy.sum(0).reshape(out.shape)) if acc else dy.sum(0)
+    ws = _scratch(dy.device)
+    check(lib.set_colsum_f32(ptr(dy), ld, rows, cols, ptr(out), int(acc), ptr(ws), ws.numel(), stream_of(dy.device)),
+          "set_colsum_f32")
+    return out
+
+
 def _bgrad(param, dy):
     if not _is_leaf_param(param):
-        return dy.sum(0).reshape(param.shape)
+        return _colsum(dy).reshape(param.shape)
     if _deferred_table() is not None:
         ent = _deferred_table().setdefault(id(param), (param, ([], None)))
         ent[1][0].append(dy)
         return None
-    g = dy.sum(0).reshape(param.shape)
     if param.grad is None:
-        param.grad = g
+        param.grad = _colsum(dy).reshape(param.shape)
     else:
-        param.grad.add_(g)
+        _colsum(dy, out=param.grad)
     return None
 
 

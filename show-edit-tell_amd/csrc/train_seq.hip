@@ -61,6 +61,31 @@ __global__ void __launch_bounds__(256) pack_k(float* dst, long long ldd, int row
     *reinterpret_cast<f32x4*>(o) = accumulate ? *reinterpret_cast<const f32x4*>(o) + v : v;
 }
 
+// column sums of a (rows, cols) matrix (bias gradients over all (t, b) rows of a sequence): pass 1 reduces row chunks
+// into partial rows, pass 2 adds the partials in chunk order (deterministic, no atomics).
+constexpr int COLSUM_CHUNKS = 64;
+__global__ void __launch_bounds__(256) colsum_partial_k(const float* x, long long ld, int rows, int cols4, float* part) {
+    __shared__ f32x4 s_red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int chunk = blockIdx.y, per = (rows + COLSUM_CHUNKS - 1) / COLSUM_CHUNKS;
+    const int r0 = chunk * per, r1 = r0 + per < rows ? r0 + per : rows;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (c < cols4)
+        for (int r = r0 + wave; r < r1; r += 4) acc += *reinterpret_cast<const f32x4*>(x + r * ld + 4 * c);
+    s_red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && c < cols4)
+        *reinterpret_cast<f32x4*>(part + ((long long)chunk * cols4 + c) * 4) = (s_red[0][lane] + s_red[1][lane]) + (s_red[2][lane] + s_red[3][lane]);
+}
+__global__ void __launch_bounds__(256) colsum_final_k(const float* part, int cols4, float* out, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols4) return;
+    f32x4 acc = accumulate ? *reinterpret_cast<const f32x4*>(out + 4 * c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < COLSUM_CHUNKS; ++k) acc += *reinterpret_cast<const f32x4*>(part + ((long long)k * cols4 + c) * 4);
+    *reinterpret_cast<f32x4*>(out + 4 * c) = acc;
+}
+
 }  // namespace set
 
 using namespace set;
@@ -110,6 +135,22 @@ int set_pack_f32(float* dst, int64_t ldd, int rows, int nseg, const float* const
     const long long n = (long long)rows * c4;
     hipLaunchKernelGGL(pack_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, (long long)ldd, rows,
                        c4, a, accumulate);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+size_t set_colsum_workspace_bytes(int cols) { return cols > 0 ? (size_t)COLSUM_CHUNKS * round_up((size_t)cols, 4) * sizeof(float) + 256 : 0; }
+
+int set_colsum_f32(const float* x, int64_t ld, int rows, int cols, float* out, int accumulate, void* ws, size_t ws_bytes,
+                   void* stream) {
+    if (!x || !out || rows <= 0 || cols <= 0) return SET_ERR_ARG;
+    if ((cols & 3) || (ld & 3) || !aligned16(x) || !aligned16(out)) return SET_ERR_UNSUPPORTED;
+    if (!ws || !aligned16(ws) || ws_bytes < set_colsum_workspace_bytes(cols) - 256) return SET_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int cols4 = cols >> 2;
+    hipLaunchKernelGGL(colsum_partial_k, dim3(cdiv(cols4, 64), COLSUM_CHUNKS), dim3(256), 0, st, x, (long long)ld, rows, cols4,
+                       (float*)ws);
+    hipLaunchKernelGGL(colsum_final_k, dim3(cdiv(cols4, 256)), dim3(256), 0, st, (const float*)ws, cols4, out, accumulate);
     SET_LAUNCH_CHECK();
     return SET_OK;
 }

@@ -433,9 +433,9 @@ class _XESequence(torch.autograd.Function):
         h1_all = L["H1"][1:].reshape(TB, D)
         W("ca_dec_w", DATT2C.view(TB, Adim), h1_all); Bg("ca_dec_b", DATT2C.view(TB, Adim))
         W("va_dec_w", DATT2V.view(TB, Adim), h1_all); Bg("va_dec_b", DATT2V.view(TB, Adim))
-        g[pidx["ca_full_w"]] = DWFC.view(TB, Adim).sum(0, keepdim=True)
+        g[pidx["ca_full_w"]] = A._colsum(DWFC.view(TB, Adim)).view(1, Adim)
         g[pidx["ca_full_b"]] = DEC.sum().reshape(1)
-        g[pidx["va_full_w"]] = DWFV.view(TB, Adim).sum(0, keepdim=True)
+        g[pidx["va_full_w"]] = A._colsum(DWFV.view(TB, Adim)).view(1, Adim)
         g[pidx["va_full_b"]] = DEV.sum().reshape(1)
         if train:
             W("va_fa_w", DATT1.view(TB * R, Adim), L["FE"].view(TB * R, D)); Bg("va_fa_b", DATT1.view(TB * R, Adim))

@@ -231,3 +231,20 @@ def test_rollout_node_equals_per_operator_rollout(monkeypatch):
             continue
         err = float((g0[k] - g1[k]).abs().max()) / max(float(g0[k].abs().max()), 1e-6 * gmax)
         assert err < 1e-3, (k, err)
+
+
+def test_colsum_kernel():
+    from show_edit_tell_amd import autograd_ops as A
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for rows, cols in ((2432, 4096), (87552, 512), (100, 64), (63, 8)):
+        x = torch.randn(rows, cols, generator=g).to(dev)
+        ref = x.double().sum(0).float()
+        out = A._colsum(x)
+        assert torch.allclose(out, ref, rtol=1e-4, atol=1e-3 * float(ref.abs().max()))
+        acc = torch.ones(cols, device=dev)
+        A._colsum(x, out=acc)
+        assert torch.allclose(acc, ref + 1.0, rtol=1e-4, atol=1e-3 * float(ref.abs().max()))
+        assert torch.equal(A._colsum(x), out)                 # deterministic
+    big = torch.randn(512, 256, generator=g).to(dev)
+    assert torch.allclose(A._colsum(big[:, 64:192]), big[:, 64:192].sum(0), atol=1e-4)

@@ -36,6 +36,7 @@ __global__ void __launch_bounds__(256) raw_mfma_k(float* out, int iters, float a
     float s = 0;
     for (int e = 0; e < 16; ++e) s += c0[e] + c1[e] + c2[e] + c3[e];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    RAW_CLOCK_END();
 }
 
 __global__ void __launch_bounds__(256) empty_k(float* out, int flag) { if (flag) out[threadIdx.x] = 0.f; }
@@ -47,7 +48,12 @@ __global__ void __launch_bounds__(256) raw_mfma_rand_k(float* out, const float* 
     f32x16_ c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
     float a[8], b[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { a[i] = src[(threadIdx.x * 8 + i) % 4096]; b[i] = src[4096 + (threadIdx.x * 8 + i + blockIdx.x) % 4096]; }
+    for (int i = 0; i < 8; ++i) {          // pseudo-random mantissas, no memory access (same start-up as the constant kernel)
+        const unsigned ha = (threadIdx.x * 2654435761u + i * 40503u + blockIdx.x * 97u) * 2246822519u;
+        const unsigned hb = (threadIdx.x * 3266489917u + i * 668265263u + blockIdx.x * 31u) * 374761393u;
+        a[i] = (__uint_as_float(0x3f800000u | (ha >> 9)) - 1.5f) * 0.2f + src[0] * 0.f;
+        b[i] = (__uint_as_float(0x3f800000u | (hb >> 9)) - 1.5f) * 0.2f;
+    }
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
