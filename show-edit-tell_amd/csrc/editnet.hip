@@ -286,7 +286,7 @@ static void build_phase_a(const SetEditNetWeights* w, const SetEditNetDims* d, E
 static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X, int bt, EditNetWs& ws,
                      const long long* tok_ids, long long tok_stride, float* dst,
                      long long ld_dst, Slabs* logits_out, hipStream_t st, const GemmProb* a_pre = nullptr,
-                     GemmProb* a_next = nullptr, bool* logits_biased = nullptr) {
+                     GemmProb* a_next = nullptr, bool* logits_biased = nullptr, int bt_next = -1) {
     const int B = d->B, T = d->T, R = d->R, F = d->F, D = d->D, A = d->A, V = d->V;
     const int tgt = gemm_target_wgs();
     const long long ld_x2h = 2LL * D + F;
@@ -373,16 +373,20 @@ static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const 
     static const int f_bm = env_int("SET_GEMM_F_BM", 0);
     if (bt > 64) f.bm_hint = f_bm;
     if (logits_biased) *logits_biased = false;
-    if (a_next && tab && !dst) {
+    if (a_next && tab) {
+        // bt_next: rows of the NEXT timestep (teacher-forced loop: the sorted batch shrinks); default = this step's rows
         GemmProb fa[3];
         fa[0] = f;
-        build_phase_a(w, d, ws, bt, true, fa + 1);
+        build_phase_a(w, d, ws, bt_next > 0 ? bt_next : bt, true, fa + 1);
         plan_ksplit(fa, 3, tgt);
-        if (fa[0].ksplit == 1) {             // unsplit fc: write the logits once, bias fused
-            fa[0].C = ws.logits; fa[0].slab_stride = 0; fa[0].bias = w->fc_b;
+        if (fa[0].ksplit == 1) {             // unsplit fc: write the scores once, bias fused (straight into dst when given)
+            fa[0].C = dst ? dst : ws.logits; fa[0].slab_stride = 0; fa[0].bias = w->fc_b;
+            if (dst) fa[0].ldc = ld_dst;
             if (logits_biased) *logits_biased = true;
         }
         SET_TRY(gemm_group(fa, 3, st, "gemm:F fc + next A"));
+        if (dst && fa[0].ksplit > 1)
+            SET_TRY(reduce_bias_act(slabs_of(fa[0]), w->fc_b, nullptr, dst, ld_dst, bt, V, SET_ACT_NONE, st));
         a_next[0] = fa[1]; a_next[1] = fa[2];
         if (logits_out) *logits_out = slabs_of(fa[0]);
         return SET_OK;
@@ -530,13 +534,25 @@ int set_editnet_xe_forward(const SetEditNetWeights* w, const SetEditNetDims* d, 
     if (caps_stride < maxT) return SET_ERR_ARG;
     SET_TRY(begin_impl(w, d, X, image_mean, prev, prevlen, W, st));
     SET_HIP_TRY(hipMemsetAsync(predictions, 0, sizeof(float) * (size_t)B * maxT * V, st));
+    // with the token table the step never reads relu(E[it]) and phase A of timestep t+1 does not depend on its token:
+    // fc(h2_t) and the phase-A products of t+1 (over the rows still in the batch then) ride one launch, as in the
+    // free-running loop
+    const bool emb_needed = !(w->tok_table && (d->D % 64 == 0) && env_int("SET_NO_FUSED", 0) == 0);
+    static const int fa_merge = env_int("SET_FA_MERGE", 1);
+    const bool merge = fa_merge && !emb_needed;
+    auto rows_at = [&](int t) { int n = 0; while (n < B && host_decode_lengths[n] > t) ++n; return n; };   // editnet.py:506
+    GemmProb a_cur[2], a_nxt[2];
+    bool have_a = false;
     for (int t = 0; t < maxT; ++t) {
-        int bt = 0;
-        while (bt < B && host_decode_lengths[bt] > t) ++bt;       // editnet.py:506
+        const int bt = rows_at(t);
         if (bt == 0) break;
-        SET_TRY(embed_relu(w->embed, caps + t, caps_stride, W.emb, d->D, bt, d->D, V, st));
+        const int btn = t + 1 < maxT ? rows_at(t + 1) : 0;
+        if (emb_needed) SET_TRY(embed_relu(w->embed, caps + t, caps_stride, W.emb, d->D, bt, d->D, V, st));
+        const bool next_a = merge && btn > 0;
         SET_TRY(step_impl(w, d, X, bt, W, (const long long*)(caps + t), caps_stride, predictions + (size_t)t * V,
-                          (long long)maxT * V, nullptr, st));
+                          (long long)maxT * V, nullptr, st, have_a ? a_cur : nullptr, next_a ? a_nxt : nullptr, nullptr, btn));
+        have_a = next_a;
+        if (next_a) { a_cur[0] = a_nxt[0]; a_cur[1] = a_nxt[1]; }
     }
     return SET_OK;
 }
