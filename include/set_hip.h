@@ -206,9 +206,19 @@ typedef struct SetDcnetWeights {
     const float *al_wih, *al_whh, *al_bih, *al_bhh;   /* attention_lstm (4D,3E),(4D,D)            */
     const float *ll_wih, *ll_whh, *ll_bih, *ll_bhh;   /* language_lstm (4D,2E),(4D,D)             */
     const float *fc_w, *fc_b;                    /* fc (V,D)                                      */
+    /* Optional inference-time token table (V, 4D + 8C) or NULL, built by set_dcnet_build_token_table:
+     *   [0, 4D)        attention_lstm.weight_ih[:, :E] relu(E[v])            (dcnet.py:336-337)
+     *   [4D, 4D+4C)    lstm_encoder.weight_ih_l0 relu(E[v]) + bias_ih_l0      (dcnet.py:233, forward direction)
+     *   [4D+4C, 4D+8C) lstm_encoder.weight_ih_l0_reverse relu(E[v]) + bias_ih_l0_reverse
+     * Valid while embed / attention_lstm.weight_ih / lstm_encoder.weight_ih* / bias_ih* are unchanged. */
+    const float* tok_table;
 } SetDcnetWeights;
 
 size_t set_dcnet_workspace_bytes(const SetDcnetDims* d);
+size_t set_dcnet_token_table_bytes(const SetDcnetDims* d);
+size_t set_dcnet_token_table_workspace_bytes(const SetDcnetDims* d);
+int set_dcnet_build_token_table(const SetDcnetWeights* w, const SetDcnetDims* d, float* table, void* ws,
+                                size_t ws_bytes, void* stream);
 /* caption_encoder (dcnet.py:220-243) + hoisted cap_features_att(enc) (dcnet.py:261) + zero state */
 int set_dcnet_begin(const SetDcnetWeights* w, const SetDcnetDims* d, const int64_t* prev,
                     const int64_t* prevlen, void* ws, size_t ws_bytes, void* stream);

@@ -130,7 +130,7 @@ DCNET_WEIGHT_FIELDS = (
 
 
 class DcnetWeights(C.Structure):
-    _fields_ = [(f, C.c_void_p) for f, _ in DCNET_WEIGHT_FIELDS]
+    _fields_ = [(f, C.c_void_p) for f, _ in DCNET_WEIGHT_FIELDS] + [("tok_table", C.c_void_p)]
 
 
 class GemmDesc(C.Structure):
@@ -170,6 +170,9 @@ PROTOTYPES = {
                                     C.POINTER(C.c_int), _P, _P, _P, _P, _Z, _P]),
     "set_editnet_ws_tensor": (_P, [C.POINTER(EditNetDims), _P, C.c_char_p]),
     "set_dcnet_workspace_bytes": (_Z, [C.POINTER(DcnetDims)]),
+    "set_dcnet_token_table_bytes": (_Z, [C.POINTER(DcnetDims)]),
+    "set_dcnet_token_table_workspace_bytes": (_Z, [C.POINTER(DcnetDims)]),
+    "set_dcnet_build_token_table": (_I, [C.POINTER(DcnetWeights), C.POINTER(DcnetDims), _P, _P, _Z, _P]),
     "set_dcnet_begin": (_I, [C.POINTER(DcnetWeights), C.POINTER(DcnetDims), _P, _P, _P, _Z, _P]),
     "set_dcnet_step": (_I, [C.POINTER(DcnetWeights), C.POINTER(DcnetDims), _P, _L, _I, _P, _L, _P, _Z, _P]),
     "set_dcnet_greedy_pick": (_I, [C.POINTER(DcnetWeights), C.POINTER(DcnetDims), _P, _L, _I, _L, _P, _P, _I, _P, _Z,

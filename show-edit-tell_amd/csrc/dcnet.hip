@@ -7,6 +7,10 @@
 //   B  att2_c = cap_decoder_att(h1), language_lstm Wih[:, :D](h1) -> caption attention (attend_cap)
 //   C  language_lstm Wih[:, D:](attend_cap)                       -> LSTM pointwise (h2, c2)
 //   D  fc(h2)
+// Inference-time token table (w->tok_table, (V, 4D + 8C), set_dcnet_build_token_table): the contractions whose only input
+// is a token — attention_lstm.W_ih[:, :E] relu(E[v]) and the two encoder input projections W_ih relu(E[v]) + b_ih — become
+// row gathers; phase A then no longer sees the current token, so fc(h2_t) and phase A of timestep t+1 ride ONE launch
+// (the same F/A merge as csrc/editnet.hip) and the prologue skips its 21.5-GFLOP input projection.
 #include <cstring>
 #include "set_common.h"
 
@@ -81,8 +85,11 @@ static int begin_impl(const SetDcnetWeights* w, const SetDcnetDims* d, const int
     const int B = d->B, T = d->T, D = d->D, A = d->A, C = d->C, E = d->E;
     const int tgt = gemm_target_wgs();
     // ---- CaptionEncoder (dcnet.py:220-243): packed BiLSTM == per-row masked recurrences
-    SET_TRY(embed_relu(w->embed, prev, 1, ws.emb_seq, E, B * T, E, d->V, st));
-    {
+    const bool fused = (C % 128 == 0) && env_int("SET_NO_FUSED", 0) == 0;
+    const bool tab = w->tok_table != nullptr && fused && (D % 64 == 0);
+    const long long ldt = 4LL * D + 8LL * C;                 // token-table row stride
+    if (!tab) SET_TRY(embed_relu(w->embed, prev, 1, ws.emb_seq, E, B * T, E, d->V, st));
+    if (!tab) {
         GemmProb p[2];
         p[0] = direct_prob(ws.xg_f, 4 * C, B * T, 4 * C, w->enc_bih_f, SET_ACT_NONE);
         p[0].add(ws.emb_seq, E, w->enc_wih_f, E, E);
@@ -95,9 +102,18 @@ static int begin_impl(const SetDcnetWeights* w, const SetDcnetDims* d, const int
     SET_TRY(zero_f32(ws.cf, (size_t)B * C, st));
     SET_TRY(zero_f32(ws.hb, (size_t)B * C, st));
     SET_TRY(zero_f32(ws.cb, (size_t)B * C, st));
-    const bool fused = (C % 128 == 0) && env_int("SET_NO_FUSED", 0) == 0;
     float *hf_cur = ws.hf, *hf_nxt = ws.s_ef, *hb_cur = ws.hb, *hb_nxt = ws.s_eb;   // ping-pong (slab regions are free)
     for (int t = 0; t < T; ++t) {
+        if (fused && tab) {                   // x W_ih^T + b_ih of every word is a row of the token table
+            SET_TRY(fused_encoder_step(hf_cur, hf_nxt, ws.cf, w->enc_whh_f, w->tok_table + 4 * D, ldt, 0, w->enc_bhh_f,
+                                       prevlen, t, 0, ws.enc, nullptr, (long long)T * 2 * C, 2 * C, 0, B, C, st, prev, T, d->V));
+            SET_TRY(fused_encoder_step(hb_cur, hb_nxt, ws.cb, w->enc_whh_b, w->tok_table + 4 * D + 4 * C, ldt, 0,
+                                       w->enc_bhh_b, prevlen, t, 1, ws.enc, nullptr, (long long)T * 2 * C, 2 * C, C, B, C, st,
+                                       prev, T, d->V));
+            float* tmp = hf_cur; hf_cur = hf_nxt; hf_nxt = tmp;
+            tmp = hb_cur; hb_cur = hb_nxt; hb_nxt = tmp;
+            continue;
+        }
         if (fused) {
             SET_TRY(fused_encoder_step(hf_cur, hf_nxt, ws.cf, w->enc_whh_f, ws.xg_f, (long long)T * 4 * C, 4 * C,
                                        w->enc_bhh_f, prevlen, t, 0, ws.enc, nullptr, (long long)T * 2 * C, 2 * C, 0, B, C,
@@ -151,22 +167,42 @@ static int begin_impl(const SetDcnetWeights* w, const SetDcnetDims* d, const int
     return SET_OK;
 }
 
-static int step_impl(const SetDcnetWeights* w, const SetDcnetDims* d, int bt, DcnetWs& ws, float* dst, long long ld_dst,
-                     Slabs* logits_out, hipStream_t st) {
-    const int B = d->B, T = d->T, D = d->D, A = d->A, C = d->C, E = d->E, V = d->V;
-    const int tgt = gemm_target_wgs();
-    const Slabs none{nullptr, 0, 0, 0};
-    GemmProb a[2];
+static bool table_active(const SetDcnetWeights* w, const SetDcnetDims* d) {
+    return w->tok_table != nullptr && (d->C % 128 == 0) && (d->D % 64 == 0) && env_int("SET_NO_FUSED", 0) == 0;
+}
+
+static void build_phase_a(const SetDcnetWeights* w, const SetDcnetDims* d, DcnetWs& ws, int bt, bool tab, GemmProb a[2]) {
+    const int B = d->B, D = d->D, C = d->C, E = d->E;
     a[0] = slab_prob(ws.sA0, bt, 4 * D, B);
-    a[0].add(ws.emb, E, w->al_wih, 3 * E, E);
+    if (!tab) a[0].add(ws.emb, E, w->al_wih, 3 * E, E);
     a[0].add(ws.h2, D, w->al_wih + E + 2 * C, 3 * E, D);
     a[0].add(ws.h1, D, w->al_whh, D, D);
     a[1] = slab_prob(ws.sA1, bt, 4 * D, B);
     a[1].add(ws.h2, D, w->ll_whh, D, D);
-    plan_ksplit(a, 2, tgt);
-    SET_TRY(gemm_group(a, 2, st, "gemm:A gates1+h2h"));
+}
+
+// tok_ids / tok_stride: the tokens of THIS timestep (table gather).  a_pre / a_next / bt_next / logits_biased: the F/A
+// merge, exactly as in csrc/editnet.hip step_impl.
+static int step_impl(const SetDcnetWeights* w, const SetDcnetDims* d, int bt, DcnetWs& ws, float* dst, long long ld_dst,
+                     Slabs* logits_out, hipStream_t st, const long long* tok_ids = nullptr, long long tok_stride = 1,
+                     const GemmProb* a_pre = nullptr, GemmProb* a_next = nullptr, bool* logits_biased = nullptr,
+                     int bt_next = -1) {
+    const int B = d->B, T = d->T, D = d->D, A = d->A, C = d->C, E = d->E, V = d->V;
+    const int tgt = gemm_target_wgs();
+    const Slabs none{nullptr, 0, 0, 0};
+    const bool tab = table_active(w, d) && tok_ids != nullptr;
+    RowGather g_gates;
+    if (tab) g_gates = RowGather{w->tok_table, tok_ids, tok_stride, 4LL * D + 8LL * C, 0, V};
+    GemmProb a[2];
+    if (a_pre) {
+        a[0] = a_pre[0]; a[1] = a_pre[1];
+    } else {
+        build_phase_a(w, d, ws, bt, tab, a);
+        plan_ksplit(a, 2, tgt);
+        SET_TRY(gemm_group(a, 2, st, "gemm:A gates1+h2h"));
+    }
     SET_TRY(lstm_pointwise(slabs_of(a[0]), none, none, ws.pre1, 4 * D, nullptr, nullptr, ws.c1, ws.c1, ws.h1, nullptr,
-                           bt, D, st));
+                           bt, D, st, g_gates));
     GemmProb b[2];
     b[0] = slab_prob(ws.sB0, bt, A, B);
     b[0].add(ws.h1, D, w->ca_dec_w, D, D);
@@ -187,6 +223,24 @@ static int step_impl(const SetDcnetWeights* w, const SetDcnetDims* d, int bt, Dc
     f.ldc = Vp;
     f.slab_stride = (long long)B * Vp;
     f.add(ws.h2, D, w->fc_w, D, D);
+    if (logits_biased) *logits_biased = false;
+    if (a_next && tab) {
+        GemmProb fa[3];
+        fa[0] = f;
+        build_phase_a(w, d, ws, bt_next > 0 ? bt_next : bt, true, fa + 1);
+        plan_ksplit(fa, 3, tgt);
+        if (fa[0].ksplit == 1) {             // unsplit fc: write the scores once, bias fused (straight into dst when given)
+            fa[0].C = dst ? dst : ws.logits; fa[0].slab_stride = 0; fa[0].bias = w->fc_b;
+            fa[0].ldc = dst ? ld_dst : Vp;
+            if (logits_biased) *logits_biased = true;
+        }
+        SET_TRY(gemm_group(fa, 3, st, "gemm:F fc + next A"));
+        if (dst && fa[0].ksplit > 1)
+            SET_TRY(reduce_bias_act(slabs_of(fa[0]), w->fc_b, nullptr, dst, ld_dst, bt, V, SET_ACT_NONE, st));
+        a_next[0] = fa[1]; a_next[1] = fa[2];
+        if (logits_out) *logits_out = slabs_of(fa[0]);
+        return SET_OK;
+    }
     plan_ksplit(&f, 1, tgt);
     if (dst && f.ksplit == 1) {
         f.C = dst; f.ldc = ld_dst; f.bias = w->fc_b; f.slab_stride = 0;
@@ -234,7 +288,8 @@ int set_dcnet_step(const SetDcnetWeights* w, const SetDcnetDims* d, const int64_
     if (bt <= 0 || bt > d->B || ld_logits < d->V) return SET_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (tokens) SET_TRY(embed_relu(w->embed, tokens, tokens_stride, W.emb, d->E, bt, d->E, d->V, st));
-    return step_impl(w, d, bt, W, logits, ld_logits, nullptr, st);
+    return step_impl(w, d, bt, W, logits, ld_logits, nullptr, st, tokens ? (const long long*)tokens : W.it,
+                     tokens ? (long long)tokens_stride : 1);
 }
 
 int set_dcnet_greedy_pick(const SetDcnetWeights* w, const SetDcnetDims* d, const float* logits, int64_t ld_logits,
@@ -265,17 +320,29 @@ static int dcnet_rollout(const SetDcnetWeights* w, const SetDcnetDims* d, const 
     SET_HIP_TRY(hipMemsetAsync(seq, 0, sizeof(int64_t) * B * max_len, st));
     SET_HIP_TRY(hipMemsetAsync(seq_logp, 0, sizeof(float) * B * max_len, st));
     SET_TRY(set_tokens(W.it, start_idx, W.unfinished, W.alive, d->maxT + 2, B, st));
-    SET_TRY(embed_relu(w->embed, (const int64_t*)W.it, 1, W.emb, d->E, B, d->E, d->V, st));
+    const bool emb_needed = !table_active(w, d);         // with the token table no consumer reads relu(E[it])
+    if (emb_needed) SET_TRY(embed_relu(w->embed, (const int64_t*)W.it, 1, W.emb, d->E, B, d->E, d->V, st));
+    static const int fa_merge = env_int("SET_FA_MERGE", 1);
+    const bool merge = fa_merge && !emb_needed;
+    GemmProb a_cur[2], a_nxt[2];
+    bool have_a = false;
     for (int t = 0; t <= max_len; ++t) {                                 // dcnet_rl.py:305,315-316
         Slabs lg;
-        SET_TRY(step_impl(w, d, B, W, nullptr, 0, &lg, st));
+        bool biased = false;
+        const bool next_a = merge && t < max_len;
+        SET_TRY(step_impl(w, d, B, W, nullptr, 0, &lg, st, W.it, 1, have_a ? a_cur : nullptr, next_a ? a_nxt : nullptr,
+                          &biased));
+        have_a = next_a;
+        if (next_a) { a_cur[0] = a_nxt[0]; a_cur[1] = a_nxt[1]; }
         if (t == max_len) break;
+        const float* pick_bias = biased ? nullptr : w->fc_b;
         if (sample)
-            SET_TRY(sample_pick(lg, w->fc_b, d->V, t, max_len, end_idx, (long long*)seq, seq_logp, W.it, W.unfinished,
-                                W.alive, w->embed, W.emb, d->E, B, seed, offset, nullptr, nullptr, nullptr, st));
+            SET_TRY(sample_pick(lg, pick_bias, d->V, t, max_len, end_idx, (long long*)seq, seq_logp, W.it, W.unfinished,
+                                W.alive, emb_needed ? w->embed : nullptr, W.emb, d->E, B, seed, offset, nullptr, nullptr,
+                                nullptr, st));
         else
-            SET_TRY(greedy_pick(lg, w->fc_b, d->V, t, max_len, end_idx, (long long*)seq, seq_logp, W.it, W.unfinished,
-                                W.alive, w->embed, W.emb, d->E, B, st));
+            SET_TRY(greedy_pick(lg, pick_bias, d->V, t, max_len, end_idx, (long long*)seq, seq_logp, W.it, W.unfinished,
+                                W.alive, emb_needed ? w->embed : nullptr, W.emb, d->E, B, st));
     }
     return SET_OK;
 }
@@ -308,14 +375,60 @@ int set_dcnet_xe_forward(const SetDcnetWeights* w, const SetDcnetDims* d, const 
     if (caps_stride < maxT) return SET_ERR_ARG;
     SET_TRY(begin_impl(w, d, prev, prevlen, W, st));
     SET_HIP_TRY(hipMemsetAsync(predictions, 0, sizeof(float) * (size_t)B * maxT * V, st));
+    const bool emb_needed = !table_active(w, d);
+    static const int fa_merge = env_int("SET_FA_MERGE", 1);
+    const bool merge = fa_merge && !emb_needed;
+    auto rows_at = [&](int t) { int n = 0; while (n < B && host_decode_lengths[n] > t) ++n; return n; };   // dcnet.py:334
+    GemmProb a_cur[2], a_nxt[2];
+    bool have_a = false;
     for (int t = 0; t < maxT; ++t) {
-        int bt = 0;
-        while (bt < B && host_decode_lengths[bt] > t) ++bt;             // dcnet.py:334
+        const int bt = rows_at(t);
         if (bt == 0) break;
-        SET_TRY(embed_relu(w->embed, caps + t, caps_stride, W.emb, d->E, bt, d->E, V, st));
-        SET_TRY(step_impl(w, d, bt, W, predictions + (size_t)t * V, (long long)maxT * V, nullptr, st));
+        const int btn = t + 1 < maxT ? rows_at(t + 1) : 0;
+        if (emb_needed) SET_TRY(embed_relu(w->embed, caps + t, caps_stride, W.emb, d->E, bt, d->E, V, st));
+        const bool next_a = merge && btn > 0;
+        SET_TRY(step_impl(w, d, bt, W, predictions + (size_t)t * V, (long long)maxT * V, nullptr, st,
+                          (const long long*)(caps + t), caps_stride, have_a ? a_cur : nullptr, next_a ? a_nxt : nullptr, nullptr,
+                          btn));
+        have_a = next_a;
+        if (next_a) { a_cur[0] = a_nxt[0]; a_cur[1] = a_nxt[1]; }
     }
     return SET_OK;
+}
+
+size_t set_dcnet_token_table_bytes(const SetDcnetDims* d) {
+    if (check_dims(d) != SET_OK) return 0;
+    return sizeof(float) * (size_t)d->V * (4 * (size_t)d->D + 8 * (size_t)d->C);
+}
+
+size_t set_dcnet_token_table_workspace_bytes(const SetDcnetDims* d) {
+    if (check_dims(d) != SET_OK) return 0;
+    return round_up(sizeof(float) * (size_t)d->V * d->E, 256) + round_up(sizeof(long long) * (size_t)d->V, 256) + 256;
+}
+
+// table[v] = [ W_ih^att[:, :E] relu(E[v]) | W_ih^enc,fwd relu(E[v]) + b_ih^fwd | W_ih^enc,bwd relu(E[v]) + b_ih^bwd ]
+int set_dcnet_build_token_table(const SetDcnetWeights* w, const SetDcnetDims* d, float* table, void* ws, size_t ws_bytes,
+                                void* stream) {
+    if (!w || !table || !ws) return SET_ERR_ARG;
+    SET_TRY(check_dims(d));
+    if (!aligned16(ws) || !aligned16(table)) return SET_ERR_ARG;
+    if (ws_bytes < set_dcnet_token_table_workspace_bytes(d) - 256) return SET_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int V = d->V, D = d->D, C = d->C, E = d->E;
+    const long long ldt = 4LL * D + 8LL * C;
+    Carver cv(ws);
+    float* remb = cv.take<float>((size_t)V * E);
+    long long* ids = cv.take<long long>((size_t)V);
+    SET_TRY(iota_i64(ids, V, st));
+    SET_TRY(embed_relu(w->embed, (const int64_t*)ids, 1, remb, E, V, E, V, st));
+    GemmProb p[3];
+    p[0] = direct_prob(table, ldt, V, 4 * D, nullptr, SET_ACT_NONE);
+    p[0].add(remb, E, w->al_wih, 3LL * E, E);
+    p[1] = direct_prob(table + 4 * D, ldt, V, 4 * C, w->enc_bih_f, SET_ACT_NONE);
+    p[1].add(remb, E, w->enc_wih_f, E, E);
+    p[2] = direct_prob(table + 4 * D + 4 * C, ldt, V, 4 * C, w->enc_bih_b, SET_ACT_NONE);
+    p[2].add(remb, E, w->enc_wih_b, E, E);
+    return gemm_group(p, 3, st, "gemm:token table");
 }
 
 void* set_dcnet_ws_tensor(const SetDcnetDims* d, void* ws, const char* name) {

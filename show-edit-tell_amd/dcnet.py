@@ -128,11 +128,26 @@ class DAE(nn.Module):
         self._ws = None
         self._ws_key = None
 
-    # the reference checkpoints pickle the whole module (dcnet.py:131-138): GPU workspaces must not travel
+    # the reference checkpoints pickle the whole module (dcnet.py:131-138): GPU workspaces and the derived token table
+    # must not travel
     def __getstate__(self):
         state = dict(self.__dict__)
         state["_ws"] = state["_ws_key"] = None
+        state.pop("_tok_state", None)
         return state
+
+    def invalidate_token_table(self):
+        """Drop the derived inference-time token table (see _token_table); same contract as editnet.DecoderC's."""
+        self.__dict__.pop("_tok_state", None)
+
+    def train(self, mode=True):
+        if bool(mode) != self.training:
+            self.invalidate_token_table()
+        return super().train(mode)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.invalidate_token_table()
+        return super().load_state_dict(*args, **kwargs)
 
     def __setstate__(self, state):
         import weakref
@@ -141,6 +156,7 @@ class DAE(nn.Module):
 
     def _apply(self, fn, *args, **kwargs):
         self._ws = self._ws_key = None
+        self.invalidate_token_table()
         return super()._apply(fn, *args, **kwargs)
 
     def init_hidden_state(self, batch_size):
@@ -149,9 +165,51 @@ class DAE(nn.Module):
                 torch.zeros(batch_size, self.decoder_dim, device=dev))
 
     # ---- runtime plumbing
-    def _weights(self):
-        return _lib.pack_weights(DcnetWeights, DCNET_WEIGHT_FIELDS, dict(self.named_parameters()),
-                                 self.fc.weight.device)
+    def _weights(self, dims=None):
+        """Pack the parameter pointers; with `dims` (no-grad decode paths) also attach the token table when valid."""
+        w = _lib.pack_weights(DcnetWeights, DCNET_WEIGHT_FIELDS, dict(self.named_parameters()), self.fc.weight.device)
+        if dims is not None:
+            tab = self._token_table(dims)
+            if tab is not None:
+                w.tok_table = tab.data_ptr()
+        return w
+
+    # The contractions whose only input is a token (attention_lstm.W_ih[:, :E] relu(E[v]) and the BiLSTM encoder's two
+    # input projections) are folded into a (V, 4D + 8C) table (include/set_hip.h: SetDcnetWeights.tok_table).  Same
+    # life cycle as editnet.DecoderC._token_table: built once the same source weights have been seen on two consecutive
+    # no-grad calls, dropped when any of them changes (tensor._version / data_ptr), on train()/eval() switches,
+    # load_state_dict() and device moves; SET_TOKEN_TABLE=0 disables, =1 forces, SET_TOKEN_TABLE_VERIFY=1 re-checks.
+    def _token_table(self, dims):
+        import os
+        mode = os.environ.get("SET_TOKEN_TABLE", "auto")
+        if mode == "0" or dims.D % 64 or dims.C % 128:
+            return None
+        enc = self.caption_encoder.lstm_encoder
+        src = (self.embed.embedding.weight, self.attention_lstm.weight_ih, enc.weight_ih_l0, enc.bias_ih_l0,
+               enc.weight_ih_l0_reverse, enc.bias_ih_l0_reverse)
+        sig = tuple((t.data_ptr(), t._version) for t in src)
+        st = self.__dict__.setdefault("_tok_state", {"sig": None, "seen": 0, "table": None})
+        if st["sig"] != sig:
+            st.update(sig=sig, seen=1, table=None)
+        else:
+            st["seen"] += 1
+        if st["table"] is None and (mode == "1" or st["seen"] >= 2):
+            lib = _lib.load()
+            dev = self.fc.weight.device
+            table = torch.empty(lib.set_dcnet_token_table_bytes(C.byref(dims)) // 4, dtype=torch.float32, device=dev)
+            ws = torch.empty(lib.set_dcnet_token_table_workspace_bytes(C.byref(dims)), dtype=torch.uint8, device=dev)
+            w = _lib.pack_weights(DcnetWeights, DCNET_WEIGHT_FIELDS, dict(self.named_parameters()), dev)
+            check(lib.set_dcnet_build_token_table(C.byref(w), C.byref(dims), ptr(table), ptr(ws), ws.numel(), stream_of(dev)),
+                  "set_dcnet_build_token_table")
+            torch.cuda.current_stream(dev).synchronize()
+            st["table"] = table
+            st["check"] = torch.stack([t.detach().double().sum() for t in src]).cpu()
+        if st["table"] is not None and os.environ.get("SET_TOKEN_TABLE_VERIFY") == "1":
+            now = torch.stack([t.detach().double().sum() for t in src]).cpu()
+            if not torch.equal(now, st["check"]):
+                raise _lib.SetError("token table is stale: a source weight changed without bumping tensor._version "
+                                    "(in-place .data write?); call dae.invalidate_token_table()")
+        return st["table"]
 
     def _dims(self, B, T, maxT):
         D, A, Cc, E = self._dims_cfg
@@ -185,7 +243,7 @@ class DAE(nn.Module):
         B, T = src.shape
         dims = self._dims(B, T, 19)
         ws = self._workspace(dims)
-        w = self._weights()
+        w = self._weights(dims)
         check(lib.set_dcnet_begin(C.byref(w), C.byref(dims), ptr(src), ptr(lens), ptr(ws), ws.numel(),
                                   stream_of(src.device)), "set_dcnet_begin")
         Cc = self._dims_cfg[2]
@@ -212,7 +270,7 @@ class DAE(nn.Module):
         maxT = max(decode_lengths)
         dims = self._dims(batch_size, prev.shape[1], maxT)
         ws = self._workspace(dims)
-        w = self._weights()
+        w = self._weights(dims)
         predictions = torch.empty(batch_size, maxT, self.vocab_size, dtype=torch.float32, device=dev)
         dl = (C.c_int * batch_size)(*decode_lengths)
         check(lib.set_dcnet_xe_forward(C.byref(w), C.byref(dims), ptr(encoded_captions), encoded_captions.shape[1], dl,

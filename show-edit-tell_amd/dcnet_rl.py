@@ -29,7 +29,7 @@ class DAE(_DAE_XE):
         B, max_len = prev.shape[0], self.max_len
         dims = self._dims(B, prev.shape[1], max_len + 1)
         ws = self._workspace(dims)
-        w = self._weights()
+        w = self._weights(dims)
         seq = torch.empty(B, max_len, dtype=torch.long, device=dev)
         seq_logp = torch.empty(B, max_len, dtype=torch.float32, device=dev)
         if sample_rl:        # multinomial sampling, eval mode, no gradients: fused device loop, Philox epilogue

@@ -93,7 +93,7 @@ class _FusedDcnet(_FusedModel):
         D, A, Cc, _ = dae._dims_cfg
         self.st = stream_of(dev)
         d_img = dae._dims(NI, T, max_steps + 1)
-        self.w = dae._weights()
+        self.w = dae._weights(d_img)
         ws_img = torch.empty(lib.set_dcnet_workspace_bytes(C.byref(d_img)), dtype=torch.uint8, device=dev)
         check(lib.set_dcnet_begin(C.byref(self.w), C.byref(d_img), ptr(prev), ptr(plen), ptr(ws_img), ws_img.numel(),
                                   self.st), "set_dcnet_begin")

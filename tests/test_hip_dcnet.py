@@ -101,3 +101,45 @@ def test_dcnet_train_step_learns():
     losses = [dcnet_xe_train_step(xe, opt, caps, clen, prev, plen)[0] for _ in range(30)]
     after = eval_loss()
     assert all(np.isfinite(losses)) and after < before - 0.2, (before, after)
+
+
+def test_dcnet_token_table_folding():
+    """The (V, 4D + 8C) token table (attention_lstm's embedding columns + both encoder input projections folded into row
+    gathers, fc(t) + phase A(t+1) in one launch) kicks in on the second no-grad call with unchanged weights, keeps parity
+    with the reference goldens in the greedy loop, the teacher-forced forward and the encoder, and is dropped when a
+    source weight changes or the module switches mode."""
+    name = "dcnet_full_b4"
+    d, xe, rl = dcnet_modules(name)
+    c, g = d["case"], parity.load(name)
+    prev, plen = to_dev(d["prev"]), to_dev(d["plen"])
+    with torch.no_grad():
+        for i in range(3):
+            seq, logp = rl(d["wm"], prev, plen, True, False)
+            assert (rl.__dict__.get("_tok_state", {}).get("table") is not None) == (i >= 1)
+            parity.check_greedy(_np(seq), _np(logp), g)
+        for i in range(2):
+            pred, caps_s, dl, sort_ind = xe(to_dev(d["caps"]), to_dev(d["clen"]), prev, plen)
+        assert xe._tok_state["table"] is not None
+        parity.check_xe(_np(pred), dl, _np(sort_ind), g, c["V"], small=False)
+        enc, fh, mask = xe.caption_encoder(prev, plen)           # encoder input projection = table rows
+        parity.assert_close(_np(enc), g["enc_out"], parity.STATE_TOL, "dcnet encoder outputs (token table)")
+        parity.assert_close(_np(fh), g["enc_final"], parity.STATE_TOL, "dcnet final_hidden (token table)")
+        # sampled rollouts use it too and stay reproducible per seed
+        torch.manual_seed(3)
+        s1, l1 = rl(d["wm"], prev, plen, False, True)
+        torch.manual_seed(3)
+        s2, l2 = rl(d["wm"], prev, plen, False, True)
+        assert torch.equal(s1, s2) and torch.equal(l1, l2)
+        rl.embed.embedding.weight.mul_(1.0)                      # in-place update bumps the version -> table invalid
+        rl(d["wm"], prev, plen, True, False)
+        assert rl._tok_state["table"] is None
+    rl(d["wm"], prev, plen, True, False) if False else None
+    xe.train()
+    assert "_tok_state" not in xe.__dict__
+    import copy, pickle
+    xe.eval()
+    with torch.no_grad():
+        xe(to_dev(d["caps"]), to_dev(d["clen"]), prev, plen)
+        xe(to_dev(d["caps"]), to_dev(d["clen"]), prev, plen)
+    assert xe._tok_state["table"] is not None
+    assert "_tok_state" not in pickle.loads(pickle.dumps(xe)).__dict__
