@@ -386,6 +386,9 @@ int set_dropout_bwd_f32(const float* dy, int64_t lddy, const float* y, int64_t l
 size_t set_colsum_workspace_bytes(int cols);
 int set_colsum_f32(const float* x, int64_t ld, int rows, int cols, float* out, int accumulate, void* ws,
                    size_t ws_bytes, void* stream);
+/* mask[r] = (sum_c x[r, c] != 0) as 0/1 floats: the data-derived region mask of the adaptive model
+ * (adaptive_features/editnet_adaptive.py:449-453) on the per-step, dropped-out region embedding. */
+int set_rowsum_mask_f32(const float* x, int64_t ld, int rows, int cols, float* mask, void* stream);
 /* dst[:, :] (+)= [src0 | src1 | ...] column blocks (1..4 segments, cols[i] floats wide, row stride ld[i]): builds the
  * concatenated LSTM input rows of editnet.py:523 / :541 inside the per-sequence operand logs (no torch.cat). */
 int set_pack_f32(float* dst, int64_t ldd, int rows, int nseg, const float* const* src, const int64_t* ld,

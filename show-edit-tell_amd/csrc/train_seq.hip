@@ -116,6 +116,13 @@ int set_dropout_bwd_f32(const float* dy, int64_t lddy, const float* y, int64_t l
     return SET_OK;
 }
 
+/* mask[r] = (sum of row r of x != 0): the adaptive model's data-derived region mask (editnet_adaptive.py:449-453) */
+int set_rowsum_mask_f32(const float* x, int64_t ld, int rows, int cols, float* mask, void* stream) {
+    if (!x || !mask || rows <= 0 || cols <= 0) return SET_ERR_ARG;
+    if ((ld & 3) || !aligned16(x)) return SET_ERR_UNSUPPORTED;
+    return rowsum_mask(x, ld, rows, cols, mask, (hipStream_t)stream);
+}
+
 int set_pack_f32(float* dst, int64_t ldd, int rows, int nseg, const float* const* src, const int64_t* ld, const int* cols,
                  int accumulate, void* stream) {
     if (!dst || !src || !ld || !cols || rows <= 0 || nseg <= 0 || nseg > 4) return SET_ERR_ARG;

@@ -598,15 +598,21 @@ class DecoderC(nn.Module):
             fe = fe * vb
             return fe, (fe.detach().sum(2) != 0).float()
 
-        if _XE_SEQUENCE and not self._adaptive and not (use_ss and ss_prob > 0.0):
+        if _XE_SEQUENCE and not (use_ss and ss_prob > 0.0):
             # the whole loop as ONE autograd node (xe_sequence.py): logs instead of cat / add / per-step bias sums
             from . import xe_sequence as S
-            Yin = Y if self.training else A.linear(Y, va.features_att.weight, va.features_att.bias)
+            Yv = Y if valid is None else Y * valid      # adaptive: padded regions stay exactly zero through the dropout
+            Yin = Yv if self.training else A.linear(Yv, va.features_att.weight, va.features_att.bias)
             cfg = S.SeqConfig(decode_lengths, self.training, self.embed.dropout.p, va.att_embed[2].p, self.dropout.p,
                               int(torch.randint(0, 2 ** 62, (1,)).item()))
-            predictions = S.xe_sequence(cfg, X, mean, H, M, final_hidden, mask, att1_c_all, Yin, encoded_captions,
-                                        S.decoder_params(self))
-            return predictions, encoded_captions, decode_lengths, sort_ind
+            if self._adaptive:
+                cfg.adaptive = True
+                cfg.rmask = None if self.training else (Yv.detach().sum(2) != 0).float()
+            out = S.xe_sequence(cfg, X, mean, H, M, final_hidden, mask, att1_c_all, Yin, encoded_captions,
+                                S.decoder_params(self))
+            if self._adaptive:
+                out, self._last_hidden = out
+            return out, encoded_captions, decode_lengths, sort_ind
 
         att1_eval = rmask_eval = None
         if not self.training:            # dropout inactive: features_att(att_embed(X)) is loop invariant

@@ -63,6 +63,11 @@ class SeqConfig:
         # free-running sampled rollout (editnet_rl.py:485-549 with sample_rl): dict(max_len, start_idx, end_idx) — the token
         # of step t is what the device sampling epilogue drew at step t-1, the node returns (seq, seq_logp)
         self.rollout = rollout
+        # adaptive features (adaptive_features/editnet_adaptive.py:438-457, 560-562): Yin arrives with the padded regions
+        # zeroed; train mode re-derives the region mask from every step's dropped-out embedding, eval mode uses `rmask`
+        # (B, R); the node also returns every row's last h2 (`decoder_last_hidden`)
+        self.adaptive = False
+        self.rmask = None
 
 
 def _z(*shape, dev):
@@ -170,6 +175,10 @@ class _XESequence(torch.autograd.Function):
             L["ATT1"] = _zl(T, B, R, Adim, dev=dev)
             L["H2D"] = _zl(T, B, D, dev=dev)
         gated, cx, aimg = _e(B, D, dev=dev), _e(B, D, dev=dev), _e(B, F, dev=dev)
+        adaptive = cfg.adaptive
+        if adaptive:
+            L["RMASK"] = _zl(T, B, R, dev=dev) if train else None
+            rmask_eval = None if train else cfg.rmask.contiguous()
 
         w = EditNetWeights()
         w.ca_dec_w, w.ca_dec_b = P["ca_dec_w"].data_ptr(), P["ca_dec_b"].data_ptr()
@@ -221,9 +230,12 @@ class _XESequence(torch.autograd.Function):
                 ops.dropout(Yin.view(B * R, D), fe.view(B * R, D), bt * R, D, cfg.p_region, cfg.seed, scale_off(2, t))
                 att1 = L["ATT1"][t]
                 ops.linear(fe.view(B * R, D), P["va_fa_w"], P["va_fa_b"], att1.view(B * R, Adim), bt * R)
+                if adaptive:
+                    check(lib.set_rowsum_mask_f32(fe.data_ptr(), D, bt * R, D, L["RMASK"][t].data_ptr(), st), "set_rowsum_mask_f32")
             else:
                 att1 = Yin
-            check(lib.set_visual_attention_masked_f32(wref, X.data_ptr(), att1.data_ptr(), None, h1.data_ptr(), aimg.data_ptr(),
+            rm = None if not adaptive else (L["RMASK"][t].data_ptr() if train else rmask_eval.data_ptr())
+            check(lib.set_visual_attention_masked_f32(wref, X.data_ptr(), att1.data_ptr(), rm, h1.data_ptr(), aimg.data_ptr(),
                                                       L["ALPHAV"][t].data_ptr(), bt, R, F, D, Adim, ws_v.data_ptr(),
                                                       ws_v.numel(), st), "set_visual_attention_masked_f32")
             sel = L["SEL"][t]
@@ -262,6 +274,10 @@ class _XESequence(torch.autograd.Function):
         ctx.cfg, ctx.L, ctx.bts, ctx.uniform, ctx.hout = cfg, L, bts, uniform, hout
         ctx.dims = (T, B, R, F, Tc, D, Adim, V)
         ctx.save_for_backward(X, H, Mem, mask, att1_c, Yin, caps, *params)
+        if adaptive:                       # h2 of every row at its last step (slot len_b of the state log), row order
+            idx = torch.tensor(lens, dtype=torch.long, device=dev)
+            last_h = L["H2"][idx, torch.arange(B, device=dev)]
+            return out, last_h
         return out
 
     @staticmethod
@@ -337,10 +353,15 @@ class _XESequence(torch.autograd.Function):
             """[(dy, w_view, out, accumulate)] -> out (+)= dy . w, one grouped launch"""
             A.gemm_group([(dy, wv, dy.shape[0], wv.shape[1], dy.shape[1], out, acc) for dy, wv, out, acc in items], False, True)
 
+        dlast = dlogp.contiguous() if (cfg.rollout is None and cfg.adaptive and dlogp is not None) else None   # 2nd output (adaptive)
         for t in range(T - 1, -1, -1):
             bt = bts[t]
             r = lambda x: _rows(x, bt)
             h1 = L["H1"][t + 1]
+            if dlast is not None:          # rows whose last step this is: d(decoder_last_hidden) joins dh2 here
+                b0 = bts[t + 1] if t + 1 < T else 0
+                if bt > b0:
+                    ops.pack(DH2[b0:], bt - b0, [dlast[b0:bt]], accumulate=True)
             # h2(t) -> fc (through the output dropout); the recurrent / next-step terms are already in DH2
             if train and cfg.p_out > 0:
                 ops.dropout_bwd(dH2D[t], L["H2D"][t], DH2, bt, D, sc_out, True)

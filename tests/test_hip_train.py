@@ -227,12 +227,15 @@ def test_scst_full_size_five_samples():
     assert all(torch.isfinite(p).all() for p in rl.parameters())
 
 
-def test_adaptive_xe_gradients_vs_reference_autograd():
+@pytest.mark.parametrize("seq", [True, False], ids=["sequence-node", "per-operator"])
+def test_adaptive_xe_gradients_vs_reference_autograd(seq, monkeypatch):
     """Adaptive features (10-100 zero-padded regions): gradients of CE + MSE(decoder_last_hidden, gd_final_hidden)
     (adaptive_features/editnet_adaptive.py:584-598) through the masked visual attention, against the reference."""
     from hip_adapter import adaptive_module
+    from show_edit_tell_amd import editnet
     from show_edit_tell_amd.autograd_ops import deferred_param_grads
     from show_edit_tell_amd.train import xe_loss_sum
+    monkeypatch.setattr(editnet, "_XE_SEQUENCE", seq)
     name = "editnet_adaptive_small"
     d, xe = adaptive_module(name)
     g = parity.load(name)
@@ -256,3 +259,10 @@ def test_adaptive_xe_gradients_vs_reference_autograd():
     ls, n, _, _ = xe_loss_sum(pred, caps_s, dl)
     (ls / n).backward()
     assert all(torch.isfinite(p.grad).all() for p in xe.parameters() if p.grad is not None)
+    # train mode without scheduled sampling (the sequence node when enabled): CE + MSE, per-step region masks
+    xe.zero_grad()
+    pred, caps_s, dl, _, gd_fh, last_h = xe(to_dev(d["X"]), to_dev(d["image_mean"]), to_dev(d["caps"]), to_dev(d["clen"]),
+                                            to_dev(d["prev"]), to_dev(d["plen"]), False, 0.0)
+    ls, n, _, _ = xe_loss_sum(pred, caps_s, dl)
+    (ls / n + torch.nn.functional.mse_loss(last_h, gd_fh)).backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in xe.parameters())
