@@ -323,10 +323,17 @@ class DAE(nn.Module):
         h1, c1 = self.init_hidden_state(batch_size)
         h2, c2 = self.init_hidden_state(batch_size)
         decode_lengths = (caption_lengths - 1).tolist()
-        embeddings = self.embed.dropout(A.embed_relu(encoded_captions, self.embed.embedding.weight))
         enc, final_hidden, mask = self._encoder_autograd(prev, plen)
         ca = self.caption_attention
         att1_c = A.linear(enc, ca.cap_features_att.weight, ca.cap_features_att.bias)       # loop invariant (dcnet.py:261)
+        from . import editnet as _editnet
+        if _editnet._XE_SEQUENCE:         # the whole loop as ONE autograd node (dcnet_sequence.py)
+            from . import dcnet_sequence as S
+            cfg = S.SeqConfig(decode_lengths, self.training, self.embed.dropout.p, 0.0, self.dropout.p,
+                              int(torch.randint(0, 2 ** 62, (1,)).item()))
+            preds = S.dcnet_sequence(cfg, enc, final_hidden, mask, att1_c, encoded_captions, S.dae_params(self))
+            return preds, encoded_captions, decode_lengths, sort_ind
+        embeddings = self.embed.dropout(A.embed_relu(encoded_captions, self.embed.embedding.weight))
         preds_t = []
         for t in range(max(decode_lengths)):
             bt = sum([l > t for l in decode_lengths])

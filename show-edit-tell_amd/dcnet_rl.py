@@ -58,6 +58,16 @@ def _dae_rollout(self, word_map, encoded_previous_captions, previous_cap_length,
     enc, final_hidden, mask = self._encoder_autograd(encoded_previous_captions, previous_cap_length)
     ca = self.caption_attention
     att1_c = A.linear(enc, ca.cap_features_att.weight, ca.cap_features_att.bias)
+    from . import editnet as _editnet
+    if sample_rl and _editnet._XE_SEQUENCE:       # the sampled rollout as ONE autograd node (dcnet_sequence.py, rollout mode)
+        from . import dcnet_sequence as S
+        sample_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        cfg = S.SeqConfig([], self.training, self.embed.dropout.p, 0.0, self.dropout.p,
+                          int(torch.randint(0, 2 ** 62, (1,)).item()),
+                          rollout=dict(max_len=max_len, start_idx=int(word_map['<start>']), end_idx=int(word_map['<end>']),
+                                       seed=sample_seed))
+        return S.dcnet_sequence(cfg, enc, final_hidden, mask, att1_c, torch.zeros(1, 1, dtype=torch.long, device=dev),
+                                S.dae_params(self))
     unfinished = None
     state = A.SampleState(B, max_len, word_map['<start>'], word_map['<end>'], dev) if sample_rl else None
     for t in range(max_len + 1):

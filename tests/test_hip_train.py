@@ -55,11 +55,14 @@ def test_xe_gradients_b128_vs_reference_autograd():
     _check_grads(xe, g, name)
 
 
+@pytest.mark.parametrize("seq", [True, False], ids=["sequence-node", "per-operator"])
 @pytest.mark.parametrize("name", ["dcnet_small", "dcnet_full_b4"])
-def test_dcnet_xe_gradients_vs_reference_autograd(name):
+def test_dcnet_xe_gradients_vs_reference_autograd(name, seq, monkeypatch):
     """DCNet (dcnet.py:353-402): all parameter gradients of the XE loss against the reference's autograd — through
     the packed BiLSTM encoder, the additive attention and both LSTM cells; immediate and time-batched weight gradients."""
     import contextlib
+    from show_edit_tell_amd import editnet
+    monkeypatch.setattr(editnet, "_XE_SEQUENCE", seq)
     from hip_adapter import dcnet_modules
     from show_edit_tell_amd.autograd_ops import deferred_param_grads
     from show_edit_tell_amd.train import xe_loss_sum

@@ -124,6 +124,20 @@ def dcnet(dev):
     return out
 
 
+def dcnet_train(dev, batch=128):
+    """DCNet XE training step (dcnet.py:352-402): train mode, B=128, fwd + bwd + clip + Adam"""
+    from show_edit_tell_amd import dcnet as dc, synth
+    from show_edit_tell_amd.train import dcnet_xe_train_step
+    wm = synth.word_map(V)
+    dae = _dcnet(dc.DAE, dev, wm)
+    opt = torch.optim.Adam(dae.parameters(), lr=5e-4, fused=True)
+    prev, plen = (torch.from_numpy(x).to(dev) for x in synth.prev_captions(7, batch, T, V, 5))
+    caps, clen = (torch.from_numpy(x).to(dev) for x in synth.captions(7, batch, V, 20, 20))
+    t, _ = _timed(lambda: dcnet_xe_train_step(dae, opt, caps, clen, prev, plen), 5, 3)
+    return {"workload": "DCNet XE training step (dcnet.py:352-402): train mode, B=%d, 19 timesteps, fwd + bwd + clip + Adam" % batch,
+            "ms_per_step": round(1e3 * t, 2)}
+
+
 def beam(dev, images=128, k=3):
     from show_edit_tell_amd import dcnet as dc, editnet, evaluate, synth
     wm = synth.word_map(V)
@@ -140,7 +154,7 @@ def beam(dev, images=128, k=3):
 
 def all_secondary(dev):
     out = {}
-    for name, fn in (("scst", scst), ("adaptive", adaptive), ("dcnet", dcnet), ("beam", beam)):
+    for name, fn in (("scst", scst), ("adaptive", adaptive), ("dcnet", dcnet), ("dcnet_train", dcnet_train), ("beam", beam)):
         try:
             out[name] = fn(dev)
         except Exception as e:              # a secondary figure must never break the bench line
