@@ -598,13 +598,15 @@ class DecoderC(nn.Module):
             fe = fe * vb
             return fe, (fe.detach().sum(2) != 0).float()
 
-        if _XE_SEQUENCE and not (use_ss and ss_prob > 0.0):
+        if _XE_SEQUENCE:
             # the whole loop as ONE autograd node (xe_sequence.py): logs instead of cat / add / per-step bias sums
             from . import xe_sequence as S
             Yv = Y if valid is None else Y * valid      # adaptive: padded regions stay exactly zero through the dropout
             Yin = Yv if self.training else A.linear(Yv, va.features_att.weight, va.features_att.bias)
             cfg = S.SeqConfig(decode_lengths, self.training, self.embed.dropout.p, va.att_embed[2].p, self.dropout.p,
                               int(torch.randint(0, 2 ** 62, (1,)).item()))
+            if use_ss and ss_prob > 0.0:
+                cfg.ss_prob = float(ss_prob)
             if self._adaptive:
                 cfg.adaptive = True
                 cfg.rmask = None if self.training else (Yv.detach().sum(2) != 0).float()

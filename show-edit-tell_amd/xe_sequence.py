@@ -18,8 +18,8 @@ Here the whole loop is one `torch.autograd.Function`:
 
 Values and gradients equal the per-operator path's (same kernels, same contraction order inside a GEMM; the sums over
 timesteps are taken in reverse time order instead of autograd's engine order) — `tests/test_hip_train.py` checks both
-against the reference's own autograd gradients.  Scheduled sampling and the adaptive-feature model keep the per-operator
-path (`DecoderC._forward_autograd`).
+against the reference's own autograd gradients.  Modes (SeqConfig): teacher-forced, teacher-forced with scheduled sampling,
+adaptive features (region masks + `decoder_last_hidden`), free-running sampled rollout (SCST).
 """
 from __future__ import annotations
 
@@ -68,6 +68,9 @@ class SeqConfig:
         # (B, R); the node also returns every row's last h2 (`decoder_last_hidden`)
         self.adaptive = False
         self.rmask = None
+        # scheduled sampling (editnet.py:508-520): from step 1 on every row's input word is, with probability ss_prob, a
+        # draw from softmax(previous step's scores) instead of the ground-truth word (device Philox draw, no host sync)
+        self.ss_prob = 0.0
 
 
 def _z(*shape, dev):
@@ -194,7 +197,16 @@ class _XESequence(torch.autograd.Function):
         ws_v = ops.ws("vis", lib.set_visual_attention_workspace_bytes(B, R, F, D, Adim))
         ws_k = ops.ws("copy", lib.set_copy_lstm_workspace_bytes(B, D, K2))
         E = P["E"]
-        cap_stride = caps.stride(0) if ro is None else 1
+        ss = ro is None and cfg.ss_prob > 0.0
+        cap_stride = caps.stride(0) if (ro is None and not ss) else 1
+        if ss:
+            L["TOK"] = caps[:, :T].t().contiguous()            # (T, B) words actually fed; rows of step t >= 1 may be replaced
+            ss_u = torch.rand(T, B, device=dev) < cfg.ss_prob
+            ss_raw = torch.empty(B, dtype=torch.long, device=dev)
+            ss_i64 = torch.zeros(2, B, dtype=torch.long, device=dev)
+            ss_i32 = torch.zeros(B + T + 4, dtype=torch.int32, device=dev)
+            ss_f32 = _e(2, B, dev=dev)
+            pred_tb = _z(T, B, V, dev=dev)
         state = None
         if ro is not None:
             state = A.SampleState(B, T, ro["start_idx"], ro["end_idx"], dev, seed=ro.get("seed"))
@@ -206,7 +218,13 @@ class _XESequence(torch.autograd.Function):
         for t in range(T):
             bt = bts[t]
             emb = L["EMB"][t]
-            tok = caps[:, t] if ro is None else state.tokens[t]
+            if ss and t >= 1:              # editnet.py:508-520 on the device: draw from softmax(scores of step t-1)
+                check(lib.set_sample_pick_f32(pred_tb[t - 1].data_ptr(), V, bt, V, 0, 1, -1, cfg.seed, scale_off(4, t),
+                                              ss_i64[0].data_ptr(), ss_i64[1].data_ptr(), ss_i32.data_ptr(),
+                                              ss_i32[B:].data_ptr(), ss_raw.data_ptr(), ss_f32[0].data_ptr(),
+                                              ss_f32[1].data_ptr(), st), "set_sample_pick_f32")
+                L["TOK"][t, :bt] = torch.where(ss_u[t, :bt], ss_raw[:bt], L["TOK"][t, :bt])
+            tok = (L["TOK"][t] if ss else caps[:, t]) if ro is None else state.tokens[t]
             check(lib.set_embed_relu_f32(E.data_ptr(), tok.data_ptr(), cap_stride, emb.data_ptr(), D, bt, D, E.shape[0], st),
                   "set_embed_relu_f32")
             if train and cfg.p_embed > 0:
@@ -248,6 +266,9 @@ class _XESequence(torch.autograd.Function):
                                               ws_k.data_ptr(), ws_k.numel(), st), "set_copy_lstm_train_f32")
             if train and cfg.p_out > 0:
                 ops.dropout(L["H2"][t + 1], L["H2D"][t], bt, D, cfg.p_out, cfg.seed, scale_off(3, t))
+            if ss:                         # the next step may sample from this step's scores: fc per step
+                hz = L["H2D"][t] if (train and cfg.p_out > 0) else L["H2"][t + 1]
+                ops.linear(hz, P["fc_w"], P["fc_b"], pred_tb[t], bt)
             if ro is not None:             # editnet_rl.py:514-547: scores of this step, then the device sampling epilogue
                 hz = L["H2D"][t] if (train and cfg.p_out > 0) else L["H2"][t + 1]
                 ops.linear(hz, P["fc_w"], P["fc_b"], L["LOGITS"][t], B)
@@ -263,7 +284,10 @@ class _XESequence(torch.autograd.Function):
             ctx.save_for_backward(X, H, Mem, mask, att1_c, Yin, caps, *params)
             ctx.mark_non_differentiable(state.seq)
             return state.seq, L["LOGP"].t()
-        if uniform:                        # fc over all timesteps at once: (T, B, V), returned as its (B, T, V) view
+        if ss:
+            cfg.fed_tokens = L["TOK"]          # (T, B): the words the steps consumed (tests / diagnostics)
+            out = pred_tb.transpose(0, 1)
+        elif uniform:                      # fc over all timesteps at once: (T, B, V), returned as its (B, T, V) view
             pred_tb = _e(T, B, V, dev=dev)
             ops.linear(hout.reshape(T * B, D), P["fc_w"], P["fc_b"], pred_tb.view(T * B, V), T * B)
             out = pred_tb.transpose(0, 1)
@@ -435,6 +459,8 @@ class _XESequence(torch.autograd.Function):
 
         g[pidx["fc_w"]], g[pidx["fc_b"]] = g_fc_w, g_fc_b
         ids = caps[:, :T].t().reshape(-1) if cfg.rollout is None else ctx.tokens[:T].reshape(-1)
+        if "TOK" in L:                     # scheduled sampling: the words actually fed
+            ids = L["TOK"].reshape(-1)
         dE = torch.zeros_like(P["E"])
         dE.index_add_(0, ids, DEMBRAW.view(TB, D))
         g[pidx["E"]] = dE

@@ -302,3 +302,56 @@ def test_dcnet_rollout_node_equals_per_operator_rollout(monkeypatch):
         res.append((pred.detach().clone(), grads(xe)))
     assert torch.equal(res[0][0], res[1][0])
     close(res[0][1], res[1][1])
+
+
+def test_scheduled_sampling_in_node(monkeypatch):
+    """editnet.py:508-520 inside the node (device Philox draw from softmax(previous scores), no host sync): about ss_prob
+    of the input words from step 1 on are replaced; feeding the SAME words teacher-forced through the per-operator route
+    reproduces the node's scores and gradients (the sampled words carry no gradient, as in the reference); train mode
+    runs and stays finite."""
+    from show_edit_tell_amd import editnet, xe_sequence
+    from show_edit_tell_amd.train import xe_loss_sum
+    V, D, A, F, B = 203, 64, 32, 256, 16
+    m = _build(V, D, A, F).eval()
+    X, caps, clen, prev, plen = _inputs(B, 36, F, 20, V, 9)
+    seen = []
+    real = xe_sequence.xe_sequence
+    monkeypatch.setattr(xe_sequence, "xe_sequence", lambda cfg, *a: (seen.append(cfg), real(cfg, *a))[1])
+    monkeypatch.setattr(editnet, "_XE_SEQUENCE", True)
+    m.zero_grad(set_to_none=True)
+    torch.manual_seed(2)
+    pred, caps_s, dl, sort_ind = m(X, caps, clen, prev, plen, True, 0.6)
+    ls, n, _, _ = xe_loss_sum(pred, caps_s, dl)
+    (ls / n).backward()
+    g_ss = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    tok = seen[-1].fed_tokens                                   # (T, B), sorted row order
+    T = tok.shape[0]
+    assert torch.equal(tok[0], caps_s[:, 0])
+    active = torch.tensor([[l > t for l in dl] for t in range(T)], device=tok.device)
+    changed = (tok != caps_s[:, :T].t()) & active
+    frac = float(changed[1:].sum()) / float(active[1:].sum())
+    assert 0.45 < frac < 0.75, frac                             # ss_prob = 0.6 (a draw may coincide with the ground truth)
+    # the same words, teacher-forced, per-operator route
+    fed = caps_s.clone()
+    fed[:, :T] = torch.where(active.t(), tok.t(), caps_s[:, :T])
+    monkeypatch.setattr(editnet, "_XE_SEQUENCE", False)
+    m.zero_grad(set_to_none=True)
+    lens_sorted = clen[sort_ind]
+    pred2, _, dl2, sort2 = m(X[sort_ind], fed, lens_sorted, prev[sort_ind], plen[sort_ind], False, 0.0)
+    assert dl2 == dl                                            # (the sort may permute rows of equal length: sort2)
+    assert torch.allclose(pred[sort2], pred2, atol=1e-5)
+    ls2, n2, _, _ = xe_loss_sum(pred2, caps_s[sort2], dl)       # targets: the ORIGINAL captions in both runs
+    (ls2 / n2).backward()
+    gmax = max(float(g.abs().max()) for g in g_ss.values())
+    for k, p in m.named_parameters():
+        if k.endswith("full_att.bias"):
+            continue
+        err = float((g_ss[k] - p.grad).abs().max()) / max(float(g_ss[k].abs().max()), 1e-6 * gmax)
+        assert err < 1e-3, (k, err)
+    # train mode
+    monkeypatch.setattr(editnet, "_XE_SEQUENCE", True)
+    m2 = _build(V, D, A, F).train()
+    pred, caps_s, dl, _ = m2(X, caps, clen, prev, plen, True, 0.5)
+    ls, n, _, _ = xe_loss_sum(pred, caps_s, dl)
+    (ls / n).backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m2.parameters())
