@@ -180,15 +180,6 @@ __global__ void __launch_bounds__(256 * KG) gemm_nt_f32(const int ntasks, const 
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-#ifdef SET_EXP_ACC2
-    f32x16 accB[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) accB[i][j][e] = 0.f;
-#endif
 
     const int frow = lane & 31;
     constexpr int KB = 4 / KG;                                    // 8-wide k-blocks of a k-tile contracted by this wave
@@ -216,20 +207,6 @@ __global__ void __launch_bounds__(256 * KG) gemm_nt_f32(const int ntasks, const 
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].w, FB[j].w, acc[i][j], 0, 0, 0); \
             }                                                                                           \
     }
-#define SET_FRAG_MFMA2(FA, FB, GA, GB)                                                                  \
-    {                                                                                                   \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                            \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].x, FB[j].x, acc[i][j], 0, 0, 0); \
-                accB[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(GA[i].x, GB[j].x, accB[i][j], 0, 0, 0); \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].y, FB[j].y, acc[i][j], 0, 0, 0); \
-                accB[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(GA[i].y, GB[j].y, accB[i][j], 0, 0, 0); \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].z, FB[j].z, acc[i][j], 0, 0, 0); \
-                accB[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(GA[i].z, GB[j].z, accB[i][j], 0, 0, 0); \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].w, FB[j].w, acc[i][j], 0, 0, 0); \
-                accB[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(GA[i].w, GB[j].w, accB[i][j], 0, 0, 0); \
-            }                                                                                           \
-    }
     // stage(kt): global loads of tile kt into a register set (no-op past the end of the slice)
 #ifdef SET_EXP_NOLOAD
 #define SET_STAGE(KT, RA, RW) if ((KT) < kt0 + 3 && (KT) < kt1) { if ((KT) == seg_end) SET_SEEK(KT); SET_GLOAD(RA, RW); }
@@ -242,25 +219,6 @@ __global__ void __launch_bounds__(256 * KG) gemm_nt_f32(const int ntasks, const 
 #endif
     // one k-tile: MFMAs from lds[BUF]; meanwhile registers (tile kt+1) -> lds[BUF^1], then reload them
     // with tile kt+3
-#ifdef SET_EXP_ACC2
-#define SET_ITER(KT, BUF, RA, RW)                                                                       \
-    {                                                                                                   \
-        const float* sA = lds[BUF] + (wm * TM * 32 + frow) * LDS_STRIDE;                                \
-        const float* sW = lds[BUF] + BM * LDS_STRIDE + (wn * TN * 32 + frow) * LDS_STRIDE;              \
-        f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN], fa2[TM], fb2[TN], fa3[TM], fb3[TN];                   \
-        SET_FRAG_LOAD(0, fa0, fb0);                                                                     \
-        SET_FRAG_LOAD(1, fa1, fb1);                                                                     \
-        SET_FRAG_LOAD(2, fa2, fb2);                                                                     \
-        SET_FRAG_LOAD(3, fa3, fb3);                                                                     \
-        SET_FRAG_MFMA2(fa0, fb0, fa1, fb1);                                                             \
-        if ((KT) + 1 < kt1) {                                                                           \
-            SET_LSTORE((BUF) ^ 1, RA, RW);                                                              \
-            SET_STAGE((KT) + 3, RA, RW);                                                                \
-        }                                                                                               \
-        SET_FRAG_MFMA2(fa2, fb2, fa3, fb3);                                                             \
-        __syncthreads();                                                                                \
-    }
-#else
 #define SET_ITER(KT, BUF, RA, RW)                                                                       \
     {                                                                                                   \
         const float* sA = lds[BUF] + (wm * TM * 32 + frow) * LDS_STRIDE;                                \
@@ -282,7 +240,6 @@ __global__ void __launch_bounds__(256 * KG) gemm_nt_f32(const int ntasks, const 
         SET_FRAG_MFMA(fa1, fb1);                                                                        \
         __syncthreads();                                                                                \
     }
-#endif
     if (kt0 < kt1) {
         SET_SEEK(kt0);
         SET_STAMP(1);
@@ -313,15 +270,6 @@ __global__ void __launch_bounds__(256 * KG) gemm_nt_f32(const int ntasks, const 
 #undef SET_STAGE
 #undef SET_FRAG_LOAD
 #undef SET_FRAG_MFMA
-#undef SET_FRAG_MFMA2
-#ifdef SET_EXP_ACC2
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] += accB[i][j][e];
-#endif
 
     // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #ifdef SET_EXP_NOEPI

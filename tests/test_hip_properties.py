@@ -105,3 +105,22 @@ def test_split_precision_gemm_keeps_parity():
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout and "failed" not in out.stdout
+
+
+@pytest.mark.parametrize("env_extra", [{"SET_GEMM_KGROUPS": "2"}, {"SET_GEMM_VEC_EPILOGUE": "0"}],
+                         ids=["8-wave k-group kernel", "scalar epilogue stores"])
+def test_gemm_kernel_variants_keep_parity(env_extra):
+    """Opt-in / fallback variants of the grouped GEMM (csrc/gemm_f32.hip): the 8-wave workgroup with an intra-workgroup
+    K split (SET_GEMM_KGROUPS=2) and the scalar epilogue (SET_GEMM_VEC_EPILOGUE=0) must pass the same golden parity
+    tests as the default kernel.  The switches are read once per process, hence the child process."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, **env_extra)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+           os.path.join(root, "tests", "test_hip_editnet.py"), os.path.join(root, "tests", "test_hip_ops.py"),
+           "-k", "full_b128 or full_b4 or v9490 or linear_shapes"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout and "failed" not in out.stdout
