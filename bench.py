@@ -17,9 +17,10 @@ Inputs and weights are synthetic (seeded generator, random-init weights of the r
 architecture, V = 10 000) and are resident in HBM before the timed region.  Multi-GPU: the path
 shards by batch with replicated weights and no data-path collective: each rank
 decodes its own 128-image batch (weak scaling); timing is barrier / sync bracketed, max over ranks.
-Each decode is a strictly sequential chain of small kernels over 128 rows, so by default
-`--streams 3` independent B=128 batches are kept in flight per GPU, each on its own HIP stream and
-workspace (the K timed steps are still K complete B=128 decodes; nothing is skipped or shared);
+Each decode is a strictly sequential chain of small kernels over 128 rows, so several independent B=128 batches are
+kept in flight per GPU, each on its own HIP stream and workspace (the K timed steps are still K complete B=128
+decodes; nothing is skipped or shared).  By default (`--streams 0`) an untimed probe before the timed region picks the
+count among 3 / 7 / 11 (`batches_in_flight_per_gpu`, `stream_probe_decode_steps_per_sec`); `--streams N` pins it;
 `single_stream_*` (top level) is the one-batch-at-a-time figure measured in the same run.
 
 Extra objects on the JSON line:
@@ -51,6 +52,7 @@ sys.path.insert(0, ROOT)
 B, R, F, T, V, D, A = 128, 36, 2048, 20, 10000, 1024, 512
 MAX_LEN = 18
 STEPS_PER_DECODE = MAX_LEN + 1          # editnet_rl.py:503 runs max_len + 1 timesteps
+STREAM_CANDIDATES = (3, 7, 11)          # batches in flight probed by --streams 0 (see main)
 PEAK_FP32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0
 PMC_FILES = ("r02_pmc_bench_traffic.json", "r01_pmc_bench_traffic.json")
@@ -210,7 +212,7 @@ def main():
     ap.add_argument("--train-steps", type=int, default=6)
     ap.add_argument("--experimental", action="store_true",
                     help="also report the opt-in split-precision (bf16x3) GEMM figure under 'experimental'")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("SET_BENCH_STREAMS", "3")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("SET_BENCH_STREAMS", "0")),
                     help="independent batches in flight per GPU (each on its own HIP stream + workspace)")
     args = ap.parse_args()
 
@@ -251,7 +253,12 @@ def main():
     prev_np, plen_np = synth.prev_captions(seed, B, T, V, 5)
     prev, plen = torch.from_numpy(prev_np).to(dev), torch.from_numpy(plen_np).to(dev)
 
-    streams = [torch.cuda.Stream(dev) for _ in range(max(1, args.streams))] if args.streams > 1 else None
+    # batches in flight per GPU: every batch decodes on its own HIP stream.  --streams 0 (default) probes a few counts
+    # before the timed region and keeps the best (how HIP streams map onto the hardware queues decides how well the
+    # launches of different decodes interleave: 3, 7 and 11 streams measured 6.46 / 6.59 / 6.62 k on one box, 4 streams
+    # 5.9 k; the probe makes the choice robust); --streams N pins it, --streams 1 is the single-stream figure.
+    pool = [torch.cuda.Stream(dev) for _ in range(max(1, args.streams if args.streams > 0 else max(STREAM_CANDIDATES)))]
+    streams = pool[:args.streams] if args.streams > 1 else (None if args.streams == 1 else pool[:STREAM_CANDIDATES[0]])
 
     def run(k):
         out = None
@@ -289,8 +296,25 @@ def main():
         barrier()
         return max_over_ranks(time.perf_counter() - t0), out
 
+    stream_probe = None
     with torch.no_grad():
         run(args.warmup)
+        if args.streams == 0:
+            # untimed probe: 48 decodes per candidate; every rank must make the same choice (max over ranks of the time)
+            stream_probe = {}
+            for n in STREAM_CANDIDATES:
+                streams = pool[:n]
+                run(n)
+                barrier()
+                t0 = time.perf_counter()
+                run(48)
+                barrier()
+                stream_probe[n] = max_over_ranks(time.perf_counter() - t0)
+            best = min(stream_probe, key=stream_probe.get)
+            streams = pool[:best]
+            args.streams = best
+            stream_probe = {str(n): round(48 * STEPS_PER_DECODE / t, 1) for n, t in stream_probe.items()}
+            run(args.warmup)
         elapsed, (seq, _) = timed_region()                 # the K timed steps `value` is computed from
         windows = [timed_region()[0] for _ in range(max(0, args.repeat - 1))]
 
@@ -366,6 +390,7 @@ def main():
         "single_stream_decode_steps_per_sec": None if single is None else round(args.steps * STEPS_PER_DECODE / single, 2),
         "single_stream_ms_per_step": None if single is None else round(1e3 * single / args.steps, 4),
         "batches_in_flight_per_gpu": max(1, args.streams),
+        "stream_probe_decode_steps_per_sec": stream_probe,
         "repeat": {"windows": len(rates), "steps_per_window": args.steps, "median": round(_median(rates), 2),
                    "min": round(rates[0], 2), "max": round(rates[-1], 2), "timed_region_s": round(elapsed, 4)},
         "config": {"workload": "EditNet greedy decode (editnet_rl.py:485-549): prologue + 19 timesteps per bench step",
