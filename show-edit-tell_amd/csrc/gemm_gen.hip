@@ -29,6 +29,7 @@ struct GenTask {
     float* C;            // C itself (ksplit == 1) or the slab base
     long long lda, ldb, ldc, slab_stride;
     int M, N, K, ktiles, ksplit, tiles_n, accumulate, wg_begin;
+    int vec_store;       // 16-byte epilogue stores allowed (N, ldc, slab stride multiples of 4 floats, C 16-byte aligned)
     // reduction pass (ksplit > 1): out (+)= sum of slabs
     float* out;
     long long ldo;
@@ -206,6 +207,33 @@ __global__ void __launch_bounds__(256) gemm_gen_f32(const GenLaunch L) {
     const bool acc_c = T.accumulate && T.ksplit == 1;
     const int crow0 = m0 + wm * TM * 32 + 4 * kh;
     const int ccol0 = n0 + wn * TN * 32 + frow;
+    if (T.vec_store) {
+        // 16-byte stores through a per-wave LDS transpose of each 32x32 sub-tile (same epilogue as gemm_nt_f32)
+        float* sT = &lds[0][0] + wave * 1024;
+        const int trow = lane >> 3, tcol = (lane & 7) * 4;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * TN * 32 + j * 32 + tcol;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (i + j) __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sT[((r & 3) + 8 * (r >> 2) + 4 * kh) * 32 + frow] = acc[i][j][r];
+                __syncthreads();
+                const int rbase = m0 + wm * TM * 32 + i * 32 + trow;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v4 = *reinterpret_cast<const f32x4*>(sT + q * 256 + lane * 4);
+                    const int row = rbase + 8 * q;
+                    if (row < T.M && col < T.N) {
+                        f32x4* p = reinterpret_cast<f32x4*>(Cs + (long long)row * T.ldc + col);
+                        *p = acc_c ? *p + v4 : v4;
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = ccol0 + j * 32;
@@ -329,6 +357,8 @@ int gemm_gen_group(const SetGemmDesc* d, int n, int a_kminor, int b_kminor, void
             red_blocks += (int)(((long long)T.M * (T.N >> 2) + 255) / 256);
             red_bytes += 4.0 * T.M * T.N * (ksplit + 1.0);
         }
+        static const int vec_epi = env_int("SET_GEMM_VEC_EPILOGUE", 1);
+        T.vec_store = vec_epi && !(T.N & 3) && !(T.ldc & 3) && !(T.slab_stride & 3) && aligned16(T.C);
         T.wg_begin = wg;
         wg += (int)(tiles[i] * ksplit);
         flops += 2.0 * T.M * T.N * (double)T.K;
