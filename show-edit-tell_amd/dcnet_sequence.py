@@ -149,8 +149,11 @@ class _DcnetSequence(torch.autograd.Function):
                         dp[t, bts[t]:].zero_()
         dp2 = dp.view(T * B, V)
         dH2D = A._dgrad(dp2, P["fc_w"]).view(T, B, D)
-        g[pidx["fc_w"]] = A._wgrad(params[pidx["fc_w"]], dp2, ctx.hout.reshape(T * B, D))
-        g[pidx["fc_b"]] = A._bgrad(params[pidx["fc_b"]], dp2)
+        need_p = ctx.needs_input_grad[6:]
+        if need_p[pidx["fc_w"]]:
+            g[pidx["fc_w"]] = A._wgrad(params[pidx["fc_w"]], dp2, ctx.hout.reshape(T * B, D))
+        if need_p[pidx["fc_b"]]:
+            g[pidx["fc_b"]] = A._bgrad(params[pidx["fc_b"]], dp2)
 
         _zl = _e if ctx.uniform else _z
         DG1, DG2 = _zl(T, B, 4 * D, dev=dev), _zl(T, B, 4 * D, dev=dev)
@@ -201,16 +204,21 @@ class _DcnetSequence(torch.autograd.Function):
         denc = _dvalues(L["ALPHAC"], DCTX, ops)
         TB = T * B
 
+        need = ctx.needs_input_grad[6:]                       # frozen parameters (requires_grad False) get no gradient
+
         def W(name, dy, x):
-            g[pidx[name]] = A._wgrad(params[pidx[name]], dy, x)
+            if need[pidx[name]]:
+                g[pidx[name]] = A._wgrad(params[pidx[name]], dy, x)
 
         def Bg(name, dy):
-            g[pidx[name]] = A._bgrad(params[pidx[name]], dy)
+            if need[pidx[name]]:
+                g[pidx[name]] = A._bgrad(params[pidx[name]], dy)
 
         ids = caps[:, :T].t().reshape(-1) if cfg.rollout is None else ctx.tokens[:T].reshape(-1)
-        dE = torch.zeros_like(P["E"])
-        dE.index_add_(0, ids, DEMBRAW.view(TB, E))
-        g[pidx["E"]] = dE
+        if need[pidx["E"]]:
+            dE = torch.zeros_like(P["E"])
+            dE.index_add_(0, ids, DEMBRAW.view(TB, E))
+            g[pidx["E"]] = dE
         dg1 = DG1.view(TB, 4 * D)
         W("al_wih", dg1, L["X1"].view(TB, -1)); W("al_whh", dg1, L["H1"][:T].reshape(TB, D))
         Bg("al_bih", dg1); Bg("al_bhh", dg1)
@@ -218,8 +226,10 @@ class _DcnetSequence(torch.autograd.Function):
         W("ll_wih", dg2, L["X2"].view(TB, -1)); W("ll_whh", dg2, L["H2"][:T].reshape(TB, D))
         Bg("ll_bih", dg2); Bg("ll_bhh", dg2)
         W("ca_dec_w", DATT2.view(TB, Adim), L["H1"][1:].reshape(TB, D)); Bg("ca_dec_b", DATT2.view(TB, Adim))
-        g[pidx["ca_full_w"]] = A._colsum(DWF.view(TB, Adim)).view(1, Adim)
-        g[pidx["ca_full_b"]] = DE.sum().reshape(1)
+        if need[pidx["ca_full_w"]]:
+            g[pidx["ca_full_w"]] = A._colsum(DWF.view(TB, Adim)).view(1, Adim)
+        if need[pidx["ca_full_b"]]:
+            g[pidx["ca_full_b"]] = DE.sum().reshape(1)
         ctx.L = None
         # inputs: cfg, enc, final_hidden, mask, att1_c, caps
         return (None, denc, dFH, None, datt1c, None) + tuple(g)

@@ -317,6 +317,7 @@ class _XESequence(torch.autograd.Function):
         train = cfg.train
         K1, K2 = 3 * D + F, 2 * D + F
 
+        need_p = ctx.needs_input_grad[10:]
         # ---- fc: dH2D for all timesteps in one contraction
         if cfg.rollout is not None:        # d seq_logp -> d scores of every step (sampling epilogue backward), then as below
             dl = dlogp.t().contiguous()                            # (T, B)
@@ -327,15 +328,15 @@ class _XESequence(torch.autograd.Function):
             L["LOGITS"] = None
             dp2 = dp.view(T * B, V)
             dH2D = A._dgrad(dp2, P["fc_w"]).view(T, B, D)
-            g_fc_w = A._wgrad(params[PARAM_NAMES.index("fc_w")], dp2, ctx.hout.reshape(T * B, D))
-            g_fc_b = A._bgrad(params[PARAM_NAMES.index("fc_b")], dp2)
+            g_fc_w = A._wgrad(params[PARAM_NAMES.index("fc_w")], dp2, ctx.hout.reshape(T * B, D)) if need_p[PARAM_NAMES.index("fc_w")] else None
+            g_fc_b = A._bgrad(params[PARAM_NAMES.index("fc_b")], dp2) if need_p[PARAM_NAMES.index("fc_b")] else None
         elif ctx.uniform:
             dp = dpred.transpose(0, 1)
             dp = dp if dp.is_contiguous() else dp.contiguous()
             dp2 = dp.view(T * B, V)
             dH2D = A._dgrad(dp2, P["fc_w"]).view(T, B, D)
-            g_fc_w = A._wgrad(params[PARAM_NAMES.index("fc_w")], dp2, ctx.hout.reshape(T * B, D))
-            g_fc_b = A._bgrad(params[PARAM_NAMES.index("fc_b")], dp2)
+            g_fc_w = A._wgrad(params[PARAM_NAMES.index("fc_w")], dp2, ctx.hout.reshape(T * B, D)) if need_p[PARAM_NAMES.index("fc_w")] else None
+            g_fc_b = A._bgrad(params[PARAM_NAMES.index("fc_b")], dp2) if need_p[PARAM_NAMES.index("fc_b")] else None
         else:
             dp = dpred.transpose(0, 1).contiguous()           # (T, B, V); rows beyond a step's batch carry zero gradient
             for t in range(T):
@@ -343,8 +344,8 @@ class _XESequence(torch.autograd.Function):
                     dp[t, bts[t]:].zero_()
             dp2 = dp.view(T * B, V)
             dH2D = A._dgrad(dp2, P["fc_w"]).view(T, B, D)
-            g_fc_w = A._wgrad(params[PARAM_NAMES.index("fc_w")], dp2, ctx.hout.reshape(T * B, D))
-            g_fc_b = A._bgrad(params[PARAM_NAMES.index("fc_b")], dp2)
+            g_fc_w = A._wgrad(params[PARAM_NAMES.index("fc_w")], dp2, ctx.hout.reshape(T * B, D)) if need_p[PARAM_NAMES.index("fc_w")] else None
+            g_fc_b = A._bgrad(params[PARAM_NAMES.index("fc_b")], dp2) if need_p[PARAM_NAMES.index("fc_b")] else None
 
         # ---- gradient logs (zero rows where a sequence has left the batch) and running accumulators
         _zl = _e if ctx.uniform else _z
@@ -451,19 +452,24 @@ class _XESequence(torch.autograd.Function):
         g = [None] * len(PARAM_NAMES)
         TB = T * B
 
+        need = ctx.needs_input_grad[10:]                       # frozen parameters (requires_grad False) get no gradient
+
         def W(name, dy, x):
-            g[pidx[name]] = A._wgrad(params[pidx[name]], dy, x)
+            if need[pidx[name]]:
+                g[pidx[name]] = A._wgrad(params[pidx[name]], dy, x)
 
         def Bg(name, dy):
-            g[pidx[name]] = A._bgrad(params[pidx[name]], dy)
+            if need[pidx[name]]:
+                g[pidx[name]] = A._bgrad(params[pidx[name]], dy)
 
         g[pidx["fc_w"]], g[pidx["fc_b"]] = g_fc_w, g_fc_b
         ids = caps[:, :T].t().reshape(-1) if cfg.rollout is None else ctx.tokens[:T].reshape(-1)
         if "TOK" in L:                     # scheduled sampling: the words actually fed
             ids = L["TOK"].reshape(-1)
-        dE = torch.zeros_like(P["E"])
-        dE.index_add_(0, ids, DEMBRAW.view(TB, D))
-        g[pidx["E"]] = dE
+        if need[pidx["E"]]:
+            dE = torch.zeros_like(P["E"])
+            dE.index_add_(0, ids, DEMBRAW.view(TB, D))
+            g[pidx["E"]] = dE
         dg1 = DG1.view(TB, 4 * D)
         W("al_wih", dg1, L["X1"].view(TB, K1)); W("al_whh", dg1, L["H1"][:T].reshape(TB, D))
         Bg("al_bih", dg1); Bg("al_bhh", dg1)
@@ -480,10 +486,14 @@ class _XESequence(torch.autograd.Function):
         h1_all = L["H1"][1:].reshape(TB, D)
         W("ca_dec_w", DATT2C.view(TB, Adim), h1_all); Bg("ca_dec_b", DATT2C.view(TB, Adim))
         W("va_dec_w", DATT2V.view(TB, Adim), h1_all); Bg("va_dec_b", DATT2V.view(TB, Adim))
-        g[pidx["ca_full_w"]] = A._colsum(DWFC.view(TB, Adim)).view(1, Adim)
-        g[pidx["ca_full_b"]] = DEC.sum().reshape(1)
-        g[pidx["va_full_w"]] = A._colsum(DWFV.view(TB, Adim)).view(1, Adim)
-        g[pidx["va_full_b"]] = DEV.sum().reshape(1)
+        if need[pidx["ca_full_w"]]:
+            g[pidx["ca_full_w"]] = A._colsum(DWFC.view(TB, Adim)).view(1, Adim)
+        if need[pidx["ca_full_b"]]:
+            g[pidx["ca_full_b"]] = DEC.sum().reshape(1)
+        if need[pidx["va_full_w"]]:
+            g[pidx["va_full_w"]] = A._colsum(DWFV.view(TB, Adim)).view(1, Adim)
+        if need[pidx["va_full_b"]]:
+            g[pidx["va_full_b"]] = DEV.sum().reshape(1)
         if train:
             W("va_fa_w", DATT1.view(TB * R, Adim), L["FE"].view(TB * R, D)); Bg("va_fa_b", DATT1.view(TB * R, Adim))
         ctx.L = None

@@ -355,3 +355,24 @@ def test_scheduled_sampling_in_node(monkeypatch):
     ls, n, _, _ = xe_loss_sum(pred, caps_s, dl)
     (ls / n).backward()
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m2.parameters())
+
+
+def test_frozen_parameters_get_no_gradient(monkeypatch):
+    """requires_grad = False on some parameters: the node must not write their .grad (an optimizer would otherwise
+    update a frozen weight) and must still produce the others"""
+    from show_edit_tell_amd import editnet
+    from show_edit_tell_amd.autograd_ops import deferred_param_grads
+    from show_edit_tell_amd.train import xe_loss_sum
+    monkeypatch.setattr(editnet, "_XE_SEQUENCE", True)
+    m = _build(203, 64, 32, 256).train()
+    frozen = [m.fc.weight, m.attention_lstm.weight_ih, m.caption_attention.cap_full_att.weight, m.copy_lstm.x2h.bias]
+    for p in frozen:
+        p.requires_grad_(False)
+    X, caps, clen, prev, plen = _inputs(6, 36, 256, 20, 203, 8)
+    pred, caps_s, dl, _ = m(X, caps, clen, prev, plen, False, 0.0)
+    ls, n, _, _ = xe_loss_sum(pred, caps_s, dl)
+    with deferred_param_grads():
+        (ls / n).backward()
+    assert all(p.grad is None for p in frozen)
+    others = [p for p in m.parameters() if p.requires_grad]
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in others)
