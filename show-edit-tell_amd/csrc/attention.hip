@@ -13,6 +13,17 @@ namespace set {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x4 ld4a(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+// streamed operands (region features X, hoisted caption projections P): read once per timestep by one workgroup and, with
+// several batches in flight, far larger than L2 + Infinity Cache -> non-temporal loads, so that they do not evict the
+// weights the GEMM launches re-read every timestep (same-box A/B: GEMM launches -1.2 %, decode rate +0.3 ... +0.7 %;
+// -DSET_ATT_PLAIN_LOADS restores ordinary loads)
+__device__ __forceinline__ f32x4 ld4s(const float* p) {
+#ifdef SET_ATT_PLAIN_LOADS
+    return *reinterpret_cast<const f32x4*>(p);
+#else
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+#endif
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -162,8 +173,8 @@ __device__ __forceinline__ void caption_attention_body(const CapAttArgs& P, int 
                 f32x4 vz[4], vs[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    vz[u] = ld4a(pp + (long long)(t + u) * 2 * Dh);
-                    vs[u] = ld4a(pp + (long long)(t + u) * 2 * Dh + Dh);
+                    vz[u] = ld4s(pp + (long long)(t + u) * 2 * Dh);
+                    vs[u] = ld4s(pp + (long long)(t + u) * 2 * Dh + Dh);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { zc += vz[u] * sc[t + u]; sv += vs[u] * sc[t + u]; }
@@ -262,7 +273,7 @@ __device__ __forceinline__ void visual_attention_body(const VisAttArgs& P, int b
     if (pre_ok) {
         const float* xp0 = X + (long long)b * R * F + f_first;
 #pragma unroll
-        for (int u = 0; u < CB; ++u) xpre[u] = ld4a(xp0 + (long long)u * F);
+        for (int u = 0; u < CB; ++u) xpre[u] = ld4s(xp0 + (long long)u * F);
     }
     constexpr int RB = 9;                                 // R = 36 regions -> one batch per wave
     for (int r0 = wave; r0 < R; r0 += 4 * RB) {
@@ -313,11 +324,11 @@ __device__ __forceinline__ void visual_attention_body(const VisAttArgs& P, int b
         for (; r + 12 <= R; r += 12) {                    // 12 regions in flight; accumulation stays in r order
             f32x4 v[12];
 #pragma unroll
-            for (int u = 0; u < 12; ++u) v[u] = ld4a(xp + (long long)(r + u) * F);
+            for (int u = 0; u < 12; ++u) v[u] = ld4s(xp + (long long)(r + u) * F);
 #pragma unroll
             for (int u = 0; u < 12; ++u) acc += v[u] * sc[r + u];
         }
-        for (; r < R; ++r) acc += ld4a(xp + (long long)r * F) * sc[r];
+        for (; r < R; ++r) acc += ld4s(xp + (long long)r * F) * sc[r];
         *reinterpret_cast<f32x4*>(ctx + (long long)b * F + f) = acc;
     }
 }
