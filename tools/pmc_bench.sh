@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/pmc_bench
 rm -rf $OUT; mkdir -p $OUT
-BENCH="python bench.py --steps 3 --warmup 1 --repeat 1 --no-cpu-baseline --no-profile --no-train --no-secondary"
+BENCH="python bench.py --steps 3 --warmup 1 --repeat 1 --streams 3 --no-cpu-baseline --no-profile --no-train --no-secondary"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- $BENCH > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- $BENCH > $OUT/write.log 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/sq -o sq -- $BENCH > $OUT/sq.log 2>&1

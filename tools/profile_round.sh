@@ -8,5 +8,5 @@ python tools/rocprof_summary.py gpurun_out/r02f/prof_train/train_results.db > gp
 bash tools/pmc_bench.sh > gpurun_out/r02f/pmc.log 2>&1
 cp gpurun_out/pmc_bench/traffic.json gpurun_out/r02f/pmc_traffic.json; cp gpurun_out/pmc_bench/sq_table.txt gpurun_out/r02f/sq_table.txt
 ( cd tools/ubench; echo "== gemm_steps_base 3000"; ./gemm_steps_base 3000; echo "== gemm_steps_stamps 300"; ./gemm_steps_stamps 300 | head -7; echo "== gemm_steps_noepi 2000 (diagnostic: epilogue stores skipped)"; ./gemm_steps_noepi 2000 | sed -n 2,13p; echo "== gemm_steps_noload 2000 (diagnostic: no global loads after the first three k-tiles)"; ./gemm_steps_noload 2000 | sed -n 7,13p; echo "== gemm_steps_samew 2000 (diagnostic: all workgroups stream the same weight rows)"; ./gemm_steps_samew 2000 | sed -n 7,13p ) > gpurun_out/r02f/gemm_steps.txt 2>&1
-rm -rf gpurun_out/r02f/prof_bench gpurun_out/r02f/prof_train
+rm -rf gpurun_out/r02f/prof_bench gpurun_out/r02f/prof_train gpurun_out/pmc_bench/fetch gpurun_out/pmc_bench/write gpurun_out/pmc_bench/sq
 ls -la gpurun_out/r02f
