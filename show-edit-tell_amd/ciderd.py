@@ -192,6 +192,58 @@ class CiderD:
         scores = out[which] if len(res) else np.zeros(0)
         return float(scores.mean()) if len(res) else 0.0, scores
 
+    def _lut_for(self, max_id):
+        """vocabulary id -> interned index of the word str(id) (the reward plumbing stringifies token ids,
+        editnet_rl.py:601-609), as a numpy lookup table grown on demand"""
+        lut = getattr(self, "_lut", None)
+        if lut is None or lut.shape[0] <= max_id:
+            n0 = 0 if lut is None else lut.shape[0]
+            n1 = max(max_id + 1, 2 * n0, 1024)
+            new = np.empty(n1, dtype=np.int64)
+            if n0:
+                new[:n0] = lut
+            tok = self._tok
+            for i in range(n0, n1):
+                new[i] = tok.setdefault(str(i), len(tok))
+            self._lut = lut = new
+        return lut
+
+    def score_token_ids(self, hyps, hyp_set, ref_sets):
+        """Integer fast path of compute_score for the self-critical reward: `hyps` (N, L) int array of decoded captions
+        (0 = <end>, everything after the first 0 is ignored, the 0 itself is a word), `hyp_set` (N,) index of each
+        caption's reference set, `ref_sets` = list of reference sets, each a list of id lists (as ground_truth_lists
+        returns them).  Same scores as compute_score on the stringified ids; needs the native scorer."""
+        nat = self._handle()
+        if nat is None:
+            raise RuntimeError("score_token_ids needs the native CIDEr-D scorer")
+        lib, h = nat
+        hyps = np.ascontiguousarray(hyps, dtype=np.int64)
+        N, L = hyps.shape
+        is0 = hyps == 0
+        first0 = np.where(is0.any(1), is0.argmax(1), L - 1)          # keep the first 0; no 0 -> the whole row
+        lens = first0 + 1
+        keep = np.arange(L)[None, :] < lens[:, None]
+        flat_refs = [c for refs in ref_sets for c in refs]
+        ref_len = np.fromiter((len(c) for c in flat_refs), dtype=np.int64, count=len(flat_refs))
+        ref_flat = np.fromiter((w for c in flat_refs for w in c), dtype=np.int64, count=int(ref_len.sum()))
+        max_id = int(max(hyps.max(initial=0), ref_flat.max(initial=0)))
+        lut = self._lut_for(max_id)
+        ht = np.ascontiguousarray(lut[hyps[keep]])
+        ho = np.zeros(N + 1, dtype=np.int64)
+        np.cumsum(lens, out=ho[1:])
+        so = np.ascontiguousarray(hyp_set, dtype=np.int32)
+        rt = np.ascontiguousarray(lut[ref_flat]) if ref_flat.size else np.zeros(1, dtype=np.int64)
+        ro = np.zeros(len(flat_refs) + 1, dtype=np.int64)
+        np.cumsum(ref_len, out=ro[1:])
+        rs = np.zeros(len(ref_sets) + 1, dtype=np.int64)
+        np.cumsum(np.fromiter((len(r) for r in ref_sets), dtype=np.int64, count=len(ref_sets)), out=rs[1:])
+        out = np.zeros(max(1, N), dtype=np.float64)
+        rc = lib.set_ciderd_score(h, ht.ctypes.data, ho.ctypes.data, N, so.ctypes.data, rt.ctypes.data, ro.ctypes.data,
+                                  rs.ctypes.data, len(ref_sets), out.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("set_ciderd_score failed with code %d" % rc)
+        return out[:N]
+
     def _compute_score_py(self, gts, res):
         """pure-Python twin of compute_score (cross-check; also the fallback when the library is not built)"""
         cache = {}
@@ -239,6 +291,20 @@ def self_critical_reward(scorer, sampled, greedy, ground_truth, cider_weight=1.0
     sampled = np.asarray(sampled.cpu() if hasattr(sampled, 'cpu') else sampled)
     greedy = np.asarray(greedy.cpu() if hasattr(greedy, 'cpu') else greedy)
     B = sampled.shape[0]
+    if getattr(scorer, "_handle", None) is not None and scorer._handle() is not None:
+        # integer fast path (no strings): the reference sets of the distinct images once, all 2B captions in one call
+        sets, index = [], {}
+        hyp_set = np.empty(2 * B, dtype=np.int32)
+        for i in range(B):
+            caps = ground_truth[i]
+            k = id(caps)
+            if k not in index:
+                index[k] = len(sets)
+                sets.append(caps)
+            hyp_set[i] = hyp_set[B + i] = index[k]
+        s = scorer.score_token_ids(np.concatenate([sampled, greedy], 0), hyp_set, sets)
+        diff = cider_weight * (s[:B] - s[B:])
+        return np.repeat(diff[:, None], sampled.shape[1], 1).astype(np.float32)
     memo = {}                    # the same image's reference lists are repeated once per sample: stringify them once
 
     def ref_strings(caps):

@@ -88,3 +88,41 @@ def test_native_scorer_matches_python_statement():
     for i in (0, 7, 14):
         assert abs(per_n[i] - s.score(res[i]["caption"][0], gts[i])) < 1e-10
     assert per_n[0] > 1.0
+
+
+def test_integer_fast_path_matches_string_path():
+    """CiderD.score_token_ids / the integer route of self_critical_reward (no strings, one native call) against the
+    string route (compute_score on stringified ids): ragged captions, captions without an <end>, empty captions (a lone 0),
+    ids the scorer has never seen, several samples per image sharing one reference set."""
+    rng = np.random.default_rng(1)
+    V, B, L, n_samples = 60, 7, 12, 3
+    gt = [[list(map(int, rng.integers(1, V, rng.integers(3, 10)))) + [0] for _ in range(5)] for _ in range(B)]
+    df, docs = ciderd.document_frequency([[ciderd.tokens_to_str(c) for c in caps] for caps in gt])
+    s = ciderd.CiderD(df, docs)
+    N = B * n_samples
+
+    def captions():
+        arr = rng.integers(1, V + 20, (N, L))
+        for i in range(N):
+            if i % 5 == 0:
+                continue                                   # no <end>: the whole row counts
+            n = int(rng.integers(0, L))
+            arr[i, n:] = 0
+        arr[3] = np.array(gt[3 % B][0][:L] + [0] * max(0, L - len(gt[3 % B][0])))[:L]      # an exact reference
+        return arr
+
+    sampled, greedy = captions(), captions()
+    gts_rep = list(gt) * n_samples
+    fast = ciderd.self_critical_reward(s, sampled, greedy, gts_rep, cider_weight=0.7)
+    assert s._native
+    # string route, explicitly
+    gts = {i: [ciderd.tokens_to_str(c) for c in gts_rep[i % N]] for i in range(2 * N)}
+    res = [{"image_id": i, "caption": [ciderd.tokens_to_str(sampled[i])]} for i in range(N)]
+    res += [{"image_id": N + i, "caption": [ciderd.tokens_to_str(greedy[i])]} for i in range(N)]
+    _, per = s.compute_score(gts, res)
+    _, per_py = s._compute_score_py(gts, res)
+    want = 0.7 * (per[:N] - per[N:])
+    assert np.allclose(per, per_py, atol=1e-10)
+    assert fast.shape == (N, L) and np.allclose(fast[:, 0], want, atol=1e-6) and np.allclose(fast, fast[:, :1])
+    direct = s.score_token_ids(np.concatenate([sampled, greedy]), np.arange(2 * N) % B, gt)
+    assert np.allclose(direct, per, atol=1e-10)
