@@ -9,6 +9,8 @@ reduced gradient equals the gradient of CrossEntropyLoss(mean) over the concaten
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch.nn.utils.rnn import pack_padded_sequence
@@ -208,6 +210,18 @@ def reward_loss_sum(sample_logprobs, seq, reward):
     return torch.sum(-sample_logprobs * reward * mask), mask.sum()
 
 
+_SCST_OVERLAP = os.environ.get("SET_SCST_OVERLAP", "1") != "0"
+_side_streams = {}
+
+
+def _side_stream(dev):
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    s = _side_streams.get(key)
+    if s is None:
+        s = _side_streams[key] = torch.cuda.Stream(dev)
+    return s
+
+
 def _scst_step(model, optimizer, greedy_fn, sample_fn, rep, ground_truth, scorer, n_samples, cider_weight, dev, group):
     """Shared body of the self-critical step (editnet_rl.py:649-686, dcnet_rl.py:451-493): greedy baseline in eval
     mode under no_grad (fused device loop), `n_samples` multinomial rollouts in train mode (autograd operators, the
@@ -217,13 +231,25 @@ def _scst_step(model, optimizer, greedy_fn, sample_fn, rep, ground_truth, scorer
     from .autograd_ops import deferred_param_grads
     for p in model.parameters():
         p.grad = None
+    # the greedy baseline (a latency-bound chain of small kernels) and the sampled rollout are independent: the baseline is
+    # enqueued on a side stream and runs underneath the rollout's forward (SET_SCST_OVERLAP=0: one after the other)
+    cur = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+    side = _side_stream(dev) if (cur is not None and _SCST_OVERLAP) else None
     model.eval()
-    with torch.no_grad():
-        greedy, _ = greedy_fn()
+    if side is not None:
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), torch.no_grad():
+            greedy, _ = greedy_fn()
+    else:
+        with torch.no_grad():
+            greedy, _ = greedy_fn()
     model.train()
     reducer = BucketedAllReduce(group)
     with deferred_param_grads(on_ready=lambda p: reducer.add(p.grad)):
         seq, logp = sample_fn()
+        if side is not None:
+            cur.wait_stream(side)
+            greedy.record_stream(cur)
         rewards = ciderd.self_critical_reward(scorer, seq, rep(greedy), list(ground_truth) * n_samples, cider_weight)
         num, cnt = reward_loss_sum(logp, seq, torch.from_numpy(rewards).to(dev))
         n_glob = global_token_count(int(cnt.item()), dev, group)
