@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 for rep in 1 2; do
 for flags in "$@"; do
   SET_HIPCC_FLAGS="$flags" python -m show_edit_tell_amd.build --force > /dev/null 2>&1 || { echo "build failed: $flags"; continue; }
-  python bench.py --no-cpu-baseline --no-train --no-secondary --repeat 2 --steps ${AB_STEPS:-150} > gpurun_out/ab.json 2> gpurun_out/ab.err
+  python bench.py --no-cpu-baseline --no-train --no-secondary --repeat 2 --steps ${AB_STEPS:-150} --streams ${AB_STREAMS:-7} > gpurun_out/ab.json 2> gpurun_out/ab.err
   python - "$flags" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/ab.json"))

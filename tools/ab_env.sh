@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 for rep in 1 2; do
 for cfg in "$@"; do
-  env $cfg python bench.py --no-cpu-baseline --no-train --no-secondary --repeat 2 --steps ${AB_STEPS:-150} > gpurun_out/ab.json 2> gpurun_out/ab.err
+  env $cfg python bench.py --no-cpu-baseline --no-train --no-secondary --repeat 2 --steps ${AB_STEPS:-150} --streams ${AB_STREAMS:-7} > gpurun_out/ab.json 2> gpurun_out/ab.err
   python - "$cfg" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/ab.json"))
