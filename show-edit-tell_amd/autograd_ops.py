@@ -179,6 +179,7 @@ def deferred_param_grads(on_ready=None):
         return
     _tls.deferred = {}
     _active[_threading.get_ident()] = _tls.deferred
+    _active_cb[id(_tls.deferred)] = on_ready
     try:
         yield
         pending, cat_cache = _tls.deferred, {}
@@ -208,9 +209,11 @@ def deferred_param_grads(on_ready=None):
                 on_ready(param)
     finally:
         _active.pop(_threading.get_ident(), None)
+        _active_cb.pop(id(_tls.deferred), None)
         _tls.deferred = None
 
 
+_active_cb = {}     # id(table) -> the context's on_ready callback (eager gradients are announced through it at once)
 _active = {}        # thread id of the thread that opened a deferred context -> its table (autograd's backward may run on
                     # a worker thread of the engine: it looks the table up through the single open context)
 
@@ -230,13 +233,34 @@ def _is_leaf_param(param):
     return _FUSED_WGRAD and isinstance(param, torch.nn.Parameter) and param.is_leaf
 
 
-def _wgrad(param, dy, x):
+def _announce(param):
+    """eager gradient inside a deferred context: tell the context's on_ready (the data-parallel reducer) right away"""
+    tab = _deferred_table()
+    cb = _active_cb.get(id(tab)) if tab is not None else None
+    if cb is not None:
+        try:
+            cb(param, eager=True)
+        except TypeError:
+            cb(param)
+
+
+def _wgrad(param, dy, x, eager=False):
     """Weight gradient dW = dy^T x, accumulated IN PLACE into param.grad (fused weight-gradient
     accumulation): returning dW to autograd would make it allocate a weight-sized temporary and run a
     separate weight-sized add per timestep (19 x 355 MB per training step).  Returns None so autograd
-    skips its own accumulation.  Leaf parameters only; anything else gets the gradient returned."""
+    skips its own accumulation.  Leaf parameters only; anything else gets the gradient returned.
+    eager: contract now even inside `deferred_param_grads()` (the caller guarantees this is the parameter's ONLY
+    contribution of the backward, e.g. fc in the sequence nodes) and announce it, so that its all-reduce can run
+    underneath the rest of the backward."""
     if not _is_leaf_param(param):
         return _wgrad_mm(dy, x)
+    if eager and _deferred_table() is not None and id(param) not in _deferred_table():
+        if param.grad is None:
+            param.grad = _wgrad_mm(dy, x)
+        else:
+            _wgrad_mm(dy, x, out=param.grad)
+        _announce(param)
+        return None
     if _deferred_table() is not None:
         ent = _deferred_table().setdefault(id(param), (param, ([], [])))
         ent[1][0].append(dy)
@@ -267,9 +291,16 @@ def _colsum(dy, out=None):
     return out
 
 
-def _bgrad(param, dy):
+def _bgrad(param, dy, eager=False):
     if not _is_leaf_param(param):
         return _colsum(dy).reshape(param.shape)
+    if eager and _deferred_table() is not None and id(param) not in _deferred_table():
+        if param.grad is None:
+            param.grad = _colsum(dy).reshape(param.shape)
+        else:
+            _colsum(dy, out=param.grad)
+        _announce(param)
+        return None
     if _deferred_table() is not None:
         ent = _deferred_table().setdefault(id(param), (param, ([], None)))
         ent[1][0].append(dy)

@@ -150,10 +150,10 @@ class _DcnetSequence(torch.autograd.Function):
         dp2 = dp.view(T * B, V)
         dH2D = A._dgrad(dp2, P["fc_w"]).view(T, B, D)
         need_p = ctx.needs_input_grad[6:]
-        if need_p[pidx["fc_w"]]:
-            g[pidx["fc_w"]] = A._wgrad(params[pidx["fc_w"]], dp2, ctx.hout.reshape(T * B, D))
         if need_p[pidx["fc_b"]]:
             g[pidx["fc_b"]] = A._bgrad(params[pidx["fc_b"]], dp2)
+        if need_p[pidx["fc_w"]]:          # final now: contracted eagerly so that its all-reduce runs underneath the BPTT loop
+            g[pidx["fc_w"]] = A._wgrad(params[pidx["fc_w"]], dp2, ctx.hout.reshape(T * B, D), eager=True)
 
         _zl = _e if ctx.uniform else _z
         DG1, DG2 = _zl(T, B, 4 * D, dev=dev), _zl(T, B, 4 * D, dev=dev)

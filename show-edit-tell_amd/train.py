@@ -58,8 +58,10 @@ class BucketedAllReduce:
         self.n_buckets = 0
         self.bytes = 0
 
-    def add(self, grad):
-        """queue one final gradient tensor (each tensor once)"""
+    def add(self, grad, flush=False):
+        """queue one final gradient tensor (each tensor once); flush: start the (partial) bucket's collective now — used
+        for gradients that are final long before the rest (fc in the sequence nodes: its all-reduce then runs underneath
+        the back-propagation through time)"""
         if not self.active or grad is None or id(grad) in self.seen:
             return
         self.seen.add(id(grad))
@@ -68,7 +70,7 @@ class BucketedAllReduce:
             self._launch()
         self.bucket.append(grad)
         self.size += nbytes
-        if self.size >= self.bucket_bytes:
+        if self.size >= self.bucket_bytes or (flush and self.size >= (8 << 20)):
             self._launch()
 
     def _launch(self):
@@ -151,7 +153,7 @@ def xe_backward(decoder, image_features, caps, caplens, previous_caption, prev_c
     reducer = BucketedAllReduce(group, enabled=grp_on)
     # one weight-gradient contraction per parameter over all timesteps; every finished gradient goes straight
     # into an all-reduce bucket, so the collectives overlap the remaining contractions
-    with deferred_param_grads(on_ready=lambda p: reducer.add(p.grad)):
+    with deferred_param_grads(on_ready=lambda p, eager=False: reducer.add(p.grad, flush=eager)):
         loss.backward()
     params = [p for p in decoder.parameters() if p.requires_grad]
     allreduce_gradients(params, group, reducer=reducer)
@@ -184,7 +186,7 @@ def dcnet_xe_backward(dae, caps, caplens, previous_caption, prev_caplen, group=N
     for p in dae.parameters():
         p.grad = None
     reducer = BucketedAllReduce(group, enabled=grp_on)
-    with deferred_param_grads(on_ready=lambda p: reducer.add(p.grad)):
+    with deferred_param_grads(on_ready=lambda p, eager=False: reducer.add(p.grad, flush=eager)):
         loss.backward()
     params = [p for p in dae.parameters() if p.requires_grad]
     allreduce_gradients(params, group, reducer=reducer)
@@ -245,7 +247,7 @@ def _scst_step(model, optimizer, greedy_fn, sample_fn, rep, ground_truth, scorer
             greedy, _ = greedy_fn()
     model.train()
     reducer = BucketedAllReduce(group)
-    with deferred_param_grads(on_ready=lambda p: reducer.add(p.grad)):
+    with deferred_param_grads(on_ready=lambda p, eager=False: reducer.add(p.grad, flush=eager)):
         seq, logp = sample_fn()
         if side is not None:
             cur.wait_stream(side)

@@ -328,15 +328,15 @@ class _XESequence(torch.autograd.Function):
             L["LOGITS"] = None
             dp2 = dp.view(T * B, V)
             dH2D = A._dgrad(dp2, P["fc_w"]).view(T, B, D)
-            g_fc_w = A._wgrad(params[PARAM_NAMES.index("fc_w")], dp2, ctx.hout.reshape(T * B, D)) if need_p[PARAM_NAMES.index("fc_w")] else None
             g_fc_b = A._bgrad(params[PARAM_NAMES.index("fc_b")], dp2) if need_p[PARAM_NAMES.index("fc_b")] else None
+            g_fc_w = A._wgrad(params[PARAM_NAMES.index("fc_w")], dp2, ctx.hout.reshape(T * B, D), eager=True) if need_p[PARAM_NAMES.index("fc_w")] else None
         elif ctx.uniform:
             dp = dpred.transpose(0, 1)
             dp = dp if dp.is_contiguous() else dp.contiguous()
             dp2 = dp.view(T * B, V)
             dH2D = A._dgrad(dp2, P["fc_w"]).view(T, B, D)
-            g_fc_w = A._wgrad(params[PARAM_NAMES.index("fc_w")], dp2, ctx.hout.reshape(T * B, D)) if need_p[PARAM_NAMES.index("fc_w")] else None
             g_fc_b = A._bgrad(params[PARAM_NAMES.index("fc_b")], dp2) if need_p[PARAM_NAMES.index("fc_b")] else None
+            g_fc_w = A._wgrad(params[PARAM_NAMES.index("fc_w")], dp2, ctx.hout.reshape(T * B, D), eager=True) if need_p[PARAM_NAMES.index("fc_w")] else None
         else:
             dp = dpred.transpose(0, 1).contiguous()           # (T, B, V); rows beyond a step's batch carry zero gradient
             for t in range(T):
@@ -344,8 +344,8 @@ class _XESequence(torch.autograd.Function):
                     dp[t, bts[t]:].zero_()
             dp2 = dp.view(T * B, V)
             dH2D = A._dgrad(dp2, P["fc_w"]).view(T, B, D)
-            g_fc_w = A._wgrad(params[PARAM_NAMES.index("fc_w")], dp2, ctx.hout.reshape(T * B, D)) if need_p[PARAM_NAMES.index("fc_w")] else None
             g_fc_b = A._bgrad(params[PARAM_NAMES.index("fc_b")], dp2) if need_p[PARAM_NAMES.index("fc_b")] else None
+            g_fc_w = A._wgrad(params[PARAM_NAMES.index("fc_w")], dp2, ctx.hout.reshape(T * B, D), eager=True) if need_p[PARAM_NAMES.index("fc_w")] else None
 
         # ---- gradient logs (zero rows where a sequence has left the batch) and running accumulators
         _zl = _e if ctx.uniform else _z
