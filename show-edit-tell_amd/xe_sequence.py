@@ -318,34 +318,29 @@ class _XESequence(torch.autograd.Function):
         K1, K2 = 3 * D + F, 2 * D + F
 
         need_p = ctx.needs_input_grad[10:]
-        # ---- fc: dH2D for all timesteps in one contraction
-        if cfg.rollout is not None:        # d seq_logp -> d scores of every step (sampling epilogue backward), then as below
+        # ---- d scores as (T, B, V), rows of finished sequences zero
+        if cfg.rollout is not None:        # d seq_logp -> d scores of every step (sampling epilogue backward)
             dl = dlogp.t().contiguous()                            # (T, B)
             dp = _e(T, B, V, dev=dev)
             for t in range(T):
                 check(lib.set_sample_logp_bwd_f32(L["LOGITS"][t].data_ptr(), V, L["LSE"][t].data_ptr(), L["RAW"][t].data_ptr(),
                                                   dl[t].data_ptr(), dp[t].data_ptr(), V, B, V, st), "set_sample_logp_bwd_f32")
             L["LOGITS"] = None
-            dp2 = dp.view(T * B, V)
-            dH2D = A._dgrad(dp2, P["fc_w"]).view(T, B, D)
-            g_fc_b = A._bgrad(params[PARAM_NAMES.index("fc_b")], dp2) if need_p[PARAM_NAMES.index("fc_b")] else None
-            g_fc_w = A._wgrad(params[PARAM_NAMES.index("fc_w")], dp2, ctx.hout.reshape(T * B, D), eager=True) if need_p[PARAM_NAMES.index("fc_w")] else None
-        elif ctx.uniform:
+        elif ctx.uniform:                  # the (B, T, V) gradient of a (T, B, V) buffer's view: usually already contiguous
             dp = dpred.transpose(0, 1)
             dp = dp if dp.is_contiguous() else dp.contiguous()
-            dp2 = dp.view(T * B, V)
-            dH2D = A._dgrad(dp2, P["fc_w"]).view(T, B, D)
-            g_fc_b = A._bgrad(params[PARAM_NAMES.index("fc_b")], dp2) if need_p[PARAM_NAMES.index("fc_b")] else None
-            g_fc_w = A._wgrad(params[PARAM_NAMES.index("fc_w")], dp2, ctx.hout.reshape(T * B, D), eager=True) if need_p[PARAM_NAMES.index("fc_w")] else None
         else:
-            dp = dpred.transpose(0, 1).contiguous()           # (T, B, V); rows beyond a step's batch carry zero gradient
+            dp = dpred.transpose(0, 1).contiguous()
             for t in range(T):
                 if bts[t] < B:
                     dp[t, bts[t]:].zero_()
-            dp2 = dp.view(T * B, V)
-            dH2D = A._dgrad(dp2, P["fc_w"]).view(T, B, D)
-            g_fc_b = A._bgrad(params[PARAM_NAMES.index("fc_b")], dp2) if need_p[PARAM_NAMES.index("fc_b")] else None
-            g_fc_w = A._wgrad(params[PARAM_NAMES.index("fc_w")], dp2, ctx.hout.reshape(T * B, D), eager=True) if need_p[PARAM_NAMES.index("fc_w")] else None
+        # ---- fc: dH2D for all timesteps in one contraction; fc.weight's gradient is final here (eager: its all-reduce
+        # runs underneath the loop below in the data-parallel step)
+        dp2 = dp.view(T * B, V)
+        dH2D = A._dgrad(dp2, P["fc_w"]).view(T, B, D)
+        i_w, i_b = PARAM_NAMES.index("fc_w"), PARAM_NAMES.index("fc_b")
+        g_fc_b = A._bgrad(params[i_b], dp2) if need_p[i_b] else None
+        g_fc_w = A._wgrad(params[i_w], dp2, ctx.hout.reshape(T * B, D), eager=True) if need_p[i_w] else None
 
         # ---- gradient logs (zero rows where a sequence has left the batch) and running accumulators
         _zl = _e if ctx.uniform else _z
