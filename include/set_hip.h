@@ -357,6 +357,19 @@ int set_encoder_cell_bwd_f32(const float* dh, const float* dc, const float* dH, 
                              float* dh_pass, int B, int D, void* stream);
 int set_select_bwd_f32(const float* dsel, const float* Mem, const float* alpha, float* dM, float* dalpha,
                        int M, int T, int D, void* stream);
+/* The attention block of one training timestep (editnet.py:534-540) in four launches: the decoder-side projections of
+ * both attentions and the [word,h1] parts of tc_affine / context_gate as one grouped GEMM, both attention roles +
+ * SelectC as one kernel, the context side of the gate, its pointwise.  att1_c (M,T,A) = cap_features_att(H),
+ * att1 (M,R,A) = features_att(att_embed(X)) (this step's, with its dropout), rmask (M,R) or NULL.  Outputs: gated (M,D)
+ * = attend_cap, alpha_c (M,T), ctx (M,D) = sum_t alpha_t H_t, zt / s / t (M,D) the gate's factors (for the backward),
+ * sel (M,D), attend_img (M,F), alpha_v (M,R). */
+size_t set_editnet_attentions_workspace_bytes(int M, int D, int A);
+int set_editnet_attentions_train_f32(const SetEditNetWeights* w, const float* H, const float* att1_c,
+                                     const float* mask, const float* Mem, const float* X, const float* att1,
+                                     const float* rmask, const float* h1, const float* word, float* gated,
+                                     float* alpha_c, float* ctx, float* zt, float* s, float* t, float* sel,
+                                     float* attend_img, float* alpha_v, int M, int T, int R, int F, int D, int A,
+                                     void* ws, size_t ws_bytes, void* stream);
 /* Accumulating forms used by the whole-sequence training node (xe_sequence.py): gradients of loop-invariant operands
  * (H, Mem, cap_features_att(H), and features_att(att_embed(X)) in eval mode) are summed over the timesteps in place
  * instead of by one tensor-sized add per timestep.  acc_* = 1: `out += contribution`, rows beyond M are not touched.

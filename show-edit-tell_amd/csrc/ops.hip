@@ -218,6 +218,61 @@ int set_visual_attention_masked_f32(const SetEditNetWeights* w, const float* X, 
                             A, st);
 }
 
+// ------------------------------------------------------------------------------- both attentions + SelectC, one timestep
+// The training node's per-step attention block (editnet.py:534-540): cap_decoder_att / decoder_att / tc_affine /
+// context_gate[word,h1] in ONE grouped launch, both attention roles and the hard selection in ONE launch
+// (step_attention_k), the context side of the gate in one launch + its pointwise — 4 launches instead of the 7 of
+// set_caption_attention_train_f32 + set_visual_attention_masked_f32 + set_select_f32 called one after the other.
+size_t set_editnet_attentions_workspace_bytes(int M, int D, int A) {
+    if (M <= 0 || D <= 0 || A <= 0) return 0;
+    return 2 * fbytes(KS * (size_t)M * A) + 4 * fbytes(KS * (size_t)M * D) + 256;
+}
+
+int set_editnet_attentions_train_f32(const SetEditNetWeights* w, const float* H, const float* att1_c, const float* mask,
+                                     const float* Mem, const float* X, const float* att1, const float* rmask,
+                                     const float* h1, const float* word, float* gated, float* alpha_c, float* ctx,
+                                     float* zt, float* s, float* t, float* sel, float* attend_img, float* alpha_v, int M,
+                                     int T, int R, int F, int D, int A, void* ws, size_t ws_bytes, void* stream) {
+    if (!w || !H || !att1_c || !mask || !Mem || !X || !att1 || !h1 || !word || !gated || !alpha_c || !ctx || !zt || !s ||
+        !t || !sel || !attend_img || !alpha_v || M <= 0 || T <= 0 || R <= 0 || F <= 0 || D <= 0 || A <= 0)
+        return SET_ERR_ARG;
+    if (!ws || !aligned16(ws) || ws_bytes < set_editnet_attentions_workspace_bytes(M, D, A) - 256) return SET_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int tgt = gemm_target_wgs();
+    Carver cv(ws);
+    float* s_a2c = cv.take<float>(KS * (size_t)M * A);
+    float* s_a2v = cv.take<float>(KS * (size_t)M * A);
+    float* s_tc = cv.take<float>(KS * (size_t)M * D);
+    float* s_cga = cv.take<float>(KS * (size_t)M * D);
+    float* s_cgb = cv.take<float>(KS * (size_t)M * D);
+    float* s_sc = cv.take<float>(KS * (size_t)M * D);
+    GemmProb b[4];
+    b[0] = slab_prob(s_a2c, M, A, M);
+    b[0].add(h1, D, w->ca_dec_w, D, D);
+    b[1] = slab_prob(s_a2v, M, A, M);
+    b[1].add(h1, D, w->va_dec_w, D, D);
+    b[2] = slab_prob(s_tc, M, D, M);
+    b[2].add(word, D, w->ca_tc_w, 2 * D, D);
+    b[2].add(h1, D, w->ca_tc_w + D, 2 * D, D);
+    b[3] = slab_prob(s_cga, M, D, M);
+    b[3].add(word, D, w->ca_gate_w, 3 * D, D);
+    b[3].add(h1, D, w->ca_gate_w + D, 3 * D, D);
+    plan_ksplit(b, 4, tgt);
+    SET_TRY(gemm_group(b, 4, st, "gemm:train att2,tc,cg"));
+    SET_TRY(step_attention(att1, slabs_of(b[1]), w->va_dec_b, w->va_full_w, w->va_full_b, X, rmask, attend_img, alpha_v, R, F,
+                           att1_c, slabs_of(b[0]), w->ca_dec_b, w->ca_full_w, w->ca_full_b, mask, H, Mem, ctx, sel, alpha_c,
+                           T, D, A, M, st, nullptr));
+    GemmProb c[2];
+    c[0] = slab_prob(s_cgb, M, D, M);
+    c[0].add(ctx, D, w->ca_gate_w + 2 * D, 3 * D, D);
+    c[1] = slab_prob(s_sc, M, D, M);
+    c[1].add(ctx, D, w->ca_sc_w, D, D);
+    plan_ksplit(c, 2, tgt);
+    SET_TRY(gemm_group(c, 2, st, "gemm:train cg_c,sc"));
+    return context_gate_pointwise(slabs_of(b[3]), slabs_of(c[0]), w->ca_gate_b, slabs_of(c[1]), w->ca_sc_b, slabs_of(b[2]),
+                                  w->ca_tc_b, gated, M, D, st, zt, s, t);
+}
+
 // ------------------------------------------------------------------------------- SelectC
 int set_select_f32(const float* Mem, const float* alpha_c, float* sel, int M, int T, int D, void* stream) {
     if (!Mem || !alpha_c || !sel || M <= 0 || T <= 0 || D <= 0) return SET_ERR_ARG;

@@ -193,8 +193,7 @@ class _XESequence(torch.autograd.Function):
         w.cl_cnew_w, w.cl_cnew_b, w.cl_cmem_w, w.cl_cmem_b = (P[k].data_ptr() for k in ("cl_cnew_w", "cl_cnew_b", "cl_cmem_w", "cl_cmem_b"))
         wref = C.byref(w)
         ws_l = ops.ws("lstm", lib.set_lstm_cell_workspace_bytes(B, D, K1))
-        ws_c = ops.ws("cap", lib.set_caption_attention_workspace_bytes(B, Tc, D, Adim))
-        ws_v = ops.ws("vis", lib.set_visual_attention_workspace_bytes(B, R, F, D, Adim))
+        ws_c = ops.ws("att", lib.set_editnet_attentions_workspace_bytes(B, D, Adim))
         ws_k = ops.ws("copy", lib.set_copy_lstm_workspace_bytes(B, D, K2))
         E = P["E"]
         ss = ro is None and cfg.ss_prob > 0.0
@@ -237,12 +236,6 @@ class _XESequence(torch.autograd.Function):
                                               P["al_bhh"].data_ptr(), h1.data_ptr(), L["C1"][t + 1].data_ptr(),
                                               L["G1"][t].data_ptr(), bt, D, ws_l.data_ptr(), ws_l.numel(), st),
                   "set_lstm_cell_train_f32")
-            check(lib.set_caption_attention_train_f32(wref, H.data_ptr(), att1_c.data_ptr(), h1.data_ptr(), emb.data_ptr(),
-                                                      mask.data_ptr(), gated.data_ptr(), L["ALPHAC"][t].data_ptr(), cx.data_ptr(),
-                                                      L["ZT"][t].data_ptr(), L["S"][t].data_ptr(), L["TT"][t].data_ptr(), bt, Tc,
-                                                      D, D, Adim, ws_c.data_ptr(), ws_c.numel(), st),
-                  "set_caption_attention_train_f32")
-            ops.pack(L["WHC"][t], bt, [emb, h1, cx])
             if train:
                 fe = L["FE"][t]
                 ops.dropout(Yin.view(B * R, D), fe.view(B * R, D), bt * R, D, cfg.p_region, cfg.seed, scale_off(2, t))
@@ -253,11 +246,16 @@ class _XESequence(torch.autograd.Function):
             else:
                 att1 = Yin
             rm = None if not adaptive else (L["RMASK"][t].data_ptr() if train else rmask_eval.data_ptr())
-            check(lib.set_visual_attention_masked_f32(wref, X.data_ptr(), att1.data_ptr(), rm, h1.data_ptr(), aimg.data_ptr(),
-                                                      L["ALPHAV"][t].data_ptr(), bt, R, F, D, Adim, ws_v.data_ptr(),
-                                                      ws_v.numel(), st), "set_visual_attention_masked_f32")
             sel = L["SEL"][t]
-            check(lib.set_select_f32(Mem.data_ptr(), L["ALPHAC"][t].data_ptr(), sel.data_ptr(), bt, Tc, D, st), "set_select_f32")
+            # both attentions + SelectC of this step: 4 launches (editnet.py:534-540)
+            check(lib.set_editnet_attentions_train_f32(wref, H.data_ptr(), att1_c.data_ptr(), mask.data_ptr(), Mem.data_ptr(),
+                                                       X.data_ptr(), att1.data_ptr(), rm, h1.data_ptr(), emb.data_ptr(),
+                                                       gated.data_ptr(), L["ALPHAC"][t].data_ptr(), cx.data_ptr(),
+                                                       L["ZT"][t].data_ptr(), L["S"][t].data_ptr(), L["TT"][t].data_ptr(),
+                                                       sel.data_ptr(), aimg.data_ptr(), L["ALPHAV"][t].data_ptr(), bt, Tc, R, F,
+                                                       D, Adim, ws_c.data_ptr(), ws_c.numel(), st),
+                  "set_editnet_attentions_train_f32")
+            ops.pack(L["WHC"][t], bt, [emb, h1, cx])
             x2 = L["X2"][t]
             ops.pack(x2, bt, [h1, gated, aimg])
             check(lib.set_copy_lstm_train_f32(wref, x2.data_ptr(), K2, K2, L["H2"][t].data_ptr(), L["C2"][t].data_ptr(),
