@@ -362,14 +362,15 @@ int set_select_bwd_f32(const float* dsel, const float* Mem, const float* alpha, 
  * SelectC as one kernel, the context side of the gate, its pointwise.  att1_c (M,T,A) = cap_features_att(H),
  * att1 (M,R,A) = features_att(att_embed(X)) (this step's, with its dropout), rmask (M,R) or NULL.  Outputs: gated (M,D)
  * = attend_cap, alpha_c (M,T), ctx (M,D) = sum_t alpha_t H_t, zt / s / t (M,D) the gate's factors (for the backward),
- * sel (M,D), attend_img (M,F), alpha_v (M,R). */
+ * sel (M,D), attend_img (M,F), alpha_v (M,R); att2_c_out / att2_v_out (M,A) or NULL: the decoder-side projections incl.
+ * bias exactly as scored (what set_attention_bwd_f32 takes as `att2`: the backward need not recompute them). */
 size_t set_editnet_attentions_workspace_bytes(int M, int D, int A);
 int set_editnet_attentions_train_f32(const SetEditNetWeights* w, const float* H, const float* att1_c,
                                      const float* mask, const float* Mem, const float* X, const float* att1,
                                      const float* rmask, const float* h1, const float* word, float* gated,
                                      float* alpha_c, float* ctx, float* zt, float* s, float* t, float* sel,
-                                     float* attend_img, float* alpha_v, int M, int T, int R, int F, int D, int A,
-                                     void* ws, size_t ws_bytes, void* stream);
+                                     float* attend_img, float* alpha_v, float* att2_c_out, float* att2_v_out, int M,
+                                     int T, int R, int F, int D, int A, void* ws, size_t ws_bytes, void* stream);
 /* Accumulating forms used by the whole-sequence training node (xe_sequence.py): gradients of loop-invariant operands
  * (H, Mem, cap_features_att(H), and features_att(att_embed(X)) in eval mode) are summed over the timesteps in place
  * instead of by one tensor-sized add per timestep.  acc_* = 1: `out += contribution`, rows beyond M are not touched.

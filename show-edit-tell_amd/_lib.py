@@ -215,7 +215,7 @@ PROTOTYPES = {
     "set_encoder_cell_bwd_f32": (_I, [_P, _P, _P, _P, _L, _L, _I, _P, _I, _P, _P, _P, _P, _L, _P, _P, _I, _I, _P]),
     "set_select_bwd_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "set_editnet_attentions_workspace_bytes": (_Z, [_I, _I, _I]),
-    "set_editnet_attentions_train_f32": (_I, [C.POINTER(EditNetWeights)] + [_P] * 18 + [_I] * 6 + [_P, _Z, _P]),
+    "set_editnet_attentions_train_f32": (_I, [C.POINTER(EditNetWeights)] + [_P] * 20 + [_I] * 6 + [_P, _Z, _P]),
     "set_select_bwd_acc_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "set_attention_bwd_acc_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "set_attention_dvalues_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -82,12 +82,14 @@ struct CapAttArgs {
     // Q[b,t] = gate_cmem.W Mem_t (B,T,Dh) likewise turns gate_cmem(sel) (editnet.py:281) into a row gather.
     const float* P; const float* Q; float* cmem_out; float* gated_out;
     Slabs cg_ab, tc; RowGather gz, gtc; const float *b_gate, *b_sc, *b_tc;
+    float* att2_out;      // (M,A) or NULL: decoder-side projection incl. its bias, as used for the scores (kept for the backward)
 };
 struct VisAttArgs {
     const float* att1; Slabs att2; const float* dec_bias; const float* w_full; const float* b_full;
     const float* X; const float* rmask; float* ctx; float* alpha_out;
     int R, F, A, fcols, fsn;
     int prefetch;
+    float* att2_out;      // (M,A) or NULL, see CapAttArgs
 };
 
 __device__ __forceinline__ void caption_attention_body(const CapAttArgs& P, int b, float* sc, int* s_arg_p) {
@@ -110,6 +112,7 @@ __device__ __forceinline__ void caption_attention_body(const CapAttArgs& P, int 
             for (int i = 1; i < att2_c.n; ++i) v += ld4a(att2_c.p + (long long)i * att2_c.stride + (long long)b * att2_c.ld + a);
             a2[q] = v + ld4a(dec_bias + a);
             wf[q] = ld4a(w_full + a);
+            if (P.att2_out && wave == 0) *reinterpret_cast<f32x4*>(P.att2_out + (long long)b * A + a) = a2[q];
         }
     }
     const float bf = b_full[0];
@@ -261,6 +264,7 @@ __device__ __forceinline__ void visual_attention_body(const VisAttArgs& P, int b
             for (int i = 1; i < att2.n; ++i) v += ld4a(att2.p + (long long)i * att2.stride + (long long)b * att2.ld + a);
             a2[q] = v + ld4a(dec_bias + a);
             wf[q] = ld4a(w_full + a);
+            if (P.att2_out && wave == 0 && fs == 0) *reinterpret_cast<f32x4*>(P.att2_out + (long long)b * A + a) = a2[q];
         }
     }
     const float bf = b_full[0];
@@ -364,15 +368,17 @@ int step_attention(const float* att1, Slabs att2, const float* v_dec_bias, const
                    const float* X, const float* rmask, float* v_ctx, float* v_alpha, int R, int F,
                    const float* att1_c, Slabs att2_c, const float* c_dec_bias, const float* c_w_full,
                    const float* c_b_full, const float* mask, const float* H, const float* Mem, float* c_ctx, float* sel,
-                   float* c_alpha, int T, int Dh, int A, int M, hipStream_t s, const CapHoist* hoist) {
+                   float* c_alpha, int T, int Dh, int A, int M, hipStream_t s, const CapHoist* hoist, float* v_att2_out,
+                   float* c_att2_out) {
     if (R > ATT_MAX_ROWS || T > ATT_MAX_ROWS || A > 512 || (A & 3) || (F & 3) || (Dh & 3)) return SET_ERR_UNSUPPORTED;
     if (M <= 0) return SET_OK;
     const int fsn = vis_fsn(M, F);
     static const int prefetch = env_int("SET_ATT_PREFETCH", 1);
-    VisAttArgs V{att1, att2, v_dec_bias, v_w_full, v_b_full, X, rmask, v_ctx, v_alpha, R, F, A, F / fsn, fsn, prefetch};
+    VisAttArgs V{att1, att2, v_dec_bias, v_w_full, v_b_full, X, rmask, v_ctx, v_alpha, R, F, A, F / fsn, fsn, prefetch, v_att2_out};
     CapAttArgs C{};
     C.att1_c = att1_c; C.att2_c = att2_c; C.dec_bias = c_dec_bias; C.w_full = c_w_full; C.b_full = c_b_full; C.mask = mask;
     C.H = H; C.Mem = Mem; C.ctx = c_ctx; C.sel = sel; C.alpha_out = c_alpha; C.T = T; C.Dh = Dh; C.A = A;
+    C.att2_out = c_att2_out;
     if (hoist && hoist->P) {
         C.P = hoist->P; C.Q = hoist->Q; C.cmem_out = hoist->cmem_out; C.gated_out = hoist->gated_out;
         C.cg_ab = hoist->cg_ab; C.tc = hoist->tc; C.gz = hoist->gz; C.gtc = hoist->gtc;
@@ -393,7 +399,7 @@ int visual_attention(const float* att1, Slabs att2, const float* dec_bias, const
     if (R > ATT_MAX_ROWS || A > 512 || (A & 3) || (F & 3)) return SET_ERR_UNSUPPORTED;
     if (M <= 0) return SET_OK;
     const int fsn = vis_fsn(M, F);
-    VisAttArgs P{att1, att2, dec_bias, w_full, b_full, X, rmask, ctx, alpha_out, R, F, A, F / fsn, fsn, 1};
+    VisAttArgs P{att1, att2, dec_bias, w_full, b_full, X, rmask, ctx, alpha_out, R, F, A, F / fsn, fsn, 1, nullptr};
     ProfScope ps("visual_attention", s, 0.0, 4.0 * M * ((double)R * A + (double)R * F + F + att2.n * A));
     hipLaunchKernelGGL(visual_attention_k, dim3(M * fsn), dim3(256), 0, s, P);
     SET_LAUNCH_CHECK();

@@ -231,8 +231,9 @@ size_t set_editnet_attentions_workspace_bytes(int M, int D, int A) {
 int set_editnet_attentions_train_f32(const SetEditNetWeights* w, const float* H, const float* att1_c, const float* mask,
                                      const float* Mem, const float* X, const float* att1, const float* rmask,
                                      const float* h1, const float* word, float* gated, float* alpha_c, float* ctx,
-                                     float* zt, float* s, float* t, float* sel, float* attend_img, float* alpha_v, int M,
-                                     int T, int R, int F, int D, int A, void* ws, size_t ws_bytes, void* stream) {
+                                     float* zt, float* s, float* t, float* sel, float* attend_img, float* alpha_v,
+                                     float* att2_c_out, float* att2_v_out, int M, int T, int R, int F, int D, int A, void* ws,
+                                     size_t ws_bytes, void* stream) {
     if (!w || !H || !att1_c || !mask || !Mem || !X || !att1 || !h1 || !word || !gated || !alpha_c || !ctx || !zt || !s ||
         !t || !sel || !attend_img || !alpha_v || M <= 0 || T <= 0 || R <= 0 || F <= 0 || D <= 0 || A <= 0)
         return SET_ERR_ARG;
@@ -261,7 +262,7 @@ int set_editnet_attentions_train_f32(const SetEditNetWeights* w, const float* H,
     SET_TRY(gemm_group(b, 4, st, "gemm:train att2,tc,cg"));
     SET_TRY(step_attention(att1, slabs_of(b[1]), w->va_dec_b, w->va_full_w, w->va_full_b, X, rmask, attend_img, alpha_v, R, F,
                            att1_c, slabs_of(b[0]), w->ca_dec_b, w->ca_full_w, w->ca_full_b, mask, H, Mem, ctx, sel, alpha_c,
-                           T, D, A, M, st, nullptr));
+                           T, D, A, M, st, nullptr, att2_v_out, att2_c_out));
     GemmProb c[2];
     c[0] = slab_prob(s_cgb, M, D, M);
     c[0].add(ctx, D, w->ca_gate_w + 2 * D, 3 * D, D);

@@ -169,7 +169,8 @@ int step_attention(const float* att1, Slabs att2, const float* v_dec_bias, const
                    const float* X, const float* rmask, float* v_ctx, float* v_alpha, int R, int F,
                    const float* att1_c, Slabs att2_c, const float* c_dec_bias, const float* c_w_full,
                    const float* c_b_full, const float* mask, const float* H, const float* Mem, float* c_ctx, float* sel,
-                   float* c_alpha, int T, int Dh, int A, int M, hipStream_t s, const CapHoist* hoist = nullptr);
+                   float* c_alpha, int T, int Dh, int A, int M, hipStream_t s, const CapHoist* hoist = nullptr,
+                   float* v_att2_out = nullptr, float* c_att2_out = nullptr);
 int region_masks(const float* X, const float* fe, float* rmask, int B, int R, int F, int D, hipStream_t s);
 int select_rows(const float* Mem, const float* alpha, float* sel, int M, int T, int D, hipStream_t s);
 

@@ -171,6 +171,7 @@ class _XESequence(torch.autograd.Function):
         L["WHC"] = _zl(T, B, 3 * D, dev=dev)                  # [word | h1 | caption context]
         L["ZT"], L["S"], L["TT"] = (_zl(T, B, D, dev=dev) for _ in range(3))
         L["ALPHAC"], L["ALPHAV"] = _zl(T, B, Tc, dev=dev), _zl(T, B, R, dev=dev)
+        L["ATT2C"], L["ATT2V"] = _e(T, B, Adim, dev=dev), _e(T, B, Adim, dev=dev)     # decoder-side projections as scored
         L["SEL"], L["CNEW"], L["CG"] = (_zl(T, B, D, dev=dev) for _ in range(3))
         L["X2"] = _zl(T, B, K2, dev=dev)
         if train:
@@ -252,7 +253,8 @@ class _XESequence(torch.autograd.Function):
                                                        X.data_ptr(), att1.data_ptr(), rm, h1.data_ptr(), emb.data_ptr(),
                                                        gated.data_ptr(), L["ALPHAC"][t].data_ptr(), cx.data_ptr(),
                                                        L["ZT"][t].data_ptr(), L["S"][t].data_ptr(), L["TT"][t].data_ptr(),
-                                                       sel.data_ptr(), aimg.data_ptr(), L["ALPHAV"][t].data_ptr(), bt, Tc, R, F,
+                                                       sel.data_ptr(), aimg.data_ptr(), L["ALPHAV"][t].data_ptr(),
+                                                       L["ATT2C"][t].data_ptr(), L["ATT2V"][t].data_ptr(), bt, Tc, R, F,
                                                        D, Adim, ws_c.data_ptr(), ws_c.numel(), st),
                   "set_editnet_attentions_train_f32")
             ops.pack(L["WHC"][t], bt, [emb, h1, cx])
@@ -358,7 +360,6 @@ class _XESequence(torch.autograd.Function):
         dcm, dcn, dop, og = (_e(B, D, dev=dev) for _ in range(4))
         dgated, daimg = _e(B, D, dev=dev), _e(B, F, dev=dev)
         demb, dalc = _e(B, D, dev=dev), _e(B, Tc, dev=dev)
-        att2 = _e(B, Adim, dev=dev)
         dfe = _e(B * R, D, dev=dev) if train else None
         gate_w, tc_w, x2h_w, wih = P["ca_gate_w"], P["ca_tc_w"], P["cl_x2h_w"], P["al_wih"]
         sc_out = 1.0 / (1.0 - cfg.p_out) if (train and cfg.p_out > 0) else 1.0
@@ -401,11 +402,10 @@ class _XESequence(torch.autograd.Function):
             check(lib.set_select_bwd_acc_f32(dcm.data_ptr(), Mem.data_ptr(), L["ALPHAC"][t].data_ptr(), dMem.data_ptr(),
                                              dalc.data_ptr(), bt, Tc, D, 1, st), "set_select_bwd_acc_f32")
             # ---- VisualAttentionC backward
-            ops.linear(h1, P["va_dec_w"], P["va_dec_b"], att2, bt)
             att1 = L["ATT1"][t] if train else Yin
             datt1 = DATT1[t] if train else dYin
             check(lib.set_attention_bwd_acc_f32(daimg.data_ptr(), None, L["ALPHAV"][t].data_ptr(), X.data_ptr(), att1.data_ptr(),
-                                                att2.data_ptr(), va_full.data_ptr(), datt1.data_ptr(), DATT2V[t].data_ptr(),
+                                                L["ATT2V"][t].data_ptr(), va_full.data_ptr(), datt1.data_ptr(), DATT2V[t].data_ptr(),
                                                 DWFV[t].data_ptr(), None, DEV[t].data_ptr(), bt, R, F, Adim, 0,
                                                 0 if train else 1, 0, st), "set_attention_bwd_acc_f32")
             gg([(r(DATT2V[t]), P["va_dec_w"], r(DH1), True)])
@@ -420,9 +420,8 @@ class _XESequence(torch.autograd.Function):
             dctx = DCTX[t]
             gg([(dz, gate_w[:, 2 * D:], r(dctx), False), (dz, gate_w[:, :D], r(demb), False), (dz, gate_w[:, D:2 * D], r(DH1), True)])
             gg([(ds, P["ca_sc_w"], r(dctx), True), (dt, tc_w[:, :D], r(demb), True), (dt, tc_w[:, D:], r(DH1), True)])
-            ops.linear(h1, P["ca_dec_w"], P["ca_dec_b"], att2, bt)
             check(lib.set_attention_bwd_acc_f32(dctx.data_ptr(), dalc.data_ptr(), L["ALPHAC"][t].data_ptr(), H.data_ptr(),
-                                                att1_c.data_ptr(), att2.data_ptr(), ca_full.data_ptr(), datt1c.data_ptr(),
+                                                att1_c.data_ptr(), L["ATT2C"][t].data_ptr(), ca_full.data_ptr(), datt1c.data_ptr(),
                                                 DATT2C[t].data_ptr(), DWFC[t].data_ptr(), None, DEC[t].data_ptr(), bt, Tc,
                                                 D, Adim, 1, 1, 0, st), "set_attention_bwd_acc_f32")
             gg([(r(DATT2C[t]), P["ca_dec_w"], r(DH1), True)])
