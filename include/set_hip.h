@@ -322,6 +322,10 @@ int set_copy_lstm_train_f32(const SetEditNetWeights* w, const float* x, int64_t 
 int set_copy_gate_bwd_f32(const float* dh, const float* dadp, const float* ogate, const float* adp,
                           const float* cg, const float* cmem, const float* c_new, float* du,
                           float* dcm_direct, float* dcn_direct, float* do_pre, int M, int D, void* stream);
+/* the same with the o-gate read in place from the saved (M,4D) gate block: ogate = gates + 3D, ld_ogate = 4D */
+int set_copy_gate_bwd_ld_f32(const float* dh, const float* dadp, const float* ogate, int64_t ld_ogate,
+                             const float* adp, const float* cg, const float* cmem, const float* c_new, float* du,
+                             float* dcm_direct, float* dcn_direct, float* do_pre, int M, int D, void* stream);
 int set_lstm_gates_bwd_f32(const float* dcn, const float* do_pre, const float* gates, const float* c_prev,
                            float* dgates, float* dc_prev, int M, int D, void* stream);
 int set_caption_attention_train_f32(const SetEditNetWeights* w, const float* H, const float* att1_c,
@@ -393,6 +397,10 @@ int set_select_bwd_acc_f32(const float* dsel, const float* Mem, const float* alp
  * cols, all leading dimensions: multiples of 4; pointers 16-byte aligned. */
 int set_dropout_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int cols, float p, uint64_t seed,
                     uint64_t offset, void* stream);
+/* EmbeddingC.forward in train mode (editnet.py:299-302) in one launch: set_embed_relu_f32 followed by set_dropout_f32
+ * in place (the same counters, hence the same mask for a (seed, offset) pair) */
+int set_embed_relu_dropout_f32(const float* table, const int64_t* ids, int64_t ids_stride, float* out, int64_t ldo,
+                               int n, int D, int V, float p, uint64_t seed, uint64_t offset, void* stream);
 int set_dropout_bwd_f32(const float* dy, int64_t lddy, const float* y, int64_t ldy, float* dx, int64_t ldx, int rows,
                         int cols, float scale, int accumulate, void* stream);
 /* out[c] (+)= sum_r x[r, c] (bias gradients over all (t, b) rows): two deterministic passes through a workspace of

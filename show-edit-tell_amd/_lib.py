@@ -216,12 +216,14 @@ PROTOTYPES = {
     "set_select_bwd_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "set_editnet_attentions_workspace_bytes": (_Z, [_I, _I, _I]),
     "set_editnet_attentions_train_f32": (_I, [C.POINTER(EditNetWeights)] + [_P] * 20 + [_I] * 6 + [_P, _Z, _P]),
+    "set_copy_gate_bwd_ld_f32": (_I, [_P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "set_select_bwd_acc_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "set_attention_bwd_acc_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "set_attention_dvalues_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "set_colsum_workspace_bytes": (_Z, [_I]),
     "set_colsum_f32": (_I, [_P, _L, _I, _I, _P, _I, _P, _Z, _P]),
     "set_dropout_f32": (_I, [_P, _L, _P, _L, _I, _I, C.c_float, _U, _U, _P]),
+    "set_embed_relu_dropout_f32": (_I, [_P, _P, _L, _P, _L, _I, _I, _I, C.c_float, _U, _U, _P]),
     "set_dropout_bwd_f32": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, C.c_float, _I, _P]),
     "set_rowsum_mask_f32": (_I, [_P, _L, _I, _I, _P, _P]),
     "set_pack_f32": (_I, [_P, _L, _I, _I, C.POINTER(_P), C.POINTER(_L), C.POINTER(_I), _I, _P]),

@@ -66,15 +66,16 @@ __global__ void __launch_bounds__(256) lstm_cell_bwd_k(const float* dh, const fl
 __global__ void __launch_bounds__(256) copy_gate_bwd_k(const float* dh, const float* dadp_in, const float* ogate,
                                                        const float* adp, const float* cg, const float* cmem,
                                                        const float* c_new, float* du, float* dcm_direct,
-                                                       float* dcn_direct, float* do_pre, int M, int D) {
+                                                       float* dcn_direct, float* do_pre, int M, int D, long long ld_og) {
     const int per_row = D >> 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)M * per_row) return;
     const long long o = idx * 4;
+    const long long m = idx / per_row;
     f32x4 dhv = {0.f, 0.f, 0.f, 0.f}, dav = {0.f, 0.f, 0.f, 0.f};
     if (dh) dhv = ldb4(dh + o);
     if (dadp_in) dav = ldb4(dadp_in + o);
-    const f32x4 og = ldb4(ogate + o), ad = ldb4(adp + o), g = ldb4(cg + o), cm = ldb4(cmem + o), cn = ldb4(c_new + o);
+    const f32x4 og = ldb4(ogate + m * ld_og + (o - m * D)), ad = ldb4(adp + o), g = ldb4(cg + o), cm = ldb4(cmem + o), cn = ldb4(c_new + o);
     f32x4 duv, dcm, dcn, dop;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -410,17 +411,23 @@ int set_lstm_cell_bwd_f32(const float* dh, const float* dc, const float* gates, 
     return SET_OK;
 }
 
+int set_copy_gate_bwd_ld_f32(const float* dh, const float* dadp, const float* ogate, int64_t ld_ogate, const float* adp,
+                             const float* cg, const float* cmem, const float* c_new, float* du, float* dcm_direct,
+                             float* dcn_direct, float* do_pre, int M, int D, void* stream) {
+    if (!ogate || !adp || !cg || !cmem || !c_new || !du || !dcm_direct || !dcn_direct || !do_pre || M <= 0 || D <= 0)
+        return SET_ERR_ARG;
+    if ((D & 3) || (ld_ogate & 3) || ld_ogate < D) return SET_ERR_UNSUPPORTED;
+    const long long n = (long long)M * (D >> 2);
+    hipLaunchKernelGGL(copy_gate_bwd_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dh, dadp, ogate,
+                       adp, cg, cmem, c_new, du, dcm_direct, dcn_direct, do_pre, M, D, (long long)ld_ogate);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
 int set_copy_gate_bwd_f32(const float* dh, const float* dadp, const float* ogate, const float* adp, const float* cg,
                           const float* cmem, const float* c_new, float* du, float* dcm_direct, float* dcn_direct,
                           float* do_pre, int M, int D, void* stream) {
-    if (!ogate || !adp || !cg || !cmem || !c_new || !du || !dcm_direct || !dcn_direct || !do_pre || M <= 0 || D <= 0)
-        return SET_ERR_ARG;
-    if (D & 3) return SET_ERR_UNSUPPORTED;
-    const long long n = (long long)M * (D >> 2);
-    hipLaunchKernelGGL(copy_gate_bwd_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dh, dadp, ogate,
-                       adp, cg, cmem, c_new, du, dcm_direct, dcn_direct, do_pre, M, D);
-    SET_LAUNCH_CHECK();
-    return SET_OK;
+    return set_copy_gate_bwd_ld_f32(dh, dadp, ogate, D, adp, cg, cmem, c_new, du, dcm_direct, dcn_direct, do_pre, M, D, stream);
 }
 
 int set_lstm_gates_bwd_f32(const float* dcn, const float* do_pre, const float* gates, const float* c_prev, float* dgates,

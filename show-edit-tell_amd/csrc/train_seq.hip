@@ -42,6 +42,28 @@ __global__ void __launch_bounds__(256) dropout_bwd_k(const float* dy, long long 
     *reinterpret_cast<f32x4*>(o) = v;
 }
 
+// EmbeddingC.forward in train mode (editnet.py:299-302): relu(table[ids]) followed by the dropout of dropout_k (same
+// counters: the result equals set_embed_relu_f32 + set_dropout_f32 in place), one launch
+__global__ void __launch_bounds__(256) embed_relu_dropout_k(const float* table, const int64_t* ids, long long ids_stride,
+                                                            float* out, long long ldo, int n, int D4, int V, float p,
+                                                            float scale, unsigned long long seed, unsigned long long offset) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)n * D4) return;
+    const int r = (int)(i / D4), c = (int)(i - (long long)r * D4);
+    long long id = ids[r * ids_stride];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(table + id * (4LL * D4) + 4 * c);
+    uint32_t k[4] = {(uint32_t)r, (uint32_t)c, (uint32_t)offset, (uint32_t)(offset >> 32)};
+    philox4x32_10(k, (uint32_t)seed, (uint32_t)(seed >> 32));
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = v[e] > 0.f ? v[e] : 0.f;
+        o[e] = ((float)(k[e] >> 8) * (1.0f / 16777216.0f) >= p) ? x * scale : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(out + r * ldo + 4 * c) = o;
+}
+
 struct PackArgs {
     const float* src[4];
     long long ld[4];
@@ -99,6 +121,19 @@ int set_dropout_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int rows
     const long long n = (long long)rows * (cols >> 2);
     hipLaunchKernelGGL(dropout_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)ldx, y,
                        (long long)ldy, rows, cols >> 2, p, 1.0f / (1.0f - p), (unsigned long long)seed,
+                       (unsigned long long)offset);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+int set_embed_relu_dropout_f32(const float* table, const int64_t* ids, int64_t ids_stride, float* out, int64_t ldo, int n,
+                               int D, int V, float p, uint64_t seed, uint64_t offset, void* stream) {
+    if (!table || !ids || !out || n < 0 || D <= 0 || V <= 0 || !(p >= 0.f) || !(p < 1.f)) return SET_ERR_ARG;
+    if ((D & 3) || (ldo & 3) || !aligned16(table) || !aligned16(out)) return SET_ERR_UNSUPPORTED;
+    if (n == 0) return SET_OK;
+    const long long t = (long long)n * (D >> 2);
+    hipLaunchKernelGGL(embed_relu_dropout_k, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, ids,
+                       (long long)ids_stride, out, (long long)ldo, n, D >> 2, V, p, 1.0f / (1.0f - p), (unsigned long long)seed,
                        (unsigned long long)offset);
     SET_LAUNCH_CHECK();
     return SET_OK;

@@ -72,10 +72,13 @@ class _DcnetSequence(torch.autograd.Function):
             bt = bts[t]
             emb = L["EMB"][t]
             tok = caps[:, t] if ro is None else state.tokens[t]
-            check(lib.set_embed_relu_f32(Etab.data_ptr(), tok.data_ptr(), cap_stride, emb.data_ptr(), E, bt, E, Etab.shape[0], st),
-                  "set_embed_relu_f32")
             if train and cfg.p_embed > 0:
-                ops.dropout(emb, emb, bt, E, cfg.p_embed, cfg.seed, off(1, t))
+                check(lib.set_embed_relu_dropout_f32(Etab.data_ptr(), tok.data_ptr(), cap_stride, emb.data_ptr(), E, bt, E,
+                                                     Etab.shape[0], cfg.p_embed, cfg.seed, off(1, t), st),
+                      "set_embed_relu_dropout_f32")
+            else:
+                check(lib.set_embed_relu_f32(Etab.data_ptr(), tok.data_ptr(), cap_stride, emb.data_ptr(), E, bt, E, Etab.shape[0], st),
+                      "set_embed_relu_f32")
             x1 = L["X1"][t]
             ops.pack(x1, bt, [emb, final_hidden, L["H2"][t]])
             h1 = L["H1"][t + 1]

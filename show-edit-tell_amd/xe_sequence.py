@@ -225,10 +225,12 @@ class _XESequence(torch.autograd.Function):
                                               ss_f32[1].data_ptr(), st), "set_sample_pick_f32")
                 L["TOK"][t, :bt] = torch.where(ss_u[t, :bt], ss_raw[:bt], L["TOK"][t, :bt])
             tok = (L["TOK"][t] if ss else caps[:, t]) if ro is None else state.tokens[t]
-            check(lib.set_embed_relu_f32(E.data_ptr(), tok.data_ptr(), cap_stride, emb.data_ptr(), D, bt, D, E.shape[0], st),
-                  "set_embed_relu_f32")
             if train and cfg.p_embed > 0:
-                ops.dropout(emb, emb, bt, D, cfg.p_embed, cfg.seed, scale_off(1, t))
+                check(lib.set_embed_relu_dropout_f32(E.data_ptr(), tok.data_ptr(), cap_stride, emb.data_ptr(), D, bt, D, E.shape[0],
+                                                     cfg.p_embed, cfg.seed, scale_off(1, t), st), "set_embed_relu_dropout_f32")
+            else:
+                check(lib.set_embed_relu_f32(E.data_ptr(), tok.data_ptr(), cap_stride, emb.data_ptr(), D, bt, D, E.shape[0], st),
+                      "set_embed_relu_f32")
             x1 = L["X1"][t]
             ops.pack(x1, bt, [emb, final_hidden, L["H2"][t]])                 # columns [0, 3D); mean is prefilled
             h1 = L["H1"][t + 1]
@@ -357,7 +359,7 @@ class _XESequence(torch.autograd.Function):
         DH1, DH2 = _z(B, D, dev=dev), _z(B, D, dev=dev)
         DC1 = [_z(B, D, dev=dev), _z(B, D, dev=dev)]
         DC2 = [_z(B, D, dev=dev), _z(B, D, dev=dev)]
-        dcm, dcn, dop, og = (_e(B, D, dev=dev) for _ in range(4))
+        dcm, dcn, dop = (_e(B, D, dev=dev) for _ in range(3))
         dgated, daimg = _e(B, D, dev=dev), _e(B, F, dev=dev)
         demb, dalc = _e(B, D, dev=dev), _e(B, Tc, dev=dev)
         dfe = _e(B * R, D, dev=dev) if train else None
@@ -387,12 +389,13 @@ class _XESequence(torch.autograd.Function):
             else:
                 ops.pack(DH2, bt, [dH2D[t]], accumulate=True)
             # ---- CopyLSTMCellC backward (editnet.py:265-285)
-            ops.pack(og, bt, [L["G2"][t][:, 3 * D:]])
             du, dgw = DU[t], DGW[t]
             dc2_in, dc2_out = DC2[t & 1], DC2[(t & 1) ^ 1]
-            check(lib.set_copy_gate_bwd_f32(DH2.data_ptr(), dc2_in.data_ptr(), og.data_ptr(), L["C2"][t + 1].data_ptr(),
-                                            L["CG"][t].data_ptr(), L["SEL"][t].data_ptr(), L["CNEW"][t].data_ptr(), du.data_ptr(),
-                                            dcm.data_ptr(), dcn.data_ptr(), dop.data_ptr(), bt, D, st), "set_copy_gate_bwd_f32")
+            check(lib.set_copy_gate_bwd_ld_f32(DH2.data_ptr(), dc2_in.data_ptr(), L["G2"][t][:, 3 * D:].data_ptr(), 4 * D,
+                                               L["C2"][t + 1].data_ptr(),
+                                               L["CG"][t].data_ptr(), L["SEL"][t].data_ptr(), L["CNEW"][t].data_ptr(),
+                                               du.data_ptr(), dcm.data_ptr(), dcn.data_ptr(), dop.data_ptr(), bt, D, st),
+                  "set_copy_gate_bwd_ld_f32")
             gg([(r(du), P["cl_cnew_w"], r(dcn), True), (r(du), P["cl_cmem_w"], r(dcm), True)])
             check(lib.set_lstm_gates_bwd_f32(dcn.data_ptr(), dop.data_ptr(), L["G2"][t].data_ptr(), L["C2"][t].data_ptr(),
                                              dgw.data_ptr(), dc2_out.data_ptr(), bt, D, st), "set_lstm_gates_bwd_f32")

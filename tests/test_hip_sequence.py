@@ -376,3 +376,23 @@ def test_frozen_parameters_get_no_gradient(monkeypatch):
     assert all(p.grad is None for p in frozen)
     others = [p for p in m.parameters() if p.requires_grad]
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in others)
+
+
+def test_fused_embedding_dropout_equals_two_kernels():
+    from show_edit_tell_amd import _lib
+    lib, dev = _lib.load(), _dev()
+    st = _lib.stream_of(dev)
+    V, D, n = 57, 64, 33
+    g = torch.Generator(device="cpu").manual_seed(2)
+    table = torch.randn(V, D, generator=g).to(dev)
+    ids = torch.randint(0, V, (n, 3), generator=g).to(dev)
+    a = torch.zeros(n, 2 * D, device=dev)
+    b = torch.zeros(n, 2 * D, device=dev)
+    _lib.check(lib.set_embed_relu_dropout_f32(table.data_ptr(), ids[:, 1].data_ptr(), 3, a[:, D:].data_ptr(), 2 * D, n, D, V, 0.5, 9,
+                                              (1 << 40) | 4, st), "set_embed_relu_dropout_f32")
+    _lib.check(lib.set_embed_relu_f32(table.data_ptr(), ids[:, 1].data_ptr(), 3, b[:, D:].data_ptr(), 2 * D, n, D, V, st),
+               "set_embed_relu_f32")
+    _lib.check(lib.set_dropout_f32(b[:, D:].data_ptr(), 2 * D, b[:, D:].data_ptr(), 2 * D, n, D, 0.5, 9, (1 << 40) | 4, st),
+               "set_dropout_f32")
+    assert torch.equal(a, b) and float(a[:, :D].abs().max()) == 0.0
+    assert 0.15 < float((a[:, D:] != 0).float().mean()) < 0.35          # relu keeps ~half, dropout half of that
