@@ -272,6 +272,11 @@ int set_caption_attention_f32(const SetEditNetWeights* w, const float* H, const 
                               const float* h1, const float* word, const float* mask, float* gated,
                               float* alpha_c, int M, int T, int Dh, int D, int A, void* ws,
                               size_t ws_bytes, void* stream);
+/* the un-gated form (DCNet, w->ca_gate_w == NULL) that also emits the decoder-side projection incl. bias it scored with,
+ * att2_out (M,A) — the `att2` operand of set_attention_bwd_f32 — for the training node */
+int set_caption_attention_att2_f32(const SetEditNetWeights* w, const float* H, const float* att1_c, const float* h1,
+                                   const float* mask, float* ctx, float* alpha_c, float* att2_out, int M, int T,
+                                   int Dh, int D, int A, void* ws, size_t ws_bytes, void* stream);
 /* VisualAttentionC.forward (editnet.py:439-447); att1 may be NULL (att_embed + features_att are
  * then recomputed exactly as the reference does every call).  adaptive != 0 selects the masked
  * variant (editnet_adaptive.py:438-457).  ctx (M,F). */

@@ -228,13 +228,14 @@ __global__ void __launch_bounds__(256) caption_attention_k(const CapAttArgs P) {
 
 int caption_attention(const float* att1_c, Slabs att2_c, const float* dec_bias, const float* w_full,
                       const float* b_full, const float* mask, const float* H, const float* Mem, float* ctx,
-                      float* sel, float* alpha_out, int M, int T, int Dh, int A, hipStream_t s) {
+                      float* sel, float* alpha_out, int M, int T, int Dh, int A, hipStream_t s, float* att2_out) {
     if (T > ATT_MAX_ROWS || A > 512 || (A & 3) || (Dh & 3)) return SET_ERR_UNSUPPORTED;
     if (M <= 0) return SET_OK;
     ProfScope ps("caption_attention", s, 0.0, 4.0 * M * ((double)T * A + (double)T * Dh + 3.0 * Dh + att2_c.n * A));
     CapAttArgs P{};
     P.att1_c = att1_c; P.att2_c = att2_c; P.dec_bias = dec_bias; P.w_full = w_full; P.b_full = b_full; P.mask = mask;
     P.H = H; P.Mem = Mem; P.ctx = ctx; P.sel = sel; P.alpha_out = alpha_out; P.T = T; P.Dh = Dh; P.A = A;
+    P.att2_out = att2_out;
     hipLaunchKernelGGL(caption_attention_k, dim3(M), dim3(256), 0, s, P);
     SET_LAUNCH_CHECK();
     return SET_OK;

@@ -92,7 +92,7 @@ size_t set_caption_attention_workspace_bytes(int M, int T, int Dh, int A) {
 static int caption_attention_impl(const SetEditNetWeights* w, const float* H, const float* att1_c, const float* h1,
                                   const float* word, const float* mask, float* gated, float* alpha_c, float* ctx_out,
                                   float* zt_out, float* s_out, float* t_out, int M, int T, int Dh, int D, int A,
-                                  void* ws, size_t ws_bytes, void* stream) {
+                                  void* ws, size_t ws_bytes, void* stream, float* att2_out = nullptr) {
     if (!w || !H || !h1 || !mask || !gated || M <= 0 || T <= 0 || Dh <= 0 || D <= 0 || A <= 0) return SET_ERR_ARG;
     if (!ws || !aligned16(ws) || ws_bytes < set_caption_attention_workspace_bytes(M, T, Dh, A) - 256)
         return SET_ERR_WORKSPACE;
@@ -131,7 +131,7 @@ static int caption_attention_impl(const SetEditNetWeights* w, const float* H, co
     plan_ksplit(b, nb, tgt);
     SET_TRY(gemm_group(b, nb, st));
     SET_TRY(caption_attention(att1_c, slabs_of(b[0]), w->ca_dec_b, w->ca_full_w, w->ca_full_b, mask, H, nullptr,
-                              gating ? ctx : gated, nullptr, alpha_c, M, T, Dh, A, st));
+                              gating ? ctx : gated, nullptr, alpha_c, M, T, Dh, A, st, att2_out));
     if (!gating) return SET_OK;
     GemmProb c[2];
     c[0] = slab_prob(s_cgb, M, D, M);
@@ -149,6 +149,16 @@ int set_caption_attention_f32(const SetEditNetWeights* w, const float* H, const 
                               int Dh, int D, int A, void* ws, size_t ws_bytes, void* stream) {
     return caption_attention_impl(w, H, att1_c, h1, word, mask, gated, alpha_c, nullptr, nullptr, nullptr, nullptr, M, T,
                                   Dh, D, A, ws, ws_bytes, stream);
+}
+
+// DCNet's un-gated attention (dcnet.py:254-270) for its training node: also emits the decoder-side projection it scored
+// with (att2_out (M,A), what set_attention_bwd_f32 takes), so the backward does not recompute it
+int set_caption_attention_att2_f32(const SetEditNetWeights* w, const float* H, const float* att1_c, const float* h1,
+                                   const float* mask, float* ctx, float* alpha_c, float* att2_out, int M, int T, int Dh,
+                                   int D, int A, void* ws, size_t ws_bytes, void* stream) {
+    if (!w || w->ca_gate_w || !att1_c || !alpha_c || !att2_out) return SET_ERR_ARG;
+    return caption_attention_impl(w, H, att1_c, h1, nullptr, mask, ctx, alpha_c, nullptr, nullptr, nullptr, nullptr, M, T, Dh,
+                                  D, A, ws, ws_bytes, stream, att2_out);
 }
 
 int set_caption_attention_train_f32(const SetEditNetWeights* w, const float* H, const float* att1_c, const float* h1,

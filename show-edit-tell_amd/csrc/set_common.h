@@ -155,7 +155,7 @@ int zero_f32(float* p, size_t n, hipStream_t s);
 int caption_attention(const float* att1_c, Slabs att2_c, const float* dec_bias, const float* w_full,
                       const float* b_full, const float* mask, const float* H, const float* Mem,
                       float* ctx, float* sel, float* alpha_out, int M, int T, int Dh, int A,
-                      hipStream_t s);
+                      hipStream_t s, float* att2_out = nullptr);
 int visual_attention(const float* att1, Slabs att2, const float* dec_bias, const float* w_full,
                      const float* b_full, const float* X, const float* rmask, float* ctx,
                      float* alpha_out, int M, int R, int F, int A, hipStream_t s);

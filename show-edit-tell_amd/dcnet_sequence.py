@@ -45,7 +45,8 @@ class _DcnetSequence(torch.autograd.Function):
         uniform = min(lens) == T
         _zl = _e if uniform else _z
         L = {"X1": _zl(T, B, K1, dev=dev), "EMB": _zl(T, B, E, dev=dev), "X2": _zl(T, B, K2, dev=dev),
-             "G1": _zl(T, B, 4 * D, dev=dev), "G2": _zl(T, B, 4 * D, dev=dev), "ALPHAC": _zl(T, B, Tc, dev=dev)}
+             "G1": _zl(T, B, 4 * D, dev=dev), "G2": _zl(T, B, 4 * D, dev=dev), "ALPHAC": _zl(T, B, Tc, dev=dev),
+             "ATT2": _e(T, B, Adim, dev=dev)}
         for k in ("H1", "C1", "H2", "C2"):
             L[k] = _zl(T + 1, B, D, dev=dev)
             if uniform:
@@ -87,9 +88,10 @@ class _DcnetSequence(torch.autograd.Function):
                                               P["al_bhh"].data_ptr(), h1.data_ptr(), L["C1"][t + 1].data_ptr(),
                                               L["G1"][t].data_ptr(), bt, D, ws_l.data_ptr(), ws_l.numel(), st),
                   "set_lstm_cell_train_f32")
-            check(lib.set_caption_attention_f32(wref, enc.data_ptr(), att1_c.data_ptr(), h1.data_ptr(), None, mask.data_ptr(),
-                                                cx.data_ptr(), L["ALPHAC"][t].data_ptr(), bt, Tc, Dh, D, Adim, ws_c.data_ptr(),
-                                                ws_c.numel(), st), "set_caption_attention_f32")
+            check(lib.set_caption_attention_att2_f32(wref, enc.data_ptr(), att1_c.data_ptr(), h1.data_ptr(), mask.data_ptr(),
+                                                     cx.data_ptr(), L["ALPHAC"][t].data_ptr(), L["ATT2"][t].data_ptr(), bt, Tc,
+                                                     Dh, D, Adim, ws_c.data_ptr(), ws_c.numel(), st),
+                  "set_caption_attention_att2_f32")
             x2 = L["X2"][t]
             ops.pack(x2, bt, [h1, cx])
             check(lib.set_lstm_cell_train_f32(x2.data_ptr(), K2, K2, L["H2"][t].data_ptr(), L["C2"][t].data_ptr(),
@@ -166,7 +168,7 @@ class _DcnetSequence(torch.autograd.Function):
         DH1, DH2 = _z(B, D, dev=dev), _z(B, D, dev=dev)
         DC1 = [_z(B, D, dev=dev), _z(B, D, dev=dev)]
         DC2 = [_z(B, D, dev=dev), _z(B, D, dev=dev)]
-        demb, att2 = _e(B, E, dev=dev), _e(B, Adim, dev=dev)
+        demb = _e(B, E, dev=dev)
         al_wih, ll_wih = P["al_wih"], P["ll_wih"]
         sc_out = 1.0 / (1.0 - cfg.p_out) if (train and cfg.p_out > 0) else 1.0
         sc_emb = 1.0 / (1.0 - cfg.p_embed) if (train and cfg.p_embed > 0) else 1.0
@@ -189,9 +191,8 @@ class _DcnetSequence(torch.autograd.Function):
                   "set_lstm_cell_bwd_f32")
             dg2, dctx = r(DG2[t]), DCTX[t]
             gg([(dg2, ll_wih[:, :D], r(DH1), True), (dg2, ll_wih[:, D:], r(dctx), False), (dg2, P["ll_whh"], r(DH2), False)])
-            ops.linear(h1, P["ca_dec_w"], P["ca_dec_b"], att2, bt)
             check(lib.set_attention_bwd_acc_f32(dctx.data_ptr(), None, L["ALPHAC"][t].data_ptr(), enc.data_ptr(),
-                                                att1_c.data_ptr(), att2.data_ptr(), ca_full.data_ptr(), datt1c.data_ptr(),
+                                                att1_c.data_ptr(), L["ATT2"][t].data_ptr(), ca_full.data_ptr(), datt1c.data_ptr(),
                                                 DATT2[t].data_ptr(), DWF[t].data_ptr(), None, DE[t].data_ptr(), bt, Tc, Dh, Adim,
                                                 1, 1, 0, st), "set_attention_bwd_acc_f32")
             gg([(r(DATT2[t]), P["ca_dec_w"], r(DH1), True)])
