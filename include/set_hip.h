@@ -383,11 +383,14 @@ int set_editnet_attentions_train_f32(const SetEditNetWeights* w, const float* H,
 /* Accumulating forms used by the whole-sequence training node (xe_sequence.py): gradients of loop-invariant operands
  * (H, Mem, cap_features_att(H), and features_att(att_embed(X)) in eval mode) are summed over the timesteps in place
  * instead of by one tensor-sized add per timestep.  acc_* = 1: `out += contribution`, rows beyond M are not touched.
+ * ld_datt2 (>= A, 0 = A): row stride of datt2, so that the two attentions of a step can write the halves of one
+ * (M, 2A) buffer whose product with the stacked decoder projections is ONE contraction.
  * select: with acc_dM only the selected row of dM changes (dalpha is always overwritten). */
 int set_attention_bwd_acc_f32(const float* dctx, const float* dalpha_ext, const float* alpha,
                               const float* values, const float* att1, const float* att2, const float* w_full,
                               float* datt1, float* datt2, float* dwfull_part, float* dvalues, float* de, int M,
-                              int L, int Dv, int A, int use_tanh, int acc_datt1, int acc_dvalues, void* stream);
+                              int L, int Dv, int A, int use_tanh, int acc_datt1, int acc_dvalues, int64_t ld_datt2,
+                              void* stream);
 /* dvalues[b, l, :] (+)= sum_t alpha[t, b, l] dctx[t, b, :] over per-sequence logs alpha (T,B,L), dctx (T,B,Dv), T <= 64:
  * the attended rows' gradient of all timesteps in one pass. */
 int set_attention_dvalues_f32(const float* alpha, const float* dctx, float* dvalues, int T, int B, int L, int Dv,

@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(256) attention_bwd_k(const float* dctx, const 
                                                        const float* Vals, const float* att1, const float* att2,
                                                        const float* w_full, float* datt1, float* datt2,
                                                        float* dwfull_part, float* dV, float* de_out, int L, int Dv,
-                                                       int A, int acc_datt1, int acc_dv) {
+                                                       int A, int acc_datt1, int acc_dv, long long ld_datt2) {
     __shared__ float s_da[ATTB_MAX];
     __shared__ float s_de[ATTB_MAX];
     __shared__ float s_dot;
@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(256) attention_bwd_k(const float* dctx, const 
                 stb4(o, acc_datt1 ? ldb4(o) + dp : dp);
             }
         }
-        stb4(datt2 + (long long)b * A + a, acc2);
+        stb4(datt2 + (long long)b * ld_datt2 + a, acc2);
         stb4(dwfull_part + (long long)b * A + a, accw);
     }
     if (dV) {
@@ -491,17 +491,18 @@ extern "C" int set_attention_dvalues_f32(const float* alpha, const float* dctx, 
 int set_attention_bwd_acc_f32(const float* dctx, const float* dalpha_ext, const float* alpha, const float* values,
                               const float* att1, const float* att2, const float* w_full, float* datt1, float* datt2,
                               float* dwfull_part, float* dvalues, float* de, int M, int L, int Dv, int A, int use_tanh,
-                              int acc_datt1, int acc_dvalues, void* stream) {
+                              int acc_datt1, int acc_dvalues, int64_t ld_datt2, void* stream) {
     if (!dctx || !alpha || !values || !att1 || !att2 || !w_full || !datt1 || !datt2 || !dwfull_part || M <= 0)
         return SET_ERR_ARG;
-    if (L > ATTB_MAX || (A & 3) || (Dv & 3) || A > 1024 || Dv > 2048) return SET_ERR_UNSUPPORTED;
+    if (ld_datt2 <= 0) ld_datt2 = A;
+    if (L > ATTB_MAX || (A & 3) || (Dv & 3) || A > 1024 || Dv > 2048 || (ld_datt2 & 3) || ld_datt2 < A) return SET_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (use_tanh)
         hipLaunchKernelGGL(attention_bwd_k<true>, dim3(M), dim3(256), 0, st, dctx, dalpha_ext, alpha, values, att1, att2,
-                           w_full, datt1, datt2, dwfull_part, dvalues, de, L, Dv, A, acc_datt1, acc_dvalues);
+                           w_full, datt1, datt2, dwfull_part, dvalues, de, L, Dv, A, acc_datt1, acc_dvalues, (long long)ld_datt2);
     else
         hipLaunchKernelGGL(attention_bwd_k<false>, dim3(M), dim3(256), 0, st, dctx, dalpha_ext, alpha, values, att1, att2,
-                           w_full, datt1, datt2, dwfull_part, dvalues, de, L, Dv, A, acc_datt1, acc_dvalues);
+                           w_full, datt1, datt2, dwfull_part, dvalues, de, L, Dv, A, acc_datt1, acc_dvalues, (long long)ld_datt2);
     SET_LAUNCH_CHECK();
     return SET_OK;
 }
@@ -511,7 +512,7 @@ int set_attention_bwd_f32(const float* dctx, const float* dalpha_ext, const floa
                           float* dwfull_part, float* dvalues, float* de, int M, int L, int Dv, int A, int use_tanh,
                           void* stream) {
     return set_attention_bwd_acc_f32(dctx, dalpha_ext, alpha, values, att1, att2, w_full, datt1, datt2, dwfull_part,
-                                     dvalues, de, M, L, Dv, A, use_tanh, 0, 0, stream);
+                                     dvalues, de, M, L, Dv, A, use_tanh, 0, 0, A, stream);
 }
 
 int set_select_bwd_acc_f32(const float* dsel, const float* Mem, const float* alpha, float* dM, float* dalpha, int M,

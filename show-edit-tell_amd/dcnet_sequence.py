@@ -194,7 +194,7 @@ class _DcnetSequence(torch.autograd.Function):
             check(lib.set_attention_bwd_acc_f32(dctx.data_ptr(), None, L["ALPHAC"][t].data_ptr(), enc.data_ptr(),
                                                 att1_c.data_ptr(), L["ATT2"][t].data_ptr(), ca_full.data_ptr(), datt1c.data_ptr(),
                                                 DATT2[t].data_ptr(), DWF[t].data_ptr(), None, DE[t].data_ptr(), bt, Tc, Dh, Adim,
-                                                1, 1, 0, st), "set_attention_bwd_acc_f32")
+                                                1, 1, 0, Adim, st), "set_attention_bwd_acc_f32")
             gg([(r(DATT2[t]), P["ca_dec_w"], r(DH1), True)])
             dc1_in, dc1_out = DC1[t & 1], DC1[(t & 1) ^ 1]
             check(lib.set_lstm_cell_bwd_f32(DH1.data_ptr(), dc1_in.data_ptr(), L["G1"][t].data_ptr(), L["C1"][t].data_ptr(),

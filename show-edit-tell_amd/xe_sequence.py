@@ -348,7 +348,9 @@ class _XESequence(torch.autograd.Function):
         _zl = _e if ctx.uniform else _z
         DG1, DGW = _zl(T, B, 4 * D, dev=dev), _zl(T, B, 4 * D, dev=dev)
         DU, DZ, DS, DT = (_zl(T, B, D, dev=dev) for _ in range(4))
-        DATT2C, DATT2V, DWFC, DWFV = (_zl(T, B, Adim, dev=dev) for _ in range(4))
+        DWFC, DWFV = _zl(T, B, Adim, dev=dev), _zl(T, B, Adim, dev=dev)
+        DATT2 = _zl(T, B, 2 * Adim, dev=dev)                   # [visual | caption] decoder-projection gradients side by side
+        dec_cat = torch.cat([P["va_dec_w"], P["ca_dec_w"]], 0) # (2A, D): both land in dh1 through ONE contraction per step
         DEC, DEV = _zl(T, B, Tc, dev=dev), _zl(T, B, R, dev=dev)
         DEMBRAW = _zl(T, B, D, dev=dev)
         DCTX = _zl(T, B, D, dev=dev)                           # d(caption context) per step: dH = sum_t alpha_t (x) dctx_t, once
@@ -408,10 +410,9 @@ class _XESequence(torch.autograd.Function):
             att1 = L["ATT1"][t] if train else Yin
             datt1 = DATT1[t] if train else dYin
             check(lib.set_attention_bwd_acc_f32(daimg.data_ptr(), None, L["ALPHAV"][t].data_ptr(), X.data_ptr(), att1.data_ptr(),
-                                                L["ATT2V"][t].data_ptr(), va_full.data_ptr(), datt1.data_ptr(), DATT2V[t].data_ptr(),
+                                                L["ATT2V"][t].data_ptr(), va_full.data_ptr(), datt1.data_ptr(), DATT2[t].data_ptr(),
                                                 DWFV[t].data_ptr(), None, DEV[t].data_ptr(), bt, R, F, Adim, 0,
-                                                0 if train else 1, 0, st), "set_attention_bwd_acc_f32")
-            gg([(r(DATT2V[t]), P["va_dec_w"], r(DH1), True)])
+                                                0 if train else 1, 0, 2 * Adim, st), "set_attention_bwd_acc_f32")
             if train:
                 A.gemm(datt1.view(B * R, Adim)[:bt * R], False, P["va_fa_w"], True, bt * R, D, Adim, out=dfe[:bt * R])
                 ops.dropout_bwd(dfe, L["FE"][t].view(B * R, D), dYin.view(B * R, D), bt * R, D, sc_reg, True)
@@ -425,9 +426,9 @@ class _XESequence(torch.autograd.Function):
             gg([(ds, P["ca_sc_w"], r(dctx), True), (dt, tc_w[:, :D], r(demb), True), (dt, tc_w[:, D:], r(DH1), True)])
             check(lib.set_attention_bwd_acc_f32(dctx.data_ptr(), dalc.data_ptr(), L["ALPHAC"][t].data_ptr(), H.data_ptr(),
                                                 att1_c.data_ptr(), L["ATT2C"][t].data_ptr(), ca_full.data_ptr(), datt1c.data_ptr(),
-                                                DATT2C[t].data_ptr(), DWFC[t].data_ptr(), None, DEC[t].data_ptr(), bt, Tc,
-                                                D, Adim, 1, 1, 0, st), "set_attention_bwd_acc_f32")
-            gg([(r(DATT2C[t]), P["ca_dec_w"], r(DH1), True)])
+                                                DATT2[t][:, Adim:].data_ptr(), DWFC[t].data_ptr(), None, DEC[t].data_ptr(), bt, Tc,
+                                                D, Adim, 1, 1, 0, 2 * Adim, st), "set_attention_bwd_acc_f32")
+            gg([(r(DATT2[t]), dec_cat, r(DH1), True)])
             # ---- attention LSTM backward
             dc1_in, dc1_out = DC1[t & 1], DC1[(t & 1) ^ 1]
             check(lib.set_lstm_cell_bwd_f32(DH1.data_ptr(), dc1_in.data_ptr(), L["G1"][t].data_ptr(), L["C1"][t].data_ptr(),
@@ -479,8 +480,9 @@ class _XESequence(torch.autograd.Function):
         W("ca_tc_w", DT.view(TB, D), whc[:, :2 * D]); Bg("ca_tc_b", DT.view(TB, D))
         W("ca_sc_w", DS.view(TB, D), whc[:, 2 * D:]); Bg("ca_sc_b", DS.view(TB, D))
         h1_all = L["H1"][1:].reshape(TB, D)
-        W("ca_dec_w", DATT2C.view(TB, Adim), h1_all); Bg("ca_dec_b", DATT2C.view(TB, Adim))
-        W("va_dec_w", DATT2V.view(TB, Adim), h1_all); Bg("va_dec_b", DATT2V.view(TB, Adim))
+        datt2 = DATT2.view(TB, 2 * Adim)
+        W("ca_dec_w", datt2[:, Adim:], h1_all); Bg("ca_dec_b", datt2[:, Adim:])
+        W("va_dec_w", datt2[:, :Adim], h1_all); Bg("va_dec_b", datt2[:, :Adim])
         if need[pidx["ca_full_w"]]:
             g[pidx["ca_full_w"]] = A._colsum(DWFC.view(TB, Adim)).view(1, Adim)
         if need[pidx["ca_full_b"]]:

@@ -170,7 +170,7 @@ def test_accumulating_backward_kernels():
         _lib.check(lib.set_attention_bwd_acc_f32(dctx.data_ptr(), dal.data_ptr(), alpha.data_ptr(), vals.data_ptr(),
                                                  att1.data_ptr(), att2.data_ptr(), wf.data_ptr(), datt1.data_ptr(),
                                                  datt2.data_ptr(), dwf.data_ptr(), dval.data_ptr(), de.data_ptr(), M, L, Dv, A, 1,
-                                                 acc1, accv, st), "set_attention_bwd_acc_f32")
+                                                 acc1, accv, 0, st), "set_attention_bwd_acc_f32")
         return datt2, dwf, de
 
     d1, dv = torch.empty(M, L, A, device=dev), torch.empty(M, L, Dv, device=dev)
