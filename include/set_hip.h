@@ -339,6 +339,10 @@ int set_caption_attention_train_f32(const SetEditNetWeights* w, const float* H, 
                                     int Dh, int D, int A, void* ws, size_t ws_bytes, void* stream);
 int set_context_gate_bwd_f32(const float* dout, const float* zt, const float* s, const float* t, float* dz,
                              float* ds, float* dt, int M, int D, void* stream);
+/* the same with a common row stride ld_out >= D for dz / ds / dt: the three can then be column blocks of one (M, 3D) buffer
+ * whose products with stacked weight blocks are single contractions */
+int set_context_gate_bwd_ld_f32(const float* dout, const float* zt, const float* s, const float* t, float* dz,
+                                float* ds, float* dt, int64_t ld_out, int M, int D, void* stream);
 /* additive-attention backward (use_tanh=1: caption attention, 0: visual attention with ReLU).
  * values (M,L,Dv) are the attended rows (H or X); att2 (M,A) includes the decoder-projection bias.
  * Outputs datt1 (M,L,A), datt2 (M,A), dwfull_part (M,A; sum over M = d full_att.weight),

@@ -119,10 +119,13 @@ __global__ void __launch_bounds__(256) lstm_gates_bwd_k(const float* dcn, const 
 //   dz_pre = dout (s - t) zt (1-zt) ; ds_pre = dout zt (1-s^2) ; dt_pre = dout (1-zt)(1-t^2)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) context_gate_bwd_k(const float* dout, const float* zt, const float* s,
-                                                          const float* t, float* dz, float* ds, float* dt, long long n4) {
+                                                          const float* t, float* dz, float* ds, float* dt, long long n4,
+                                                          int D4, long long ld_out) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n4) return;
     const long long o = idx * 4;
+    const long long m = idx / D4;
+    const long long oo = m * ld_out + (o - m * 4 * D4);       // the three outputs share a row stride (>= D)
     const f32x4 d = ldb4(dout + o), z = ldb4(zt + o), sv = ldb4(s + o), tv = ldb4(t + o);
     f32x4 a, b, c;
 #pragma unroll
@@ -131,7 +134,7 @@ __global__ void __launch_bounds__(256) context_gate_bwd_k(const float* dout, con
         b[e] = d[e] * z[e] * (1.f - sv[e] * sv[e]);
         c[e] = d[e] * (1.f - z[e]) * (1.f - tv[e] * tv[e]);
     }
-    stb4(dz + o, a); stb4(ds + o, b); stb4(dt + o, c);
+    stb4(dz + oo, a); stb4(ds + oo, b); stb4(dt + oo, c);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -441,15 +444,20 @@ int set_lstm_gates_bwd_f32(const float* dcn, const float* do_pre, const float* g
     return SET_OK;
 }
 
-int set_context_gate_bwd_f32(const float* dout, const float* zt, const float* s, const float* t, float* dz, float* ds,
-                             float* dt, int M, int D, void* stream) {
+int set_context_gate_bwd_ld_f32(const float* dout, const float* zt, const float* s, const float* t, float* dz, float* ds,
+                                float* dt, int64_t ld_out, int M, int D, void* stream) {
     if (!dout || !zt || !s || !t || !dz || !ds || !dt || M <= 0 || D <= 0) return SET_ERR_ARG;
-    if (D & 3) return SET_ERR_UNSUPPORTED;
+    if ((D & 3) || (ld_out & 3) || ld_out < D) return SET_ERR_UNSUPPORTED;
     const long long n = (long long)M * (D >> 2);
     hipLaunchKernelGGL(context_gate_bwd_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dout, zt, s,
-                       t, dz, ds, dt, n);
+                       t, dz, ds, dt, n, D >> 2, (long long)ld_out);
     SET_LAUNCH_CHECK();
     return SET_OK;
+}
+
+int set_context_gate_bwd_f32(const float* dout, const float* zt, const float* s, const float* t, float* dz, float* ds,
+                             float* dt, int M, int D, void* stream) {
+    return set_context_gate_bwd_ld_f32(dout, zt, s, t, dz, ds, dt, D, M, D, stream);
 }
 
 // dvalues[b, l, :] (+)= sum_t alpha[t, b, l] * dctx[t, b, :]  — the attended rows' gradient of ALL timesteps of a sequence at

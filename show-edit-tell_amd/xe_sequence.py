@@ -347,7 +347,10 @@ class _XESequence(torch.autograd.Function):
         # ---- gradient logs (zero rows where a sequence has left the batch) and running accumulators
         _zl = _e if ctx.uniform else _z
         DG1, DGW = _zl(T, B, 4 * D, dev=dev), _zl(T, B, 4 * D, dev=dev)
-        DU, DZ, DS, DT = (_zl(T, B, D, dev=dev) for _ in range(4))
+        DU = _zl(T, B, D, dev=dev)
+        # context-gate factor gradients side by side, [ds | dz | dt]: [ds | dz] and [dz | dt] are then contiguous column
+        # ranges, and each of d(context), d(word), dh1 is ONE contraction against two stacked weight blocks
+        DSZT = _zl(T, B, 3 * D, dev=dev)
         DWFC, DWFV = _zl(T, B, Adim, dev=dev), _zl(T, B, Adim, dev=dev)
         DATT2 = _zl(T, B, 2 * Adim, dev=dev)                   # [visual | caption] decoder-projection gradients side by side
         dec_cat = torch.cat([P["va_dec_w"], P["ca_dec_w"]], 0) # (2A, D): both land in dh1 through ONE contraction per step
@@ -366,6 +369,9 @@ class _XESequence(torch.autograd.Function):
         demb, dalc = _e(B, D, dev=dev), _e(B, Tc, dev=dev)
         dfe = _e(B * R, D, dev=dev) if train else None
         gate_w, tc_w, x2h_w, wih = P["ca_gate_w"], P["ca_tc_w"], P["cl_x2h_w"], P["al_wih"]
+        w_ctx = torch.cat([P["ca_sc_w"], gate_w[:, 2 * D:]], 0)        # (2D, D) against [ds | dz]
+        w_word = torch.cat([gate_w[:, :D], tc_w[:, :D]], 0)            # (2D, D) against [dz | dt]
+        w_h1 = torch.cat([gate_w[:, D:2 * D], tc_w[:, D:]], 0)         # (2D, D) against [dz | dt]
         sc_out = 1.0 / (1.0 - cfg.p_out) if (train and cfg.p_out > 0) else 1.0
         sc_emb = 1.0 / (1.0 - cfg.p_embed) if (train and cfg.p_embed > 0) else 1.0
         sc_reg = 1.0 / (1.0 - cfg.p_region) if train else 1.0
@@ -417,13 +423,13 @@ class _XESequence(torch.autograd.Function):
                 A.gemm(datt1.view(B * R, Adim)[:bt * R], False, P["va_fa_w"], True, bt * R, D, Adim, out=dfe[:bt * R])
                 ops.dropout_bwd(dfe, L["FE"][t].view(B * R, D), dYin.view(B * R, D), bt * R, D, sc_reg, True)
             # ---- CaptionAttentionC backward
-            check(lib.set_context_gate_bwd_f32(dgated.data_ptr(), L["ZT"][t].data_ptr(), L["S"][t].data_ptr(),
-                                               L["TT"][t].data_ptr(), DZ[t].data_ptr(), DS[t].data_ptr(), DT[t].data_ptr(), bt, D, st),
-                  "set_context_gate_bwd_f32")
-            dz, ds, dt = r(DZ[t]), r(DS[t]), r(DT[t])
+            dszt = DSZT[t]
+            check(lib.set_context_gate_bwd_ld_f32(dgated.data_ptr(), L["ZT"][t].data_ptr(), L["S"][t].data_ptr(),
+                                                  L["TT"][t].data_ptr(), dszt[:, D:].data_ptr(), dszt.data_ptr(),
+                                                  dszt[:, 2 * D:].data_ptr(), 3 * D, bt, D, st), "set_context_gate_bwd_ld_f32")
             dctx = DCTX[t]
-            gg([(dz, gate_w[:, 2 * D:], r(dctx), False), (dz, gate_w[:, :D], r(demb), False), (dz, gate_w[:, D:2 * D], r(DH1), True)])
-            gg([(ds, P["ca_sc_w"], r(dctx), True), (dt, tc_w[:, :D], r(demb), True), (dt, tc_w[:, D:], r(DH1), True)])
+            gg([(r(dszt)[:, :2 * D], w_ctx, r(dctx), False), (r(dszt)[:, D:], w_word, r(demb), False),
+                (r(dszt)[:, D:], w_h1, r(DH1), True)])
             check(lib.set_attention_bwd_acc_f32(dctx.data_ptr(), dalc.data_ptr(), L["ALPHAC"][t].data_ptr(), H.data_ptr(),
                                                 att1_c.data_ptr(), L["ATT2C"][t].data_ptr(), ca_full.data_ptr(), datt1c.data_ptr(),
                                                 DATT2[t][:, Adim:].data_ptr(), DWFC[t].data_ptr(), None, DEC[t].data_ptr(), bt, Tc,
@@ -476,9 +482,11 @@ class _XESequence(torch.autograd.Function):
         W("cl_cnew_w", du, L["CNEW"].view(TB, D)); W("cl_cmem_w", du, L["SEL"].view(TB, D))
         Bg("cl_cnew_b", du); Bg("cl_cmem_b", du)
         whc = L["WHC"].view(TB, 3 * D)
-        W("ca_gate_w", DZ.view(TB, D), whc); Bg("ca_gate_b", DZ.view(TB, D))
-        W("ca_tc_w", DT.view(TB, D), whc[:, :2 * D]); Bg("ca_tc_b", DT.view(TB, D))
-        W("ca_sc_w", DS.view(TB, D), whc[:, 2 * D:]); Bg("ca_sc_b", DS.view(TB, D))
+        dszt = DSZT.view(TB, 3 * D)
+        d_s, d_z, d_t = dszt[:, :D], dszt[:, D:2 * D], dszt[:, 2 * D:]
+        W("ca_gate_w", d_z, whc); Bg("ca_gate_b", d_z)
+        W("ca_tc_w", d_t, whc[:, :2 * D]); Bg("ca_tc_b", d_t)
+        W("ca_sc_w", d_s, whc[:, 2 * D:]); Bg("ca_sc_b", d_s)
         h1_all = L["H1"][1:].reshape(TB, D)
         datt2 = DATT2.view(TB, 2 * Adim)
         W("ca_dec_w", datt2[:, Adim:], h1_all); Bg("ca_dec_b", datt2[:, Adim:])
