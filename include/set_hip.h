@@ -316,6 +316,15 @@ int set_lstm_cell_train_f32(const float* x, int64_t ldx, int Kx, const float* h,
                             const float* b_hh, float* h_out, float* c_out, float* gates_out, int M, int D,
                             void* ws, size_t ws_bytes, void* stream);
 /* dgates (M,4D) = pre-activation gate gradients, dc_prev (M,D); dh / dc may be NULL (zero) */
+/* nn.LSTMCell forward (training form, gates saved) for an input that is a concatenation with loop-invariant column
+ * blocks: gates = x0 w0^T (+ x1 w1^T) + h w_hh^T + pre, where w0 / w1 are column blocks of weight_ih (row strides
+ * ld_w0 / ld_w1) and pre (M,4D) holds the invariant blocks' products plus both biases, contracted once per sequence by
+ * the caller (editnet.py:523: final_hidden and image_mean; dcnet.py:336: final_hidden).  x1 may be NULL. */
+int set_lstm_cell_pre_train_f32(const float* x0, int64_t ld_x0, const float* w0, int64_t ld_w0, int K0,
+                                const float* x1, int64_t ld_x1, const float* w1, int64_t ld_w1, int K1,
+                                const float* h, const float* w_hh, const float* pre, int64_t ld_pre, const float* c,
+                                float* h_out, float* c_out, float* gates_out, int M, int D, void* ws,
+                                size_t ws_bytes, void* stream);
 int set_lstm_cell_bwd_f32(const float* dh, const float* dc, const float* gates, const float* c_prev,
                           const float* c_new, float* dgates, float* dc_prev, int M, int D, void* stream);
 int set_copy_lstm_train_f32(const SetEditNetWeights* w, const float* x, int64_t ldx, int Kx,

@@ -220,6 +220,8 @@ PROTOTYPES = {
     "set_caption_attention_att2_f32": (_I, [C.POINTER(EditNetWeights), _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P,
                                             _Z, _P]),
     "set_context_gate_bwd_ld_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    "set_lstm_cell_pre_train_f32": (_I, [_P, _L, _P, _L, _I, _P, _L, _P, _L, _I, _P, _P, _P, _L, _P, _P, _P, _P, _I, _I, _P, _Z,
+                                         _P]),
     "set_select_bwd_acc_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "set_attention_bwd_acc_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _P]),
     "set_attention_dvalues_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -233,15 +233,36 @@ def _is_leaf_param(param):
     return _FUSED_WGRAD and isinstance(param, torch.nn.Parameter) and param.is_leaf
 
 
-def _announce(param):
-    """eager gradient inside a deferred context: tell the context's on_ready (the data-parallel reducer) right away"""
+def _announce(param, eager=True):
+    """finished gradient inside a deferred context: tell the context's on_ready (the data-parallel reducer) right away"""
     tab = _deferred_table()
     cb = _active_cb.get(id(tab)) if tab is not None else None
     if cb is not None:
         try:
-            cb(param, eager=True)
+            cb(param, eager=eager)
         except TypeError:
             cb(param)
+
+
+def _wgrad_blocks(param, blocks):
+    """Weight gradient assembled from column blocks: dW[:, c0:c0+Kb] (+)= dy^T x for every (dy, x, c0) — the blocks cover
+    all columns of `param` and may contract over different row counts (a per-timestep input block over all T*B rows, a
+    loop-invariant input block over B rows against sum_t dy).  This is the parameter's ONLY contribution of the backward:
+    written straight into param.grad (see `_wgrad`) and announced; non-leaf tensors get the gradient returned."""
+    leaf = _is_leaf_param(param)
+    acc = leaf and param.grad is not None
+    out = param.grad if acc else torch.empty_like(param)
+    N = param.shape[0]
+    for dy, x, c0 in blocks:
+        Kb = x.shape[1]
+        if (Kb & 3) or (N & 3) or (c0 & 3):
+            raise _lib.SetError("column-block weight gradient needs multiples of 4 (got N=%d, K=%d at column %d)" % (N, Kb, c0))
+        gemm(dy, True, x, True, N, Kb, dy.shape[0], out=out[:, c0:c0 + Kb], accumulate=acc)
+    if not leaf:
+        return out
+    param.grad = out
+    _announce(param, eager=False)
+    return None
 
 
 def _wgrad(param, dy, x, eager=False):

@@ -82,6 +82,31 @@ int set_lstm_cell_train_f32(const float* x, int64_t ldx, int Kx, const float* h,
                           stream);
 }
 
+// nn.LSTMCell whose input is a concatenation with loop-invariant column blocks (editnet.py:523 [emb | final_hidden | h2 |
+// image_mean], dcnet.py:336 [emb | final_hidden | h2]): the caller contracts the invariant blocks ONCE per sequence
+// (`pre` (M,4D) = their products + both biases) and passes only the per-step blocks as up to two (x, W column block)
+// segments — half of the attention LSTM's contraction length, and the X-side weight gradient of the invariant columns
+// becomes (sum_t dgates) x (invariant input) instead of a product over all T*B rows.
+int set_lstm_cell_pre_train_f32(const float* x0, int64_t ld_x0, const float* w0, int64_t ld_w0, int K0, const float* x1,
+                                int64_t ld_x1, const float* w1, int64_t ld_w1, int K1, const float* h, const float* w_hh,
+                                const float* pre, int64_t ld_pre, const float* c, float* h_out, float* c_out,
+                                float* gates_out, int M, int D, void* ws, size_t ws_bytes, void* stream) {
+    if (!x0 || !w0 || !h || !w_hh || !pre || !c || !h_out || !c_out || !gates_out || M <= 0 || D <= 0 || K0 <= 0)
+        return SET_ERR_ARG;
+    if (x1 && (!w1 || K1 <= 0)) return SET_ERR_ARG;
+    if (!ws || !aligned16(ws) || ws_bytes < set_lstm_cell_workspace_bytes(M, D, K0) - 256) return SET_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    GemmProb p = slab_prob((float*)ws, M, 4 * D, M);
+    p.add(x0, ld_x0, w0, ld_w0, K0);
+    if (x1) p.add(x1, ld_x1, w1, ld_w1, K1);
+    p.add(h, D, w_hh, D, D);
+    plan_ksplit(&p, 1, gemm_target_wgs());
+    SET_TRY(gemm_group(&p, 1, st));
+    const Slabs none{nullptr, 0, 0, 0};
+    return lstm_pointwise(slabs_of(p), none, none, pre, ld_pre, nullptr, nullptr, c, c_out, h_out, nullptr, M, D, st,
+                          RowGather(), gates_out);
+}
+
 // ------------------------------------------------------------------------------- CaptionAttentionC
 size_t set_caption_attention_workspace_bytes(int M, int T, int Dh, int A) {
     if (M <= 0 || T <= 0 || Dh <= 0 || A <= 0) return 0;

@@ -44,7 +44,7 @@ class _DcnetSequence(torch.autograd.Function):
         enc, final_hidden, mask, att1_c, caps = (t.contiguous() for t in (enc, final_hidden, mask, att1_c, caps))
         uniform = min(lens) == T
         _zl = _e if uniform else _z
-        L = {"X1": _zl(T, B, K1, dev=dev), "EMB": _zl(T, B, E, dev=dev), "X2": _zl(T, B, K2, dev=dev),
+        L = {"FH": final_hidden, "EMB": _zl(T, B, E, dev=dev), "X2": _zl(T, B, K2, dev=dev),
              "G1": _zl(T, B, 4 * D, dev=dev), "G2": _zl(T, B, 4 * D, dev=dev), "ALPHAC": _zl(T, B, Tc, dev=dev),
              "ATT2": _e(T, B, Adim, dev=dev)}
         for k in ("H1", "C1", "H2", "C2"):
@@ -54,6 +54,11 @@ class _DcnetSequence(torch.autograd.Function):
         if train and cfg.p_out > 0:
             L["H2D"] = _zl(T, B, D, dev=dev)
         cx = _e(B, Dh, dev=dev)
+        # dcnet.py:336 feeds [emb | final_hidden | h2] to the attention LSTM: the final_hidden columns (+ both biases) are
+        # contracted once per sequence, every step contracts only the emb / h2 column blocks of weight_ih
+        al_wih = P["al_wih"]
+        pre1 = _e(B, 4 * D, dev=dev)
+        ops.linear(final_hidden, al_wih[:, E:E + Dh], P["al_bih"] + P["al_bhh"], pre1, B)
         w = EditNetWeights()          # the attention kernel reads its four caption-attention pointers from this struct
         w.ca_dec_w, w.ca_dec_b = P["ca_dec_w"].data_ptr(), P["ca_dec_b"].data_ptr()
         w.ca_full_w, w.ca_full_b = P["ca_full_w"].data_ptr(), P["ca_full_b"].data_ptr()
@@ -80,14 +85,12 @@ class _DcnetSequence(torch.autograd.Function):
             else:
                 check(lib.set_embed_relu_f32(Etab.data_ptr(), tok.data_ptr(), cap_stride, emb.data_ptr(), E, bt, E, Etab.shape[0], st),
                       "set_embed_relu_f32")
-            x1 = L["X1"][t]
-            ops.pack(x1, bt, [emb, final_hidden, L["H2"][t]])
             h1 = L["H1"][t + 1]
-            check(lib.set_lstm_cell_train_f32(x1.data_ptr(), K1, K1, L["H1"][t].data_ptr(), L["C1"][t].data_ptr(),
-                                              P["al_wih"].data_ptr(), K1, P["al_whh"].data_ptr(), P["al_bih"].data_ptr(),
-                                              P["al_bhh"].data_ptr(), h1.data_ptr(), L["C1"][t + 1].data_ptr(),
-                                              L["G1"][t].data_ptr(), bt, D, ws_l.data_ptr(), ws_l.numel(), st),
-                  "set_lstm_cell_train_f32")
+            check(lib.set_lstm_cell_pre_train_f32(emb.data_ptr(), E, al_wih.data_ptr(), K1, E, L["H2"][t].data_ptr(), D,
+                                                  al_wih[:, E + Dh:].data_ptr(), K1, D, L["H1"][t].data_ptr(),
+                                                  P["al_whh"].data_ptr(), pre1.data_ptr(), 4 * D, L["C1"][t].data_ptr(),
+                                                  h1.data_ptr(), L["C1"][t + 1].data_ptr(), L["G1"][t].data_ptr(), bt, D,
+                                                  ws_l.data_ptr(), ws_l.numel(), st), "set_lstm_cell_pre_train_f32")
             check(lib.set_caption_attention_att2_f32(wref, enc.data_ptr(), att1_c.data_ptr(), h1.data_ptr(), mask.data_ptr(),
                                                      cx.data_ptr(), L["ALPHAC"][t].data_ptr(), L["ATT2"][t].data_ptr(), bt, Tc,
                                                      Dh, D, Adim, ws_c.data_ptr(), ws_c.numel(), st),
@@ -164,7 +167,7 @@ class _DcnetSequence(torch.autograd.Function):
         DG1, DG2 = _zl(T, B, 4 * D, dev=dev), _zl(T, B, 4 * D, dev=dev)
         DATT2, DWF, DE = _zl(T, B, Adim, dev=dev), _zl(T, B, Adim, dev=dev), _zl(T, B, Tc, dev=dev)
         DCTX, DEMBRAW = _zl(T, B, Dh, dev=dev), _zl(T, B, E, dev=dev)
-        dFH, datt1c = _z(B, Dh, dev=dev), torch.zeros_like(att1_c)
+        datt1c = torch.zeros_like(att1_c)
         DH1, DH2 = _z(B, D, dev=dev), _z(B, D, dev=dev)
         DC1 = [_z(B, D, dev=dev), _z(B, D, dev=dev)]
         DC2 = [_z(B, D, dev=dev), _z(B, D, dev=dev)]
@@ -201,12 +204,14 @@ class _DcnetSequence(torch.autograd.Function):
                                             L["C1"][t + 1].data_ptr(), DG1[t].data_ptr(), dc1_out.data_ptr(), bt, D, st),
                   "set_lstm_cell_bwd_f32")
             dg1 = r(DG1[t])
-            gg([(dg1, al_wih[:, :E], r(demb), False), (dg1, al_wih[:, E:E + Dh], r(dFH), True),
-                (dg1, al_wih[:, E + Dh:], r(DH2), True), (dg1, P["al_whh"], r(DH1), False)])
+            # (the final_hidden columns are loop-invariant: their gradients come from sum_t dgates after the loop)
+            gg([(dg1, al_wih[:, :E], r(demb), False), (dg1, al_wih[:, E + Dh:], r(DH2), True), (dg1, P["al_whh"], r(DH1), False)])
             ops.dropout_bwd(demb, L["EMB"][t], DEMBRAW[t], bt, E, sc_emb, False)
 
         denc = _dvalues(L["ALPHAC"], DCTX, ops)
         TB = T * B
+        sdg1 = DG1.sum(0)                  # loop-invariant input: d final_hidden = (sum_t dgates) . W_ih[:, E:E+Dh]
+        dFH = A.gemm(sdg1, False, al_wih[:, E:E + Dh], True, B, Dh, 4 * D)
 
         need = ctx.needs_input_grad[6:]                       # frozen parameters (requires_grad False) get no gradient
 
@@ -224,7 +229,10 @@ class _DcnetSequence(torch.autograd.Function):
             dE.index_add_(0, ids, DEMBRAW.view(TB, E))
             g[pidx["E"]] = dE
         dg1 = DG1.view(TB, 4 * D)
-        W("al_wih", dg1, L["X1"].view(TB, -1)); W("al_whh", dg1, L["H1"][:T].reshape(TB, D))
+        if need[pidx["al_wih"]]:           # column blocks [emb | final_hidden | h2]; the invariant one from sum_t dgates
+            g[pidx["al_wih"]] = A._wgrad_blocks(params[pidx["al_wih"]], [
+                (dg1, L["EMB"].view(TB, E), 0), (sdg1, L["FH"], E), (dg1, L["H2"][:T].reshape(TB, D), E + Dh)])
+        W("al_whh", dg1, L["H1"][:T].reshape(TB, D))
         Bg("al_bih", dg1); Bg("al_bhh", dg1)
         dg2 = DG2.view(TB, 4 * D)
         W("ll_wih", dg2, L["X2"].view(TB, -1)); W("ll_whh", dg2, L["H2"][:T].reshape(TB, D))

@@ -160,8 +160,14 @@ class _XESequence(torch.autograd.Function):
         uniform = min(lens) == T
         _zl = _e if uniform else _z
         L = {}
-        L["X1"] = _zl(T, B, K1, dev=dev)
-        L["X1"][:, :, 3 * D:].copy_(mean.unsqueeze(0).expand(T, B, F))
+        # editnet.py:523 feeds [emb | final_hidden | h2 | image_mean] to the attention LSTM: the final_hidden and image_mean
+        # columns do not change over the sequence, so their products (+ both biases) are contracted once (`pre1`) and
+        # every step contracts only the emb / h2 column blocks of weight_ih (half the contraction length)
+        wih = P["al_wih"]
+        pre1 = _e(B, 4 * D, dev=dev)
+        ops.linear(final_hidden, wih[:, D:2 * D], P["al_bih"] + P["al_bhh"], pre1, B)
+        A.gemm(mean, False, wih[:, 3 * D:], False, B, 4 * D, F, out=pre1, accumulate=True)
+        L["FH"], L["MEAN"] = final_hidden, mean
         L["EMB"] = _zl(T, B, D, dev=dev)
         for k in ("H1", "C1", "H2", "C2"):                    # slot t = state BEFORE step t; slot 0 = the zero initial state
             L[k] = _zl(T + 1, B, D, dev=dev)
@@ -231,14 +237,12 @@ class _XESequence(torch.autograd.Function):
             else:
                 check(lib.set_embed_relu_f32(E.data_ptr(), tok.data_ptr(), cap_stride, emb.data_ptr(), D, bt, D, E.shape[0], st),
                       "set_embed_relu_f32")
-            x1 = L["X1"][t]
-            ops.pack(x1, bt, [emb, final_hidden, L["H2"][t]])                 # columns [0, 3D); mean is prefilled
             h1 = L["H1"][t + 1]
-            check(lib.set_lstm_cell_train_f32(x1.data_ptr(), K1, K1, L["H1"][t].data_ptr(), L["C1"][t].data_ptr(),
-                                              P["al_wih"].data_ptr(), K1, P["al_whh"].data_ptr(), P["al_bih"].data_ptr(),
-                                              P["al_bhh"].data_ptr(), h1.data_ptr(), L["C1"][t + 1].data_ptr(),
-                                              L["G1"][t].data_ptr(), bt, D, ws_l.data_ptr(), ws_l.numel(), st),
-                  "set_lstm_cell_train_f32")
+            check(lib.set_lstm_cell_pre_train_f32(emb.data_ptr(), D, wih.data_ptr(), K1, D, L["H2"][t].data_ptr(), D,
+                                                  wih[:, 2 * D:].data_ptr(), K1, D, L["H1"][t].data_ptr(),
+                                                  P["al_whh"].data_ptr(), pre1.data_ptr(), 4 * D, L["C1"][t].data_ptr(),
+                                                  h1.data_ptr(), L["C1"][t + 1].data_ptr(), L["G1"][t].data_ptr(), bt, D,
+                                                  ws_l.data_ptr(), ws_l.numel(), st), "set_lstm_cell_pre_train_f32")
             if train:
                 fe = L["FE"][t]
                 ops.dropout(Yin.view(B * R, D), fe.view(B * R, D), bt * R, D, cfg.p_region, cfg.seed, scale_off(2, t))
@@ -359,7 +363,7 @@ class _XESequence(torch.autograd.Function):
         DCTX = _zl(T, B, D, dev=dev)                           # d(caption context) per step: dH = sum_t alpha_t (x) dctx_t, once
         DATT1 = _zl(T, B, R, Adim, dev=dev) if train else None
         dMem = torch.zeros_like(Mem)
-        dFH, datt1c = _z(B, D, dev=dev), torch.zeros_like(att1_c)
+        datt1c = torch.zeros_like(att1_c)
         dYin = torch.zeros_like(Yin)                           # train: d relu(att_embed(X)); eval: d features_att(.)
         DH1, DH2 = _z(B, D, dev=dev), _z(B, D, dev=dev)
         DC1 = [_z(B, D, dev=dev), _z(B, D, dev=dev)]
@@ -441,14 +445,17 @@ class _XESequence(torch.autograd.Function):
                                             L["C1"][t + 1].data_ptr(), DG1[t].data_ptr(), dc1_out.data_ptr(), bt, D, st),
                   "set_lstm_cell_bwd_f32")
             dg1 = r(DG1[t])
-            gg([(dg1, wih[:, :D], r(demb), True), (dg1, wih[:, D:2 * D], r(dFH), True),
-                (dg1, wih[:, 2 * D:3 * D], r(DH2), True), (dg1, P["al_whh"], r(DH1), False)])
+            # (the final_hidden / image_mean columns are loop-invariant: their gradients come from sum_t dgates below)
+            gg([(dg1, wih[:, :D], r(demb), True), (dg1, wih[:, 2 * D:3 * D], r(DH2), True), (dg1, P["al_whh"], r(DH1), False)])
             # ---- embedding: dropout + ReLU backward; the table rows are scattered once after the loop
             ops.dropout_bwd(demb, L["EMB"][t], DEMBRAW[t], bt, D, sc_emb, False)
 
         # dH[b, l, :] = sum_t alpha_c[t, b, l] dctx[t, b, :]: one batched (Tc x T)(T x D) product per sample over the logs
         # instead of a read-modify-write of all of dH in every timestep
         dH = _dvalues(L["ALPHAC"], DCTX, ops)
+        # loop-invariant inputs of the attention LSTM: d final_hidden = (sum_t dgates) . W_ih[:, D:2D]
+        sdg1 = DG1.sum(0)
+        dFH = A.gemm(sdg1, False, wih[:, D:2 * D], True, B, D, 4 * D)
         # ---- parameter gradients: one contraction per parameter over all (t, b) rows
         pidx = {n: i for i, n in enumerate(PARAM_NAMES)}
         g = [None] * len(PARAM_NAMES)
@@ -473,7 +480,11 @@ class _XESequence(torch.autograd.Function):
             dE.index_add_(0, ids, DEMBRAW.view(TB, D))
             g[pidx["E"]] = dE
         dg1 = DG1.view(TB, 4 * D)
-        W("al_wih", dg1, L["X1"].view(TB, K1)); W("al_whh", dg1, L["H1"][:T].reshape(TB, D))
+        if need[pidx["al_wih"]]:           # column blocks [emb | final_hidden | h2 | image_mean]; the invariant ones from sum_t
+            g[pidx["al_wih"]] = A._wgrad_blocks(params[pidx["al_wih"]], [
+                (dg1, L["EMB"].view(TB, D), 0), (sdg1, L["FH"], D), (dg1, L["H2"][:T].reshape(TB, D), 2 * D),
+                (sdg1, L["MEAN"], 3 * D)])
+        W("al_whh", dg1, L["H1"][:T].reshape(TB, D))
         Bg("al_bih", dg1); Bg("al_bhh", dg1)
         dgw = DGW.view(TB, 4 * D)
         W("cl_x2h_w", dgw, L["X2"].view(TB, K2)); W("cl_h2h_w", dgw, L["H2"][:T].reshape(TB, D))

@@ -52,12 +52,14 @@ def _loss_and_grads(m, inputs, seq, deferred, monkeypatch):
 @pytest.mark.parametrize("B,V,D,A,F,min_len,deferred", [(4, 203, 64, 32, 256, 8, False), (6, 203, 64, 32, 256, 20, True),
                                                        (16, 1000, 256, 128, 2048, 6, True)])
 def test_sequence_node_equals_per_operator_route(B, V, D, A, F, min_len, deferred, monkeypatch):
-    """same kernels, two host schedules: identical scores; gradients equal up to the order of the sums over timesteps"""
+    """same kernels, two host schedules: the node contracts the loop-invariant final_hidden / image_mean columns of the
+    attention LSTM once per sequence (as the decode path does), so scores agree to fp32 summation order; gradients equal
+    up to the order of the sums over timesteps"""
     m = _build(V, D, A, F).eval()
     inputs = _inputs(B, 36, F, 20, V, min_len)
     p0, g0 = _loss_and_grads(m, inputs, False, deferred, monkeypatch)
     p1, g1 = _loss_and_grads(m, inputs, True, deferred, monkeypatch)
-    assert torch.equal(p0, p1)
+    assert float((p0 - p1).abs().max()) <= 2e-5 * max(1.0, float(p0.abs().max()))
     assert set(g0) == set(g1)
     gmax = max(float(g.abs().max()) for g in g0.values())
     for k in g0:
@@ -300,7 +302,7 @@ def test_dcnet_rollout_node_equals_per_operator_rollout(monkeypatch):
         ls, n, _, _ = xe_loss_sum(pred, caps_s, dl)
         (ls / n).backward()
         res.append((pred.detach().clone(), grads(xe)))
-    assert torch.equal(res[0][0], res[1][0])
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 2e-5 * max(1.0, float(res[0][0].abs().max()))
     close(res[0][1], res[1][1])
 
 
