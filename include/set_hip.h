@@ -316,6 +316,22 @@ int set_lstm_cell_train_f32(const float* x, int64_t ldx, int Kx, const float* h,
                             const float* b_hh, float* h_out, float* c_out, float* gates_out, int M, int D,
                             void* ws, size_t ws_bytes, void* stream);
 /* dgates (M,4D) = pre-activation gate gradients, dc_prev (M,D); dh / dc may be NULL (zero) */
+/* The tail of the training step — torch.nn.utils.clip_grad_norm_(params, max_norm) followed by torch.optim.Adam.step()
+ * (editnet.py:580-581, dcnet.py:399-400, editnet_rl.py:684-686) — over n fp32 tensors in two launches per 40 tensors:
+ * per-chunk sums of squares, then the Adam update with the clipping coefficient min(1, max_norm / (norm + 1e-6)) folded
+ * into the gradient read (deterministic norm, no host round trip).  All arrays are HOST arrays of length n; the pointers
+ * in params / grads / exp_avg / exp_avg_sq are 16-byte aligned DEVICE pointers to numel[i] contiguous floats.  step[i] is
+ * the 1-based step count of tensor i (bias corrections and 1 - beta are formed on the host in double, as torch forms
+ * them, then rounded to fp32), lr / beta1 / beta2 / eps / weight_decay the hyper-parameters of its param group (weight_decay in torch.optim.Adam's L2 form).  max_norm <= 0: no
+ * clipping.  scale_grads != 0: the clipped gradient is also written back (clip_grad_norm_'s in-place effect; costs one
+ * more gradient-sized write).  total_norm_out (device, 1 float, may be NULL) receives the gradient norm.
+ * ws: set_clip_adam_workspace_bytes(n, numel) bytes. */
+size_t set_clip_adam_workspace_bytes(int n, const int64_t* numel);
+int set_clip_adam_f32(int n, float* const* params, const float* const* grads, float* const* exp_avg,
+                      float* const* exp_avg_sq, const int64_t* numel, const int64_t* step, const double* lr,
+                      const double* beta1, const double* beta2, const double* eps, const double* weight_decay,
+                      float max_norm, int scale_grads, float* total_norm_out, void* ws, size_t ws_bytes, void* stream);
+
 /* nn.LSTMCell forward (training form, gates saved) for an input that is a concatenation with loop-invariant column
  * blocks: gates = x0 w0^T (+ x1 w1^T) + h w_hh^T + pre, where w0 / w1 are column blocks of weight_ih (row strides
  * ld_w0 / ld_w1) and pre (M,4D) holds the invariant blocks' products plus both biases, contracted once per sequence by

@@ -15,6 +15,8 @@ import torch
 import torch.nn.functional as F
 from torch.nn.utils.rnn import pack_padded_sequence
 
+from .optim import clip_grad_norm_and_step
+
 GRAD_CLIP = 0.25                     # editnet.py:580
 BUCKET_BYTES = 64 << 20              # xGMI rings are per-link bound: few, large buckets
 
@@ -168,8 +170,7 @@ def xe_train_step(decoder, optimizer, image_features, caps, caplens, previous_ca
     loss, n_tok, _ = xe_backward(decoder, image_features, caps, caplens, previous_caption, prev_caplen, use_ss, ss_prob,
                                  group, reduce)
     params = [p for p in decoder.parameters() if p.requires_grad]
-    torch.nn.utils.clip_grad_norm_(params, GRAD_CLIP)
-    optimizer.step()
+    clip_grad_norm_and_step(params, optimizer, GRAD_CLIP)
     return loss, n_tok
 
 
@@ -199,8 +200,7 @@ def dcnet_xe_train_step(dae, optimizer, caps, caplens, previous_caption, prev_ca
     dae.train()
     loss, n_tok, _ = dcnet_xe_backward(dae, caps, caplens, previous_caption, prev_caplen, group, reduce)
     params = [p for p in dae.parameters() if p.requires_grad]
-    torch.nn.utils.clip_grad_norm_(params, GRAD_CLIP)
-    optimizer.step()
+    clip_grad_norm_and_step(params, optimizer, GRAD_CLIP)
     return loss, n_tok
 
 
@@ -260,8 +260,7 @@ def _scst_step(model, optimizer, greedy_fn, sample_fn, rep, ground_truth, scorer
     reward_mean, loss_val = float(rewards[:, 0].mean()), _global_loss(num, n_glob, group)
     params = [p for p in model.parameters() if p.requires_grad]
     allreduce_gradients(params, group, reducer=reducer)
-    torch.nn.utils.clip_grad_norm_(params, GRAD_CLIP)
-    optimizer.step()
+    clip_grad_norm_and_step(params, optimizer, GRAD_CLIP)
     return reward_mean, loss_val
 
 

@@ -76,6 +76,7 @@ def scst(dev, batch=64, samples=5, steps=3):
 def adaptive(dev, batch=64, regions=100):
     from show_edit_tell_amd import editnet_adaptive, synth
     from show_edit_tell_amd.autograd_ops import deferred_param_grads
+    from show_edit_tell_amd.optim import clip_grad_norm_and_step
     from show_edit_tell_amd.train import xe_loss_sum
     wm = synth.word_map(V)
     dec = _editnet(editnet_adaptive.DecoderC, dev, wm)
@@ -96,8 +97,7 @@ def adaptive(dev, batch=64, regions=100):
         loss = ls / n + torch.nn.functional.mse_loss(last_h, gd_fh)          # editnet_adaptive.py:594-596
         with deferred_param_grads():
             loss.backward()
-        torch.nn.utils.clip_grad_norm_(dec.parameters(), 0.25)
-        opt.step()
+        clip_grad_norm_and_step(list(dec.parameters()), opt, 0.25)
 
     t_train, _ = _timed(train_step, 4, 2)
     return {"workload": "adaptive features (editnet_adaptive.py), B=%d, R=%d (%d..%d valid regions)" % (
