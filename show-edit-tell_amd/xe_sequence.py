@@ -221,6 +221,18 @@ class _XESequence(torch.autograd.Function):
             L["LSE"], L["LOGP"] = _e(T, B, dev=dev), _e(T, B, dev=dev)
         scale_off = lambda site, t: (site << 40) | t
 
+        # editnet.py:441-443 in train mode: att1(t) = features_att(dropout_t(relu(att_embed(X)))) does not depend on the
+        # recurrent state, so all T region projections run as ONE (T*B*R, D) x (D, A) product before the loop (19 products of
+        # B*R = 4608 rows each leave the chip 1.1 rounds of tiles; 87552 rows fill it).  Ragged batches with many finished
+        # rows keep the per-step products over the live rows only.
+        att1_hoisted = train and sum(bts) * 4 >= 3 * T * B
+        if train:
+            for t in range(T):
+                rows_t = B if att1_hoisted else bts[t]
+                ops.dropout(Yin.view(B * R, D), L["FE"][t].view(B * R, D), rows_t * R, D, cfg.p_region, cfg.seed, scale_off(2, t))
+            if att1_hoisted:
+                ops.linear(L["FE"].view(T * B * R, D), P["va_fa_w"], P["va_fa_b"], L["ATT1"].view(T * B * R, Adim), T * B * R)
+
         for t in range(T):
             bt = bts[t]
             emb = L["EMB"][t]
@@ -245,9 +257,9 @@ class _XESequence(torch.autograd.Function):
                                                   ws_l.data_ptr(), ws_l.numel(), st), "set_lstm_cell_pre_train_f32")
             if train:
                 fe = L["FE"][t]
-                ops.dropout(Yin.view(B * R, D), fe.view(B * R, D), bt * R, D, cfg.p_region, cfg.seed, scale_off(2, t))
                 att1 = L["ATT1"][t]
-                ops.linear(fe.view(B * R, D), P["va_fa_w"], P["va_fa_b"], att1.view(B * R, Adim), bt * R)
+                if not att1_hoisted:
+                    ops.linear(fe.view(B * R, D), P["va_fa_w"], P["va_fa_b"], att1.view(B * R, Adim), bt * R)
                 if adaptive:
                     check(lib.set_rowsum_mask_f32(fe.data_ptr(), D, bt * R, D, L["RMASK"][t].data_ptr(), st), "set_rowsum_mask_f32")
             else:
