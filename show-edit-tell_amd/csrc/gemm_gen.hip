@@ -320,22 +320,19 @@ int gemm_gen_group(const SetGemmDesc* d, int n, int a_kminor, int b_kminor, void
         T.A = p.A; T.B = p.B; T.lda = p.lda; T.ldb = p.ldb;
         T.M = p.M; T.N = p.N; T.K = p.K; T.ktiles = cdiv(p.K, GEMM_BK); T.tiles_n = cdiv(p.N, 64);
         T.accumulate = p.accumulate; T.out = p.C; T.ldo = p.ldc;
-        tiles[i] = (long long)cdiv(p.M, bm) * T.tiles_n;
-        tiles_total += tiles[i];
         if (T.ktiles > max_kt) max_kt = T.ktiles;
     }
-    // Split depth.  Cost model in units of one k-tile of one workgroup (measured, tools/bench_gen_split.py): workgroups
-    // that share a CU share its MFMA pipe, so a launch of W workgroups of `kper` k-tiles each takes about
-    // ceil(W / 256) x (kper + c0) — W just above a multiple of the CU count wastes a whole round (304 tiles of the
-    // all-timestep fc dX: 2 rounds of 297 k-tiles unsplit, 6 rounds of 60 split five ways: 607 -> 410 us) — plus, when
-    // anything is split, the reduction launch and one slab write + read per split.  c0 = prologue + epilogue.
-    const int slots = bm == 64 ? 768 : 512;
-    int kper = max_kt;                                    // = no split
     static const int plan_model = env_int("SET_GEMM_GEN_PLAN", 1);
-    if (const char* e = getenv("SET_EXP_GEN_KPER")) {      // experiment knob (tools/bench_gen_split.py)
-        kper = atoi(e) > 0 ? atoi(e) : max_kt;
-    } else if (plan_model) {
-        const double unit_us = bm == 64 ? 0.54 : 1.08, c0 = 3.0, red_fixed_us = 4.0;
+    // Split depth (and, above 512 rows, the row-tile class).  Cost model, measured with tools/bench_gen_split.py:
+    // workgroups that share a CU share its MFMA pipe, so a launch of W workgroups of `kper` k-tiles each takes about
+    // ceil(W / 256) x (kper + c0) k-tile times — W just above a multiple of the CU count wastes a whole round (304 tiles
+    // of the all-timestep fc dX: 2 rounds of 297 k-tiles unsplit, 6 rounds of 60 split five ways: 607 -> 410 us; 576
+    // 128-row tiles of the region dX: 3 rounds, as 1152 64-row tiles 5 half-sized ones: 61 -> 53 us) — plus, when
+    // anything is split, the reduction launch and one slab write + read per split.  c0 = prologue + epilogue.
+    auto plan = [&](int bm_c, int* kper_out) -> double {
+        const double unit_us = bm_c == 64 ? 0.57 : 1.08, c0 = 3.0, red_fixed_us = 4.0;
+        long long tl[GEN_MAX_TASKS];
+        for (int i = 0; i < n; ++i) tl[i] = (long long)cdiv(L.t[i].M, bm_c) * L.t[i].tiles_n;
         double best = 1e30;
         for (int kp = max_kt; kp >= 4; --kp) {
             long long wgs = 0;
@@ -345,17 +342,36 @@ int gemm_gen_group(const SetGemmDesc* d, int n, int a_kminor, int b_kminor, void
                 const int kt = L.t[i].ktiles;
                 int ks = kt < 8 ? 1 : cdiv(kt, kp);
                 if (ks > 64) ks = 64;
-                wgs += tiles[i] * ks;
+                wgs += tl[i] * ks;
                 if (cdiv(kt, ks) > deepest) deepest = cdiv(kt, ks);
                 if (ks > 1) slab_bytes += 4.0 * ks * L.t[i].M * L.t[i].N;
             }
-            const int rounds = cdiv((int)wgs, 256);
+            const long long rounds = (wgs + 255) / 256;
             // one workgroup per CU cannot hide its own load latency (measured ~1.3x per k-tile)
             double us = rounds * (deepest + c0) * unit_us * (rounds == 1 ? 1.3 : 1.0);
             // slabs are written once and read once: from the last-level cache while they fit, else HBM
             if (slab_bytes > 0.0) us += red_fixed_us + 2.0 * slab_bytes / (slab_bytes < 48e6 ? 8.0e6 : 3.0e6);
-            if (us < best * 0.98) { best = us; kper = kp; }     // deeper splits must pay for themselves
+            if (us < best * 0.98) { best = us; *kper_out = kp; }     // deeper splits must pay for themselves
         }
+        return best;
+    };
+    int kper = max_kt;                                    // = no split
+    if (plan_model && !getenv("SET_EXP_GEN_KPER")) {
+        int kp64 = max_kt, kp128 = max_kt;
+        if (bm == 128) {
+            const double us128 = plan(128, &kp128), us64 = plan(64, &kp64);
+            if (us64 < us128 * 0.97) bm = 64;
+        } else plan(64, &kp64);
+        kper = bm == 64 ? kp64 : kp128;
+    }
+    for (int i = 0; i < n; ++i) {
+        tiles[i] = (long long)cdiv(L.t[i].M, bm) * L.t[i].tiles_n;
+        tiles_total += tiles[i];
+    }
+    const int slots = bm == 64 ? 768 : 512;
+    if (const char* e = getenv("SET_EXP_GEN_KPER")) {      // experiment knob (tools/bench_gen_split.py)
+        kper = atoi(e) > 0 ? atoi(e) : max_kt;
+    } else if (plan_model) {
     } else if (tiles_total < slots * 3 / 4) {
         for (kper = 4; kper < max_kt; ++kper) {
             long long wgs = 0;
