@@ -316,6 +316,21 @@ int set_lstm_cell_train_f32(const float* x, int64_t ldx, int Kx, const float* h,
                             const float* b_hh, float* h_out, float* c_out, float* gates_out, int M, int D,
                             void* ws, size_t ws_bytes, void* stream);
 /* dgates (M,4D) = pre-activation gate gradients, dc_prev (M,D); dh / dc may be NULL (zero) */
+/* Token cross-entropy of the training loops (editnet.py:571-577, dcnet.py:391-397: pack_padded_sequence of scores and
+ * targets, CrossEntropyLoss) on the (B, T, V) scores in place: element (b, t, v) at scores[b*stride_b + t*stride_t + v],
+ * target word of (b, t) at targets[b*tstride_b + t*tstride_t].  The batch is sorted by decreasing decode length and
+ * live[t] (HOST array, T <= 64 entries, non-increasing) = number of sequences with decode length > t: row (b, t) is one
+ * of the packed rows iff b < live[t].  Forward: rowloss / lse (T*B floats each, index t*B + b; zeros for dead rows) and
+ * loss_sum (1 float) = the SUM of the token losses (divide by the token count for CrossEntropyLoss's mean).
+ * Backward: grad (T, B, ld_grad) with ld_grad = V rounded up to 4 — (softmax - onehot) * dloss[0] for live rows, zeros for
+ * dead rows and for the padding columns (so the buffer can feed set_gemm_f32 as a zero-padded k-major operand). */
+int set_xe_loss_f32(const float* scores, int64_t stride_b, int64_t stride_t, const int64_t* targets, int64_t tstride_b,
+                    int64_t tstride_t, const int* live, int B, int T, int V, float* rowloss, float* lse,
+                    float* loss_sum, void* stream);
+int set_xe_loss_bwd_f32(const float* scores, int64_t stride_b, int64_t stride_t, const int64_t* targets,
+                        int64_t tstride_b, int64_t tstride_t, const int* live, int B, int T, int V, const float* lse,
+                        const float* dloss, float* grad, int64_t ld_grad, void* stream);
+
 /* The tail of the training step — torch.nn.utils.clip_grad_norm_(params, max_norm) followed by torch.optim.Adam.step()
  * (editnet.py:580-581, dcnet.py:399-400, editnet_rl.py:684-686) — over n fp32 tensors in two launches per 40 tensors:
  * per-chunk sums of squares, then the Adam update with the clipping coefficient min(1, max_norm / (norm + 1e-6)) folded
@@ -494,8 +509,10 @@ int set_beam_gather_f32(float* s0, float* s1, float* s2, float* s3, const int32_
  *     a(m,k) = a_kminor ? A[k*lda + m] : A[m*lda + k];   b(n,k) = b_kminor ? B[k*ldb + n] : B[n*ldb + k]
  * accumulate != 0 adds into C (in-place .grad accumulation).  `ws` is scratch for split-K slabs (may be
  * NULL: the contraction is then never split).  Leading dimensions are multiples of 4 floats; a k-minor
- * operand needs its own dimension (M or N) to be a multiple of 4; a k-major one needs K % 4 == 0, or rows that
- * are zero-padded by the caller up to the next multiple of 4 (leading dimension >= round_up(K,4)). */
+ * operand needs its own dimension (M or N) to be a multiple of 4 — for A, alternatively rows that are readable up
+ * to the next multiple of 4 (lda >= round_up(M,4); output rows >= M are never stored) —; a k-major one needs
+ * K % 4 == 0, or rows that are zero-padded by the caller up to the next multiple of 4 (leading dimension >=
+ * round_up(K,4)). */
 int set_gemm_f32(const float* A, long long lda, int a_kminor, const float* B, long long ldb, int b_kminor,
                  float* C, long long ldc, int M, int N, int K, int accumulate, void* ws, size_t ws_bytes,
                  void* stream);

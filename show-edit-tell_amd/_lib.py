@@ -225,6 +225,8 @@ PROTOTYPES = {
     "set_select_bwd_acc_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "set_attention_bwd_acc_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _L, _P]),
     "set_attention_dvalues_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "set_xe_loss_f32": (_I, [_P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "set_xe_loss_bwd_f32": (_I, [_P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _P, _P, _P, _L, _P]),
     "set_clip_adam_workspace_bytes": (_Z, [_I, _P]),
     "set_clip_adam_f32": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _I, _P, _P, _Z, _P]),
     "set_colsum_workspace_bytes": (_Z, [_I]),

@@ -119,11 +119,73 @@ def _native_ok(*ts):
     return all(t.is_cuda and t.dtype == torch.float32 for t in ts)
 
 
+# Buffers whose rows are ALREADY padded with zeros to a multiple of 4 floats (the score gradient written by
+# set_xe_loss_bwd_f32): storage data pointer -> weak reference of the owning tensor.  A 2-D view (M, N) of such a buffer
+# with row stride N4 is read by the contractions in place, as its (M, N4) form.
+import weakref as _weakref
+
+_zero_padded = {}
+
+
+def register_zero_padded(buf):
+    for k in [k for k, r in _zero_padded.items() if r() is None]:
+        del _zero_padded[k]
+    _zero_padded[buf.untyped_storage().data_ptr()] = _weakref.ref(buf)
+
+
+def _padded_view(t):
+    """the (M, N4) form of a 2-D view (M, N) of a registered zero-padded buffer, or None"""
+    if t.dim() != 2 or not (t.shape[1] & 3):
+        return None
+    ref = _zero_padded.get(t.untyped_storage().data_ptr())
+    if ref is None or ref() is None:
+        return None
+    n4 = (t.shape[1] + 3) & ~3
+    if t.stride(1) != 1 or t.stride(0) != n4 or t.data_ptr() % 16 or t.dtype != torch.float32:
+        return None
+    return t.as_strided((t.shape[0], n4), (n4, 1), t.storage_offset())
+
+
+def zero_padded_rows(T, B, V, device):
+    """a (T, B, V) fp32 view whose rows are padded with zeros to a multiple of 4 floats (registered: the contractions
+    read its 2-D forms in place); the V columns are NOT initialised"""
+    n4 = (V + 3) & ~3
+    buf = torch.empty(T, B, n4, dtype=torch.float32, device=device)
+    if n4 != V:
+        buf[:, :, V:].zero_()
+    register_zero_padded(buf)
+    return buf[:, :, :V]
+
+
+def score_grad_rows(dpred, bts, uniform):
+    """the (B, T, V) gradient of a node's scores -> its (T*B, V) rows in (t, b) order with the rows of finished sequences
+    zeroed.  A gradient that already lives in a zero-padded (T, B, V4) buffer (set_xe_loss_bwd_f32) is used where it lies;
+    anything else is brought into (T, B, V) order with one copy."""
+    B, T, V = dpred.shape
+    dp = dpred.transpose(0, 1)
+    n4 = (V + 3) & ~3
+    ref = _zero_padded.get(dp.untyped_storage().data_ptr())
+    if (V & 3) and ref is not None and ref() is not None and dp.stride() == (B * n4, n4, 1) and dp.data_ptr() % 16 == 0:
+        rows = dp.as_strided((T * B, V), (n4, 1), dp.storage_offset())
+    else:
+        dp = dp if (dp.is_contiguous() and uniform) else dp.contiguous()
+        rows = dp.view(T * B, V)
+    if not uniform:
+        for t in range(T):
+            if bts[t] < B:
+                rows[t * B + bts[t]:(t + 1) * B].zero_()
+    return rows
+
+
 def _pad_cols4(t):
-    """(M, N) -> (M, N4) zero-padded copy with N4 = N rounded up to 4 (only for feature counts that are not a multiple
-    of 4, e.g. a vocabulary of 9490 words): the kernel reads 16-byte chunks along its unit-stride dimension."""
+    """(M, N) -> (M, N4) zero-padded form with N4 = N rounded up to 4 (only for feature counts that are not a multiple
+    of 4, e.g. a vocabulary of 9490 words): the kernel reads 16-byte chunks along its unit-stride dimension.  A copy,
+    unless `t` already lives in a zero-padded buffer."""
     pad = (-t.shape[1]) % 4
-    return t if pad == 0 else torch.nn.functional.pad(t, (0, pad))
+    if pad == 0:
+        return t
+    v = _padded_view(t)
+    return v if v is not None else torch.nn.functional.pad(t, (0, pad))
 
 
 def _dgrad(dy, w, out=None):
@@ -144,6 +206,10 @@ def _wgrad_mm(dy, x, out=None):
     K = x.shape[1]
     if (K & 3) or K < 4:
         raise _lib.SetError("dW = dY^T.X needs an input feature count that is a multiple of 4 (got %d)" % K)
+    if (N & 3) and N >= 4 and (out is None or out.is_contiguous()):
+        dyp = _padded_view(dy)
+        if dyp is not None:    # rows readable up to N4: the kernel reads them in place and never stores rows >= N
+            return gemm(dyp, True, x, True, N, K, M, out=out, accumulate=out is not None)
     if (N & 3) or N < 4 or (out is not None and not out.is_contiguous()):
         # ragged output-feature count (e.g. V = 9490 rows of fc.weight): contract into a padded buffer, keep N rows
         dyp = _pad_cols4(dy)
@@ -295,6 +361,9 @@ def _wgrad(param, dy, x, eager=False):
 
 def _colsum(dy, out=None):
     """sum over the rows of a 2-D fp32 matrix on the library's two-pass kernel (set_colsum_f32); out (+)= when given"""
+    if dy.is_cuda and dy.dim() == 2 and dy.shape[1] % 4 and dy.shape[0] >= 64 and _padded_view(dy) is not None:
+        g = _colsum(_padded_view(dy))[:dy.shape[1]]          # zero-padded rows: sum the padded form, drop the padding
+        return g.clone() if out is None else out.add_(g.reshape(out.shape))
     if not (dy.is_cuda and dy.dtype == torch.float32 and dy.dim() == 2 and dy.shape[1] % 4 == 0 and dy.shape[0] >= 64):
         g = dy.sum(0)
         return g if out is None else out.add_(g.reshape(out.shape))

@@ -79,7 +79,8 @@ __global__ void __launch_bounds__(256) gemm_gen_f32(const GenLaunch L) {
             ka[i] = scol; sa[i] = (srow + 32 * i) * 32 + sswz;
         } else {
             const int f = tid + 256 * i, kr = f / (BM / 4), c4 = (f % (BM / 4)) * 4;
-            int c = m0 + c4; c = c + 4 <= T.M ? c : T.M - 4;
+            const int Mr = (T.M + 3) & ~3;       // a ragged M is accepted when the rows are readable up to Mr (host check)
+            int c = m0 + c4; c = c + 4 <= Mr ? c : Mr - 4;
             pa[i] = T.A + (long long)kr * T.lda + c;
             ka[i] = kr; sa[i] = kr * BM + c4;
         }
@@ -311,7 +312,9 @@ int gemm_gen_group(const SetGemmDesc* d, int n, int a_kminor, int b_kminor, void
             const long long K4 = ((long long)p.K + 3) & ~3LL;
             if ((!a_kminor && p.lda < K4) || (!b_kminor && p.ldb < K4)) return SET_ERR_UNSUPPORTED;
         }
-        if (a_kminor && ((p.M & 3) || p.M < 4)) return SET_ERR_UNSUPPORTED;
+        // a k-minor A is read in float4 along M: a ragged M (e.g. the 9490 rows of d fc.weight = dY^T X) is accepted when
+        // A's rows are readable up to the next multiple of 4 (lda >= round_up(M, 4)); output rows >= M are never stored
+        if (a_kminor && (p.M < 4 || ((p.M & 3) && p.lda < (((long long)p.M + 3) & ~3LL)))) return SET_ERR_UNSUPPORTED;
         if (b_kminor && ((p.N & 3) || p.N < 4)) return SET_ERR_UNSUPPORTED;
         const int b = p.M <= bm64_upto ? 64 : 128;
         if (bm && b != bm) return SET_ERR_ARG;

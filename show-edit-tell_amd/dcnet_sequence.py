@@ -143,19 +143,15 @@ class _DcnetSequence(torch.autograd.Function):
         g = [None] * len(PARAM_NAMES)
         if cfg.rollout is not None:
             dl = dlogp.t().contiguous()
-            dp = _e(T, B, V, dev=dev)
+            dp = A.zero_padded_rows(T, B, V, dev)          # rows padded to 16 bytes: the fc contractions read them in place
             for t in range(T):
                 check(lib.set_sample_logp_bwd_f32(L["LOGITS"][t].data_ptr(), V, L["LSE"][t].data_ptr(), L["RAW"][t].data_ptr(),
-                                                  dl[t].data_ptr(), dp[t].data_ptr(), V, B, V, st), "set_sample_logp_bwd_f32")
+                                                  dl[t].data_ptr(), dp[t].data_ptr(), dp.stride(1), B, V, st),
+                      "set_sample_logp_bwd_f32")
             L["LOGITS"] = None
+            dp2 = dp.as_strided((T * B, V), (dp.stride(1), 1), dp.storage_offset())
         else:
-            dp = dpred.transpose(0, 1)
-            dp = dp if (dp.is_contiguous() and ctx.uniform) else dp.contiguous()
-            if not ctx.uniform:
-                for t in range(T):
-                    if bts[t] < B:
-                        dp[t, bts[t]:].zero_()
-        dp2 = dp.view(T * B, V)
+            dp2 = A.score_grad_rows(dpred, bts, ctx.uniform)
         dH2D = A._dgrad(dp2, P["fc_w"]).view(T, B, D)
         need_p = ctx.needs_input_grad[6:]
         if need_p[pidx["fc_b"]]:

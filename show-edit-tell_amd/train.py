@@ -15,6 +15,7 @@ import torch
 import torch.nn.functional as F
 from torch.nn.utils.rnn import pack_padded_sequence
 
+from . import loss as _loss
 from .optim import clip_grad_norm_and_step
 
 GRAD_CLIP = 0.25                     # editnet.py:580
@@ -22,8 +23,11 @@ BUCKET_BYTES = 64 << 20              # xGMI rings are per-link bound: few, large
 
 
 def xe_loss_sum(scores, caps_sorted, decode_lengths):
-    """Summed token cross-entropy over the packed rows + token count (editnet.py:571-577)."""
+    """Summed token cross-entropy over the packed rows + token count (editnet.py:571-577).  Returns (loss sum, token
+    count, packed scores, packed targets); the packed tensors are None when the loss ran on the library's kernels."""
     targets = caps_sorted[:, 1:]
+    if _loss.fusable(scores, targets, decode_lengths):       # device scores: the library's loss kernels, nothing is packed
+        return _loss.xe_loss_sum(scores, targets, decode_lengths), int(sum(int(l) for l in decode_lengths)), None, None
     sc = pack_padded_sequence(scores, decode_lengths, batch_first=True).data
     tg = pack_padded_sequence(targets, decode_lengths, batch_first=True).data
     return F.cross_entropy(sc, tg, reduction="sum"), sc.shape[0], sc, tg

@@ -339,22 +339,17 @@ class _XESequence(torch.autograd.Function):
         # ---- d scores as (T, B, V), rows of finished sequences zero
         if cfg.rollout is not None:        # d seq_logp -> d scores of every step (sampling epilogue backward)
             dl = dlogp.t().contiguous()                            # (T, B)
-            dp = _e(T, B, V, dev=dev)
+            dp = A.zero_padded_rows(T, B, V, dev)          # rows padded to 16 bytes: the fc contractions read them in place
             for t in range(T):
                 check(lib.set_sample_logp_bwd_f32(L["LOGITS"][t].data_ptr(), V, L["LSE"][t].data_ptr(), L["RAW"][t].data_ptr(),
-                                                  dl[t].data_ptr(), dp[t].data_ptr(), V, B, V, st), "set_sample_logp_bwd_f32")
+                                                  dl[t].data_ptr(), dp[t].data_ptr(), dp.stride(1), B, V, st),
+                      "set_sample_logp_bwd_f32")
             L["LOGITS"] = None
-        elif ctx.uniform:                  # the (B, T, V) gradient of a (T, B, V) buffer's view: usually already contiguous
-            dp = dpred.transpose(0, 1)
-            dp = dp if dp.is_contiguous() else dp.contiguous()
-        else:
-            dp = dpred.transpose(0, 1).contiguous()
-            for t in range(T):
-                if bts[t] < B:
-                    dp[t, bts[t]:].zero_()
+            dp2 = dp.as_strided((T * B, V), (dp.stride(1), 1), dp.storage_offset())
+        else:                              # the (B, T, V) gradient of the scores, as (t, b) rows
+            dp2 = A.score_grad_rows(dpred, bts, ctx.uniform)
         # ---- fc: dH2D for all timesteps in one contraction; fc.weight's gradient is final here (eager: its all-reduce
         # runs underneath the loop below in the data-parallel step)
-        dp2 = dp.view(T * B, V)
         dH2D = A._dgrad(dp2, P["fc_w"]).view(T, B, D)
         i_w, i_b = PARAM_NAMES.index("fc_w"), PARAM_NAMES.index("fc_b")
         g_fc_b = A._bgrad(params[i_b], dp2) if need_p[i_b] else None
