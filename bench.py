@@ -452,7 +452,7 @@ def train_leg(args, dec, wm, X, caps, clen, prev, plen, dev, dist, rank, world, 
     xe = editnet.DecoderC(wm, D, D, D, A, F)
     xe.load_state_dict(dec.state_dict())
     xe = xe.to(dev)
-    opt = torch.optim.Adam(xe.parameters(), lr=5e-4, fused=True)         # editnet.py:749 (torch's single-kernel Adam)
+    opt = torch.optim.Adam(xe.parameters(), lr=5e-4)         # editnet.py:749; clip + step run on set_clip_adam_f32 (optim.py)
     K = max(2, args.train_steps)
 
     windows = []

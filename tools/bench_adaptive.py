@@ -26,7 +26,7 @@ def tm(fn, n=10, w=3):
 dec.eval()
 with torch.no_grad():
     t_fwd = tm(lambda: dec(X, mean, caps, clen, prev, plen, False, 0.0))
-opt = torch.optim.Adam(dec.parameters(), lr=5e-4, fused=True)
+opt = torch.optim.Adam(dec.parameters(), lr=5e-4)
 def train_step():
     dec.train(); opt.zero_grad()
     pred, caps_s, dl, _, gd_fh, last_h = dec(X, mean, caps, clen, prev, plen, False, 0.0)

@@ -29,7 +29,7 @@ def main():
     sd = synth.editnet_state(14, V, D, A, F, emb_scale=3.0, fc_scale=8.0, gain=3.0)
     sd["caption_encoder.embed.embedding.weight"] = sd["embed.embedding.weight"]
     dec.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}); dec = dec.to(dev)
-    opt = torch.optim.Adam(dec.parameters(), lr=5e-5, fused=True)
+    opt = torch.optim.Adam(dec.parameters(), lr=5e-5)
     seed = 41 + rank
     X = torch.from_numpy(synth.features(seed, B, R, F)).to(dev)
     prev, plen = (torch.from_numpy(x).to(dev) for x in synth.prev_captions(seed, B, T, V, 5))

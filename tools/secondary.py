@@ -52,7 +52,7 @@ def scst(dev, batch=64, samples=5, steps=3):
     from show_edit_tell_amd.train import scst_train_step
     wm = synth.word_map(V)
     dec = _editnet(editnet_rl.DecoderC, dev, wm)
-    opt = torch.optim.Adam(dec.parameters(), lr=5e-5, fused=True)
+    opt = torch.optim.Adam(dec.parameters(), lr=5e-5)
     X = torch.from_numpy(synth.features(41, batch, R, F)).to(dev)
     prev, plen = (torch.from_numpy(x).to(dev) for x in synth.prev_captions(41, batch, T, V, 5))
     rng = np.random.default_rng(41)
@@ -87,7 +87,7 @@ def adaptive(dev, batch=64, regions=100):
     dec.eval()
     with torch.no_grad():
         t_fwd, _ = _timed(lambda: dec(X, mean, caps, clen, prev, plen, False, 0.0), 8, 3)
-    opt = torch.optim.Adam(dec.parameters(), lr=5e-4, fused=True)
+    opt = torch.optim.Adam(dec.parameters(), lr=5e-4)
 
     def train_step():
         dec.train()
@@ -130,7 +130,7 @@ def dcnet_train(dev, batch=128):
     from show_edit_tell_amd.train import dcnet_xe_train_step
     wm = synth.word_map(V)
     dae = _dcnet(dc.DAE, dev, wm)
-    opt = torch.optim.Adam(dae.parameters(), lr=5e-4, fused=True)
+    opt = torch.optim.Adam(dae.parameters(), lr=5e-4)
     prev, plen = (torch.from_numpy(x).to(dev) for x in synth.prev_captions(7, batch, T, V, 5))
     caps, clen = (torch.from_numpy(x).to(dev) for x in synth.captions(7, batch, V, 20, 20))
     t, _ = _timed(lambda: dcnet_xe_train_step(dae, opt, caps, clen, prev, plen), 5, 3)

@@ -69,7 +69,7 @@ B = 128
 X = torch.from_numpy(synth.features(3, B, 36, 2048)).to(dev)
 prev, plen = (torch.from_numpy(x).to(dev) for x in synth.prev_captions(3, B, 20, 10000, 5))
 caps, clen = (torch.from_numpy(x).to(dev) for x in synth.captions(3, B, 10000, 20, 20))
-opt = torch.optim.Adam(m.parameters(), lr=5e-4, fused=True)
+opt = torch.optim.Adam(m.parameters(), lr=5e-4)
 for seq in (False, True):
     editnet._XE_SEQUENCE = seq
     m.train()
