@@ -66,11 +66,21 @@ def scst(dev, batch=64, samples=5, steps=3):
     gt = ciderd.ground_truth_lists(allcaps, wm)
     df, docs = ciderd.document_frequency([[ciderd.tokens_to_str(c) for c in caps] for caps in gt])
     scorer = ciderd.CiderD(df, docs)
-    t, _ = _timed(lambda: scst_train_step(dec, opt, wm, X, prev, plen, gt, scorer, n_samples=samples), steps, 1)
+    # the step contains host work (rewards) and a host sync: time every step on its own, report the median
+    step = lambda: scst_train_step(dec, opt, wm, X, prev, plen, gt, scorer, n_samples=samples)
+    step()
+    times = []
+    for _ in range(max(steps, 5)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times))
     return {"workload": "SCST step (editnet_rl.py:649-686): B=%d, %d sampled rollouts per image + greedy baseline + CIDEr-D "
                         "reward + backward + clip + Adam" % (batch, samples),
-            "ms_per_step": round(1e3 * t, 2), "decode_steps_per_sec": round(19 * (samples + 1) / t, 1),
-            "native_ciderd": bool(scorer._native)}
+            "ms_per_step": round(1e3 * t, 2), "steps_ms": [round(1e3 * x, 1) for x in times],
+            "decode_steps_per_sec": round(19 * (samples + 1) / t, 1), "native_ciderd": bool(scorer._native)}
 
 
 def adaptive(dev, batch=64, regions=100):
