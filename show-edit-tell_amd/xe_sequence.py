@@ -120,6 +120,9 @@ class _Ops:
                                       M, N, K, _lib.ACT_NONE, ws.data_ptr(), ws.numel(), self.st), "set_linear_f32")
 
 
+_ATT1_HOIST_LIVE = 0.75     # all-timestep region projection when at least this fraction of the (t, b) rows is live
+
+
 def _dvalues(alpha, dctx, ops):
     """dH (B, Tc, D) = sum_t alpha[t, b, :] (outer) dctx[t, b, :] over the per-sequence logs (rows of finished sequences are
     zero in both), one launch"""
@@ -225,7 +228,7 @@ class _XESequence(torch.autograd.Function):
         # recurrent state, so all T region projections run as ONE (T*B*R, D) x (D, A) product before the loop (19 products of
         # B*R = 4608 rows each leave the chip 1.1 rounds of tiles; 87552 rows fill it).  Ragged batches with many finished
         # rows keep the per-step products over the live rows only.
-        att1_hoisted = train and sum(bts) * 4 >= 3 * T * B
+        att1_hoisted = train and sum(bts) >= _ATT1_HOIST_LIVE * T * B
         if train:
             for t in range(T):
                 rows_t = B if att1_hoisted else bts[t]

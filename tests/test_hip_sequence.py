@@ -398,3 +398,28 @@ def test_fused_embedding_dropout_equals_two_kernels():
                "set_dropout_f32")
     assert torch.equal(a, b) and float(a[:, :D].abs().max()) == 0.0
     assert 0.15 < float((a[:, D:] != 0).float().mean()) < 0.35          # relu keeps ~half, dropout half of that
+
+
+@pytest.mark.parametrize("min_len", [5, 20])
+def test_all_timestep_region_projection_equals_per_step(min_len, monkeypatch):
+    """train mode: att1(t) = features_att(dropout_t(.)) contracted for all timesteps at once before the loop, or per
+    timestep over the live rows only — same Philox masks, same scores, same gradients (ragged and uniform batches)"""
+    from show_edit_tell_amd import editnet, xe_sequence
+    from show_edit_tell_amd.train import xe_loss_sum
+    monkeypatch.setattr(editnet, "_XE_SEQUENCE", True)
+    m = _build(203, 64, 32, 256).train()
+    X, caps, clen, prev, plen = _inputs(8, 36, 256, 20, 203, min_len)
+    res = []
+    for live in (0.0, 2.0):                          # always hoisted / never hoisted
+        monkeypatch.setattr(xe_sequence, "_ATT1_HOIST_LIVE", live)
+        m.zero_grad(set_to_none=True)
+        torch.manual_seed(17)
+        pred, caps_s, dl, _ = m(X, caps, clen, prev, plen, False, 0.0)
+        ls, n, _, _ = xe_loss_sum(pred, caps_s, dl)
+        (ls / n).backward()
+        res.append((pred.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}))
+    (p0, g0), (p1, g1) = res
+    assert float((p0 - p1).abs().max()) <= 2e-5 * max(1.0, float(p0.abs().max()))
+    gmax = max(float(g.abs().max()) for g in g0.values())
+    for k in g0:
+        assert float((g0[k] - g1[k]).abs().max()) <= 1e-4 * max(float(g0[k].abs().max()), 1e-3 * gmax), k
