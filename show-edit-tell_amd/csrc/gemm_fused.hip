@@ -119,7 +119,11 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
 
+#ifdef SET_EXP_ENC_NOK
+    const int nkt = (EPI == EPI_ENCLSTM) ? SET_EXP_ENC_NOK : P.K / BK;     // diagnostic: truncated contraction
+#else
     const int nkt = P.K / BK;
+#endif
     const int frow = lane & 31, fk = (lane >> 5) * 4;
     FS_GLOAD(ra0, rw0);                                  // tile 0
     if (nkt > 1) FS_GLOAD(ra1, rw1);                     // tile 1

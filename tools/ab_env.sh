@@ -9,7 +9,7 @@ import json, sys
 d = json.load(open("gpurun_out/ab.json"))
 k = d["kernels"]
 sel = {n: round(1e3 * k[n]["ms_per_step"] / max(k[n]["launches_per_step"], 1), 2) for n in k if any(x in n for x in ("attention", "copy_gate", "encoder", "pointwise", "pick", "gemm_nt_f32"))}
-print("[%s] value %.0f  single %.0f  frac %s us/launch %s" % (sys.argv[1], d["value"], d["single_stream_decode_steps_per_sec"], d.get("roofline", {}).get("frac"), sel))
+print("[%s] value %.0f  single %.0f  frac %s us/launch %s" % (sys.argv[1], d["value"], (d.get("single_stream_decode_steps_per_sec") or d["value"]), d.get("roofline", {}).get("frac"), sel))
 PY
 done
 done
