@@ -381,7 +381,10 @@ class _XESequence(torch.autograd.Function):
         dcm, dcn, dop = (_e(B, D, dev=dev) for _ in range(3))
         dgated, daimg = _e(B, D, dev=dev), _e(B, F, dev=dev)
         demb, dalc = _e(B, D, dev=dev), _e(B, Tc, dev=dev)
-        dfe = _e(B * R, D, dev=dev) if train else None
+        # d(region embedding) = datt1 . W_fa does not feed the recurrence: with (nearly) full batches it is contracted for all
+        # timesteps at once after the loop (87552 rows fill the chip; 4608-row products leave it 2.25 rounds of tiles)
+        dfe_after = train and sum(bts) >= _ATT1_HOIST_LIVE * T * B
+        dfe = _e(B * R, D, dev=dev) if (train and not dfe_after) else None
         gate_w, tc_w, x2h_w, wih = P["ca_gate_w"], P["ca_tc_w"], P["cl_x2h_w"], P["al_wih"]
         w_ctx = torch.cat([P["ca_sc_w"], gate_w[:, 2 * D:]], 0)        # (2D, D) against [ds | dz]
         w_word = torch.cat([gate_w[:, :D], tc_w[:, :D]], 0)            # (2D, D) against [dz | dt]
@@ -433,7 +436,7 @@ class _XESequence(torch.autograd.Function):
                                                 L["ATT2V"][t].data_ptr(), va_full.data_ptr(), datt1.data_ptr(), DATT2[t].data_ptr(),
                                                 DWFV[t].data_ptr(), None, DEV[t].data_ptr(), bt, R, F, Adim, 0,
                                                 0 if train else 1, 0, 2 * Adim, st), "set_attention_bwd_acc_f32")
-            if train:
+            if train and not dfe_after:
                 A.gemm(datt1.view(B * R, Adim)[:bt * R], False, P["va_fa_w"], True, bt * R, D, Adim, out=dfe[:bt * R])
                 ops.dropout_bwd(dfe, L["FE"][t].view(B * R, D), dYin.view(B * R, D), bt * R, D, sc_reg, True)
             # ---- CaptionAttentionC backward
@@ -462,6 +465,11 @@ class _XESequence(torch.autograd.Function):
 
         # dH[b, l, :] = sum_t alpha_c[t, b, l] dctx[t, b, :]: one batched (Tc x T)(T x D) product per sample over the logs
         # instead of a read-modify-write of all of dH in every timestep
+        if dfe_after:                      # rows of finished sequences are zero in DATT1, hence in DFE
+            DFE = A.gemm(DATT1.view(T * B * R, Adim), False, P["va_fa_w"], True, T * B * R, D, Adim).view(T, B * R, D)
+            for t in range(T):
+                ops.dropout_bwd(DFE[t], L["FE"][t].view(B * R, D), dYin.view(B * R, D), bts[t] * R, D, sc_reg, True)
+            del DFE
         dH = _dvalues(L["ALPHAC"], DCTX, ops)
         # loop-invariant inputs of the attention LSTM: d final_hidden = (sum_t dgates) . W_ih[:, D:2D]
         sdg1 = DG1.sum(0)
