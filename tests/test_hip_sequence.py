@@ -423,3 +423,24 @@ def test_all_timestep_region_projection_equals_per_step(min_len, monkeypatch):
     gmax = max(float(g.abs().max()) for g in g0.values())
     for k in g0:
         assert float((g0[k] - g1[k]).abs().max()) <= 1e-4 * max(float(g0[k].abs().max()), 1e-3 * gmax), k
+
+
+def test_column_block_weight_gradient():
+    """dW assembled from column blocks with different contraction lengths (per-timestep input over T*B rows, loop-invariant
+    input over B rows against sum_t dY): written into .grad in place (first call creates it, second accumulates), returned
+    for non-leaf tensors"""
+    from show_edit_tell_amd import autograd_ops as A
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    T, B, N = 5, 8, 64
+    dy = torch.randn(T * B, N, generator=g).to(dev)
+    sdy = dy.view(T, B, N).sum(0)
+    x0, x1, x2 = (torch.randn(r, k, generator=g).to(dev) for r, k in ((T * B, 32), (B, 16), (T * B, 24)))
+    ref = torch.cat([dy.t() @ x0, sdy.t() @ x1, dy.t() @ x2], 1)
+    blocks = [(dy, x0, 0), (sdy, x1, 32), (dy, x2, 48)]
+    w = torch.nn.Parameter(torch.zeros(N, 72, device=dev))
+    assert A._wgrad_blocks(w, blocks) is None and torch.allclose(w.grad, ref, rtol=1e-4, atol=1e-5)
+    A._wgrad_blocks(w, blocks)
+    assert torch.allclose(w.grad, 2 * ref, rtol=1e-4, atol=1e-5)
+    out = A._wgrad_blocks(torch.zeros(N, 72, device=dev), blocks)          # not a leaf parameter: returned
+    assert torch.allclose(out, ref, rtol=1e-4, atol=1e-5)
