@@ -562,6 +562,12 @@ int set_encoder_cell_train_f32(const float* xg, int64_t ld_xg_row, int64_t ld_xg
         return SET_ERR_UNSUPPORTED;
     if (!ws || !aligned16(ws) || ws_bytes < set_encoder_cell_workspace_bytes(B, D) - 256) return SET_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    // one launch: the contraction with the cell update as its epilogue (the decode path's encoder kernel, keeping what
+    // the backward needs), when the hidden size allows its 128-wide k-tiles; else split-K slabs + the pointwise kernel
+    static const int fused = env_int("SET_ENC_TRAIN_FUSED", 1);
+    if (fused && D % 128 == 0 && h_out != h && c_out != c)
+        return fused_encoder_step_train(h, c, h_out, c_out, w_hh, xg, ld_xg_row, ld_xg_t, b_hh, lens, t, H, Mem, Hprev, ld_out_b,
+                                        ld_out_t, out_col0, gates, B, D, st);
     GemmProb p = slab_prob((float*)ws, B, 4 * D, B);
     p.add(h, D, w_hh, D, D);
     plan_ksplit(&p, 1, gemm_target_wgs());

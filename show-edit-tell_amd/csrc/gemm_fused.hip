@@ -42,6 +42,10 @@ struct FusedArgs {
     // tiles whose rows have all finished (sorted position >= nactive[t]) skip the contraction (the reference shrinks
     // its length-sorted batch prefix the same way, editnet.py:333-335)
     const int* perm; const int* nactive;
+    // ENCLSTM in a grad-enabled forward (gates != nullptr): the cell state is read from c_in and written to o1 (the
+    // backward needs both), the post-activation gates (i, f, g, o) go to gates[b, q*N + unit], the incoming h to hprev
+    // (same indexing as H), and finished rows store zeros to H / Mem / gates and carry h and c
+    const float* c_in; float* gates; float* hprev;
 };
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
@@ -171,8 +175,8 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
                     eg[q] = xr[q * P.N + unit];
                     if (P.b0) eg[q] += P.b0[q * P.N + unit];
                 }
-                ecp = P.o1[em * P.N + unit];
             }
+            if (P.t < elen || P.gates) ecp = (P.gates ? P.c_in : P.o1)[em * P.N + unit];
         }
     }
 
@@ -239,15 +243,29 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
                 float g[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) g[q] = rsum(0, erow, q * 8 + eu) + eg[q];
-                const float cn = sigm(g[1]) * ecp + sigm(g[0]) * tanhf(g[2]);
-                const float hn = sigm(g[3]) * tanhf(cn);
+                const float ai = sigm(g[0]), af = sigm(g[1]), ag = tanhf(g[2]), ao = sigm(g[3]);
+                const float cn = af * ecp + ai * ag;
+                const float hn = ao * tanhf(cn);
                 P.o1[em * D + unit] = cn;
                 P.o0[em * D + unit] = hn;
                 P.o2[em * P.ld_out_b + (long long)epos * P.ld_out_t + P.out_col0 + unit] = hn;
                 if (P.o3) P.o3[em * P.ld_out_b + (long long)epos * P.ld_out_t + P.out_col0 + unit] = cn;
+                if (P.gates) {
+                    float* gr = P.gates + em * 4 * D + unit;
+                    gr[0] = ai; gr[D] = af; gr[2 * D] = ag; gr[3 * D] = ao;
+                }
             } else {
                 P.o0[em * D + unit] = ehin;                  // finished rows carry their state
+                if (P.gates) {                               // grad-enabled forward: position t of a finished row
+                    const long long o = em * P.ld_out_b + (long long)P.t * P.ld_out_t + P.out_col0 + unit;
+                    P.o1[em * D + unit] = ecp;
+                    P.o2[o] = 0.f;
+                    if (P.o3) P.o3[o] = 0.f;
+                    float* gr = P.gates + em * 4 * D + unit;
+                    gr[0] = 0.f; gr[D] = 0.f; gr[2 * D] = 0.f; gr[3 * D] = 0.f;
+                }
             }
+            if (P.hprev) P.hprev[em * P.ld_out_b + (long long)P.t * P.ld_out_t + P.out_col0 + unit] = ehin;
         }
         return;
     }
@@ -388,6 +406,25 @@ int fused_encoder_step(const float* h_in, float* h_out, float* c, const float* w
     P.perm = perm; P.nactive = nactive;
     const int grid = cdiv(B, 32) * cdiv(D, 8);
     ProfScope ps("fused_encoder_step", s, 8.0 * B * D * D, 4.0 * (4.0 * D * D + 8.0 * B * D));
+    return launch_fused<1, true, 128, EPI_ENCLSTM>(P, grid, s);
+}
+
+// the same step inside a grad-enabled forward (position = t for every row, no token table, no row ordering): c is not
+// updated in place, gates / previous h are kept for the backward, finished rows are written as zeros
+int fused_encoder_step_train(const float* h_in, const float* c_in, float* h_out, float* c_out, const float* w_hh,
+                             const float* xg, long long ld_xg_row, long long ld_xg_t, const float* b_hh, const int64_t* lens,
+                             int t, float* H, float* Mem, float* Hprev, long long ld_out_b, long long ld_out_t, int out_col0,
+                             float* gates, int B, int D, hipStream_t s) {
+    if (D % 128) return SET_ERR_UNSUPPORTED;
+    FusedArgs P{};
+    P.A[0] = h_in; P.lda[0] = D; P.W[0] = w_hh; P.ldw[0] = D;
+    P.K = D; P.M = B; P.N = D; P.gate_stride = D;
+    P.b0 = b_hh; P.e0 = xg; P.e1 = h_in; P.o0 = h_out; P.o1 = c_out; P.o2 = H; P.o3 = Mem; P.lens = lens;
+    P.ld_xg_row = ld_xg_row; P.ld_xg_t = ld_xg_t; P.ld_out_b = ld_out_b; P.ld_out_t = ld_out_t;
+    P.t = t; P.reverse = 0; P.out_col0 = out_col0; P.seq = nullptr; P.seq_T = 0; P.seq_V = 1;
+    P.c_in = c_in; P.gates = gates; P.hprev = Hprev;
+    const int grid = cdiv(B, 32) * cdiv(D, 8);
+    ProfScope ps("fused_encoder_step(train)", s, 8.0 * B * D * D, 4.0 * (4.0 * D * D + 16.0 * B * D));
     return launch_fused<1, true, 128, EPI_ENCLSTM>(P, grid, s);
 }
 

@@ -180,6 +180,10 @@ int fused_context_gate(const float* ctx, const float* w_gate_ctx, long long ld_g
                        hipStream_t s, RowGather gz = RowGather(), RowGather gtc = RowGather());
 int fused_copy_gate(const float* c_new, const float* sel, const float* ogate, const float* w_cnew, const float* w_cmem,
                     const float* b_cnew, const float* b_cmem, float* c_out, float* h_out, int M, int D, hipStream_t s);
+int fused_encoder_step_train(const float* h_in, const float* c_in, float* h_out, float* c_out, const float* w_hh,
+                             const float* xg, long long ld_xg_row, long long ld_xg_t, const float* b_hh, const int64_t* lens,
+                             int t, float* H, float* Mem, float* Hprev, long long ld_out_b, long long ld_out_t, int out_col0,
+                             float* gates, int B, int D, hipStream_t s);
 int fused_copy_gate_pre(const float* c_new, const float* sel, const float* cmem_pre, const float* ogate,
                         const float* w_cnew, const float* b_cnew, const float* b_cmem, float* c_out, float* h_out, int M,
                         int D, hipStream_t s);
