@@ -588,7 +588,28 @@ int gemm_tile_m(int M) {
 static int gemm_kgroups() { static int v = env_int("SET_GEMM_KGROUPS", 1); return v; }
 static int gemm_bn128() { static int v = env_int("SET_GEMM_BN128", 0); return v; }
 static int tile_m_of(const GemmProb& p) { return (p.bm_hint == 64 || p.bm_hint == 128) ? p.bm_hint : gemm_tile_m(p.M); }
-static int tile_n_of(const GemmProb& p) { const int bm = tile_m_of(p); return (bm == 32 || (bm == 128 && gemm_bn128())) ? 128 : 64; }
+// Row-tile class of one launch.  Up to 512 rows: from M (above).  Beyond: 128x64 tiles unless 64x64 tiles leave the CUs a
+// more even load — a launch takes about ceil(workgroups / 256 CUs) rounds of one tile's k-loop, and a 64-row tile's k-loop
+// is half as long: att_embed (4608 x 1024: 576 tiles = 3 rounds, as 1152 half-size tiles 5) 203 -> 170 us, features_att
+// (288 tiles = 2 rounds, as 576: 3 half rounds) 75 -> 56 us; the large products of the training step (fc over all
+// timesteps, the all-timestep region projection: >= 11 rounds either way) stay on 128x64.
+static int launch_tile_m(const GemmProb* probs, int n) {
+    const int bm = tile_m_of(probs[0]);
+    static const int model = env_int("SET_GEMM_TILE_MODEL", 1);
+    if (!model || probs[0].bm_hint || bm != 128 || gemm_split_mode() || gemm_bn128()) return bm;
+    long long t128 = 0, t64 = 0;
+    for (int i = 0; i < n; ++i) {
+        if (gemm_tile_m(probs[i].M) != 128) return bm;
+        t128 += (long long)cdiv(probs[i].M, 128) * cdiv(probs[i].N, 64);
+        t64 += (long long)cdiv(probs[i].M, 64) * cdiv(probs[i].N, 64);
+    }
+    const double c128 = (double)((t128 + 255) / 256) * 1.08, c64 = (double)((t64 + 255) / 256) * 0.57;
+    return c64 < 0.97 * c128 ? 64 : 128;
+}
+static int launch_tile_n(const GemmProb* probs, int n) {
+    const int bm = launch_tile_m(probs, n);
+    return (bm == 32 || (bm == 128 && gemm_bn128())) ? 128 : 64;
+}
 
 // Split-K plan for one grouped launch: every workgroup should run about the same number of k-tiles
 // (`kper`) and the whole launch should fit the chip in ONE round: 256 CUs x 2 resident workgroups =
@@ -599,12 +620,13 @@ void plan_ksplit(GemmProb* probs, int n, int cap_wgs) {
     // the cap is given for 128-row tiles (2 workgroups per CU); 64x64 workgroups are half as large: 3 per CU
     static const int pct64 = env_int("SET_GEMM_WGS64_PCT", 150);
     static const int pct32 = env_int("SET_GEMM_WGS32_PCT", 50);
-    if (n > 0 && tile_m_of(probs[0]) == 64) cap_wgs = cap_wgs * pct64 / 100;
+    const int bm_l = n > 0 ? launch_tile_m(probs, n) : 128, bn_l = n > 0 ? launch_tile_n(probs, n) : 64;
+    if (n > 0 && bm_l == 64) cap_wgs = cap_wgs * pct64 / 100;
     // <= 32 rows: the launch only streams weights; fewer, longer workgroups halve the slab traffic (measured +5 %)
-    if (n > 0 && tile_m_of(probs[0]) == 32) cap_wgs = cap_wgs * pct32 / 100;
+    if (n > 0 && bm_l == 32) cap_wgs = cap_wgs * pct32 / 100;
     int tiles[GEMM_MAX_TASKS], kts[GEMM_MAX_TASKS], max_kt = 1;
     for (int i = 0; i < n; ++i) {
-        const int bm = tile_m_of(probs[0]), bn = tile_n_of(probs[0]);
+        const int bm = bm_l, bn = bn_l;
         tiles[i] = cdiv(probs[i].M, bm) * cdiv(probs[i].N, bn);
         kts[i] = probs[i].ktiles();
         if (kts[i] > max_kt) max_kt = kts[i];
@@ -653,12 +675,13 @@ int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag
     L.stamps = g_gemm_stamps;
 #endif
     int wg = 0;
-    const int bm = tile_m_of(probs[0]), bn = tile_n_of(probs[0]);
+    const int bm = launch_tile_m(probs, n), bn = launch_tile_n(probs, n);
+    const int bm_class = tile_m_of(probs[0]);
     for (int i = 0; i < n; ++i) {
         const GemmProb& p = probs[i];
         GemmTask& t = L.t[i];
         if (p.M <= 0 || p.N <= 0 || p.nseg <= 0 || p.nseg > GEMM_MAX_SEG || !p.C) return SET_ERR_ARG;
-        if (!probs[0].bm_hint && gemm_tile_m(p.M) != bm) return SET_ERR_ARG;   // one tile shape per launch
+        if (!probs[0].bm_hint && gemm_tile_m(p.M) != bm_class) return SET_ERR_ARG;   // one row-tile class per launch
         int kt = 0;
         for (int s = 0; s < GEMM_MAX_SEG; ++s) {
             if (s < p.nseg) {
