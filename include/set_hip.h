@@ -455,6 +455,11 @@ int set_embed_relu_dropout_f32(const float* table, const int64_t* ids, int64_t i
                                int n, int D, int V, float p, uint64_t seed, uint64_t offset, void* stream);
 int set_dropout_bwd_f32(const float* dy, int64_t lddy, const float* y, int64_t ldy, float* dx, int64_t ldx, int rows,
                         int cols, float scale, int accumulate, void* stream);
+/* backward of set_dropout_f32 with the keep mask regenerated from (seed, offset): dx (+)= dy * keep / (1 - p).  For the
+ * site that does not follow a ReLU (h2 before fc, editnet.py:545), where an exactly-zero kept input must still pass its
+ * gradient — nn.Dropout's backward multiplies by the mask, not by the output's zero pattern. */
+int set_dropout_bwd_philox_f32(const float* dy, int64_t lddy, float* dx, int64_t ldx, int rows, int cols, float p,
+                               uint64_t seed, uint64_t offset, int accumulate, void* stream);
 /* out[c] (+)= sum_r x[r, c] (bias gradients over all (t, b) rows): two deterministic passes through a workspace of
  * set_colsum_workspace_bytes(cols); cols, ld multiples of 4. */
 size_t set_colsum_workspace_bytes(int cols);

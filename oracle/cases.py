@@ -43,6 +43,21 @@ DCNET_CASES = {
 }
 
 
+# At-size cases of the B = 64 / B = 128 configurations (BASELINE.json configs[3], configs[0]'s model at the metric batch):
+# summaries only (oracle/make_atsize_golden.py -> tests/golden/atsize_*.npz); caption lengths repeat, so rows of equal
+# length may be permuted between implementations (parity.check_xe compares per original sample)
+ATSIZE_ADAPTIVE_CASES = {
+    "editnet_adaptive_full_b64": dict(FULL, V=10000, R=100, T=18, B=64, wseed=19, iseed=33, nvalid_lo=10,
+                                      force_nvalid=(10, 37, 100), ragged_caps=True, **SCALES),
+}
+ATSIZE_DCNET_CASES = {
+    "dcnet_full_b128": dict(D=1024, A=512, C=512, E=1024, V=10000, T=20, B=128, wseed=20, iseed=34,
+                            ragged_caps=True, **SCALES),
+}
+ADAPTIVE_ALL = dict(ADAPTIVE_CASES, **ATSIZE_ADAPTIVE_CASES)
+DCNET_ALL = dict(DCNET_CASES, **ATSIZE_DCNET_CASES)
+
+
 def _prev(c):
     prev, plen = synth.prev_captions(c["iseed"], c["B"], c["T"], c["V"], min_len=1)
     # force the extreme lengths 1 and T; keep padding consistent
@@ -82,13 +97,13 @@ def _boost_end(sd, c):
 
 
 def build_editnet(name):
-    c = dict(EDITNET_CASES.get(name) or ADAPTIVE_CASES[name])
+    c = dict(EDITNET_CASES.get(name) or ADAPTIVE_ALL[name])
     sd = synth.editnet_state(c["wseed"], c["V"], c["D"], c["A"], c["F"], c["emb_scale"], c["fc_scale"], c["gain"])
     sd = _boost_end(sd, c)
     prev, plen = _prev(c)
     caps, clen = _caps(c)
     out = dict(case=c, sd=sd, prev=prev, plen=plen, caps=caps, clen=clen, wm=synth.word_map(c["V"]))
-    if name in ADAPTIVE_CASES:
+    if name in ADAPTIVE_ALL:
         X, mean, n = synth.adaptive_features(c["iseed"], c["B"], c["R"], c["F"], c["nvalid_lo"])
         if c.get("force_nvalid"):
             for b, nv in enumerate(c["force_nvalid"]):
@@ -113,7 +128,7 @@ def build_editnet(name):
 
 
 def build_dcnet(name):
-    c = dict(DCNET_CASES[name])
+    c = dict(DCNET_ALL[name])
     sd = synth.dcnet_state(c["wseed"], c["V"], c["D"], c["A"], c["C"], c["E"], c["emb_scale"], c["fc_scale"], c["gain"])
     sd = _boost_end(sd, c)
     prev, plen = _prev(c)

@@ -1,0 +1,276 @@
+"""ORACLE tooling (authoring container only): TRAIN-MODE golden vectors from the reference itself.
+
+    python -m oracle.make_train_golden            # rewrites tests/golden/train_*.npz
+
+The reference's train mode draws three kinds of dropout mask from torch's global generator (`EmbeddingC` editnet.py:300-304
+— called once by the caption encoder :329 and once per timestep :513 —, `att_embed[2]` :430-432,441 once per timestep,
+`DecoderC.dropout` :545 once per timestep) and, with scheduled sampling, a coin and a multinomial draw per timestep
+(:509,517).  This package draws all of them from Philox streams addressed by (seed, site, timestep, row, column)
+(show_edit_tell_amd/rng.py), which numpy regenerates (oracle/philox_np.py).  Here the reference's OWN classes (AST-sliced
+from /root/reference, oracle/ref_slice.py) are instantiated in train() mode with every `nn.Dropout` replaced by a module
+that multiplies by `keep / (1 - p)` with exactly those masks, mapped to whatever row order the reference presents the
+operand in (the encoder's internal length sort, the adaptive model's packed valid regions, DCNet's all-positions-at-once
+embedding); the scheduled-sampling coin and draw are fed through a `torch` proxy in the sliced namespace.  The reference's
+as-written forward (nothing hoisted) + `loss.backward()` then give scores and gradients that the HIP routes must
+reproduce with the same seed (tests/test_hip_train_mode.py).  Only numbers computed by the reference are stored.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn.utils.rnn import pack_padded_sequence
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from oracle import cases, philox_np as PH, ref_slice  # noqa: E402
+from oracle.make_golden import OUT, T_, _np, _summ_logits  # noqa: E402
+
+# (case, seed, scheduled-sampling probability)
+TRAIN_CASES = (
+    ("editnet_small", 0x1234_5678_9ABC, 0.0),
+    ("editnet_small", 0x0BAD_CAFE_F00D_18, 0.25),          # scheduled sampling (editnet.py:508-520)
+    ("editnet_full_b4", 0x2345_6789_ABCD, 0.0),
+    ("editnet_adaptive_small", 0x3456_789A_BCDE, 0.0),
+    ("dcnet_small", 0x4567_89AB_CDEF, 0.0),
+    ("dcnet_full_b4", 0x5678_9ABC_DEF0, 0.0),
+)
+
+
+class InjectedDropout(nn.Module):
+    """nn.Dropout(p) with a supplied keep mask: y = x * keep / (1 - p) in train mode"""
+
+    def __init__(self, p, keep_fn):
+        super().__init__()
+        self.p, self.keep_fn, self.calls = p, keep_fn, 0
+
+    def forward(self, x):
+        if not self.training:
+            return x
+        keep = self.keep_fn(self.calls, x)
+        self.calls += 1
+        assert keep.shape == tuple(x.shape), (keep.shape, x.shape)
+        return x * T_(keep.astype(np.float32)) / (1.0 - self.p)
+
+
+def _encoder_keep(seed, site, p, lens_in_caller_order, shape, perm):
+    """mask for the reference's `self.embed(sorted_sequences)` (editnet.py:329) / `self.embed(src)` (dcnet.py:224): ours
+    is addressed by (caller row b, position l) as row b * Tmax + l of a (B * Tmax, E) operand; the reference presents rows
+    permuted by `perm` (its internal length sort; None for DCNet) and all padded positions (never consumed beyond Tmax)."""
+    B, T, E = shape
+    tmax = int(max(lens_in_caller_order))
+    mine = PH.dropout_keep(seed, PH.site_offset(site), B * tmax, E, p).reshape(B, tmax, E)
+    keep = np.ones((B, T, E), bool)
+    keep[:, :tmax] = mine if perm is None else mine[perm]
+    return keep
+
+
+class TorchProxy:
+    """stands in for `torch` inside the sliced reference namespace during a scheduled-sampling forward: the coin
+    `torch.zeros(bt).uniform_(0, 1)` (editnet.py:509) and the draw `torch.multinomial(prob_prev, 1)` (:517) come from the
+    Philox streams of rng.py; everything else is the real module."""
+
+    def __init__(self, seed, B, T):
+        self._seed, self._B = seed, B
+        self._coin = PH.uniforms(T * B, seed, PH.site_offset(PH.SITE_SS_COIN)).reshape(T, B)
+        self._t = 0                      # the loop asks for a coin at every t >= 1, in order
+        self.margins, self.fed = [], []
+
+    def __getattr__(self, k):
+        return getattr(torch, k)
+
+    def zeros(self, *a, **k):
+        if len(a) == 1 and isinstance(a[0], int) and not k:
+            self._t += 1
+            proxy, bt = self, a[0]
+
+            class _Coin:
+                def uniform_(self, lo, hi):
+                    return T_(proxy._coin[proxy._t, :bt].copy())
+            return _Coin()
+        return torch.zeros(*a, **k)
+
+    def multinomial(self, prob, n):
+        assert n == 1
+        logits = np.log(_np(prob).astype(np.float64)).astype(np.float32)      # prob = exp(scores): log gives the scores back
+        ids, margin = PH.categorical_draw(logits, self._seed, PH.site_offset(PH.SITE_SS_DRAW, self._t))
+        self.margins.append(margin)
+        return T_(ids).view(-1, 1)
+
+
+def _grads(module, small, out, prefix):
+    for k, p in module.named_parameters():
+        g = _np(p.grad)
+        out[prefix + "gradnorm." + k] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        if small:
+            out[prefix + "grad." + k] = g
+        else:
+            out[prefix + "gradslice." + k] = g.reshape(-1)[:: max(1, g.size // 64)][:64].copy()
+
+
+def _store_pred(pred, small, V, out, prefix):
+    if small:
+        out[prefix + "pred"] = pred
+        return
+    flat = pred.reshape(-1, V)
+    for k, v in _summ_logits(flat, V).items():
+        out[prefix + "pred_" + k] = v.reshape(pred.shape[0], pred.shape[1], *v.shape[1:])
+
+
+def make_editnet(name, seed, ss_prob):
+    adaptive = name in cases.ADAPTIVE_CASES
+    d = cases.build_editnet(name)
+    c, wm = d["case"], d["wm"]
+    small = c["D"] < 1024
+    B, R, D, V = c["B"], c["R"], c["D"], c["V"]
+    cls = ref_slice.editnet_adaptive() if adaptive else ref_slice.editnet_xe()
+    dec = ref_slice.load_state(cls["DecoderC"](wm, D, D, D, c["A"], c["F"]), d["sd"]).train()
+    X, prev, plen, caps, clen = (T_(d[k]) for k in ("X", "prev", "plen", "caps", "clen"))
+    # the decoder's row order (distinct caption lengths in these cases: the sort is unambiguous)
+    clen_s, sort_ind = clen.squeeze(1).sort(dim=0, descending=True)
+    assert len(set(clen_s.tolist())) == B, "train-mode cases need distinct caption lengths"
+    dl = (clen_s - 1).tolist()
+    Tm = max(dl)
+    bts = [sum(l > t for l in dl) for t in range(Tm)]
+    plen_s = plen[sort_ind]
+    enc_perm = _np(plen_s.squeeze(1).sort(dim=0, descending=True)[1])         # the call CaptionEncoderC.forward makes (:322)
+    Xs = X[sort_ind]
+    p_emb, p_reg, p_out = 0.5, 0.5, 0.5
+
+    n_enc = 2 if adaptive else 1
+
+    def embed_keep(call, x):
+        if call == 0:                       # caption_encoder(previous captions), editnet.py:501
+            return _encoder_keep(seed, PH.SITE_ENC_EMBED, p_emb, _np(plen_s).reshape(-1), x.shape, enc_perm)
+        if adaptive and call == 1:          # caption_encoder(ground-truth captions), editnet_adaptive.py:516 (already sorted)
+            perm = _np(clen_s.sort(dim=0, descending=True)[1])
+            return _encoder_keep(seed, PH.SITE_ENC2_EMBED, p_emb, clen_s.tolist(), x.shape, perm)
+        t = call - n_enc
+        assert x.shape == (bts[t], D)
+        return PH.dropout_keep(seed, PH.site_offset(PH.SITE_EMBED, t), bts[t], D, p_emb)
+
+    def region_keep(t, x):
+        bt = bts[t]
+        mine = PH.dropout_keep(seed, PH.site_offset(PH.SITE_REGION, t), bt * R, D, p_reg)
+        if not adaptive:
+            return mine.reshape(bt, R, D)
+        # editnet_adaptive.py:440-442: att_embed sees only the packed valid rows; find each packed row's (b, r)
+        att_len = (Xs[:bt].sum(2) != 0).sum(1).tolist()
+        idx = torch.arange(bt * R, dtype=torch.float32).view(bt, R, 1)
+        flat = pack_padded_sequence(idx, att_len, batch_first=True, enforce_sorted=False).data.view(-1).long().numpy()
+        return mine[flat]
+
+    def out_keep(t, x):
+        return PH.dropout_keep(seed, PH.site_offset(PH.SITE_OUT, t), bts[t], D, p_out)
+
+    dec.embed.dropout = InjectedDropout(p_emb, embed_keep)
+    dec.visual_attention.att_embed[2] = InjectedDropout(p_reg, region_keep)
+    dec.dropout = InjectedDropout(p_out, out_keep)
+    dec.train()
+    proxy = None
+    if ss_prob > 0:
+        proxy = TorchProxy(seed, B, Tm)
+        cls["DecoderC"].forward.__globals__["torch"] = proxy
+    try:
+        dec.zero_grad()
+        if adaptive:
+            pred, caps_s, dlr, si, gd_fh, last_h = dec(X, T_(d["image_mean"]), caps, clen, prev, plen, ss_prob > 0, ss_prob)
+        else:
+            pred, caps_s, dlr, si = dec(X, caps, clen, prev, plen, ss_prob > 0, ss_prob)
+    finally:
+        if proxy is not None:
+            cls["DecoderC"].forward.__globals__["torch"] = torch
+    assert dlr == dl and torch.equal(si, sort_ind)
+    assert dec.embed.dropout.calls == n_enc + Tm and dec.dropout.calls == Tm and dec.visual_attention.att_embed[2].calls == Tm
+    loss = nn.CrossEntropyLoss()(pack_padded_sequence(pred, dl, batch_first=True).data,
+                                 pack_padded_sequence(caps_s[:, 1:], dl, batch_first=True).data)
+    if adaptive:                            # editnet_adaptive.py:594-596
+        loss = loss + nn.MSELoss()(last_h, gd_fh)
+    loss.backward()
+    pre = "train_ss." if ss_prob > 0 else "train."
+    out = {pre + "seed": np.uint64(seed), pre + "loss": np.float64(loss.item()), pre + "sort_ind": _np(sort_ind)}
+    _store_pred(_np(pred), small, V, out, pre)
+    if adaptive:
+        out[pre + "gd_final"], out[pre + "last_hidden"] = _np(gd_fh), _np(last_h)
+    _grads(dec, small, out, pre)
+    if proxy is not None:
+        out[pre + "ss_prob"] = np.float64(ss_prob)
+        out[pre + "draw_margin_min"] = np.float64(min(m.min() for m in proxy.margins))
+        # the words the steps consumed, (T, B): ground truth unless the coin fell below ss_prob
+        fed = _np(caps_s[:, :Tm]).T.copy()
+        coin = proxy._coin < np.float32(ss_prob)
+        sc = _np(pred)
+        for t in range(1, Tm):
+            ids, _ = PH.categorical_draw(sc[:bts[t], t - 1], seed, PH.site_offset(PH.SITE_SS_DRAW, t))
+            fed[t, :bts[t]] = np.where(coin[t, :bts[t]], ids, fed[t, :bts[t]])
+        out[pre + "fed_tokens"] = fed
+        out[pre + "n_replaced"] = np.int64(sum(int(coin[t, :bts[t]].sum()) for t in range(1, Tm)))
+    return out
+
+
+def make_dcnet(name, seed):
+    d = cases.build_dcnet(name)
+    c, wm = d["case"], d["wm"]
+    small = c["D"] < 1024
+    B, D, E, V = c["B"], c["D"], c["E"], c["V"]
+    dae = ref_slice.load_state(ref_slice.dcnet_xe()["DAE"](wm, None, D, c["A"], c["C"], E), d["sd"]).train()
+    prev, plen, caps, clen = (T_(d[k]) for k in ("prev", "plen", "caps", "clen"))
+    clen_s, sort_ind = clen.squeeze(1).sort(dim=0, descending=True)
+    assert len(set(clen_s.tolist())) == B
+    dl = (clen_s - 1).tolist()
+    Tm = max(dl)
+    bts = [sum(l > t for l in dl) for t in range(Tm)]
+    plen_s = plen[sort_ind]
+    p_emb = p_out = 0.5
+
+    def embed_keep(call, x):
+        if call == 0:                       # dcnet.py:325: all caption positions at once; position t feeds timestep t only
+            keep = np.ones(tuple(x.shape), bool)
+            for t in range(Tm):
+                keep[:bts[t], t] = PH.dropout_keep(seed, PH.site_offset(PH.SITE_EMBED, t), bts[t], E, p_emb)
+            return keep
+        assert call == 1                    # caption_encoder(previous captions), dcnet.py:224 (no internal sort)
+        return _encoder_keep(seed, PH.SITE_ENC_EMBED, p_emb, _np(plen_s).reshape(-1), x.shape, None)
+
+    def out_keep(t, x):
+        return PH.dropout_keep(seed, PH.site_offset(PH.SITE_OUT, t), bts[t], D, p_out)
+
+    dae.embed.dropout = InjectedDropout(p_emb, embed_keep)
+    dae.dropout = InjectedDropout(p_out, out_keep)
+    dae.train()
+    dae.zero_grad()
+    pred, caps_s, dlr, si = dae(caps, clen, prev, plen)
+    assert dlr == dl and torch.equal(si, sort_ind) and dae.embed.dropout.calls == 2 and dae.dropout.calls == Tm
+    loss = nn.CrossEntropyLoss()(pack_padded_sequence(pred, dl, batch_first=True).data,
+                                 pack_padded_sequence(caps_s[:, 1:], dl, batch_first=True).data)
+    loss.backward()
+    out = {"train.seed": np.uint64(seed), "train.loss": np.float64(loss.item()), "train.sort_ind": _np(sort_ind)}
+    _store_pred(_np(pred), small, V, out, "train.")
+    _grads(dae, small, out, "train.")
+    return out
+
+
+def main(argv):
+    assert ref_slice.have_reference(), "needs /root/reference (authoring container only)"
+    torch.manual_seed(0)
+    want = set(argv[1:])
+    files = {}
+    for name, seed, ss in TRAIN_CASES:
+        if want and name not in want:
+            continue
+        o = make_dcnet(name, seed) if name in cases.DCNET_CASES else make_editnet(name, seed, ss)
+        files.setdefault(name, {}).update(o)
+    for name, o in files.items():
+        path = os.path.join(OUT, "train_" + name + ".npz")
+        np.savez_compressed(path, **o)
+        extra = ""
+        if "train_ss.draw_margin_min" in o:
+            extra = "  ss: %d words replaced, min draw margin %.2e" % (o["train_ss.n_replaced"], o["train_ss.draw_margin_min"])
+        print("%-30s %8.1f KiB  loss %.6f%s" % ("train_" + name, os.path.getsize(path) / 1024, o["train.loss"], extra))
+
+
+if __name__ == "__main__":
+    main(sys.argv)

@@ -35,3 +35,61 @@ def sample_uniform(seed, offset, rows, t):
                     np.full_like(rows, (offset >> 32) & 0xFFFFFFFF)], 1)
     w = philox4x32_10(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))
     return ((w[:, 0] >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0))
+
+
+# ---- the train-mode streams of show_edit_tell_amd/rng.py (dropout masks, scheduled-sampling coin and draw) ----------
+SITE_ENC_EMBED, SITE_EMBED, SITE_REGION, SITE_OUT, SITE_SS_DRAW, SITE_ENC2_EMBED, SITE_SS_COIN, SITE_ROLLOUT = range(8)
+
+
+def site_offset(site, t=0):
+    return (int(site) << 40) | int(t)
+
+
+def _key(seed):
+    return (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+
+
+def dropout_keep(seed, offset, rows, cols, p):
+    """keep mask (rows, cols) bool of csrc/train_seq.hip `dropout_k`: element (r, c) uses counter
+    (r, c // 4, offset_lo, offset_hi), key seed, word c % 4; kept iff (word >> 8) * 2^-24 >= p."""
+    assert cols % 4 == 0
+    c4 = cols // 4
+    r = np.repeat(np.arange(rows, dtype=np.uint64), c4)
+    c = np.tile(np.arange(c4, dtype=np.uint64), rows)
+    ctr = np.stack([r, c, np.full_like(r, offset & 0xFFFFFFFF), np.full_like(r, (offset >> 32) & 0xFFFFFFFF)], 1)
+    w = philox4x32_10(ctr, _key(seed))                       # (rows * c4, 4)
+    u = (w >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return (u >= np.float32(p)).reshape(rows, cols)
+
+
+def uniforms(n, seed, offset):
+    """element i: (word 0 of counter (i, 0, offset) >> 8) * 2^-24 — show_edit_tell_amd.rng.uniforms"""
+    i = np.arange(n, dtype=np.uint64)
+    ctr = np.stack([i, np.zeros_like(i), np.full_like(i, offset & 0xFFFFFFFF), np.full_like(i, (offset >> 32) & 0xFFFFFFFF)], 1)
+    w = philox4x32_10(ctr, _key(seed))
+    return (w[:, 0] >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+
+
+def categorical_draw(logits, seed, offset, t=0):
+    """the sampling epilogue's draw (csrc/epilogue.hip `sample_pick_k`) for every row of `logits` (B, V): inverse CDF of
+    softmax(logits) over the kernel's fixed enumeration of the vocabulary (thread tid of 256 owns the words
+    (tid + 256 q) * 4 + e, q = 0.., e = 0..3, in that order), uniform of counter (row, t, offset).  Returns (ids (B,),
+    margin (B,)): margin = distance of the target from the nearest CDF boundary, relative to the total mass — draws with
+    a margin below ~1e-5 may legitimately differ between the fp32 device scan and this fp64 one."""
+    B, V = logits.shape
+    nq = -(-V // 1024)
+    order = np.array([(tid + 256 * q) * 4 + e for tid in range(256) for q in range(nq) for e in range(4)])
+    order = order[order < V]
+    lg = logits.astype(np.float64)
+    pe = np.exp(lg - lg.max(1, keepdims=True))[:, order]
+    cdf = np.cumsum(pe, 1)
+    u = sample_uniform(seed, offset, np.arange(B), t).astype(np.float64)
+    target = u * cdf[:, -1]
+    ids, margin = np.zeros(B, np.int64), np.zeros(B)
+    for b in range(B):
+        j = int(np.searchsorted(cdf[b], target[b], side="right"))
+        j = min(j, len(order) - 1)
+        ids[b] = order[j]
+        lo = cdf[b, j - 1] if j else 0.0
+        margin[b] = min(target[b] - lo, cdf[b, j] - target[b]) / cdf[b, -1]
+    return ids, margin

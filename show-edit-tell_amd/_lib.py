@@ -234,6 +234,7 @@ PROTOTYPES = {
     "set_dropout_f32": (_I, [_P, _L, _P, _L, _I, _I, C.c_float, _U, _U, _P]),
     "set_embed_relu_dropout_f32": (_I, [_P, _P, _L, _P, _L, _I, _I, _I, C.c_float, _U, _U, _P]),
     "set_dropout_bwd_f32": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, C.c_float, _I, _P]),
+    "set_dropout_bwd_philox_f32": (_I, [_P, _L, _P, _L, _I, _I, C.c_float, _U, _U, _I, _P]),
     "set_rowsum_mask_f32": (_I, [_P, _L, _I, _I, _P, _P]),
     "set_pack_f32": (_I, [_P, _L, _I, _I, C.POINTER(_P), C.POINTER(_L), C.POINTER(_I), _I, _P]),
     "set_sample_pick_f32": (_I, [_P, _L, _I, _I, _I, _I, _L, _U, _U, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -18,6 +18,7 @@ import ctypes as C
 import torch
 
 from . import _lib
+from . import rng as _rng
 from ._lib import EditNetWeights, check, ptr, stream_of
 
 
@@ -594,6 +595,45 @@ def encoder_lstm(emb, lens, w_ih, b_ih, w_hh, b_hh, reverse=False, want_mem=True
 
 
 # ------------------------------------------------------------------------------------------------
+# nn.Dropout(p) of the train-mode path on the library's Philox stream (rng.py: one seed per forward call, one offset per
+# (site, timestep)): the same masks on the whole-sequence nodes and on the per-operator route, reproducible in numpy
+# (oracle/philox_np.dropout_mask) — which is what pins train mode to the reference's autograd
+# ------------------------------------------------------------------------------------------------
+class _PhiloxDropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed, offset):
+        lib = _lib.load()
+        x = _c(x)
+        cols = x.shape[-1]
+        rows = x.numel() // cols
+        y = torch.empty_like(x)
+        check(lib.set_dropout_f32(ptr(x), cols, ptr(y), cols, rows, cols, float(p), int(seed), int(offset),
+                                  stream_of(x.device)), "set_dropout_f32")
+        ctx.args = (rows, cols, float(p), int(seed), int(offset))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        rows, cols, p, seed, offset = ctx.args
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        check(lib.set_dropout_bwd_philox_f32(ptr(dy), cols, ptr(dx), cols, rows, cols, p, seed, offset, 0,
+                                             stream_of(dy.device)), "set_dropout_bwd_philox_f32")
+        return dx, None, None, None
+
+
+def philox_dropout(x, p, seed, offset, training=True):
+    """nn.Dropout(p)(x) with the mask of (seed, offset): element (r, c) of x viewed as (rows, last dim) is kept iff the
+    24-bit uniform of counter (r, c // 4, offset), word c % 4 is >= p.  Identity when not training or p == 0."""
+    if not training or p <= 0.0 or x.numel() == 0:
+        return x
+    if x.shape[-1] & 3:
+        raise _lib.SetError("Philox dropout needs a feature count that is a multiple of 4 (got %d)" % x.shape[-1])
+    return _PhiloxDropout.apply(x, p, seed, offset)
+
+
+# ------------------------------------------------------------------------------------------------
 # additive attention backward shared by the caption (tanh) and visual (relu) attentions
 # ------------------------------------------------------------------------------------------------
 def _attention_bwd(dctx, dalpha_ext, alpha, values, att1, att2, w_full, use_tanh, want_dvalues):
@@ -849,7 +889,7 @@ class SampleState:
         self.tokens[0].fill_(int(start_idx))
         self.unfinished = torch.empty(B, dtype=torch.int32, device=device)
         self.alive = torch.empty(max_len + 2, dtype=torch.int32, device=device)
-        self.seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)
+        self.seed = _rng.next_seed() if seed is None else int(seed)
         self.offset = int(offset)
 
 
@@ -879,6 +919,23 @@ class _SamplePick(torch.autograd.Function):
         check(lib.set_sample_logp_bwd_f32(ptr(logits), logits.stride(0), ptr(lse), ptr(raw), ptr(_c(g)), ptr(d),
                                           d.stride(0), B, V, stream_of(logits.device)), "set_sample_logp_bwd_f32")
         return d, None, None
+
+
+def philox_categorical(logits, seed, offset):
+    """it ~ softmax(logits) per row (no gradient, no bookkeeping): the scheduled-sampling draw of editnet.py:515-517
+    (`torch.multinomial(torch.exp(scores))` normalises, i.e. samples softmax(scores)) on the device sampling epilogue:
+    row b uses the uniform of counter (b, 0, offset), inverse CDF over the epilogue's fixed word enumeration."""
+    lib = _lib.load()
+    logits = _c(logits)
+    B, V = logits.shape
+    dev = logits.device
+    i64 = torch.zeros(3, B, dtype=torch.long, device=dev)
+    i32 = torch.zeros(B + 8, dtype=torch.int32, device=dev)
+    f32 = torch.empty(2, B, dtype=torch.float32, device=dev)
+    check(lib.set_sample_pick_f32(ptr(logits), logits.stride(0), B, V, 0, 1, -1, int(seed), int(offset), ptr(i64[0]),
+                                  ptr(i64[1]), ptr(i32), ptr(i32[B:]), ptr(i64[2]), ptr(f32[0]), ptr(f32[1]),
+                                  stream_of(dev)), "set_sample_pick_f32")
+    return i64[2]
 
 
 def sample_pick(logits, state, t):

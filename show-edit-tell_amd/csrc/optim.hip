@@ -78,7 +78,7 @@ __device__ __forceinline__ float clip_coef(const float* partials, int n_partials
     if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) *norm_out = norm;
     if (max_norm <= 0.f) return 1.f;
     const float c = max_norm / (norm + 1e-6f);
-    return c < 1.f ? c : 1.f;
+    return (c < 1.f || c != c) ? c : 1.f;   // torch.clamp(max=1) lets a NaN norm through to the gradients; so do we
 }
 
 template <bool SCALE_G>

@@ -42,6 +42,25 @@ __global__ void __launch_bounds__(256) dropout_bwd_k(const float* dy, long long 
     *reinterpret_cast<f32x4*>(o) = v;
 }
 
+// dx (+)= dy * keep / (1 - p) with the keep mask REGENERATED from (seed, offset) — the backward of dropout_k for a site
+// that does not follow a ReLU (h2 before fc, editnet.py:545): an input that is exactly 0 and kept still passes its
+// gradient, which the zero pattern of the output cannot tell from "dropped".
+__global__ void __launch_bounds__(256) dropout_bwd_philox_k(const float* dy, long long lddy, float* dx, long long ldx, int rows,
+                                                            int cols4, float p, float scale, unsigned long long seed,
+                                                            unsigned long long offset, int accumulate) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)rows * cols4) return;
+    const int r = (int)(i / cols4), c = (int)(i - (long long)r * cols4);
+    uint32_t k[4] = {(uint32_t)r, (uint32_t)c, (uint32_t)offset, (uint32_t)(offset >> 32)};
+    philox4x32_10(k, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * lddy + 4 * c);
+    float* o = dx + r * ldx + 4 * c;
+    f32x4 v = accumulate ? *reinterpret_cast<const f32x4*>(o) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += ((float)(k[e] >> 8) * (1.0f / 16777216.0f) >= p) ? g[e] * scale : 0.f;
+    *reinterpret_cast<f32x4*>(o) = v;
+}
+
 // EmbeddingC.forward in train mode (editnet.py:299-302): relu(table[ids]) followed by the dropout of dropout_k (same
 // counters: the result equals set_embed_relu_f32 + set_dropout_f32 in place), one launch
 __global__ void __launch_bounds__(256) embed_relu_dropout_k(const float* table, const int64_t* ids, long long ids_stride,
@@ -147,6 +166,18 @@ int set_dropout_bwd_f32(const float* dy, int64_t lddy, const float* y, int64_t l
     const long long n = (long long)rows * (cols >> 2);
     hipLaunchKernelGGL(dropout_bwd_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy,
                        (long long)lddy, y, (long long)ldy, dx, (long long)ldx, rows, cols >> 2, scale, accumulate);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+int set_dropout_bwd_philox_f32(const float* dy, int64_t lddy, float* dx, int64_t ldx, int rows, int cols, float p,
+                               uint64_t seed, uint64_t offset, int accumulate, void* stream) {
+    if (!dy || !dx || rows <= 0 || cols <= 0 || !(p >= 0.f) || !(p < 1.f)) return SET_ERR_ARG;
+    if ((cols & 3) || (lddy & 3) || (ldx & 3) || !aligned16(dy) || !aligned16(dx)) return SET_ERR_UNSUPPORTED;
+    const long long n = (long long)rows * (cols >> 2);
+    hipLaunchKernelGGL(dropout_bwd_philox_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy,
+                       (long long)lddy, dx, (long long)ldx, rows, cols >> 2, p, 1.0f / (1.0f - p), (unsigned long long)seed,
+                       (unsigned long long)offset, accumulate);
     SET_LAUNCH_CHECK();
     return SET_OK;
 }

@@ -35,7 +35,10 @@ class Embedding(nn.Module):
         _require_cuda(x, "token ids")
         if self.training or _wants_grad(self):
             from . import autograd_ops as A
-            return self.dropout(A.embed_relu(_i64c(x), self.embedding.weight))      # dcnet.py:203-205
+            from . import rng
+            # dcnet.py:203-205; a direct call draws its own seed (DAE.forward addresses the site itself)
+            return A.philox_dropout(A.embed_relu(_i64c(x), self.embedding.weight), self.dropout.p, rng.next_seed(),
+                                    rng.offset(rng.SITE_EMBED), self.training)
         lib = _lib.load()
         ids = _i64c(x)
         n, D = ids.numel(), self.emb_dim
@@ -187,7 +190,8 @@ class DAE(nn.Module):
         enc = self.caption_encoder.lstm_encoder
         src = (self.embed.embedding.weight, self.attention_lstm.weight_ih, enc.weight_ih_l0, enc.bias_ih_l0,
                enc.weight_ih_l0_reverse, enc.bias_ih_l0_reverse)
-        sig = tuple((t.data_ptr(), t._version) for t in src)
+        from . import optim as _optim
+        sig = tuple((t.data_ptr(), t._version) for t in src) + (_optim.weights_epoch(),)
         st = self.__dict__.setdefault("_tok_state", {"sig": None, "seen": 0, "table": None})
         if st["sig"] != sig:
             st.update(sig=sig, seen=1, table=None)
@@ -262,7 +266,7 @@ class DAE(nn.Module):
         lib = _lib.load()
         dev = encoded_captions.device
         batch_size = encoded_captions.size(0)
-        caption_lengths, sort_ind = caption_lengths.squeeze(1).sort(dim=0, descending=True)
+        caption_lengths, sort_ind = caption_lengths.squeeze(1).sort(dim=0, descending=True, stable=True)
         encoded_captions = _i64c(encoded_captions[sort_ind])
         prev = _i64c(encoded_previous_captions[sort_ind])
         plen = _i64c(previous_cap_length[sort_ind].reshape(-1))
@@ -280,15 +284,18 @@ class DAE(nn.Module):
 
 
     # ---- grad-enabled path (HIP forward operators, autograd backward) ------------------------
-    def _encoder_autograd(self, src, src_len):
-        """CaptionEncoder.forward (dcnet.py:220-243): packed BiLSTM == per-row masked recurrences."""
+    def _encoder_autograd(self, src, src_len, seed=None):
+        """CaptionEncoder.forward (dcnet.py:220-243): packed BiLSTM == per-row masked recurrences.  The embedding's
+        dropout (dcnet.py:224) is the Philox stream (seed, SITE_ENC_EMBED): row b * Tmax + l, see rng.py."""
         from . import autograd_ops as A
+        from . import rng
         enc = self.caption_encoder
         lstm = enc.lstm_encoder
         lens = src_len.reshape(-1)
         tmax = int(lens.max().item())
         B, Cc = src.shape[0], enc.enc_hid_dim
-        emb = self.embed.dropout(A.embed_relu(src[:, :tmax], self.embed.embedding.weight))
+        emb = A.philox_dropout(A.embed_relu(src[:, :tmax], self.embed.embedding.weight), self.embed.dropout.p,
+                               rng.next_seed() if seed is None else seed, rng.offset(rng.SITE_ENC_EMBED), self.embed.training)
         outs, finals = [], []
         for sfx, reverse in (("", False), ("_reverse", True)):      # each direction = one autograd node
             w_ih, w_hh = getattr(lstm, "weight_ih_l0" + sfx), getattr(lstm, "weight_hh_l0" + sfx)
@@ -315,31 +322,37 @@ class DAE(nn.Module):
     def _forward_autograd(self, encoded_captions, caption_lengths, encoded_previous_captions, previous_cap_length):
         """dcnet.py:303-350 over autograd ops."""
         from . import autograd_ops as A
+        from . import rng
         batch_size = encoded_captions.size(0)
-        caption_lengths, sort_ind = caption_lengths.squeeze(1).sort(dim=0, descending=True)
+        caption_lengths, sort_ind = caption_lengths.squeeze(1).sort(dim=0, descending=True, stable=True)
         encoded_captions = encoded_captions[sort_ind]
         prev = encoded_previous_captions[sort_ind]
         plen = previous_cap_length[sort_ind]
         h1, c1 = self.init_hidden_state(batch_size)
         h2, c2 = self.init_hidden_state(batch_size)
         decode_lengths = (caption_lengths - 1).tolist()
-        enc, final_hidden, mask = self._encoder_autograd(prev, plen)
+        seed = self.__dict__["_fwd_seed"] = rng.next_seed()       # one seed per forward call, one Philox offset per site (rng.py)
+        training, p_emb, p_out = self.training, self.embed.dropout.p, self.dropout.p
+        enc, final_hidden, mask = self._encoder_autograd(prev, plen, seed)
         ca = self.caption_attention
         att1_c = A.linear(enc, ca.cap_features_att.weight, ca.cap_features_att.bias)       # loop invariant (dcnet.py:261)
         from . import editnet as _editnet
         if _editnet._XE_SEQUENCE:         # the whole loop as ONE autograd node (dcnet_sequence.py)
             from . import dcnet_sequence as S
-            cfg = S.SeqConfig(decode_lengths, self.training, self.embed.dropout.p, 0.0, self.dropout.p,
-                              int(torch.randint(0, 2 ** 62, (1,)).item()))
+            cfg = S.SeqConfig(decode_lengths, training, p_emb, 0.0, p_out, seed)
             preds = S.dcnet_sequence(cfg, enc, final_hidden, mask, att1_c, encoded_captions, S.dae_params(self))
             return preds, encoded_captions, decode_lengths, sort_ind
-        embeddings = self.embed.dropout(A.embed_relu(encoded_captions, self.embed.embedding.weight))
+        # dcnet.py:325 embeds (and drops out) all positions at once; position t is consumed by timestep t only, so its
+        # mask is the (SITE_EMBED, t) stream over the rows still in the batch — as on the whole-sequence node
+        raw = A.embed_relu(encoded_captions, self.embed.embedding.weight)
         preds_t = []
         for t in range(max(decode_lengths)):
             bt = sum([l > t for l in decode_lengths])
-            h1, c1, h2, c2 = self._step_autograd(embeddings[:bt, t], final_hidden[:bt], enc[:bt], mask[:bt], h1[:bt],
+            emb = A.philox_dropout(raw[:bt, t], p_emb, seed, rng.offset(rng.SITE_EMBED, t), training)
+            h1, c1, h2, c2 = self._step_autograd(emb, final_hidden[:bt], enc[:bt], mask[:bt], h1[:bt],
                                                  c1[:bt], h2[:bt], c2[:bt], att1_c[:bt])
-            preds = A.linear(self.dropout(h2), self.fc.weight, self.fc.bias)
+            preds = A.linear(A.philox_dropout(h2, p_out, seed, rng.offset(rng.SITE_OUT, t), training),
+                             self.fc.weight, self.fc.bias)
             if bt < batch_size:
                 preds = torch.cat([preds, preds.new_zeros(batch_size - bt, preds.shape[1])], 0)
             preds_t.append(preds)

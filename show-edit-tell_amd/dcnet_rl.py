@@ -33,9 +33,11 @@ class DAE(_DAE_XE):
         seq = torch.empty(B, max_len, dtype=torch.long, device=dev)
         seq_logp = torch.empty(B, max_len, dtype=torch.float32, device=dev)
         if sample_rl:        # multinomial sampling, eval mode, no gradients: fused device loop, Philox epilogue
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            from . import rng
+            seed = rng.next_seed()
             check(lib.set_dcnet_sample(C.byref(w), C.byref(dims), ptr(prev), ptr(plen), int(word_map['<start>']),
-                                       int(word_map['<end>']), max_len, seed, 0, ptr(seq), ptr(seq_logp), ptr(ws),
+                                       int(word_map['<end>']), max_len, seed, rng.offset(rng.SITE_ROLLOUT), ptr(seq),
+                                       ptr(seq_logp), ptr(ws),
                                        ws.numel(), stream_of(dev)), "set_dcnet_sample")
             return seq, seq_logp
         check(lib.set_dcnet_greedy(C.byref(w), C.byref(dims), ptr(prev), ptr(plen), int(word_map['<start>']),
@@ -48,34 +50,36 @@ def _dae_rollout(self, word_map, encoded_previous_captions, previous_cap_length,
     """dcnet_rl.py:286-346 over autograd-wrapped HIP operators (sampled SCST rollout / multinomial sampling)."""
     import torch.nn.functional as F
     from . import autograd_ops as A
+    from . import rng
     dev = encoded_previous_captions.device
     B, max_len = encoded_previous_captions.shape[0], self.max_len
+    seed = self.__dict__["_fwd_seed"] = rng.next_seed()       # one seed per forward call (rng.py)
+    training, p_emb, p_out = self.training, self.embed.dropout.p, self.dropout.p
     seq = torch.zeros(B, max_len, dtype=torch.long, device=dev)
     logps = []
     it = torch.full((B,), int(word_map['<start>']), dtype=torch.long, device=dev)
     h1, c1 = self.init_hidden_state(B)
     h2, c2 = self.init_hidden_state(B)
-    enc, final_hidden, mask = self._encoder_autograd(encoded_previous_captions, previous_cap_length)
+    enc, final_hidden, mask = self._encoder_autograd(encoded_previous_captions, previous_cap_length, seed)
     ca = self.caption_attention
     att1_c = A.linear(enc, ca.cap_features_att.weight, ca.cap_features_att.bias)
     from . import editnet as _editnet
     if sample_rl and _editnet._XE_SEQUENCE:       # the sampled rollout as ONE autograd node (dcnet_sequence.py, rollout mode)
         from . import dcnet_sequence as S
-        sample_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-        cfg = S.SeqConfig([], self.training, self.embed.dropout.p, 0.0, self.dropout.p,
-                          int(torch.randint(0, 2 ** 62, (1,)).item()),
+        cfg = S.SeqConfig([], training, p_emb, 0.0, p_out, seed,
                           rollout=dict(max_len=max_len, start_idx=int(word_map['<start>']), end_idx=int(word_map['<end>']),
-                                       seed=sample_seed))
+                                       seed=seed, offset=rng.offset(rng.SITE_ROLLOUT)))
         return S.dcnet_sequence(cfg, enc, final_hidden, mask, att1_c, torch.zeros(1, 1, dtype=torch.long, device=dev),
                                 S.dae_params(self))
     unfinished = None
-    state = A.SampleState(B, max_len, word_map['<start>'], word_map['<end>'], dev) if sample_rl else None
+    state = (A.SampleState(B, max_len, word_map['<start>'], word_map['<end>'], dev, seed=seed,
+                           offset=rng.offset(rng.SITE_ROLLOUT)) if sample_rl else None)
     for t in range(max_len + 1):
         if sample_rl:
             it = state.tokens[t]
-        emb = self.embed.dropout(A.embed_relu(it, self.embed.embedding.weight))
+        emb = A.philox_dropout(A.embed_relu(it, self.embed.embedding.weight), p_emb, seed, rng.offset(rng.SITE_EMBED, t), training)
         h1, c1, h2, c2 = self._step_autograd(emb, final_hidden, enc, mask, h1, c1, h2, c2, att1_c)
-        logits = A.linear(self.dropout(h2), self.fc.weight, self.fc.bias)
+        logits = A.linear(A.philox_dropout(h2, p_out, seed, rng.offset(rng.SITE_OUT, t), training), self.fc.weight, self.fc.bias)
         if t == max_len:
             break
         if sample_rl:                    # dcnet_rl.py:320-340 on the device (Philox draw), no host sync

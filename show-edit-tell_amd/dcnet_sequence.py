@@ -10,6 +10,7 @@ import torch
 
 from . import _lib
 from . import autograd_ops as A
+from . import rng
 from ._lib import EditNetWeights, check
 from .xe_sequence import SeqConfig, _Ops, _dvalues, _e, _rows, _z  # noqa: F401
 
@@ -67,10 +68,10 @@ class _DcnetSequence(torch.autograd.Function):
         ws_c = ops.ws("cap", lib.set_caption_attention_workspace_bytes(B, Tc, max(Dh, D), Adim))
         Etab = P["E"]
         cap_stride = caps.stride(0) if ro is None else 1
-        off = lambda site, t: (site << 40) | t
+        off = rng.offset
         state = None
         if ro is not None:
-            state = A.SampleState(B, T, ro["start_idx"], ro["end_idx"], dev, seed=ro.get("seed"))
+            state = A.SampleState(B, T, ro["start_idx"], ro["end_idx"], dev, seed=ro.get("seed"), offset=ro.get("offset", 0))
             L["LOGITS"] = _e(T, B, V, dev=dev)
             L["RAW"] = torch.empty(T, B, dtype=torch.long, device=dev)
             L["LSE"], L["LOGP"] = _e(T, B, dev=dev), _e(T, B, dev=dev)
@@ -180,8 +181,9 @@ class _DcnetSequence(torch.autograd.Function):
             bt = bts[t]
             r = lambda x: _rows(x, bt)
             h1 = L["H1"][t + 1]
-            if train and cfg.p_out > 0:
-                ops.dropout_bwd(dH2D[t], L["H2D"][t], DH2, bt, D, sc_out, True)
+            if train and cfg.p_out > 0:    # h2 does not follow a ReLU: the mask is regenerated, not read off the zero pattern
+                check(lib.set_dropout_bwd_philox_f32(dH2D[t].data_ptr(), D, DH2.data_ptr(), D, bt, D, cfg.p_out, cfg.seed,
+                                                     rng.offset(rng.SITE_OUT, t), 1, st), "set_dropout_bwd_philox_f32")
             else:
                 ops.pack(DH2, bt, [dH2D[t]], accumulate=True)
             dc2_in, dc2_out = DC2[t & 1], DC2[(t & 1) ^ 1]

@@ -147,7 +147,10 @@ class EmbeddingC(nn.Module):
         _require_cuda(x, "token ids")
         if self.training or _wants_grad(self):
             from . import autograd_ops as A
-            return self.dropout(A.embed_relu(_i64c(x), self.embedding.weight))      # editnet.py:301-303
+            from . import rng
+            # editnet.py:301-303; a direct call draws its own seed (DecoderC.forward addresses the site itself)
+            return A.philox_dropout(A.embed_relu(_i64c(x), self.embedding.weight), self.dropout.p, rng.next_seed(),
+                                    rng.offset(rng.SITE_EMBED), self.training)
         lib = _lib.load()
         ids = _i64c(x)
         n, D = ids.numel(), self.emb_dim
@@ -196,14 +199,19 @@ class CaptionEncoderC(nn.Module):
         return H[:, :tmax], M[:, :tmax], fh, mask[:, :tmax]
 
 
-def _caption_encoder_autograd(enc, seq, seq_len):
+def _caption_encoder_autograd(enc, seq, seq_len, seed=None, site=None):
     """CaptionEncoderC.forward (editnet.py:319-348), grad-enabled: embedding (+ its dropout) for all positions, then the
-    whole recurrence as one autograd node (autograd_ops.encoder_lstm: rows advance while t < len, padded outputs zero)."""
+    whole recurrence as one autograd node (autograd_ops.encoder_lstm: rows advance while t < len, padded outputs zero).
+    The embedding's dropout mask (editnet.py:329 calls the shared EmbeddingC) is the Philox stream (seed, site): element
+    (b, l, :) is row b * Tmax + l of the (B * Tmax, E) operand, rows in the caller's order (rng.py)."""
     from . import autograd_ops as A
+    from . import rng
     cell = enc.lstm_encoder_cell
     lens = seq_len.reshape(-1)
     tmax = int(lens.max().item())
-    emb = enc.embed.dropout(A.embed_relu(seq[:, :tmax], enc.embed.embedding.weight))
+    seed = rng.next_seed() if seed is None else seed
+    emb = A.philox_dropout(A.embed_relu(seq[:, :tmax], enc.embed.embedding.weight), enc.embed.dropout.p, seed,
+                           rng.offset(rng.SITE_ENC_EMBED if site is None else site), enc.embed.training)
     H, M, h_last = A.encoder_lstm(emb, lens, cell.x2h.weight, cell.x2h.bias, cell.h2h.weight, cell.h2h.bias)
     mask = (M.detach().sum(2) != 0).float()
     final_hidden = A.linear(h_last, enc.affine_hn.weight, enc.affine_hn.bias, _lib.ACT_TANH)
@@ -306,8 +314,10 @@ class VisualAttentionC(nn.Module):
             if self.adaptive:
                 raise NotImplementedError("direct differentiable calls of the adaptive VisualAttentionC go through "
                                           "DecoderC.forward (editnet_adaptive.py:438-457)")
+            from . import rng
             X = _f32c(image_features)
-            fe = self.att_embed[2](A.linear(X, self.att_embed[0].weight, self.att_embed[0].bias, _lib.ACT_RELU))
+            fe = A.philox_dropout(A.linear(X, self.att_embed[0].weight, self.att_embed[0].bias, _lib.ACT_RELU),
+                                  self.att_embed[2].p, rng.next_seed(), rng.offset(rng.SITE_REGION), self.training)
             att1 = A.linear(fe, self.features_att.weight, self.features_att.bias)
             return A.visual_attention_from_att1(X, att1, _f32c(decoder_hidden), self.decoder_att.weight,
                                                 self.decoder_att.bias, self.full_att.weight, self.full_att.bias)
@@ -398,7 +408,7 @@ class DecoderC(nn.Module):
     # ---- runtime state is NOT part of the module's persistent state --------------------------------------
     # The reference checkpoints pickle the whole module (editnet.py:168-175, `'decoder': decoder`) and callers may
     # copy.deepcopy a decoder: GPU workspaces, the derived token table and the last autograd graph must not travel.
-    _RUNTIME_ATTRS = ("_ws", "_ws_key", "_ws_cache", "_tok_state", "_last_hidden")
+    _RUNTIME_ATTRS = ("_ws", "_ws_key", "_ws_cache", "_tok_state", "_last_hidden", "_fwd_seed", "_fed_tokens")
 
     def __getstate__(self):
         state = dict(self.__dict__)
@@ -467,7 +477,8 @@ class DecoderC(nn.Module):
         cell = self.caption_encoder.lstm_encoder_cell
         src = (self.embed.embedding.weight, self.attention_lstm.weight_ih, self.caption_attention.tc_affine.weight,
                self.caption_attention.context_gate.weight, cell.x2h.weight, cell.x2h.bias)
-        sig = tuple((t.data_ptr(), t._version) for t in src)
+        from . import optim as _optim
+        sig = tuple((t.data_ptr(), t._version) for t in src) + (_optim.weights_epoch(),)
         st = self.__dict__.setdefault("_tok_state", {"sig": None, "seen": 0, "table": None})
         if st["sig"] != sig:
             st.update(sig=sig, seen=1, table=None)
@@ -538,7 +549,7 @@ class DecoderC(nn.Module):
         lib = _lib.load()
         dev = image_features.device
         batch_size = encoded_captions.size(0)
-        caption_lengths, sort_ind = caption_lengths.squeeze(1).sort(dim=0, descending=True)
+        caption_lengths, sort_ind = caption_lengths.squeeze(1).sort(dim=0, descending=True, stable=True)
         X = _f32c(image_features[sort_ind])
         encoded_captions = _i64c(encoded_captions[sort_ind])
         prev = _i64c(encoded_previous_captions[sort_ind])
@@ -558,16 +569,19 @@ class DecoderC(nn.Module):
 
 
     # ---- grad-enabled path -------------------------------------------------------------------
-    def _encoder_autograd(self, seq, seq_len):
-        return _caption_encoder_autograd(self.caption_encoder, seq, seq_len)
+    def _encoder_autograd(self, seq, seq_len, seed=None, site=None):
+        return _caption_encoder_autograd(self.caption_encoder, seq, seq_len, seed, site)
 
     def _forward_autograd(self, image_features, encoded_captions, caption_lengths, encoded_previous_captions,
                           previous_cap_length, use_ss, ss_prob, image_mean=None):
         """The reference loop (editnet.py:479-548), one autograd-wrapped HIP operator per module call."""
         from . import autograd_ops as A
+        from . import rng
         dev = image_features.device
         batch_size = encoded_captions.size(0)
-        caption_lengths, sort_ind = caption_lengths.squeeze(1).sort(dim=0, descending=True)
+        # (stable: rows of equal length keep their input order — any order is a valid outcome of the reference's unstable
+        # sort, this one makes the row <-> dropout-stream assignment a function of the inputs alone)
+        caption_lengths, sort_ind = caption_lengths.squeeze(1).sort(dim=0, descending=True, stable=True)
         X = _f32c(image_features[sort_ind])
         encoded_captions = encoded_captions[sort_ind]
         prev = encoded_previous_captions[sort_ind]
@@ -576,7 +590,11 @@ class DecoderC(nn.Module):
         h2, c2 = self.init_hidden_state(batch_size)
         decode_lengths = (caption_lengths - 1).tolist()
         preds_t = []
-        H, M, final_hidden, mask = self._encoder_autograd(prev, plen)
+        # ONE seed per forward call; every dropout / sampling site is its own Philox offset (rng.py)
+        seed = self.__dict__["_fwd_seed"] = rng.next_seed()
+        p_emb, p_reg, p_out = self.embed.dropout.p, self.visual_attention.att_embed[2].p, self.dropout.p
+        training = self.training
+        H, M, final_hidden, mask = self._encoder_autograd(prev, plen, seed)
         mean = X.mean(1) if image_mean is None else image_mean[sort_ind]
         ca, va, cl, al = self.caption_attention, self.visual_attention, self.copy_lstm, self.attention_lstm
         E = self.embed.embedding.weight
@@ -591,8 +609,8 @@ class DecoderC(nn.Module):
         # as the reference writes it; values and gradients are those of the reference for the same masks.
         Y = A.linear(X, va.att_embed[0].weight, va.att_embed[0].bias, _lib.ACT_RELU)
 
-        def embed_regions(Yb, vb):
-            fe = va.att_embed[2](Yb)                    # fresh dropout mask per call in train mode
+        def embed_regions(Yb, vb, t=0):
+            fe = A.philox_dropout(Yb, p_reg, seed, rng.offset(rng.SITE_REGION, t), training)   # fresh mask per timestep
             if vb is None:
                 return fe, None
             fe = fe * vb
@@ -603,8 +621,7 @@ class DecoderC(nn.Module):
             from . import xe_sequence as S
             Yv = Y if valid is None else Y * valid      # adaptive: padded regions stay exactly zero through the dropout
             Yin = Yv if self.training else A.linear(Yv, va.features_att.weight, va.features_att.bias)
-            cfg = S.SeqConfig(decode_lengths, self.training, self.embed.dropout.p, va.att_embed[2].p, self.dropout.p,
-                              int(torch.randint(0, 2 ** 62, (1,)).item()))
+            cfg = S.SeqConfig(decode_lengths, self.training, p_emb, p_reg, p_out, seed)
             if use_ss and ss_prob > 0.0:
                 cfg.ss_prob = float(ss_prob)
             if self._adaptive:
@@ -614,13 +631,17 @@ class DecoderC(nn.Module):
                                 S.decoder_params(self))
             if self._adaptive:
                 out, self._last_hidden = out
+            if cfg.ss_prob > 0.0:
+                self.__dict__["_fed_tokens"] = cfg.fed_tokens       # (T, B) words the steps consumed (diagnostics / tests)
             return out, encoded_captions, decode_lengths, sort_ind
 
         att1_eval = rmask_eval = None
         if not self.training:            # dropout inactive: features_att(att_embed(X)) is loop invariant
             fe, rmask_eval = embed_regions(Y, valid)
             att1_eval = A.linear(fe, va.features_att.weight, va.features_att.bias)
-        prev_scores = None
+        prev_scores = ss_coin = None
+        if use_ss and ss_prob > 0.0:
+            fed = self.__dict__["_fed_tokens"] = encoded_captions[:, :max(decode_lengths)].t().clone()
         last_parts = []                  # rows leaving the batch after this step, with their final h2 (adaptive :560)
 
         def head(x, n):                  # x[:n] without a SliceBackward (zero-fill + copy of the whole tensor) when n is all rows
@@ -634,13 +655,14 @@ class DecoderC(nn.Module):
             bt = sum([l > t for l in decode_lengths])
             it = encoded_captions[:bt, t]
             if use_ss and t >= 1 and ss_prob > 0.0:                                   # editnet.py:508-520
-                sample_mask = torch.zeros(bt, device=dev).uniform_(0, 1) < ss_prob
-                if sample_mask.sum() != 0:
-                    sample_ind = sample_mask.nonzero().view(-1)
-                    it = it.clone()
-                    prob_prev = torch.exp(prev_scores[:bt].detach())
-                    it.index_copy_(0, sample_ind, torch.multinomial(prob_prev, 1).view(-1).index_select(0, sample_ind))
-            emb = self.embed.dropout(A.embed_relu(it, E))
+                # the coin and the draw come from the same Philox streams as on the whole-sequence node (rng.py)
+                if ss_coin is None:
+                    ss_coin = (rng.uniforms(max(decode_lengths) * batch_size, seed, rng.offset(rng.SITE_SS_COIN), dev)
+                               < ss_prob).view(-1, batch_size)
+                drawn = A.philox_categorical(prev_scores[:bt].detach(), seed, rng.offset(rng.SITE_SS_DRAW, t))
+                it = torch.where(ss_coin[t, :bt], drawn, it)
+                fed[t, :bt] = it
+            emb = A.philox_dropout(A.embed_relu(it, E), p_emb, seed, rng.offset(rng.SITE_EMBED, t), training)
             x1 = torch.cat([emb, head(final_hidden, bt), head(h2, bt), head(mean, bt)], 1)
             h1, c1 = A.lstm_cell(x1, head(h1, bt), head(c1, bt), al.weight_ih, al.weight_hh, al.bias_ih, al.bias_hh)
             attend_cap, alpha_c = A.caption_attention(
@@ -651,7 +673,7 @@ class DecoderC(nn.Module):
             if att1_eval is not None:
                 att1, rmask = head(att1_eval, bt), (None if rmask_eval is None else head(rmask_eval, bt))
             else:                                                                     # fresh dropout mask per step
-                fe, rmask = embed_regions(head(Y, bt), None if valid is None else head(valid, bt))
+                fe, rmask = embed_regions(head(Y, bt), None if valid is None else head(valid, bt), t)
                 att1 = A.linear(fe, va.features_att.weight, va.features_att.bias)
             attend_img = A.visual_attention_from_att1(head(X, bt), att1, h1, va.decoder_att.weight, va.decoder_att.bias,
                                                       va.full_att.weight, va.full_att.bias, rmask)
@@ -662,10 +684,11 @@ class DecoderC(nn.Module):
             bt_next = sum([l > t + 1 for l in decode_lengths])
             if bt_next < bt:
                 last_parts.append(h2[bt_next:bt])
+            h2d = A.philox_dropout(h2, p_out, seed, rng.offset(rng.SITE_OUT, t), training)
             if batch_fc:
-                h2_t.append(self.dropout(h2))
+                h2_t.append(h2d)
                 continue
-            preds = A.linear(self.dropout(h2), self.fc.weight, self.fc.bias)
+            preds = A.linear(h2d, self.fc.weight, self.fc.bias)
             prev_scores = preds
             if bt < batch_size:
                 preds = torch.cat([preds, preds.new_zeros(batch_size - bt, preds.shape[1])], 0)

@@ -33,7 +33,10 @@ class DecoderC(_DecoderXE):
         sorted_lengths = caption_lengths.squeeze(1)[sort_ind].unsqueeze(1)
         if pred.requires_grad:           # grad-enabled path: both extra outputs stay in the autograd graph (MSE loss :594-596)
             decoder_last_hidden = self.__dict__.pop("_last_hidden")        # do not keep the graph alive on the module
-            _, _, gd_final_hidden, _ = self._encoder_autograd(caps_sorted, sorted_lengths)
+            from . import rng
+            # editnet_adaptive.py:516: the second encoder pass shares the forward call's seed at its own site (rng.py)
+            _, _, gd_final_hidden, _ = self._encoder_autograd(caps_sorted, sorted_lengths, self.__dict__.pop("_fwd_seed", None),
+                                                              rng.SITE_ENC2_EMBED)
             return pred, caps_sorted, decode_lengths, sort_ind, gd_final_hidden, decoder_last_hidden
         dims = self._dims(B, encoded_previous_captions.shape[1], image_features.shape[1], max(decode_lengths))
         # decoder_last_hidden[:bt] = h2 at every step (:560) == the h2 state left in the workspace

@@ -46,9 +46,11 @@ class DecoderC(_DecoderXE):
         seq = torch.empty(B, max_len, dtype=torch.long, device=dev)
         seq_logp = torch.empty(B, max_len, dtype=torch.float32, device=dev)
         if sample_rl:        # multinomial sampling, eval mode, no gradients: fused device loop with the Philox epilogue
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item())          # torch.manual_seed() makes it reproducible
+            from . import rng
+            seed = rng.next_seed()                                      # torch.manual_seed() makes it reproducible
             check(lib.set_editnet_sample(C.byref(w), C.byref(dims), ptr(X), ptr(mean), ptr(prev), ptr(plen),
-                                         int(word_map['<start>']), int(word_map['<end>']), max_len, seed, 0, ptr(seq),
+                                         int(word_map['<start>']), int(word_map['<end>']), max_len, seed,
+                                         rng.offset(rng.SITE_ROLLOUT), ptr(seq),
                                          ptr(seq_logp), ptr(ws), ws.numel(), stream_of(dev)), "set_editnet_sample")
             return seq, seq_logp
         check(lib.set_editnet_greedy(C.byref(w), C.byref(dims), ptr(X), ptr(mean), ptr(prev), ptr(plen),
@@ -64,8 +66,13 @@ class DecoderC(_DecoderXE):
         log-prob gather, <end> / unfinished / break bookkeeping on the device): the sampled loop never synchronises
         with the host (the reference does every step, editnet_rl.py:546)."""
         from . import autograd_ops as A
+        from . import rng
         if self._adaptive:
             raise NotImplementedError("rollout with adaptive features is not built yet")
+        # ONE seed per forward call: dropout sites and the multinomial draws are separate Philox offsets of it (rng.py)
+        seed = self.__dict__["_fwd_seed"] = rng.next_seed()
+        training = self.training
+        p_emb, p_reg, p_out = self.embed.dropout.p, self.visual_attention.att_embed[2].p, self.dropout.p
         dev = image_features.device
         X = _f32c(image_features)
         B, max_len = X.shape[0], self.max_len
@@ -74,7 +81,7 @@ class DecoderC(_DecoderXE):
         it = torch.full((B,), int(word_map['<start>']), dtype=torch.long, device=dev)
         h1, c1 = self.init_hidden_state(B)
         h2, c2 = self.init_hidden_state(B)
-        H, M, final_hidden, mask = self._encoder_autograd(encoded_previous_captions, previous_cap_length)
+        H, M, final_hidden, mask = self._encoder_autograd(encoded_previous_captions, previous_cap_length, seed)
         mean = X.mean(1) if image_mean is None else image_mean
         ca, va, cl, al = self.caption_attention, self.visual_attention, self.copy_lstm, self.attention_lstm
         E = self.embed.embedding.weight
@@ -89,19 +96,18 @@ class DecoderC(_DecoderXE):
             # the sampled rollout as ONE autograd node (xe_sequence.py, rollout mode): the same kernels, logs instead of
             # per-step autograd nodes; the final, unused step of the reference loop (t == max_len) is not run
             from . import xe_sequence as S
-            sample_seed = int(torch.randint(0, 2 ** 62, (1,)).item())      # first draw, as A.SampleState does on the per-operator route
-            cfg = S.SeqConfig([], self.training, self.embed.dropout.p, va.att_embed[2].p, self.dropout.p,
-                              int(torch.randint(0, 2 ** 62, (1,)).item()),
+            cfg = S.SeqConfig([], training, p_emb, p_reg, p_out, seed,
                               rollout=dict(max_len=max_len, start_idx=int(word_map['<start>']), end_idx=int(word_map['<end>']),
-                                           seed=sample_seed))
+                                           seed=seed, offset=rng.offset(rng.SITE_ROLLOUT)))
             return S.xe_sequence(cfg, X, mean, H, M, final_hidden, mask, att1_c_all, Y if self.training else att1_eval,
                                  torch.zeros(1, 1, dtype=torch.long, device=dev), S.decoder_params(self))
         unfinished = None
-        state = A.SampleState(B, max_len, word_map['<start>'], word_map['<end>'], dev) if sample_rl else None
+        state = (A.SampleState(B, max_len, word_map['<start>'], word_map['<end>'], dev, seed=seed,
+                               offset=rng.offset(rng.SITE_ROLLOUT)) if sample_rl else None)
         for t in range(max_len + 1):
             if sample_rl:
                 it = state.tokens[t]
-            emb = self.embed.dropout(A.embed_relu(it, E))
+            emb = A.philox_dropout(A.embed_relu(it, E), p_emb, seed, rng.offset(rng.SITE_EMBED, t), training)
             h1, c1 = A.lstm_cell(torch.cat([emb, final_hidden, h2, mean], 1), h1, c1, al.weight_ih, al.weight_hh,
                                  al.bias_ih, al.bias_hh)
             attend_cap, alpha_c = A.caption_attention(
@@ -112,14 +118,16 @@ class DecoderC(_DecoderXE):
             if att1_eval is not None:
                 att1 = att1_eval
             else:
-                att1 = A.linear(va.att_embed[2](Y), va.features_att.weight, va.features_att.bias)
+                att1 = A.linear(A.philox_dropout(Y, p_reg, seed, rng.offset(rng.SITE_REGION, t), training),
+                                va.features_att.weight, va.features_att.bias)
             attend_img = A.visual_attention_from_att1(X, att1, h1, va.decoder_att.weight, va.decoder_att.bias,
                                                       va.full_att.weight, va.full_att.bias)
             sel = A.select(M, alpha_c)
             h2, c2 = A.copy_lstm(torch.cat([h1, attend_cap, attend_img], 1), h2, c2, sel, cl.x2h.weight, cl.x2h.bias,
                                  cl.h2h.weight, cl.h2h.bias, cl.gate_cnew.weight, cl.gate_cnew.bias,
                                  cl.gate_cmem.weight, cl.gate_cmem.bias)
-            logits = A.linear(self.dropout(h2), self.fc.weight, self.fc.bias)
+            logits = A.linear(A.philox_dropout(h2, p_out, seed, rng.offset(rng.SITE_OUT, t), training),
+                              self.fc.weight, self.fc.bias)
             if t == max_len:
                 break
             if sample_rl:                # editnet_rl.py:521-543 on the device, no host sync

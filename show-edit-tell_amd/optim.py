@@ -20,6 +20,19 @@ from ._lib import check, stream_of
 
 _FUSED = os.environ.get("SET_FUSED_ADAM", "1") != "0"
 _ws = {}
+# Process-wide count of weight updates done behind autograd's back (raw-pointer kernels, collectives on `.data`).  Part of
+# the token tables' cache signature next to (data_ptr, _version), so ANY such writer invalidates every derived table even
+# when it cannot name the tensors it touched.
+_weights_epoch = 0
+
+
+def weights_epoch():
+    return _weights_epoch
+
+
+def bump_weights_epoch():
+    global _weights_epoch
+    _weights_epoch += 1
 
 
 def _plain_adam(opt):
@@ -72,9 +85,10 @@ def clip_grad_norm_and_step(parameters, optimizer, max_norm, scale_grads=False):
         if not (m.is_contiguous() and v.is_contiguous() and m.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0 and
                 m.device == dev and v.device == dev and st["step"].device.type == "cpu"):
             raise _lib.SetError("Adam state of a parameter is not a dense fp32 device tensor with a host step counter")
-        st["step"] += 1
         P[i], G[i], M[i], V[i] = p.data_ptr(), p.grad.data_ptr(), m.data_ptr(), v.data_ptr()
-        numel[i], step[i] = p.numel(), int(st["step"].item())
+        # the step counters only advance once the launch has been accepted (below): an error half-way through the
+        # marshalling must not skew the bias correction of the parameters already visited
+        numel[i], step[i] = p.numel(), int(st["step"].item()) + 1
         lr[i], b1[i], b2[i], eps[i], wd[i] = g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"]
     nbytes = lib.set_clip_adam_workspace_bytes(n, numel)
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
@@ -84,4 +98,16 @@ def clip_grad_norm_and_step(parameters, optimizer, max_norm, scale_grads=False):
     norm = torch.empty((), dtype=torch.float32, device=dev)
     check(lib.set_clip_adam_f32(n, P, G, M, V, numel, step, lr, b1, b2, eps, wd, float(max_norm), int(bool(scale_grads)),
                                 norm.data_ptr(), ws.data_ptr(), ws.numel(), stream_of(dev)), "set_clip_adam_f32")
+    touched = []
+    for p, _ in todo:
+        st = optimizer.state[p]
+        st["step"] += 1
+        touched += [p, st["exp_avg"], st["exp_avg_sq"]]
+    # The kernel wrote through raw pointers.  torch.optim.Adam's in-place ops bump tensor._version, and the modules'
+    # derived caches (the inference-time token tables, editnet.py / dcnet.py `_token_table`) key on it: bump it here
+    # too, so that a no-grad decode after this step never reads a table built from the old weights.
+    if scale_grads:
+        touched += [p.grad for p, _ in todo]
+    torch.autograd.graph.increment_version(touched)
+    bump_weights_epoch()
     return norm

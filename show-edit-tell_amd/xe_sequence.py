@@ -29,6 +29,7 @@ import torch
 
 from . import _lib
 from . import autograd_ops as A
+from . import rng
 from ._lib import EditNetWeights, check, ptr, stream_of
 
 PARAM_NAMES = (
@@ -210,7 +211,7 @@ class _XESequence(torch.autograd.Function):
         cap_stride = caps.stride(0) if (ro is None and not ss) else 1
         if ss:
             L["TOK"] = caps[:, :T].t().contiguous()            # (T, B) words actually fed; rows of step t >= 1 may be replaced
-            ss_u = torch.rand(T, B, device=dev) < cfg.ss_prob
+            ss_u = (rng.uniforms(T * B, cfg.seed, rng.offset(rng.SITE_SS_COIN), dev) < cfg.ss_prob).view(T, B)
             ss_raw = torch.empty(B, dtype=torch.long, device=dev)
             ss_i64 = torch.zeros(2, B, dtype=torch.long, device=dev)
             ss_i32 = torch.zeros(B + T + 4, dtype=torch.int32, device=dev)
@@ -218,11 +219,11 @@ class _XESequence(torch.autograd.Function):
             pred_tb = _z(T, B, V, dev=dev)
         state = None
         if ro is not None:
-            state = A.SampleState(B, T, ro["start_idx"], ro["end_idx"], dev, seed=ro.get("seed"))
+            state = A.SampleState(B, T, ro["start_idx"], ro["end_idx"], dev, seed=ro.get("seed"), offset=ro.get("offset", 0))
             L["LOGITS"] = _e(T, B, V, dev=dev)
             L["RAW"] = torch.empty(T, B, dtype=torch.long, device=dev)
             L["LSE"], L["LOGP"] = _e(T, B, dev=dev), _e(T, B, dev=dev)
-        scale_off = lambda site, t: (site << 40) | t
+        scale_off = rng.offset              # (site, t) -> Philox offset; sites 1 = embedding, 2 = regions, 3 = h2 before fc, 4 = SS draw
 
         # editnet.py:441-443 in train mode: att1(t) = features_att(dropout_t(relu(att_embed(X)))) does not depend on the
         # recurrent state, so all T region projections run as ONE (T*B*R, D) x (D, A) product before the loop (19 products of
@@ -409,8 +410,9 @@ class _XESequence(torch.autograd.Function):
                 if bt > b0:
                     ops.pack(DH2[b0:], bt - b0, [dlast[b0:bt]], accumulate=True)
             # h2(t) -> fc (through the output dropout); the recurrent / next-step terms are already in DH2
-            if train and cfg.p_out > 0:
-                ops.dropout_bwd(dH2D[t], L["H2D"][t], DH2, bt, D, sc_out, True)
+            if train and cfg.p_out > 0:    # h2 does not follow a ReLU: the mask is regenerated, not read off the zero pattern
+                check(lib.set_dropout_bwd_philox_f32(dH2D[t].data_ptr(), D, DH2.data_ptr(), D, bt, D, cfg.p_out, cfg.seed,
+                                                     rng.offset(rng.SITE_OUT, t), 1, st), "set_dropout_bwd_philox_f32")
             else:
                 ops.pack(DH2, bt, [dH2D[t]], accumulate=True)
             # ---- CopyLSTMCellC backward (editnet.py:265-285)

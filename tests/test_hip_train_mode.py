@@ -1,0 +1,250 @@
+"""GPU: TRAIN-MODE (dropout on) forward + backward of both grad-enabled routes against the REFERENCE's own autograd.
+
+tests/golden/train_*.npz were produced by oracle/make_train_golden.py: the reference's classes in train() mode, every
+nn.Dropout replaced by a module that applies the Philox keep masks of show_edit_tell_amd/rng.py (regenerated in numpy),
+the reference's as-written forward (region embedding recomputed per timestep, nothing hoisted) + loss.backward().  With
+`rng.dropout_seed(seed)` the HIP routes draw the same masks: scores within 1e-4, every parameter gradient within 1e-4
+relative.  This is what pins the train-mode-only optimisations (relu(att_embed X) contracted once per sequence with its
+weight gradient from the sum over timesteps of the masked upstream gradients, the all-timestep region projection, the
+loop-invariant LSTM columns) and the dropout kernels themselves (one mask per site and timestep, 1 / (1 - p) scaling,
+backward through the mask) to the reference — not to the package's other route."""
+import contextlib
+
+import numpy as np
+import pytest
+import torch
+
+import parity
+from hip_adapter import adaptive_module, dcnet_modules, editnet_modules, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _check_pred(pred, g, pre, V, small, dl):
+    pred = _np(pred)
+    if small:
+        parity.assert_close(pred, g[pre + "pred"], parity.LOGIT_TOL, pre + "scores")
+        return
+    B, Tm = pred.shape[:2]
+    rows = [(b, t) for b in range(B) for t in range(Tm) if t < dl[b]]
+    bi, ti = np.array([r[0] for r in rows]), np.array([r[1] for r in rows])
+    gs = {k: v[bi, ti] for k, v in g.items() if k.startswith(pre + "pred_")}
+    parity.check_logit_summary(pred[bi, ti], gs, pre + "pred_", V, what=pre + "scores")
+    pad = np.array([[t >= dl[b] for t in range(Tm)] for b in range(B)])
+    assert not pred[pad].any()
+
+
+def _check_grads(mod, g, pre, what):
+    floor = 1e-6 * max(float(g[pre + "gradnorm." + k]) for k, _ in mod.named_parameters())
+    worst = 0.0
+    for k, p in mod.named_parameters():
+        assert p.grad is not None, k
+        got = p.grad.detach().cpu().numpy()
+        gn = float(g[pre + "gradnorm." + k])
+        mine = float(np.sqrt((got.astype(np.float64) ** 2).sum()))
+        assert abs(mine - gn) <= 1e-4 * gn + floor, (what, k, mine, gn)
+        if pre + "grad." + k in g:
+            ref = g[pre + "grad." + k]
+            err, scale = np.abs(got - ref).max(), max(np.abs(ref).max(), 1e-6)
+            worst = max(worst, err / scale)
+            assert err <= 1e-4 * scale + floor, (what, k, err, scale)
+        else:
+            ref = g[pre + "gradslice." + k]
+            sl = got.reshape(-1)[:: max(1, got.size // 64)][:64]
+            assert np.abs(sl - ref).max() <= 1e-4 * max(np.abs(ref).max(), gn / np.sqrt(got.size)) + floor, (what, k)
+    print(what, "worst relative gradient error", worst)
+
+
+def _routes(monkeypatch, seq):
+    from show_edit_tell_amd import editnet
+    monkeypatch.setattr(editnet, "_XE_SEQUENCE", seq)
+
+
+@pytest.mark.parametrize("seq", [True, False], ids=["sequence-node", "per-operator"])
+@pytest.mark.parametrize("deferred", [False, True], ids=["immediate", "deferred"])
+@pytest.mark.parametrize("name", ["editnet_small", "editnet_full_b4"])
+def test_editnet_train_mode_vs_reference_autograd(name, deferred, seq, monkeypatch):
+    from show_edit_tell_amd import rng
+    from show_edit_tell_amd.autograd_ops import deferred_param_grads
+    from show_edit_tell_amd.train import xe_loss_sum
+    _routes(monkeypatch, seq)
+    d, xe, _ = editnet_modules(name)
+    g = parity.load("train_" + name)
+    c = d["case"]
+    xe.train()
+    with rng.dropout_seed(int(g["train.seed"])):
+        pred, caps_s, dl, sort_ind = xe(to_dev(d["X"]), to_dev(d["caps"]), to_dev(d["clen"]), to_dev(d["prev"]),
+                                        to_dev(d["plen"]), False, 0.0)
+    assert np.array_equal(_np(sort_ind), g["train.sort_ind"])
+    _check_pred(pred, g, "train.", c["V"], c["D"] < 1024, dl)
+    loss_sum, n_tok, _, _ = xe_loss_sum(pred, caps_s, dl)
+    loss = loss_sum / n_tok
+    assert abs(float(loss.detach()) - float(g["train.loss"])) < 1e-4
+    with (deferred_param_grads() if deferred else contextlib.nullcontext()):
+        loss.backward()
+    _check_grads(xe, g, "train.", "%s train-mode %s" % (name, "node" if seq else "per-op"))
+
+
+@pytest.mark.parametrize("seq", [True, False], ids=["sequence-node", "per-operator"])
+def test_editnet_scheduled_sampling_vs_reference_autograd(seq, monkeypatch):
+    """editnet.py:508-520 in train mode: the coin and the draw are Philox streams too; the reference was fed the same coin
+    and the inverse-CDF draws from ITS OWN previous-step scores — the device must feed the same words and then match scores
+    and gradients"""
+    from show_edit_tell_amd import rng
+    from show_edit_tell_amd.train import xe_loss_sum
+    _routes(monkeypatch, seq)
+    name = "editnet_small"
+    d, xe, _ = editnet_modules(name)
+    g = parity.load("train_" + name)
+    c = d["case"]
+    xe.train()
+    ssp = float(g["train_ss.ss_prob"])
+    with rng.dropout_seed(int(g["train_ss.seed"])):
+        pred, caps_s, dl, sort_ind = xe(to_dev(d["X"]), to_dev(d["caps"]), to_dev(d["clen"]), to_dev(d["prev"]),
+                                        to_dev(d["plen"]), True, ssp)
+    fed, ref = _np(xe._fed_tokens), g["train_ss.fed_tokens"]
+    bts = [sum(1 for l in dl if l > t) for t in range(max(dl))]
+    assert int(g["train_ss.n_replaced"]) >= 10
+    for t, bt in enumerate(bts):            # (rows that left the batch are not fed at all)
+        assert np.array_equal(fed[t, :bt], ref[t, :bt]), ("words fed at step %d differ" % t, fed[t, :bt], ref[t, :bt])
+    _check_pred(pred, g, "train_ss.", c["V"], True, dl)
+    loss_sum, n_tok, _, _ = xe_loss_sum(pred, caps_s, dl)
+    loss = loss_sum / n_tok
+    assert abs(float(loss.detach()) - float(g["train_ss.loss"])) < 1e-4
+    loss.backward()
+    _check_grads(xe, g, "train_ss.", "scheduled sampling %s" % ("node" if seq else "per-op"))
+
+
+@pytest.mark.parametrize("seq", [True, False], ids=["sequence-node", "per-operator"])
+def test_adaptive_train_mode_vs_reference_autograd(seq, monkeypatch):
+    """adaptive features (editnet_adaptive.py:438-457, 489-562) in train mode: the region dropout acts on the packed valid
+    rows, the score mask is re-derived from every step's dropped-out embedding, the ground-truth captions go through the
+    encoder too (its own dropout site), loss = CE + MSE(decoder_last_hidden, gd_final_hidden)"""
+    from show_edit_tell_amd import rng
+    from show_edit_tell_amd.train import xe_loss_sum
+    _routes(monkeypatch, seq)
+    name = "editnet_adaptive_small"
+    d, xe = adaptive_module(name)
+    g = parity.load("train_" + name)
+    c = d["case"]
+    xe.train()
+    with rng.dropout_seed(int(g["train.seed"])):
+        pred, caps_s, dl, sort_ind, gd_fh, last_h = xe(to_dev(d["X"]), to_dev(d["image_mean"]), to_dev(d["caps"]),
+                                                       to_dev(d["clen"]), to_dev(d["prev"]), to_dev(d["plen"]), False, 0.0)
+    assert np.array_equal(_np(sort_ind), g["train.sort_ind"])
+    _check_pred(pred, g, "train.", c["V"], True, dl)
+    parity.assert_close(_np(gd_fh), g["train.gd_final"], parity.STATE_TOL, "gd_final_hidden")
+    parity.assert_close(_np(last_h), g["train.last_hidden"], parity.STATE_TOL, "decoder_last_hidden")
+    loss_sum, n_tok, _, _ = xe_loss_sum(pred, caps_s, dl)
+    loss = loss_sum / n_tok + torch.nn.functional.mse_loss(last_h, gd_fh)
+    assert abs(float(loss.detach()) - float(g["train.loss"])) < 1e-4
+    loss.backward()
+    _check_grads(xe, g, "train.", "adaptive train-mode %s" % ("node" if seq else "per-op"))
+
+
+@pytest.mark.parametrize("seq", [True, False], ids=["sequence-node", "per-operator"])
+@pytest.mark.parametrize("name", ["dcnet_small", "dcnet_full_b4"])
+def test_dcnet_train_mode_vs_reference_autograd(name, seq, monkeypatch):
+    from show_edit_tell_amd import rng
+    from show_edit_tell_amd.autograd_ops import deferred_param_grads
+    from show_edit_tell_amd.train import xe_loss_sum
+    _routes(monkeypatch, seq)
+    g = parity.load("train_" + name)
+    for deferred in (False, True):
+        d, dae, _ = dcnet_modules(name)
+        c = d["case"]
+        dae.train()
+        with rng.dropout_seed(int(g["train.seed"])):
+            pred, caps_s, dl, sort_ind = dae(to_dev(d["caps"]), to_dev(d["clen"]), to_dev(d["prev"]), to_dev(d["plen"]))
+        assert np.array_equal(_np(sort_ind), g["train.sort_ind"])
+        _check_pred(pred, g, "train.", c["V"], c["D"] < 1024, dl)
+        loss_sum, n_tok, _, _ = xe_loss_sum(pred, caps_s, dl)
+        loss = loss_sum / n_tok
+        assert abs(float(loss.detach()) - float(g["train.loss"])) < 1e-4
+        with (deferred_param_grads() if deferred else contextlib.nullcontext()):
+            loss.backward()
+        _check_grads(dae, g, "train.", "%s train-mode %s" % (name, "node" if seq else "per-op"))
+
+
+def test_dropout_masks_equal_the_numpy_streams():
+    """the device keep masks are exactly oracle/philox_np.dropout_keep (what the goldens were generated with); the
+    mask-regenerating backward passes the gradient of an exactly-zero kept input; coin uniforms and the categorical draw
+    match their numpy statements"""
+    from oracle import philox_np as PH
+    from show_edit_tell_amd import autograd_ops as A, rng
+    dev = torch.device("cuda:0")
+    seed, off = 0x1234_5678_9ABC_DE, rng.offset(rng.SITE_REGION, 7)
+    x = torch.ones(37, 64, device=dev)
+    x[3, 5] = 0.0                           # an exactly-zero input
+    xr = x.clone().requires_grad_(True)
+    y = A.philox_dropout(xr, 0.5, seed, off)
+    keep = PH.dropout_keep(seed, off, 37, 64, 0.5)
+    assert keep[3, 5] or True
+    want = np.where(keep, 2.0, 0.0).astype(np.float32)
+    want[3, 5] = 0.0
+    assert np.array_equal(_np(y), want)
+    y.sum().backward()
+    assert np.array_equal(_np(xr.grad), np.where(keep, 2.0, 0.0).astype(np.float32))     # incl. (3, 5) if it was kept
+    for p in (0.1, 0.9):
+        k = PH.dropout_keep(seed, off, 16, 128, p)
+        got = _np(A.philox_dropout(torch.ones(16, 128, device=dev), p, seed, off)) != 0
+        assert np.array_equal(got, k)
+    u = _np(rng.uniforms(101, seed, rng.offset(rng.SITE_SS_COIN), dev))
+    assert np.array_equal(u, PH.uniforms(101, seed, PH.site_offset(PH.SITE_SS_COIN)))
+    gen = torch.Generator().manual_seed(3)
+    for V in (203, 10000):
+        lg = (torch.randn(64, V, generator=gen) * 3).to(dev)
+        ids = _np(A.philox_categorical(lg, seed, rng.offset(rng.SITE_SS_DRAW, 4)))
+        ref, margin = PH.categorical_draw(_np(lg), seed, PH.site_offset(PH.SITE_SS_DRAW, 4))
+        ok = margin > 1e-5
+        assert ok.mean() > 0.9 and np.array_equal(ids[ok], ref[ok])
+
+
+def test_fused_optimizer_step_invalidates_the_token_table(monkeypatch):
+    """editnet.py:580-581 through optim.clip_grad_norm_and_step (a raw-pointer kernel) while the module STAYS in eval
+    mode (no train()/eval() flip to hide it): the next no-grad forward must not read a token table built from the old
+    weights — it has to equal a forward with the table disabled, bit for bit"""
+    from show_edit_tell_amd import optim
+    from show_edit_tell_amd.train import xe_backward
+    d, xe, rl = editnet_modules("editnet_small")
+    xargs = (to_dev(d["X"]), to_dev(d["caps"]), to_dev(d["clen"]), to_dev(d["prev"]), to_dev(d["plen"]))
+    xe.eval()
+    opt = torch.optim.Adam(xe.parameters(), lr=5e-2)
+    with torch.no_grad():
+        xe(*xargs, False, 0.0)
+        pred0 = xe(*xargs, False, 0.0)[0].clone()
+    assert xe._tok_state["table"] is not None
+    v0 = xe.embed.embedding.weight._version
+    xe_backward(xe, *xargs)                                   # eval-mode fine-tuning step: the mode is not toggled
+    assert not xe.training
+    optim.clip_grad_norm_and_step([p for p in xe.parameters() if p.grad is not None], opt, 0.25)
+    assert xe.embed.embedding.weight._version > v0, "the raw-pointer update must bump tensor._version"
+    with torch.no_grad():
+        pred1 = xe(*xargs, False, 0.0)[0].clone()             # first call after the update: the old table is dropped
+        assert xe._tok_state["table"] is None
+        pred2 = xe(*xargs, False, 0.0)[0].clone()             # rebuilt from the NEW weights
+        assert xe._tok_state["table"] is not None
+        monkeypatch.setenv("SET_TOKEN_TABLE", "0")
+        pred3 = xe(*xargs, False, 0.0)[0].clone()
+    assert float((pred0 - pred3).abs().max()) > 1e-2, "the step must have changed the scores"
+    assert torch.equal(pred1, pred3)
+    assert float((pred2 - pred3).abs().max()) < 1e-4          # (table folding = another summation order)
+
+
+def test_weights_epoch_invalidates_the_token_table():
+    """any writer that cannot bump tensor._version (a collective on `.data`, a foreign kernel) can call
+    optim.bump_weights_epoch(): every derived table is rebuilt"""
+    from show_edit_tell_amd import optim
+    d, xe, rl = editnet_modules("editnet_small")
+    args = (d["wm"], to_dev(d["prev"]), to_dev(d["plen"]), to_dev(d["X"]), True, False)
+    with torch.no_grad():
+        rl(*args)
+        rl(*args)
+        assert rl._tok_state["table"] is not None
+        optim.bump_weights_epoch()
+        rl(*args)
+        assert rl._tok_state["table"] is None

@@ -131,3 +131,24 @@ def test_dcnet(name):
     parity.check_xe(pred, dl, sort_ind, g, c["V"], small=c["D"] < 1024)
     seq, logp = DN.greedy_decode(P, wm["<start>"], wm["<end>"], d["prev"], d["plen"])
     parity.check_greedy(seq, logp, g)
+
+
+def test_atsize_fixtures_vs_numpy_oracle():
+    """the at-size fixtures (oracle/make_atsize_golden.py): the numpy oracle reproduces the reference's adaptive B = 64
+    forward and DCNet's B = 128 forward + greedy decode"""
+    name = "editnet_adaptive_full_b64"
+    d = cases.build_editnet(name)
+    g = parity.load("atsize_" + name)
+    P = EN.cast_params(d["sd"])
+    pred, caps_s, dl, sort_ind = EN.xe_forward(P, d["X"], d["caps"], d["clen"], d["prev"], d["plen"],
+                                               image_mean=d["image_mean"], adaptive=True)
+    parity.check_xe(pred, dl, sort_ind, g, d["case"]["V"], small=False)
+    assert abs(EN.xe_loss(pred, caps_s, dl) - float(g["xe_loss"])) < 1e-4
+    name = "dcnet_full_b128"
+    d = cases.build_dcnet(name)
+    g = parity.load("atsize_" + name)
+    Pd = DN.cast_params(d["sd"])
+    pred, caps_s, dl, sort_ind = DN.xe_forward(Pd, d["caps"], d["clen"], d["prev"], d["plen"])
+    parity.check_xe(pred, dl, sort_ind, g, d["case"]["V"], small=False)
+    seq, logp = DN.greedy_decode(Pd, d["wm"]["<start>"], d["wm"]["<end>"], d["prev"], d["plen"])
+    parity.check_greedy(seq, logp, g)
