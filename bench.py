@@ -55,7 +55,9 @@ STEPS_PER_DECODE = MAX_LEN + 1          # editnet_rl.py:503 runs max_len + 1 tim
 STREAM_CANDIDATES = (3, 7, 11)          # batches in flight probed by --streams 0 (see main)
 PEAK_FP32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0
-PMC_FILES = ("r02_pmc_bench_traffic.json", "r01_pmc_bench_traffic.json")
+TRAIN_TFLOP_PER_STEP = 1.23             # contractions of one B=128 XE training step as executed
+SURVEY_GFLOP_PER_TIMESTEP = 16.88       # SURVEY.md 8d, B = 128, eval mode, loop invariants hoisted
+PMC_FILES = ("r03_pmc_bench_traffic.json", "r02_pmc_bench_traffic.json", "r01_pmc_bench_traffic.json")
 
 
 def pmc_traffic():
@@ -315,8 +317,15 @@ def main():
             args.streams = best
             stream_probe = {str(n): round(48 * STEPS_PER_DECODE / t, 1) for n, t in stream_probe.items()}
             run(args.warmup)
-        elapsed, (seq, _) = timed_region()                 # the K timed steps `value` is computed from
-        windows = [timed_region()[0] for _ in range(max(0, args.repeat - 1))]
+        elapsed, (seq, _) = timed_region()                 # the first window of exactly K timed steps
+        # short regions (the driver's --steps 20 is a 60-ms window) are repeated at least 15 times and `value` is the MEDIAN
+        # window: one window of 20 decodes moves by a few percent with host jitter; every window is exactly K steps between
+        # barrier + synchronize on both sides, max over ranks
+        n_win = max(args.repeat, 15) if elapsed < 0.5 else args.repeat
+        windows = [timed_region()[0] for _ in range(max(0, n_win - 1))]
+        first_elapsed = elapsed
+        if elapsed < 0.5:
+            elapsed = _median([elapsed] + windows)
 
         single = None
         if streams is not None and rank == 0:
@@ -373,7 +382,7 @@ def main():
 
     n_gpus = world
     total_steps = n_gpus * args.steps * STEPS_PER_DECODE
-    rates = sorted(total_steps / e for e in [elapsed] + windows)
+    rates = sorted(total_steps / e for e in [first_elapsed] + windows)
     line = {
         "metric": "decode-steps/sec (B=128, 36x2048 feats, seqlen=20)",
         "value": round(total_steps / elapsed, 2),
@@ -392,7 +401,12 @@ def main():
         "batches_in_flight_per_gpu": max(1, args.streams),
         "stream_probe_decode_steps_per_sec": stream_probe,
         "repeat": {"windows": len(rates), "steps_per_window": args.steps, "median": round(_median(rates), 2),
-                   "min": round(rates[0], 2), "max": round(rates[-1], 2), "timed_region_s": round(elapsed, 4)},
+                   "min": round(rates[0], 2), "max": round(rates[-1], 2), "timed_region_s": round(elapsed, 4),
+                   "value_is": "median window" if first_elapsed < 0.5 else "first window"},
+        # SURVEY.md 8d's own bound: 16.88 GFLOP per B=128 timestep against the 157.3 TFLOP/s fp32-MFMA peak (107 us)
+        "end_to_end_frac": round(SURVEY_GFLOP_PER_TIMESTEP * 1e9 * (total_steps / elapsed) / n_gpus / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+        "single_stream_end_to_end_frac": None if single is None else round(
+            SURVEY_GFLOP_PER_TIMESTEP * 1e9 * (args.steps * STEPS_PER_DECODE / single) / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
         "config": {"workload": "EditNet greedy decode (editnet_rl.py:485-549): prologue + 19 timesteps per bench step",
                    "batch_per_gpu": B, "regions": R, "feat_dim": F, "prev_caption_len": T, "vocab": V,
                    "decoder_dim": D, "attention_dim": A, "timesteps_per_bench_step": STEPS_PER_DECODE,
@@ -420,10 +434,14 @@ def main():
                 "algorithmic_GBs": round(g["bytes"] / (g["ms"] * 1e-3) / 1e9, 1),
                 "timing": "HIP events on the launch stream, second identical pass of %d steps (profiled ms_per_step %.3f)"
                           % (nprof, 1e3 * prof_elapsed / nprof)}
-        line["kernels"] = {p["tag"]: {"launches_per_step": round(p["launches"] / nprof, 2),
-                                      "ms_per_step": round(p["ms"] / nprof, 4),
-                                      "GBs": round(p["bytes"] / max(p["ms"], 1e-9) / 1e6, 1),
-                                      "TFLOPs": round(p["flops"] / max(p["ms"], 1e-9) / 1e9, 2)} for p in prof}
+        def _kernel(p):
+            gbs, tfl = p["bytes"] / max(p["ms"], 1e-9) / 1e6, p["flops"] / max(p["ms"], 1e-9) / 1e9
+            mfma = p["flops"] > 0
+            return {"launches_per_step": round(p["launches"] / nprof, 2), "ms_per_step": round(p["ms"] / nprof, 4),
+                    "us_per_launch": round(1e3 * p["ms"] / max(p["launches"], 1), 2), "GBs": round(gbs, 1), "TFLOPs": round(tfl, 2),
+                    "bound": "mfma" if mfma else "hbm",
+                    "frac": round(tfl / PEAK_FP32_MFMA_TFLOPS if mfma else gbs / PEAK_HBM_GBS, 4)}
+        line["kernels"] = {p["tag"]: _kernel(p) for p in prof}
     if train is not None:
         line["train"] = train
     split_env = os.environ.get("SET_GEMM_SPLIT", "0") not in ("", "0")
@@ -454,6 +472,7 @@ def train_leg(args, dec, wm, X, caps, clen, prev, plen, dev, dist, rank, world, 
     xe = xe.to(dev)
     opt = torch.optim.Adam(xe.parameters(), lr=5e-4)         # editnet.py:749; clip + step run on set_clip_adam_f32 (optim.py)
     K = max(2, args.train_steps)
+    clen_host = clen.cpu()                  # the data loader's host copy of the lengths (editnet.py:560-563 moves them to the device)
 
     windows = []
 
@@ -461,12 +480,13 @@ def train_leg(args, dec, wm, X, caps, clen, prev, plen, dev, dist, rank, world, 
         """median of n_windows barrier-bracketed windows of K steps (the step is host-launch heavy, so a single short
         window picks up host jitter: 26-37 ms seen for the same build on one box)"""
         for _ in range(3):
-            xe_train_step(xe, opt, X, caps, clen, prev, plen, False, 0.0, reduce=reduce)
+            xe_train_step(xe, opt, X, caps, clen, prev, plen, False, 0.0, reduce=reduce, caplens_host=clen_host)
         ts, losses = [], []
         for _ in range(n_windows):
             barrier()
             t0 = time.perf_counter()
-            losses += [xe_train_step(xe, opt, X, caps, clen, prev, plen, False, 0.0, reduce=reduce)[0] for _ in range(K)]
+            losses += [xe_train_step(xe, opt, X, caps, clen, prev, plen, False, 0.0, reduce=reduce, caplens_host=clen_host)[0]
+                       for _ in range(K)]
             barrier()
             ts.append(max_over_ranks(time.perf_counter() - t0))
         windows.append([round(1e3 * t / K, 3) for t in ts])
@@ -478,13 +498,40 @@ def train_leg(args, dec, wm, X, caps, clen, prev, plen, dev, dist, rank, world, 
            "n_gpus": world, "steps": K, "ms_per_train_step": round(1e3 * t_dp / K, 3), "windows_ms": windows[0],
            "train_decode_steps_per_sec": round(world * K * STEPS_PER_DECODE / t_dp, 2),
            "gradient_MB": round(sum(p.numel() for p in xe.parameters()) * 4 / 1e6, 1),
+           # 1.23 TFLOP of contractions per step (forward as executed + backward)
+           "achieved_TFLOPs_per_gpu": round(TRAIN_TFLOP_PER_STEP / (t_dp / K), 1),
+           "frac_of_fp32_mfma_peak": round(TRAIN_TFLOP_PER_STEP / (t_dp / K) / PEAK_FP32_MFMA_TFLOPS, 4),
            "loss_first": round(losses[0], 4), "loss_last": round(losses[-1], 4)}
     if world > 1:
         t_local, _ = timed(False)
+        # the collective alone: the step's flat gradient buckets (`.grad` are views of them) all-reduced back to back
+        from show_edit_tell_amd.train import _all_reduce_sum
+        fb = xe.__dict__.get("_grad_buckets")
+        ar_ms = None
+        if fb is not None:
+            for _ in range(2):
+                for f in fb.flat:
+                    _all_reduce_sum(dist, f, None)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                works = [_all_reduce_sum(dist, f, None, async_op=True) for f in fb.flat]
+                for w_ in works:
+                    if w_ is not None:
+                        w_.wait()
+            barrier()
+            ar_ms = round(1e3 * max_over_ranks(time.perf_counter() - t0) / 5, 3)
+        # which devices / backend the ranks really ran on (all-gathered)
+        seen = [None] * world
+        dist.all_gather_object(seen, {"rank": rank, "device": torch.cuda.current_device(),
+                                      "name": torch.cuda.get_device_name(), "backend": dist.get_backend()})
         out.update(ms_per_train_step_no_allreduce=round(1e3 * t_local / K, 3),
-                   allreduce_exposed_ms=round(1e3 * (t_dp - t_local) / K, 3),
-                   allreduce="bucketed SUM all-reduce, 64 MB flat buckets, launched as the deferred weight-gradient "
-                             "contractions finish (train.BucketedAllReduce)")
+                   allreduce_exposed_ms=round(1e3 * (t_dp - t_local) / K, 3), allreduce_ms=ar_ms,
+                   allreduce_buckets=None if fb is None else [round(f.numel() * 4 / 1e6, 1) for f in fb.flat],
+                   ranks_seen=seen,
+                   allreduce="SUM all-reduce in place on persistent flat gradient buckets (`.grad` tensors are views), "
+                             "fc's bucket launched at the start of the backward, the others as the deferred weight-gradient "
+                             "contractions finish (train.FlatGradBuckets / BucketedAllReduce)")
     del opt, xe
     torch.cuda.empty_cache()
     return out

@@ -83,6 +83,9 @@ struct CapAttArgs {
     const float* P; const float* Q; float* cmem_out; float* gated_out;
     Slabs cg_ab, tc; RowGather gz, gtc; const float *b_gate, *b_sc, *b_tc;
     float* att2_out;      // (M,A) or NULL: decoder-side projection incl. its bias, as used for the scores (kept for the backward)
+    // small batches: the Dh output columns of a row are split over dsn workgroups (each recomputes the T scores and owns
+    // dcols columns) so that a handful of rows still covers the chip; dsn == 0 / 1: one workgroup per row
+    int dcols, dsn;
 };
 struct VisAttArgs {
     const float* att1; Slabs att2; const float* dec_bias; const float* w_full; const float* b_full;
@@ -92,7 +95,7 @@ struct VisAttArgs {
     float* att2_out;      // (M,A) or NULL, see CapAttArgs
 };
 
-__device__ __forceinline__ void caption_attention_body(const CapAttArgs& P, int b, float* sc, int* s_arg_p) {
+__device__ __forceinline__ void caption_attention_body(const CapAttArgs& P, int b, float* sc, int* s_arg_p, int ds = 0) {
     const float* att1_c = P.att1_c; const Slabs att2_c = P.att2_c; const float* dec_bias = P.dec_bias;
     const float* w_full = P.w_full; const float* b_full = P.b_full; const float* mask = P.mask;
     const float* H = P.H; const float* Mem = P.Mem; float* ctx = P.ctx; float* sel = P.sel;
@@ -112,10 +115,11 @@ __device__ __forceinline__ void caption_attention_body(const CapAttArgs& P, int 
             for (int i = 1; i < att2_c.n; ++i) v += ld4a(att2_c.p + (long long)i * att2_c.stride + (long long)b * att2_c.ld + a);
             a2[q] = v + ld4a(dec_bias + a);
             wf[q] = ld4a(w_full + a);
-            if (P.att2_out && wave == 0) *reinterpret_cast<f32x4*>(P.att2_out + (long long)b * A + a) = a2[q];
+            if (P.att2_out && wave == 0 && ds == 0) *reinterpret_cast<f32x4*>(P.att2_out + (long long)b * A + a) = a2[q];
         }
     }
     const float bf = b_full[0];
+    const int d_lo = P.dsn > 1 ? ds * P.dcols : 0, d_hi = P.dsn > 1 ? d_lo + P.dcols : Dh;      // this workgroup's columns
     // each wave scores rows wave, wave+4, ...; RB rows are loaded before any is reduced so that their
     // HBM/L2 round trips overlap (the reductions are 6-step cross-lane chains)
     constexpr int RB = 5;
@@ -151,14 +155,14 @@ __device__ __forceinline__ void caption_attention_body(const CapAttArgs& P, int 
     __syncthreads();
     block_softmax(sc, T, tid, &s_arg);
     __syncthreads();
-    if (alpha_out)
+    if (alpha_out && ds == 0)
         for (int t = tid; t < T; t += 256) alpha_out[(long long)b * T + t] = sc[t];
     const int js = s_arg;
     const float aj = sc[js];
     const float wj = aj * 1.f + (1.f - aj);            // the reference's fp32 expression (editnet.py:417-418)
     if (P.P) {
         // ---- hoisted projections + fused context gate
-        for (int d = tid * 4; d < Dh; d += 1024) {
+        for (int d = d_lo + tid * 4; d < d_hi; d += 1024) {
             // operands that do not depend on the attention weights first: their latency overlaps the P stream
             const long long m = b;
             f32x4 pre0 = {0.f, 0.f, 0.f, 0.f}, pre1 = {0.f, 0.f, 0.f, 0.f};
@@ -200,7 +204,7 @@ __device__ __forceinline__ void caption_attention_body(const CapAttArgs& P, int 
         }
         return;
     }
-    for (int d = tid * 4; d < Dh; d += 1024) {
+    for (int d = d_lo + tid * 4; d < d_hi; d += 1024) {
         const float* hp = H + (long long)b * T * Dh + d;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         int t = 0;
@@ -223,8 +227,20 @@ __device__ __forceinline__ void caption_attention_body(const CapAttArgs& P, int 
 __global__ void __launch_bounds__(256) caption_attention_k(const CapAttArgs P) {
     __shared__ float sc[ATT_MAX_ROWS];
     __shared__ int s_arg;
-    caption_attention_body(P, blockIdx.x, sc, &s_arg);
+    const int dsn = P.dsn > 1 ? P.dsn : 1;
+    caption_attention_body(P, blockIdx.x / dsn, sc, &s_arg, blockIdx.x % dsn);
 }
+
+// column slices of the caption role for small batches: enough workgroups for ~half the chip, slices of >= 128 columns
+static int cap_dsn(int M, int Dh) {
+    static const int on = env_int("SET_ATT_SMALL_SLICES", 1);
+    int dsn = 1;
+    if (!on || M >= 64) return 1;
+    while (M * dsn < 128 && Dh / (dsn * 2) >= 128 && (Dh % (dsn * 2 * 4)) == 0) dsn *= 2;
+    return dsn;
+}
+
+__global__ void caption_attention_v2_k(const CapAttArgs C);
 
 int caption_attention(const float* att1_c, Slabs att2_c, const float* dec_bias, const float* w_full,
                       const float* b_full, const float* mask, const float* H, const float* Mem, float* ctx,
@@ -236,7 +252,15 @@ int caption_attention(const float* att1_c, Slabs att2_c, const float* dec_bias, 
     P.att1_c = att1_c; P.att2_c = att2_c; P.dec_bias = dec_bias; P.w_full = w_full; P.b_full = b_full; P.mask = mask;
     P.H = H; P.Mem = Mem; P.ctx = ctx; P.sel = sel; P.alpha_out = alpha_out; P.T = T; P.Dh = Dh; P.A = A;
     P.att2_out = att2_out;
-    hipLaunchKernelGGL(caption_attention_k, dim3(M), dim3(256), 0, s, P);
+    static const int v2 = env_int("SET_ATT_V2", 1);
+    static const int v2_maxm = env_int("SET_ATT_V2_MAXM", 32);
+    if (v2 && M <= v2_maxm && Dh <= 1024) {  // 512 threads per row, all H rows requested before the scoring phase (see v2 below)
+        hipLaunchKernelGGL(caption_attention_v2_k, dim3(M), dim3(512), 0, s, P);
+        SET_LAUNCH_CHECK();
+        return SET_OK;
+    }
+    P.dsn = cap_dsn(M, Dh); P.dcols = Dh / P.dsn;
+    hipLaunchKernelGGL(caption_attention_k, dim3(M * P.dsn), dim3(256), 0, s, P);
     SET_LAUNCH_CHECK();
     return SET_OK;
 }
@@ -350,18 +374,290 @@ __global__ void __launch_bounds__(256) visual_attention_k(const VisAttArgs P) {
 __global__ void __launch_bounds__(256) step_attention_k(const VisAttArgs V, const CapAttArgs C, int nvis) {
     __shared__ float sc[ATT_MAX_ROWS];
     __shared__ int s_arg;
-    if ((int)blockIdx.x < nvis)
+    if ((int)blockIdx.x < nvis) {
         visual_attention_body(V, blockIdx.x / V.fsn, blockIdx.x % V.fsn, sc);
-    else
-        caption_attention_body(C, blockIdx.x - nvis, sc, &s_arg);
+    } else {
+        const int i = blockIdx.x - nvis, dsn = C.dsn > 1 ? C.dsn : 1;
+        caption_attention_body(C, i / dsn, sc, &s_arg, i % dsn);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// v2 of the merged attention launch (round 3): 512 threads per row, and EVERY streamed operand of a row is requested
+// before the scoring phase.  The 256-thread bodies above walk a chain of dependent round trips per row — decoder
+// projection slabs -> att1 rows -> (softmax) -> 12 regions -> 12 regions -> 12 regions — which costs ~24 us whether the
+// launch has 4 rows or 128; bytes per CU are not what bounds it.  Here the region rows X[b, r, :] (visual role) and the
+// hoisted projection rows P[b, t, :] / encoder rows H[b, t, :] (caption role) do not depend on the scores, so each of
+// the two thread halves requests its half of the rows (18 regions x 2 column groups, or 10 caption rows x 2 operands: 36 /
+// 20 loads of 16 bytes in flight per thread, the whole 295 KB row at once) first; scoring runs on 8 waves underneath;
+// after the softmax only FMAs on registers, one LDS exchange between the halves and the stores remain.
+// Accumulation order: regions / positions ascending inside a half, then half 0 + half 1 (deterministic).
+// ---------------------------------------------------------------------------------------------
+constexpr int V2_PB = 18;      // prefetched regions per half (R <= 36 is fully covered)
+constexpr int V2_PT = 10;      // prefetched caption positions per half (T <= 20 is fully covered)
+
+__device__ __forceinline__ void visual_attention_v2(const VisAttArgs& P, int b, float* sc, f32x4* xch) {
+    const float* att1 = P.att1; const Slabs att2 = P.att2; const float* X = P.X; const float* rmask = P.rmask;
+    const int R = P.R, F = P.F, A = P.A;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = tid >> 8, cg = tid & 255;
+    // fixed blocks of V2_PB regions alternate between the two halves (block k -> half k & 1): which half sums a region does
+    // not depend on R, so zero-weight padding regions / positions never change a bit of the result
+    const int r_lo = half * V2_PB, r_hi = (r_lo + V2_PB < R) ? r_lo + V2_PB : R;
+    const float* xrow = X + (long long)b * R * F;
+    const int f0 = cg * 4, f1 = (cg + 256) * 4;
+    // ---- all of this thread's first V2_PB regions, both column groups: requested now
+    f32x4 xp0[V2_PB], xp1[V2_PB];
+#pragma unroll
+    for (int u = 0; u < V2_PB; ++u) {
+        const int r = r_lo + u;
+        xp0[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        xp1[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (r < r_hi) {
+            if (f0 < F) xp0[u] = ld4s(xrow + (long long)r * F + f0);
+            if (f1 < F) xp1[u] = ld4s(xrow + (long long)r * F + f1);
+        }
+    }
+    // ---- decoder projection (+ bias) and the scoring vector: per lane a = lane*4 + 256 q
+    const int nq = (A + 255) / 256;
+    f32x4 a2[2], wf[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        a2[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        wf[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int a = lane * 4 + 256 * q;
+        if (q < nq && a < A) {
+            f32x4 v = ld4a(att2.p + (long long)b * att2.ld + a);
+            for (int i = 1; i < att2.n; ++i) v += ld4a(att2.p + (long long)i * att2.stride + (long long)b * att2.ld + a);
+            a2[q] = v + ld4a(P.dec_bias + a);
+            wf[q] = ld4a(P.w_full + a);
+            if (P.att2_out && wave == 0) *reinterpret_cast<f32x4*>(P.att2_out + (long long)b * A + a) = a2[q];
+        }
+    }
+    const float bf = P.b_full[0];
+    constexpr int RB = 5;                                 // 8 waves x 5 rows: R <= 40 in one batch
+    for (int r0 = wave; r0 < R; r0 += 8 * RB) {
+        f32x4 v[RB][2];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int r = r0 + 8 * u;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int a = lane * 4 + 256 * q;
+                v[u][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (r < R && q < nq && a < A) v[u][q] = ld4a(att1 + ((long long)b * R + r) * A + a);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int r = r0 + 8 * u;
+            if (r >= R) break;
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int a = lane * 4 + 256 * q;
+                if (q < nq && a < A) {
+                    const f32x4 x = v[u][q] + a2[q];
+                    s += wf[q][0] * fmaxf(x[0], 0.f) + wf[q][1] * fmaxf(x[1], 0.f) + wf[q][2] * fmaxf(x[2], 0.f) +
+                         wf[q][3] * fmaxf(x[3], 0.f);
+                }
+            }
+            s = wave_sum(s);
+            if (lane == 0) sc[r] = (rmask && rmask[(long long)b * R + r] == 0.f) ? -1e10f : (s + bf);
+        }
+    }
+    __syncthreads();
+    block_softmax(sc, R, tid, nullptr);
+    __syncthreads();
+    if (P.alpha_out)
+        for (int r = tid; r < R; r += 512) P.alpha_out[(long long)b * R + r] = sc[r];
+    // ---- context from the registers (+ the rows beyond the prefetched ones when R > 36)
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < V2_PB; ++u)
+        if (r_lo + u < r_hi) { acc0 += xp0[u] * sc[r_lo + u]; acc1 += xp1[u] * sc[r_lo + u]; }
+    for (int rb = r_lo + 2 * V2_PB; rb < R; rb += 2 * V2_PB) {      // further blocks of this half (R > 36: adaptive features)
+        const int re = (rb + V2_PB < R) ? rb + V2_PB : R;
+        for (int r = rb; r < re; r += 6) {                  // 12 loads in flight; accumulation stays in r order
+            f32x4 v0[6], v1[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                v0[u] = (f32x4){0.f, 0.f, 0.f, 0.f}; v1[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (r + u < re) {
+                    if (f0 < F) v0[u] = ld4s(xrow + (long long)(r + u) * F + f0);
+                    if (f1 < F) v1[u] = ld4s(xrow + (long long)(r + u) * F + f1);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 6; ++u)
+                if (r + u < re) { acc0 += v0[u] * sc[r + u]; acc1 += v1[u] * sc[r + u]; }
+        }
+    }
+    // halves: half 1 hands its partial sums over, half 0 adds (half 0 + half 1) and stores
+    if (half == 1) { xch[cg] = acc0; xch[256 + cg] = acc1; }
+    __syncthreads();
+    if (half == 0) {
+        if (f0 < F) *reinterpret_cast<f32x4*>(P.ctx + (long long)b * F + f0) = acc0 + xch[cg];
+        if (f1 < F) *reinterpret_cast<f32x4*>(P.ctx + (long long)b * F + f1) = acc1 + xch[256 + cg];
+    }
+    // feature columns beyond 2048 (not a reference shape): the plain loop, all regions, by the first 256 threads
+    for (int f = f0 + 2048; f < F && half == 0; f += 1024) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < R; ++r) acc += ld4s(xrow + (long long)r * F + f) * sc[r];
+        *reinterpret_cast<f32x4*>(P.ctx + (long long)b * F + f) = acc;
+    }
+}
+
+__device__ __forceinline__ void caption_attention_v2(const CapAttArgs& P, int b, float* sc, int* s_arg_p, f32x4* xch) {
+    const Slabs att2_c = P.att2_c; const float* Mem = P.Mem; const int T = P.T, Dh = P.Dh, A = P.A;
+    int& s_arg = *s_arg_p;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = tid >> 8, cg = tid & 255;
+    const int t_lo = half * V2_PT, t_hi = (t_lo + V2_PT < T) ? t_lo + V2_PT : T;      // fixed blocks, as in the visual role
+    const int d0 = cg * 4;
+    const bool col_ok = d0 < Dh;
+    const bool hoisted = P.P != nullptr;
+    // ---- this thread's rows of the streamed operand(s): requested now
+    //      hoisted mode: P[b, t, d0] (context-gate part) and P[b, t, Dh + d0] (sc_affine part); plain mode: H[b, t, d0]
+    f32x4 pz[V2_PT], ps[V2_PT];
+    const float* prow = hoisted ? P.P + (long long)b * T * 2 * Dh + d0 : P.H + (long long)b * T * Dh + d0;
+    const long long pstride = hoisted ? 2LL * Dh : (long long)Dh;
+#pragma unroll
+    for (int u = 0; u < V2_PT; ++u) {
+        pz[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        ps[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (col_ok && t_lo + u < t_hi) {
+            pz[u] = hoisted ? ld4s(prow + (t_lo + u) * pstride) : ld4a(prow + (t_lo + u) * pstride);
+            if (hoisted) ps[u] = ld4s(prow + (t_lo + u) * pstride + Dh);
+        }
+    }
+    // operands of the gate epilogue that do not depend on the attention weights (half 0 runs the epilogue)
+    f32x4 pre0 = {0.f, 0.f, 0.f, 0.f}, pre1 = {0.f, 0.f, 0.f, 0.f}, bg = pre0, bs = pre0, bt = pre0;
+    if (hoisted && half == 0 && col_ok) {
+        const long long m = b;
+        for (int i = 0; i < P.cg_ab.n; ++i) pre0 += ld4a(P.cg_ab.p + (long long)i * P.cg_ab.stride + m * P.cg_ab.ld + d0);
+        for (int i = 0; i < P.tc.n; ++i) pre1 += ld4a(P.tc.p + (long long)i * P.tc.stride + m * P.tc.ld + d0);
+        if (P.gz.tab) pre0 += ld4a(P.gz.row(m) + d0);
+        if (P.gtc.tab) pre1 += ld4a(P.gtc.row(m) + d0);
+        bg = ld4a(P.b_gate + d0); bs = ld4a(P.b_sc + d0); bt = ld4a(P.b_tc + d0);
+    }
+    // ---- scores
+    const int nq = (A + 255) / 256;
+    f32x4 a2[2], wf[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        a2[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        wf[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int a = lane * 4 + 256 * q;
+        if (q < nq && a < A) {
+            f32x4 v = ld4a(att2_c.p + (long long)b * att2_c.ld + a);
+            for (int i = 1; i < att2_c.n; ++i) v += ld4a(att2_c.p + (long long)i * att2_c.stride + (long long)b * att2_c.ld + a);
+            a2[q] = v + ld4a(P.dec_bias + a);
+            wf[q] = ld4a(P.w_full + a);
+            if (P.att2_out && wave == 0) *reinterpret_cast<f32x4*>(P.att2_out + (long long)b * A + a) = a2[q];
+        }
+    }
+    const float bf = P.b_full[0];
+    constexpr int RB = 3;                                 // 8 waves x 3 rows: T <= 24 in one batch
+    for (int t0 = wave; t0 < T; t0 += 8 * RB) {
+        f32x4 v[RB][2];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int t = t0 + 8 * u;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int a = lane * 4 + 256 * q;
+                v[u][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (t < T && q < nq && a < A) v[u][q] = ld4a(P.att1_c + ((long long)b * T + t) * A + a);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int t = t0 + 8 * u;
+            if (t >= T) break;
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int a = lane * 4 + 256 * q;
+                if (q < nq && a < A) {
+                    const f32x4 x = v[u][q] + a2[q];
+                    s += wf[q][0] * tanhf(x[0]) + wf[q][1] * tanhf(x[1]) + wf[q][2] * tanhf(x[2]) + wf[q][3] * tanhf(x[3]);
+                }
+            }
+            s = wave_sum(s);
+            if (lane == 0) sc[t] = (P.mask[(long long)b * T + t] == 0.f) ? -1e10f : (s + bf);
+        }
+    }
+    __syncthreads();
+    block_softmax(sc, T, tid, &s_arg);
+    __syncthreads();
+    if (P.alpha_out)
+        for (int t = tid; t < T; t += 512) P.alpha_out[(long long)b * T + t] = sc[t];
+    const int js = s_arg;
+    const float aj = sc[js];
+    const float wj = aj * 1.f + (1.f - aj);            // the reference's fp32 expression (editnet.py:417-418)
+    // the selected rows depend on the arg-max: half 1 fetches them while half 0 finishes the context
+    if (half == 1 && col_ok) {
+        if (Mem) *reinterpret_cast<f32x4*>(P.sel + (long long)b * Dh + d0) = ld4a(Mem + ((long long)b * T + js) * Dh + d0) * wj;
+        if (hoisted && P.Q)
+            *reinterpret_cast<f32x4*>(P.cmem_out + (long long)b * Dh + d0) = ld4a(P.Q + ((long long)b * T + js) * Dh + d0) * wj;
+    }
+    f32x4 zc = {0.f, 0.f, 0.f, 0.f}, sv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < V2_PT; ++u)
+        if (t_lo + u < t_hi) { zc += pz[u] * sc[t_lo + u]; sv += ps[u] * sc[t_lo + u]; }
+    if (col_ok)
+        for (int tb = t_lo + 2 * V2_PT; tb < T; tb += 2 * V2_PT) {      // further blocks of this half (T > 20)
+            const int te = (tb + V2_PT < T) ? tb + V2_PT : T;
+            for (int t = tb; t < te; ++t) {
+                zc += ld4a(prow + t * pstride) * sc[t];
+                if (hoisted) sv += ld4a(prow + t * pstride + Dh) * sc[t];
+            }
+        }
+    if (half == 1) { xch[cg] = zc; xch[256 + cg] = sv; }
+    __syncthreads();
+    if (half == 0 && col_ok) {
+        zc += xch[cg];
+        sv += xch[256 + cg];
+        if (hoisted) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // reference: ONE Linear over cat([word, h1, ctx]): the [word,h1] part first, then the ctx part, then bias
+                const float z = (pre0[e] + zc[e]) + bg[e];
+                const float zt = 1.f / (1.f + expf(-z));
+                o[e] = zt * tanhf(sv[e] + bs[e]) + (1.f - zt) * tanhf(pre1[e] + bt[e]);
+            }
+            *reinterpret_cast<f32x4*>(P.gated_out + (long long)b * Dh + d0) = o;
+        } else {
+            *reinterpret_cast<f32x4*>(P.ctx + (long long)b * Dh + d0) = zc;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(512) step_attention_v2_k(const VisAttArgs V, const CapAttArgs C, int nvis) {
+    __shared__ float sc[ATT_MAX_ROWS];
+    __shared__ int s_arg;
+    __shared__ f32x4 xch[512];
+    if ((int)blockIdx.x < nvis) visual_attention_v2(V, blockIdx.x, sc, xch);
+    else caption_attention_v2(C, blockIdx.x - nvis, sc, &s_arg, xch);
+}
+
+__global__ void __launch_bounds__(512) caption_attention_v2_k(const CapAttArgs C) {
+    __shared__ float sc[ATT_MAX_ROWS];
+    __shared__ int s_arg;
+    __shared__ f32x4 xch[512];
+    caption_attention_v2(C, blockIdx.x, sc, &s_arg, xch);
 }
 
 static int vis_fsn(int M, int F) {
     // enough workgroups to cover the chip: split the feature axis while slices stay >= 1024 columns
     // measured at B=128: one slice per sample (128 + 128 workgroups) beats 2 or 4 slices (each slice recomputes the scores)
+    // small batches (round 3): a handful of rows at one workgroup each leaves the kernel at one CU's streaming rate per
+    // row (B = 4: 23 us for 1.2 MB); slices down to 128 columns put ~half the chip on it
     static const int min_cols = env_int("SET_ATT_MIN_COLS", 2048);
+    static const int small = env_int("SET_ATT_SMALL_SLICES", 1);
+    const int mc = (small && M < 64) ? 128 : min_cols, want = (small && M < 64) ? 128 : 512;
     int fsn = 1;
-    while (M * fsn < 512 && F / (fsn * 2) >= min_cols && (F % (fsn * 2 * 4)) == 0) fsn *= 2;
+    while (M * fsn < want && F / (fsn * 2) >= mc && (F % (fsn * 2 * 4)) == 0) fsn *= 2;
     return fsn;
 }
 
@@ -389,7 +685,20 @@ int step_attention(const float* att1, Slabs att2, const float* v_dec_bias, const
                                                 : (double)T * Dh + 3.0 * Dh;
     ProfScope ps("step_attention", s, 0.0,
                  4.0 * M * ((double)R * A * fsn + (double)R * F + F + (double)T * A + cap_rows));
-    hipLaunchKernelGGL(step_attention_k, dim3(M * fsn + M), dim3(256), 0, s, V, C, M * fsn);
+    // v2 (512 threads per row, every streamed operand requested before the scoring phase) when the columns fit its layout
+    // Default: up to SET_ATT_V2_MAXM rows (32).  Measured at B = 128 (round 3): 26.4 -> 24.3 us per launch single stream, but a
+    // 512-thread / 236-register workgroup leaves no room for another batch's kernels on its CU: 6.75 k -> 6.41 k with 7
+    // batches in flight; at B = 4 26.3 -> 21.5 us and nothing else is there to displace.
+    static const int v2 = env_int("SET_ATT_V2", 1);
+    static const int v2_maxm = env_int("SET_ATT_V2_MAXM", 32);
+    if (v2 && M <= v2_maxm && F <= 2048 && Dh <= 1024) {
+        V.fcols = F; V.fsn = 1;
+        hipLaunchKernelGGL(step_attention_v2_k, dim3(2 * M), dim3(512), 0, s, V, C, M);
+        SET_LAUNCH_CHECK();
+        return SET_OK;
+    }
+    C.dsn = cap_dsn(M, Dh); C.dcols = Dh / C.dsn;
+    hipLaunchKernelGGL(step_attention_k, dim3(M * fsn + M * C.dsn), dim3(256), 0, s, V, C, M * fsn);
     SET_LAUNCH_CHECK();
     return SET_OK;
 }

@@ -43,6 +43,7 @@ struct EditNetWs {
     // prologue scratch
     float *enc_h, *enc_c, *xg, *emb_seq, *fe, *s_enc, *s_aff, *s_pre;
     int* enc_order;                   // [perm (B) | nactive (T)] of the length-ordered encoder
+    char* enc_bar;                    // barrier words of the persistent encoder
     size_t bytes;
 };
 
@@ -113,6 +114,7 @@ static EditNetWs carve(const SetEditNetDims* d, void* base) {
     w.s_aff = c.take<float>(KS * B * D);
     w.s_pre = c.take<float>(KS * B * 4 * D);
     w.enc_order = c.take<int>(B + T);
+    w.enc_bar = c.take<char>(persistent_encoder_bar_bytes());
     w.bytes = c.off;
     return w;
 }
@@ -146,7 +148,7 @@ GemmProb direct_prob(float* out, long long ldo, int M, int N, const float* bias,
 // t < len[b]; H / Mem rows beyond a caption's length stay zero; mask = (Mem.sum(2) != 0).
 int editnet_encoder(const SetEditNetWeights* w, const int64_t* seq, const int64_t* lens, float* H, float* Mem,
                     float* final_hidden, float* mask, int B, int T, int D, int V, float* emb_seq, float* xg,
-                    float* enc_h, float* enc_c, float* s_enc, float* s_aff, hipStream_t st, int* order) {
+                    float* enc_h, float* enc_c, float* s_enc, float* s_aff, hipStream_t st, int* order, void* enc_bar) {
     const int tgt = gemm_target_wgs();
     const bool fused = (D % 128 == 0) && env_int("SET_NO_FUSED", 0) == 0;
     // with the token table the hoisted input projection x W_xh^T + b_xh is a row gather done by the step kernel
@@ -171,7 +173,18 @@ int editnet_encoder(const SetEditNetWeights* w, const int64_t* seq, const int64_
         perm = order; nactive = order + B;
         SET_TRY(encoder_order(lens, B, T, perm, nactive, st));
     }
-    for (int t = 0; t < T; ++t) {
+    // the whole recurrence as ONE weights-stationary launch (encoder_persistent.hip) when the shape allows it
+    bool persistent = fused && perm && enc_bar && persistent_encoder_ok(B, D, T);
+    if (persistent) {
+        const int rc = tab ? persistent_encoder(w->enc_h2h_w, w->tok_table + 6 * D, 10LL * D, 0, w->enc_h2h_b, lens, seq, T, V,
+                                                h_cur, h_nxt, H, Mem, (long long)T * D, D, perm, nactive, enc_bar, B, D, T, st)
+                           : persistent_encoder(w->enc_h2h_w, xg, (long long)T * 4 * D, 4 * D, w->enc_h2h_b, lens, nullptr, 0, 0,
+                                                h_cur, h_nxt, H, Mem, (long long)T * D, D, perm, nactive, enc_bar, B, D, T, st);
+        if (rc == SET_OK) { if (T & 1) { float* tmp = h_cur; h_cur = h_nxt; h_nxt = tmp; } }
+        else if (rc == SET_ERR_UNSUPPORTED) persistent = false;
+        else return rc;
+    }
+    for (int t = 0; t < T && !persistent; ++t) {
         if (fused) {
             if (tab)
                 SET_TRY(fused_encoder_step(h_cur, h_nxt, enc_c, w->enc_h2h_w, w->tok_table + 6 * D, 10LL * D, 0,
@@ -210,7 +223,7 @@ static int begin_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const
     const int tgt = gemm_target_wgs();
     // ---- caption encoder (editnet.py:319-348)
     SET_TRY(editnet_encoder(w, prev, prevlen, ws.H, ws.Mem, ws.final_hidden, ws.mask, B, T, D, d->V, ws.emb_seq, ws.xg,
-                            ws.enc_h, ws.enc_c, ws.s_enc, ws.s_aff, st, ws.enc_order));
+                            ws.enc_h, ws.enc_c, ws.s_enc, ws.s_aff, st, ws.enc_order, ws.enc_bar));
     // ---- hoisted, loop-invariant projections (eval mode)
     {
         // one grouped launch over the encoder outputs: att1_c (editnet.py:370) and the contractions that are linear in
@@ -601,7 +614,7 @@ void* set_editnet_ws_tensor(const SetEditNetDims* d, void* ws, const char* name)
         {"c1", W.c1}, {"h2", W.h2}, {"c2", W.c2}, {"emb", W.emb}, {"ctx_cap", W.ctx_cap},
         {"attend_cap", W.attend_cap}, {"attend_img", W.attend_img}, {"sel", W.sel}, {"c_new", W.c_new},
         {"alpha_c", W.alpha_c}, {"alpha", W.alpha}, {"logits", W.logits}, {"it", W.it},
-        {"cap_proj", W.cap_proj}, {"mem_proj", W.mem_proj},
+        {"cap_proj", W.cap_proj}, {"mem_proj", W.mem_proj}, {"enc_bar", W.enc_bar},
         {"unfinished", W.unfinished}, {"alive", W.alive}};
     for (auto& e : tab)
         if (!strcmp(e.n, name)) return e.p;

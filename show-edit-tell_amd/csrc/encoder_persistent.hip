@@ -1,0 +1,315 @@
+// Weights-stationary persistent caption encoder: the whole recurrence of CaptionEncoderC.forward (editnet.py:331-338) —
+// T dependent steps of  gates = h W_hh^T + (hoisted x W_xh^T + b),  LSTM cell update, H / Mem stores — in ONE launch.
+//
+// The per-step launch (gemm_fused_k<..., ENCLSTM>) costs ~19.5 us for 1.07 GFLOP (6.8 us of matrix-pipe time): every
+// launch re-streams the 16.8 MB of W_hh through LDS and pays a launch boundary + start-up + cross-wave reduction.  Here
+//   * W_hh is split over G = D / 4 workgroups (256 at D = 1024, one per CU): a workgroup owns 4 hidden units = 16 gate rows
+//     of W_hh (64 KB at D = 1024) and keeps them IN REGISTERS for all T steps — each of its 4 waves holds the 16 rows over
+//     one quarter of K (64 VGPRs per lane) as ready-made B operands of v_mfma_f32_16x16x4_f32;
+//   * per step a wave contracts every 16-row tile of h (read as 16-byte pieces straight from L2: one load per lane feeds
+//     four MFMAs, K permuted identically in A and B) against its K quarter, the four partial tiles are added through LDS
+//     in fixed wave order, and 2 (row, unit) pairs per thread run the cell update with c and h kept in registers;
+//   * rows are visited longest first (perm / nactive, as in the per-step path): 16-row tiles whose rows have all finished
+//     skip their loads and MFMAs, finished rows carry their state;
+//   * the new h (2 KB per workgroup) is published with write-through (sc1) stores and the steps are separated by a grid
+//     barrier: per-shard arrival counters (blockIdx % 8), a top counter, per-shard generation words polled by ONE lane with
+//     relaxed loads + s_sleep, one agent-scope acquire per workgroup after the match (MI355X_MICROARCH.md, barrier-xcd /
+//     Guideline 16 R1).  Sharding is by block id, not by XCC id: correct for ANY placement; faster when block b runs on
+//     XCD b % 8, which is what the dispatcher does.
+// Residency: the barrier needs all G workgroups resident at once.  G <= 256 workgroups of 256 threads, <= 32 KB of LDS; the
+// default small-batch instantiation (B <= 32) stays within 256 registers (__launch_bounds__(256, 2)), so any two instances
+// fit the chip together (two processes sharing one GPU, e.g. the world-size-2 tests, cannot starve each other; the opt-in
+// B <= 128 instantiation takes a wave slot per SIMD alone); the host side serialises instances of this kernel across
+// streams with an event chain (at most one runs at a time in this process), other kernels sharing the chip always finish on
+// their own, and every spin is bounded (a timeout raises the status word instead of hanging the queue).
+#include <mutex>
+#include "set_common.h"
+
+namespace set {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const f32x4 __attribute__((address_space(1)))* gptr4;
+
+constexpr int PENC_BAR_STRIDE = 32;                 // unsigned words between two barrier words (128 bytes)
+constexpr int PENC_BAR_WORDS = (8 + 1 + 8) * PENC_BAR_STRIDE;
+constexpr unsigned PENC_SPIN_LIMIT = 4000000u;
+
+struct PEncArgs {
+    const float* w_hh;               // (4D, D), gate q of unit u at row q*D + u
+    const float* xg;                 // hoisted input projection: token table rows (seq != NULL) or (B, T, 4D)
+    long long ld_xg_row, ld_xg_t;
+    const float* b_extra;            // (4D) added to xg, or NULL
+    const int64_t* lens;             // (B)
+    const int64_t* seq;              // (B, seq_T) token ids when xg is a token table
+    int seq_T, seq_V;
+    float* hbuf0; float* hbuf1;      // (B, D) ping-pong; hbuf0 = initial state (zeros)
+    float* H; float* Mem;            // (B, T, D) outputs (zero-initialised by the caller)
+    long long ld_out_b, ld_out_t;
+    const int* perm; const int* nactive;
+    unsigned* bar;                   // PENC_BAR_WORDS zeroed words
+    unsigned* status;                // set to 1 on a barrier timeout
+    int B, D, T;
+};
+
+__device__ __forceinline__ float psigm(float x) { return 1.f / (1.f + expf(-x)); }
+
+// grid barrier, epoch = 1, 2, ... within the launch; `pop` = workgroups per shard, `ns` = shards.  Split in two so that work
+// which does not depend on the other workgroups (the H / Mem stores, the next step's input-projection gather) sits
+// between the arrival and the wait.  Data crossing the barrier (h) is stored AND loaded write-through / L1-bypassing (sc1
+// both sides, Guideline 16), so no release or acquire fence is needed: only the drain of this wave's own sc1 stores.
+__device__ __forceinline__ void penc_arrive(unsigned* bar, unsigned epoch, int shard, unsigned pop, unsigned ns) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave: its write-through stores are out
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned* mine = bar + shard * PENC_BAR_STRIDE;
+        const unsigned prev = __hip_atomic_fetch_add(mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev + 1u == epoch * pop) {                           // last arrival of this shard
+            const unsigned p2 = __hip_atomic_fetch_add(bar + 8 * PENC_BAR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p2 + 1u == epoch * ns)                            // last shard: release every shard's pollers
+                for (unsigned s = 0; s < ns; ++s)
+                    __hip_atomic_store(bar + (9 + s) * PENC_BAR_STRIDE, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+__device__ __forceinline__ void penc_wait(unsigned* bar, unsigned epoch, int shard, unsigned* status) {
+    if (threadIdx.x == 0) {
+        unsigned* gen = bar + (9 + shard) * PENC_BAR_STRIDE;
+        unsigned spins = 0;
+        // bounded spin; a timeout is sticky (later barriers of this launch do not wait again) and raises the status word
+        while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 1023u) == 0u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            if (spins > PENC_SPIN_LIMIT) { __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+    }
+    __syncthreads();
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// 16-byte sc1 load (L1 bypassed, served by L2 / memory): the reading side of the write-through h exchange
+__device__ __forceinline__ f32x4 ld_sc1(__amdgpu_buffer_rsrc_t rs, int byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16));
+}
+
+// acc[0..N) += h tiles (rows arow[rt], this wave's K quarter at hk) x the stationary W operands; loads run one k-block ahead
+template <int NT, int KB, int N>
+__device__ __forceinline__ void penc_contract(f32x4 (&acc)[NT], __amdgpu_buffer_rsrc_t hrs, int koff, const int (&aoff)[NT],
+                                              const f32x4 (&wreg)[KB]) {
+    f32x4 a0[N], a1[N];
+#pragma unroll
+    for (int rt = 0; rt < N; ++rt) a0[rt] = ld_sc1(hrs, aoff[rt] + koff);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        f32x4(&cur)[N] = (kb & 1) ? a1 : a0;
+        f32x4(&nxt)[N] = (kb & 1) ? a0 : a1;
+        if (kb + 1 < KB) {
+#pragma unroll
+            for (int rt = 0; rt < N; ++rt) nxt[rt] = ld_sc1(hrs, aoff[rt] + koff + 64 * (kb + 1));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int rt = 0; rt < N; ++rt)
+                acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[rt][j], wreg[kb][j], acc[rt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);           // keep the loads one k-block ahead, not sixteen (register budget)
+    }
+}
+
+// NT = 16-row tiles held (B <= 16 NT), KB = 16-wide k-blocks per wave (D = 64 KB)
+template <int NT, int KB>
+__global__ void __launch_bounds__(256, (NT <= 2 ? 2 : 1)) encoder_persistent_k(const PEncArgs P) {
+    constexpr int PAIRS = NT >= 4 ? NT / 4 : 1;      // (row, unit) pairs per thread: 16 NT rows x 4 units over 256 threads
+    extern __shared__ __attribute__((aligned(16))) float red[];       // [4 waves][16 NT rows][16 cols]
+    const int tid = threadIdx.x, lane = tid & 63, kq = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int D = P.D, B = P.B, K4 = D >> 2;
+    const int unit0 = blockIdx.x * 4;
+    const unsigned G = gridDim.x, ns = G < 8u ? G : 8u;
+    const int shard = (int)(blockIdx.x % ns);
+    const unsigned pop = G / ns + ((unsigned)shard < G % ns ? 1u : 0u);
+
+    // ---- stationary B operands: W_hh[gate row of column r][kq*K4 + 16 kb + 4 g .. +3]
+    f32x4 wreg[KB];
+    {
+        const float* wrow = P.w_hh + ((long long)(r >> 2) * D + unit0 + (r & 3)) * D + kq * K4 + 4 * g;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) wreg[kb] = *(gptr4)(wrow + 16 * kb);
+    }
+    // rows of this lane's A fragments (sorted position 16 rt + r -> batch row), clamped
+    int aoff[NT];                                    // byte offset of the row inside an h buffer (B * D * 4 < 2^31: B <= 256)
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) { const int p = 16 * rt + r; aoff[rt] = P.perm[p < B ? p : B - 1] * D * 4; }
+    const int hbytes = B * D * 4;
+    const __amdgpu_buffer_rsrc_t hrs0 = __builtin_amdgcn_make_buffer_rsrc((void*)P.hbuf0, 0, hbytes, 0x00027000);
+    const __amdgpu_buffer_rsrc_t hrs1 = __builtin_amdgcn_make_buffer_rsrc((void*)P.hbuf1, 0, hbytes, 0x00027000);
+    const int koff = (kq * K4 + 4 * g) * 4;
+    // (row, unit) pairs of this thread for the cell update: pair p = tid + 256 i -> sorted row p >> 2, unit p & 3
+    int prow[PAIRS], plen[PAIRS];
+    float creg[PAIRS], hreg[PAIRS];
+#pragma unroll
+    for (int i = 0; i < PAIRS; ++i) {
+        const int rs = (tid + 256 * i) >> 2;
+        prow[i] = rs < B ? P.perm[rs] : -1;
+        plen[i] = rs < B ? (int)P.lens[prow[i]] : 0;
+        creg[i] = 0.f;
+        hreg[i] = rs < B ? P.hbuf0[(long long)prow[i] * D + unit0 + ((tid + 256 * i) & 3)] : 0.f;
+    }
+
+    // the hoisted input projection of step t for this thread's pairs: it does not depend on the recurrence, so step t + 1's
+    // is requested between the arrival at step t's barrier and the wait (off the dependent chain)
+    float eg[PAIRS][4];
+#define PENC_GATHER(TT)                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < PAIRS; ++i) {                                                   \
+        const int u_ = unit0 + ((tid + 256 * i) & 3);                                                     \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) eg[i][q] = 0.f;                                     \
+        if (prow[i] >= 0 && (TT) < plen[i]) {                                                             \
+            const float* xr_;                                                                             \
+            if (P.seq) {                                                                                  \
+                long long tok_ = P.seq[(long long)prow[i] * P.seq_T + (TT)];                              \
+                tok_ = tok_ < 0 ? 0 : (tok_ >= P.seq_V ? P.seq_V - 1 : tok_);   /* same clamp as embed_relu_k */ \
+                xr_ = P.xg + tok_ * P.ld_xg_row;                                                          \
+            } else {                                                                                      \
+                xr_ = P.xg + (long long)prow[i] * P.ld_xg_row + (long long)(TT) * P.ld_xg_t;              \
+            }                                                                                             \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                 \
+                eg[i][q] = xr_[q * D + u_] + (P.b_extra ? P.b_extra[q * D + u_] : 0.f);                   \
+        }                                                                                                 \
+    }
+    PENC_GATHER(0);
+    for (int t = 0; t < P.T; ++t) {
+        const int nact = P.nactive[t];
+        const int nt_act = (nact + 15) >> 4;                       // wave-uniform: tiles with at least one live row
+        const __amdgpu_buffer_rsrc_t hrs = (t & 1) ? hrs1 : hrs0;
+        float* hout = (t & 1) ? P.hbuf0 : P.hbuf1;
+        // ---- contraction of the live row tiles against this wave's K quarter (static tile counts: 2, 4, 6, ... NT; the
+        // tiles beyond nt_act inside a variant hold finished rows only and their results are never read)
+        f32x4 acc[NT];
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (nt_act > 0) {
+            if constexpr (NT >= 16) { if (nt_act > 12) { penc_contract<NT, KB, 16>(acc, hrs, koff, aoff, wreg); goto contracted; } }
+            if constexpr (NT >= 12) { if (nt_act > 8) { penc_contract<NT, KB, 12>(acc, hrs, koff, aoff, wreg); goto contracted; } }
+            if constexpr (NT >= 8) { if (nt_act > 6) { penc_contract<NT, KB, 8>(acc, hrs, koff, aoff, wreg); goto contracted; } }
+            if constexpr (NT >= 6) { if (nt_act > 4) { penc_contract<NT, KB, 6>(acc, hrs, koff, aoff, wreg); goto contracted; } }
+            if constexpr (NT >= 4) { if (nt_act > 2) { penc_contract<NT, KB, 4>(acc, hrs, koff, aoff, wreg); goto contracted; } }
+            if (nt_act > 1) penc_contract<NT, KB, 2>(acc, hrs, koff, aoff, wreg);
+            else penc_contract<NT, KB, 1>(acc, hrs, koff, aoff, wreg);
+        }
+    contracted:
+        // ---- partial tiles -> LDS: C/D map of 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
+#pragma unroll
+        for (int rt = 0; rt < NT; ++rt)
+            if (rt < nt_act) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) red[((kq * NT + rt) * 16 + 4 * g + e) * 16 + r] = acc[rt][e];
+            }
+        __syncthreads();
+        // ---- cell update of this thread's pairs; h published write-through first, the barrier arrival next, and only then
+        // the H / Mem stores (plain: read after the launch) and the gather of the next step's input projection
+        float hn_[PAIRS], cn_[PAIRS];
+        bool live_[PAIRS];
+#pragma unroll
+        for (int i = 0; i < PAIRS; ++i) {
+            const int p = tid + 256 * i, rs = p >> 2, u = p & 3;
+            live_[i] = prow[i] >= 0 && t < plen[i];
+            if (prow[i] < 0) continue;
+            if (live_[i]) {
+                float gq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int o = rs * 16 + q * 4 + u;
+                    gq[q] = (((red[o] + red[NT * 256 + o]) + red[2 * NT * 256 + o]) + red[3 * NT * 256 + o]) + eg[i][q];
+                }
+                const float ai = psigm(gq[0]), af = psigm(gq[1]), ag = tanhf(gq[2]), ao = psigm(gq[3]);
+                const float cn = af * creg[i] + ai * ag;
+                const float hn = ao * tanhf(cn);
+                creg[i] = cn;
+                hreg[i] = hn;
+            }
+            hn_[i] = hreg[i]; cn_[i] = creg[i];
+            __hip_atomic_store(hout + (long long)prow[i] * D + unit0 + u, hreg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const bool more = t + 1 < P.T;
+        if (more) penc_arrive(P.bar, (unsigned)(t + 1), shard, pop, ns);
+#pragma unroll
+        for (int i = 0; i < PAIRS; ++i)
+            if (live_[i]) {
+                const long long o = (long long)prow[i] * P.ld_out_b + (long long)t * P.ld_out_t + unit0 + ((tid + 256 * i) & 3);
+                P.H[o] = hn_[i];
+                P.Mem[o] = cn_[i];
+            }
+        if (more) {
+            PENC_GATHER(t + 1);
+            penc_wait(P.bar, (unsigned)(t + 1), shard, P.status);
+        }
+    }
+#undef PENC_GATHER
+}
+
+static std::mutex g_penc_mutex;
+static hipEvent_t g_penc_event[64] = {};
+
+size_t persistent_encoder_bar_bytes() { return sizeof(unsigned) * (PENC_BAR_WORDS + PENC_BAR_STRIDE); }
+
+bool persistent_encoder_ok(int B, int D, int T) {
+    // default: small batches only (SET_ENC_PERSISTENT_MAXB rows).  Measured (round 3): a step of the dependent chain —
+    // drain the sc1 stores, two-level arrival, poll, re-read h from L2 — costs ~6-9 us, the per-step launch ~14 us + its
+    // matrix work: at B = 4 the recurrence takes 174 us instead of 280, at B = 128 385 us instead of 400 while the spinning
+    // workgroups take CU slots from the other batches in flight (headline -4 %)
+    static const int on = env_int("SET_ENC_PERSISTENT", 1);
+    static const int maxb = env_int("SET_ENC_PERSISTENT_MAXB", 32);
+    if (B > maxb) return false;
+    // 16-row tiles held in registers: 8 (B <= 128) fit the 256-register budget of two co-resident instances at D = 512 / 1024;
+    // 16 tiles would spill there (only the reduced test dimension takes them)
+    return on && B >= 1 && T >= 1 && ((B <= 128 && (D == 512 || D == 1024)) || (B <= 256 && D == 64));
+}
+
+template <int NT, int KB>
+static int launch_penc(const PEncArgs& P, hipStream_t s) {
+    const int lds = 4 * NT * 256 * (int)sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+        SET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&encoder_persistent_k<NT, KB>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        configured = true;
+    }
+    hipLaunchKernelGGL((encoder_persistent_k<NT, KB>), dim3(P.D / 4), dim3(256), lds, s, P);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+// the whole recurrence; hbuf0 must hold the initial state (zeros), H / Mem must be zero-filled, bar is scratch of
+// persistent_encoder_bar_bytes().  The final state is left in (T & 1) ? hbuf1 : hbuf0.
+int persistent_encoder(const float* w_hh, const float* xg, long long ld_xg_row, long long ld_xg_t, const float* b_extra,
+                       const int64_t* lens, const int64_t* seq, int seq_T, int seq_V, float* hbuf0, float* hbuf1, float* H,
+                       float* Mem, long long ld_out_b, long long ld_out_t, const int* perm, const int* nactive, void* bar,
+                       int B, int D, int T, hipStream_t s) {
+    if (!persistent_encoder_ok(B, D, T) || !perm || !nactive || !bar) return SET_ERR_UNSUPPORTED;
+    PEncArgs P{};
+    P.w_hh = w_hh; P.xg = xg; P.ld_xg_row = ld_xg_row; P.ld_xg_t = ld_xg_t; P.b_extra = b_extra; P.lens = lens;
+    P.seq = seq; P.seq_T = seq_T; P.seq_V = seq_V > 0 ? seq_V : 1; P.hbuf0 = hbuf0; P.hbuf1 = hbuf1; P.H = H; P.Mem = Mem;
+    P.ld_out_b = ld_out_b; P.ld_out_t = ld_out_t; P.perm = perm; P.nactive = nactive;
+    P.bar = (unsigned*)bar; P.status = (unsigned*)bar + PENC_BAR_WORDS; P.B = B; P.D = D; P.T = T;
+    ProfScope ps("persistent_encoder", s, 8.0 * B * D * D * T, 4.0 * (4.0 * D * D + 8.0 * B * D * T));
+    SET_HIP_TRY(hipMemsetAsync(bar, 0, persistent_encoder_bar_bytes(), s));
+    // at most ONE instance of this kernel runs at a time in this process: every launch waits for the previous one's
+    // completion event (a no-op when that was on the same stream); see the residency note at the top of the file
+    int dev = 0;
+    SET_HIP_TRY(hipGetDevice(&dev));
+    dev &= 63;
+    std::lock_guard<std::mutex> lk(g_penc_mutex);
+    static const int serialise = env_int("SET_ENC_PERSISTENT_SERIALISE", 1);
+    if (serialise) {
+        if (!g_penc_event[dev]) SET_HIP_TRY(hipEventCreateWithFlags(&g_penc_event[dev], hipEventDisableTiming));
+        else SET_HIP_TRY(hipStreamWaitEvent(s, g_penc_event[dev], 0));
+    }
+    int rc;
+    const int nt = (B + 15) / 16;
+    if (D == 1024) rc = nt <= 2 ? launch_penc<2, 16>(P, s) : launch_penc<8, 16>(P, s);
+    else if (D == 512) rc = nt <= 2 ? launch_penc<2, 8>(P, s) : launch_penc<8, 8>(P, s);
+    else rc = nt <= 2 ? launch_penc<2, 1>(P, s) : (nt <= 8 ? launch_penc<8, 1>(P, s) : launch_penc<16, 1>(P, s));
+    if (rc == SET_OK && serialise) SET_HIP_TRY(hipEventRecord(g_penc_event[dev], s));
+    return rc;
+}
+
+}  // namespace set

@@ -271,91 +271,7 @@ __global__ void __launch_bounds__(256 * KG) gemm_nt_f32(const int ntasks, const 
 #undef SET_FRAG_LOAD
 #undef SET_FRAG_MFMA
 
-    // ---- epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-#ifdef SET_EXP_NOEPI
-    if (T.M > 0) { if (acc[0][0][0] == 12345.678f) T.C[0] = 1.f; return; }
-#endif
-    if constexpr (KG == 2) {
-        // add the two k-groups' partial tiles: group 1 parks its accumulators in LDS (lane-major, conflict-free), group 0
-        // adds them to its own; only group 0 stores below
-        float* sR = &lds[1][0] + wave * (TM * TN * 1024) + lane;
-        if (kg == 1) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sR[((i * TN + j) * 16 + r) * 64] = acc[i][j][r];
-        }
-        __syncthreads();
-        if (kg == 0) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] += sR[((i * TN + j) * 16 + r) * 64];
-        }
-    }
-    const bool writer = (kg == 0);
-    float* Cs = T.C + (long long)ks * T.slab_stride;
-    const bool fused = (T.ksplit == 1);
-    const int crow0 = m0 + wm * TM * 32 + 4 * (lane >> 5);
-    const int ccol0 = n0 + wn * TN * 32 + (lane & 31);
-    if (T.vec_store) {
-        // 16-byte stores: each wave transposes its 32x32 sub-tiles through a private 4 KB LDS patch (the operand stages
-        // are dead after the loop's last barrier), so one store instruction writes 8 complete 128-byte rows instead of
-        // two (16 four-byte store instructions per sub-tile become 4; measured -0.8 us per decode-shape launch, +2.2 % on
-        // the bench; SET_GEMM_VEC_EPILOGUE=0 restores the scalar stores)
-        float* sT = &lds[0][0] + wave * 1024;
-        const int trow = lane >> 3, tcol = (lane & 7) * 4;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int colw = ccol0 + j * 32;
-            const float bv = (fused && T.bias && colw < T.N) ? T.bias[colw] : 0.f;
-            const int col = n0 + wn * TN * 32 + j * 32 + tcol;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                if (i + j) __syncthreads();                   // the previous sub-tile's reads are done
-                if (writer) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float v = acc[i][j][r];
-                        if (fused) v = apply_act(v + bv, T.act);
-                        sT[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = v;
-                    }
-                }
-                __syncthreads();
-                const int rbase = m0 + wm * TM * 32 + i * 32 + trow;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(sT + q * 256 + lane * 4);
-                    const int row = rbase + 8 * q;
-                    if (writer && row < T.M && col < T.N)     // N % 4 == 0 on this path: a 4-column group is all in or all out
-                        *reinterpret_cast<f32x4*>(Cs + (long long)row * T.ldc + col) = v4;
-                }
-            }
-        }
-    } else {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = ccol0 + j * 32;
-        if (col >= T.N) continue;
-        const float bv = (fused && T.bias) ? T.bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = crow0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                if (writer && row < T.M) {
-                    float v = acc[i][j][r];
-                    if (fused) v = apply_act(v + bv, T.act);
-                    Cs[(long long)row * T.ldc + col] = v;
-                }
-            }
-        }
-    }
-    }
+#include "gemm_f32_epilogue.inc"
 #ifdef SET_EXP_STAMPS
     SET_STAMP(6);
     if (tid == 0 && L.stamps) {
@@ -372,6 +288,164 @@ __global__ void __launch_bounds__(256 * KG) gemm_nt_f32(const int ntasks, const 
 #undef SET_GLOAD
 #undef SET_SEEK
 #undef SET_LSTORE
+
+// ---------------------------------------------------------------------------------------------
+// The same grouped GEMM with the operand tiles staged by LDS-DMA (`global_load_lds_dwordx4`): no VGPR round trip and no
+// ds_write pass.  A wave-instruction lands 64 x 16 B = 1 KB = eight 128-byte rows of the stage CONTIGUOUSLY (the LDS
+// destination is wave-uniform base + lane * 16), so the XOR swizzle of the 16-byte chunks is applied on the SOURCE side:
+// lane l of the piece that fills rows r0..r0+7 writes chunk position c' = l & 7 of row r = r0 + (l >> 3) and therefore
+// fetches logical chunk c = c' ^ ((r >> 1) & 7) of that row — still one full 128-byte line per 8 lanes.  The MFMA fragment
+// reads are those of gemm_nt_f32 (same image).  Three stages: while tile kt is contracted, tile kt+1 has landed or is
+// landing and tile kt+2 is being requested; one raw s_barrier per k-tile, counted vmcnt so that a DMA stays in flight
+// across the barrier (__syncthreads() would drain it: an LDS-DMA is a pending LDS write on the VM counter).
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_vptr;
+typedef const __attribute__((address_space(1))) void* glb_vptr;
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ void __launch_bounds__(256) gemm_nt_f32_dma(const int ntasks, const int wb1, const int wb2, const int wb3,
+                                                       const int wb4, const int wb5, const GemmLaunch L) {
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+    constexpr int KG = 1;
+    constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
+    constexpr int ROWS = BM + BN;                        // rows of one stage: A tile rows, then W tile rows
+    constexpr int PIECES = ROWS / 32;                    // 8-row DMA pieces per wave per k-tile
+    static_assert(ROWS % 32 == 0 && TM >= 1 && TN >= 1, "tile");
+    constexpr int NSTAGE = 3;
+    __shared__ __attribute__((aligned(16))) float lds[NSTAGE][ROWS * LDS_STRIDE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, kg = 0;
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+    int ti = 0;
+    {
+        const int bid = (int)blockIdx.x;
+        if (1 < ntasks && bid >= wb1) ti = 1;
+        if (2 < ntasks && bid >= wb2) ti = 2;
+        if (3 < ntasks && bid >= wb3) ti = 3;
+        if (4 < ntasks && bid >= wb4) ti = 4;
+        if (5 < ntasks && bid >= wb5) ti = 5;
+    }
+    const GemmTask& T = L.t[ti];
+    const int local = (int)blockIdx.x - T.wg_begin;
+    const int tm = local / T.tm_stride;
+    const int rem = local - tm * T.tm_stride;
+    if (rem >= T.tiles_n * T.ksplit) return;          // padding slot
+    const int ks = rem % T.ksplit;
+    const int tn = rem / T.ksplit;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kt0 = (int)(((long long)ks * T.ktiles) / T.ksplit);
+    const int kt1 = (int)(((long long)(ks + 1) * T.ktiles) / T.ksplit);
+
+    // ---- DMA assignment: piece i of this wave fills stage rows [8 * (wave * PIECES + i), +8); lane -> (row, chunk position)
+    int prow[PIECES];            // global row (clamped) of this lane's stage row, in A (stage row < BM) or W
+    int pcol[PIECES];            // float offset of the logical chunk this lane fetches
+    bool pisw[PIECES];
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+        const int sr = 8 * (wave * PIECES + i) + (lane >> 3);        // stage row
+        pisw[i] = sr >= BM;
+        int r = pisw[i] ? n0 + (sr - BM) : m0 + sr;
+        const int lim = pisw[i] ? T.N : T.M;
+        prow[i] = r < lim ? r : lim - 1;
+        pcol[i] = ((lane & 7) ^ ((sr >> 1) & 7)) * 4;
+    }
+    const float* pp[PIECES];     // running per-lane source pointers inside the current K segment
+    int seg_end = 0;
+#define DMA_SEEK(KT)                                                                                    \
+    {                                                                                                   \
+        const int kt_ = (KT);                                                                           \
+        int s_ = 0, kbase_ = 0;                                                                         \
+        _Pragma("unroll") for (int i = 0; i < GEMM_MAX_SEG - 1; ++i)                                    \
+            if (i + 1 < T.nseg && kt_ >= T.kt_end[i]) { s_ = i + 1; kbase_ = T.kt_end[i]; }             \
+        const float* Ab_ = T.A[0];                                                                      \
+        const float* Wb_ = T.W[0];                                                                      \
+        long long lda_ = T.lda[0], ldw_ = T.ldw[0];                                                     \
+        seg_end = T.kt_end[0];                                                                          \
+        _Pragma("unroll") for (int i = 1; i < GEMM_MAX_SEG; ++i)                                        \
+            if (s_ == i) { Ab_ = T.A[i]; Wb_ = T.W[i]; lda_ = T.lda[i]; ldw_ = T.ldw[i]; seg_end = T.kt_end[i]; } \
+        const long long koff_ = (long long)(kt_ - kbase_) * GEMM_BK;                                    \
+        _Pragma("unroll") for (int i = 0; i < PIECES; ++i)                                              \
+            pp[i] = (pisw[i] ? Wb_ + prow[i] * ldw_ : Ab_ + prow[i] * lda_) + koff_ + pcol[i];          \
+    }
+    // request tile KT into stage SLOT (no-op past the end of the slice)
+#define DMA_ISSUE(KT, SLOT)                                                                             \
+    if ((KT) < kt1) {                                                                                   \
+        if ((KT) == seg_end) DMA_SEEK(KT);                                                              \
+        _Pragma("unroll") for (int i = 0; i < PIECES; ++i) {                                            \
+            __builtin_amdgcn_global_load_lds((glb_vptr)pp[i],                                           \
+                (lds_vptr)(&lds[SLOT][(8 * (wave * PIECES + i)) * LDS_STRIDE]), 16, 0, 0);              \
+            pp[i] += GEMM_BK;                                                                           \
+        }                                                                                               \
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int frow = lane & 31;
+    int fo[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) fo[kk] = (((kk * 2 + (lane >> 5)) ^ ((frow >> 1) & 7)) * 4);
+
+    if (kt0 < kt1) {
+        DMA_SEEK(kt0);
+        DMA_ISSUE(kt0, 0);
+        DMA_ISSUE(kt0 + 1, 1);
+    }
+    int slot = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        // tile kt has landed once this wave's older pieces are done (the PIECES of tile kt+1 may still fly) and every wave
+        // has said so at the barrier; the barrier also tells that everybody is done READING stage (kt-1) % 3 = (kt+2) % 3
+        if (kt + 1 < kt1) { if constexpr (PIECES == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                            else if constexpr (PIECES == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int nslot = slot == 0 ? 2 : slot - 1;             // (slot + 2) % 3
+        DMA_ISSUE(kt + 2, nslot);
+        const float* sA = &lds[slot][0] + (wm * TM * 32 + frow) * LDS_STRIDE;
+        const float* sW = &lds[slot][0] + BM * LDS_STRIDE + (wn * TN * 32 + frow) * LDS_STRIDE;
+        f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+#define DMA_FRAG(KK, FA, FB)                                                                            \
+        {                                                                                               \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
+                FA[i] = *reinterpret_cast<const f32x4*>(sA + i * 32 * LDS_STRIDE + fo[KK]);             \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                              \
+                FB[j] = *reinterpret_cast<const f32x4*>(sW + j * 32 * LDS_STRIDE + fo[KK]);             \
+        }
+#define DMA_MFMA(FA, FB)                                                                                \
+        {                                                                                               \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                        \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].x, FB[j].x, acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].y, FB[j].y, acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].z, FB[j].z, acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].w, FB[j].w, acc[i][j], 0, 0, 0); \
+                }                                                                                       \
+        }
+        DMA_FRAG(0, fa0, fb0);
+        DMA_FRAG(1, fa1, fb1);
+        DMA_MFMA(fa0, fb0);
+        DMA_FRAG(2, fa0, fb0);
+        DMA_MFMA(fa1, fb1);
+        DMA_FRAG(3, fa1, fb1);
+        DMA_MFMA(fa0, fb0);
+        DMA_MFMA(fa1, fb1);
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+#undef DMA_FRAG
+#undef DMA_MFMA
+#undef DMA_ISSUE
+#undef DMA_SEEK
+    __syncthreads();                                     // all fragment reads done: the stages are free for the epilogue
+#include "gemm_f32_epilogue.inc"
+}
 
 // ---------------------------------------------------------------------------------------------
 // EXPERIMENTAL, opt-in (SET_GEMM_SPLIT=1; never the default, never the headline number): the same grouped
@@ -576,6 +650,100 @@ __global__ void __launch_bounds__(256) gemm_nt_split_bf16(const GemmLaunch L) {
 
 
 
+
+// ---------------------------------------------------------------------------------------------
+// <= 16 rows (the decode batch of BASELINE.json configs[0], beam search, the tail of a ragged teacher-forced batch): the
+// launch is pure weight streaming (0.5 flop per weight byte at M = 4) and the 32x128 LDS-staged tile above reaches ~3 TB/s
+// of it.  Here nothing goes through LDS: a wave owns 16 weight rows (= 16 output columns) over the workgroup's K slice and
+// streams them straight into registers — lane (n = l & 15, g = l >> 4) fetches W[n][k + 4g .. +3] as ONE 16-byte load that
+// feeds four v_mfma_f32_16x16x4_f32 (K inside a 16-block is permuted identically for the activations), eight such loads
+// in flight per lane before the first MFMA — against the <= 16 activation rows (rows >= M repeat row M - 1 and are never
+// stored), which come from L1/L2.  Same task descriptors, K segments, split-K slabs and fused bias / activation as
+// gemm_nt_f32; workgroup = 4 waves = 64 columns of one task x one K slice, no barrier anywhere.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gemv_nt_f32(const int ntasks, const int wb1, const int wb2, const int wb3,
+                                                   const int wb4, const int wb5, const GemmLaunch L) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    int ti = 0;
+    {
+        const int bid = (int)blockIdx.x;
+        if (1 < ntasks && bid >= wb1) ti = 1;
+        if (2 < ntasks && bid >= wb2) ti = 2;
+        if (3 < ntasks && bid >= wb3) ti = 3;
+        if (4 < ntasks && bid >= wb4) ti = 4;
+        if (5 < ntasks && bid >= wb5) ti = 5;
+    }
+    const GemmTask& T = L.t[ti];
+    const int local = (int)blockIdx.x - T.wg_begin;
+    if (local >= T.tiles_n * T.ksplit) return;
+    const int ks = local % T.ksplit;
+    const int tn = local / T.ksplit;
+    const int n0 = tn * 64 + wave * 16;
+    if (n0 >= T.N) return;
+    const int kt0 = (int)(((long long)ks * T.ktiles) / T.ksplit);
+    const int kt1 = (int)(((long long)(ks + 1) * T.ktiles) / T.ksplit);
+    const int wrow = n0 + r < T.N ? n0 + r : T.N - 1;
+    const int arow = r < T.M ? r : T.M - 1;
+
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#define GV_MFMA(A4, W4)                                                                  \
+    {                                                                                    \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).x, (W4).x, acc, 0, 0, 0);        \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).y, (W4).y, acc, 0, 0, 0);        \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).z, (W4).z, acc, 0, 0, 0);        \
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).w, (W4).w, acc, 0, 0, 0);        \
+    }
+    int sb = 0;
+#pragma unroll
+    for (int s = 0; s < GEMM_MAX_SEG; ++s) {
+        if (s >= T.nseg) break;
+        const int se = T.kt_end[s];
+        const int a = kt0 > sb ? kt0 : sb, b = kt1 < se ? kt1 : se;
+        if (a < b) {
+            const float* pa = T.A[s] + (long long)arow * T.lda[s] + (long long)(a - sb) * GEMM_BK + 4 * g;
+            const float* pw = T.W[s] + (long long)wrow * T.ldw[s] + (long long)(a - sb) * GEMM_BK + 4 * g;
+            int kt = a;
+            for (; kt + 4 <= b; kt += 4) {              // 4 k-tiles = eight 16-byte weight loads in flight per lane
+                f32x4 w[8], x[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) w[i] = *(gptr4)(pw + 16 * i);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = *(gptr4)(pa + 16 * i);
+                __builtin_amdgcn_sched_barrier(0);      // all sixteen requests out before the first MFMA waits for one
+#pragma unroll
+                for (int i = 0; i < 8; ++i) GV_MFMA(x[i], w[i]);
+                __builtin_amdgcn_sched_barrier(0);
+                pa += 4 * GEMM_BK; pw += 4 * GEMM_BK;
+            }
+            for (; kt < b; ++kt) {
+                const f32x4 w0 = *(gptr4)(pw), w1 = *(gptr4)(pw + 16), x0 = *(gptr4)(pa), x1 = *(gptr4)(pa + 16);
+                GV_MFMA(x0, w0);
+                GV_MFMA(x1, w1);
+                pa += GEMM_BK; pw += GEMM_BK;
+            }
+        }
+        sb = se;
+    }
+#undef GV_MFMA
+    // C/D map of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
+    float* Cs = T.C + (long long)ks * T.slab_stride;
+    const int col = n0 + r;
+    if (col < T.N) {
+        const bool fused = (T.ksplit == 1);
+        const float bv = (fused && T.bias) ? T.bias[col] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = 4 * g + e;
+            if (row < T.M) {
+                float v = acc[e];
+                if (fused) v = apply_act(v + bv, T.act);
+                Cs[(long long)row * T.ldc + col] = v;
+            }
+        }
+    }
+}
+
 int gemm_tile_m(int M) {
     // 64x64 tiles up to M = 512 (measured: +4-5 % at M = 128, +10 % at M = 256-384; big-M prologue / training products
     // stay on 128x64): at the decode batch two 64-row tiles per weight block (the second one hits the
@@ -583,8 +751,12 @@ int gemm_tile_m(int M) {
     // and 32 KB workgroups pack three per CU.  Measured +4-5 % on the bench against the 128x64 tile.
     static const int bm64_upto = env_int("SET_GEMM_BM64_UPTO", gemm_split_mode() ? 64 : 512);   // the split kernel is 128x64 only
     static const int bm32_upto = env_int("SET_GEMM_BM32_UPTO", 32);
-    return M <= bm32_upto ? 32 : (M <= bm64_upto ? 64 : 128);
+    // <= 16 rows (configs[0]'s batch of 4, beam search, the tail of a ragged teacher-forced batch): the launch only streams
+    // weights; gemv_nt_f32 (no LDS, one 16x16 MFMA tile per wave, loads straight into registers) instead of a 32-row tile
+    static const int bm16_upto = env_int("SET_GEMM_BM16_UPTO", 16);
+    return M <= bm16_upto ? 16 : (M <= bm32_upto ? 32 : (M <= bm64_upto ? 64 : 128));
 }
+static int gemm_dma() { static int v = env_int("SET_GEMM_DMA", 0); return v; }
 static int gemm_kgroups() { static int v = env_int("SET_GEMM_KGROUPS", 1); return v; }
 static int gemm_bn128() { static int v = env_int("SET_GEMM_BN128", 0); return v; }
 static int tile_m_of(const GemmProb& p) { return (p.bm_hint == 64 || p.bm_hint == 128) ? p.bm_hint : gemm_tile_m(p.M); }
@@ -594,7 +766,11 @@ static int tile_m_of(const GemmProb& p) { return (p.bm_hint == 64 || p.bm_hint =
 // (288 tiles = 2 rounds, as 576: 3 half rounds) 75 -> 56 us; the large products of the training step (fc over all
 // timesteps, the all-timestep region projection: >= 11 rounds either way) stay on 128x64.
 static int launch_tile_m(const GemmProb* probs, int n) {
-    const int bm = tile_m_of(probs[0]);
+    // one row-tile class per launch: the largest any problem asks for (the teacher-forced loop merges fc over this step's
+    // rows with phase A over the next step's, and the sorted batch may shrink across a class boundary in between)
+    int bm = tile_m_of(probs[0]);
+    if (!probs[0].bm_hint)
+        for (int i = 1; i < n; ++i) { const int c = tile_m_of(probs[i]); if (c > bm) bm = c; }
     static const int model = env_int("SET_GEMM_TILE_MODEL", 1);
     if (!model || probs[0].bm_hint || bm != 128 || gemm_split_mode() || gemm_bn128()) return bm;
     long long t128 = 0, t64 = 0;
@@ -608,7 +784,7 @@ static int launch_tile_m(const GemmProb* probs, int n) {
 }
 static int launch_tile_n(const GemmProb* probs, int n) {
     const int bm = launch_tile_m(probs, n);
-    return (bm == 32 || (bm == 128 && gemm_bn128())) ? 128 : 64;
+    return (bm == 32 || (bm == 128 && gemm_bn128())) ? 128 : 64;      // (class 16: 4 waves x 16 columns)
 }
 
 // Split-K plan for one grouped launch: every workgroup should run about the same number of k-tiles
@@ -624,6 +800,9 @@ void plan_ksplit(GemmProb* probs, int n, int cap_wgs) {
     if (n > 0 && bm_l == 64) cap_wgs = cap_wgs * pct64 / 100;
     // <= 32 rows: the launch only streams weights; fewer, longer workgroups halve the slab traffic (measured +5 %)
     if (n > 0 && bm_l == 32) cap_wgs = cap_wgs * pct32 / 100;
+    // <= 16 rows: 64-column workgroups without LDS, many fit a CU; slabs are a few KB, so split generously for bytes in flight
+    static const int pct16 = env_int("SET_GEMM_WGS16_PCT", 200);
+    if (n > 0 && bm_l == 16) cap_wgs = cap_wgs * pct16 / 100;
     int tiles[GEMM_MAX_TASKS], kts[GEMM_MAX_TASKS], max_kt = 1;
     for (int i = 0; i < n; ++i) {
         const int bm = bm_l, bn = bn_l;
@@ -676,12 +855,11 @@ int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag
 #endif
     int wg = 0;
     const int bm = launch_tile_m(probs, n), bn = launch_tile_n(probs, n);
-    const int bm_class = tile_m_of(probs[0]);
     for (int i = 0; i < n; ++i) {
         const GemmProb& p = probs[i];
         GemmTask& t = L.t[i];
         if (p.M <= 0 || p.N <= 0 || p.nseg <= 0 || p.nseg > GEMM_MAX_SEG || !p.C) return SET_ERR_ARG;
-        if (!probs[0].bm_hint && gemm_tile_m(p.M) != bm_class) return SET_ERR_ARG;   // one row-tile class per launch
+        if (bm == 16 && p.M > 16) return SET_ERR_ARG;
         int kt = 0;
         for (int s = 0; s < GEMM_MAX_SEG; ++s) {
             if (s < p.nseg) {
@@ -717,7 +895,7 @@ int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag
         flops += 2.0 * t.M * t.N * K;
         bytes += 4.0 * ((double)t.M * K + (double)t.N * K + (double)t.M * t.N * t.ksplit);
     }
-    const char* kname = bm == 128 ? "gemm_nt_f32<128,64>" : (bm == 64 ? "gemm_nt_f32<64,64>" : "gemm_nt_f32<32,128>");
+    const char* kname = bm == 128 ? "gemm_nt_f32<128,64>" : (bm == 64 ? "gemm_nt_f32<64,64>" : (bm == 32 ? "gemm_nt_f32<32,128>" : "gemv_nt_f32<16,64>"));
     ProfScope ps(kname, stream, flops, bytes);
     static const bool sites = env_int("SET_PROFILE_SITES", 0) != 0;   // per-call-site breakdown (nested events)
     ProfScope ps2(sites ? (tag ? tag : "gemm:other") : nullptr, stream, flops, bytes);
@@ -736,12 +914,18 @@ int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag
     } else {
         const int nt = L.ntasks, w1 = L.t[1].wg_begin, w2 = L.t[2].wg_begin, w3 = L.t[3].wg_begin, w4 = L.t[4].wg_begin,
                   w5 = L.t[5].wg_begin;
-        if (bm == 128 && bn == 128)
+        if (bm == 16)
+            hipLaunchKernelGGL(gemv_nt_f32, grid, block, 0, stream, nt, w1, w2, w3, w4, w5, L);
+        else if (bm == 128 && bn == 128)
             hipLaunchKernelGGL((gemm_nt_f32<128, 128, 2, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, L);
+        else if (bm == 128 && gemm_dma())
+            hipLaunchKernelGGL((gemm_nt_f32_dma<128, 64, 2, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, L);
         else if (bm == 128)
             hipLaunchKernelGGL((gemm_nt_f32<128, 64, 2, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, L);
         else if (bm == 64 && gemm_kgroups() == 2)
             hipLaunchKernelGGL((gemm_nt_f32<64, 64, 2, 2, 2>), grid, dim3(512), 0, stream, nt, w1, w2, w3, w4, w5, L);
+        else if (bm == 64 && gemm_dma())
+            hipLaunchKernelGGL((gemm_nt_f32_dma<64, 64, 2, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, L);
         else if (bm == 64)
             hipLaunchKernelGGL((gemm_nt_f32<64, 64, 2, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, L);
         else

@@ -112,7 +112,15 @@ GemmProb slab_prob(float* slab, int M, int N, int Bmax);
 GemmProb direct_prob(float* out, long long ldo, int M, int N, const float* bias, int act);
 int editnet_encoder(const SetEditNetWeights* w, const int64_t* seq, const int64_t* lens, float* H, float* Mem,
                     float* final_hidden, float* mask, int B, int T, int D, int V, float* emb_seq, float* xg,
-                    float* enc_h, float* enc_c, float* s_enc, float* s_aff, hipStream_t st, int* order = nullptr);
+                    float* enc_h, float* enc_c, float* s_enc, float* s_aff, hipStream_t st, int* order = nullptr,
+                    void* enc_bar = nullptr);
+// encoder_persistent.hip: the whole encoder recurrence in one weights-stationary launch with grid barriers
+size_t persistent_encoder_bar_bytes();
+bool persistent_encoder_ok(int B, int D, int T);
+int persistent_encoder(const float* w_hh, const float* xg, long long ld_xg_row, long long ld_xg_t, const float* b_extra,
+                       const int64_t* lens, const int64_t* seq, int seq_T, int seq_V, float* hbuf0, float* hbuf1, float* H,
+                       float* Mem, long long ld_out_b, long long ld_out_t, const int* perm, const int* nactive, void* bar,
+                       int B, int D, int T, hipStream_t s);
 
 // a per-row gathered addend: value(m, n) = tab[ids[m*id_stride]*ld + col0 + n]   (tab == NULL: none)
 struct RowGather {

@@ -20,6 +20,7 @@ from .optim import clip_grad_norm_and_step
 
 GRAD_CLIP = 0.25                     # editnet.py:580
 BUCKET_BYTES = 64 << 20              # xGMI rings are per-link bound: few, large buckets
+_FLAT_BUCKETS = os.environ.get("SET_FLAT_GRAD_BUCKETS", "1") != "0"   # data-parallel: `.grad` as views of persistent flat buckets
 
 
 def xe_loss_sum(scores, caps_sorted, decode_lengths):
@@ -45,15 +46,75 @@ def _all_reduce_sum(dist, t, group=None, async_op=False):
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 
+class FlatGradBuckets:
+    """Persistent flat fp32 gradient buffers of one module: every parameter's `.grad` is a VIEW into a bucket, so a
+    bucket's all-reduce runs IN PLACE — no `torch.cat` into a fresh 64 MB buffer before every collective, no copy back
+    after it (2 x 355 MB of traffic and the allocator churn per step otherwise).  Buckets follow the order in which the
+    backward finishes gradients: `first` (fc, whose gradient is final when the sequence node's backward starts) gets a
+    bucket of its own so that its collective runs underneath the whole back-propagation through time; the rest are
+    packed in parameter order into <= bucket_bytes buckets (xGMI rings are per-link bound: few, large collectives).
+    `attach()` zeroes the buffers and points every `.grad` at its view; the backward then accumulates into them."""
+
+    ALIGN = 64                      # floats: every view starts on a 256-byte boundary (16-byte kernel loads, Adam kernel)
+
+    def __init__(self, params, bucket_bytes, first=()):
+        first_ids = {id(p) for p in first}
+        order = [p for p in params if id(p) in first_ids] + [p for p in params if id(p) not in first_ids]
+        assert order and all(p.dtype == torch.float32 for p in order)
+        self.params = order
+        self.sig = tuple((id(p), p.numel(), p.device) for p in params)
+        dev = order[0].device
+        plan, cur, cur_n, cap = [], [], 0, max(1, bucket_bytes // 4)
+        for i, p in enumerate(order):
+            n = -(-p.numel() // self.ALIGN) * self.ALIGN
+            boundary = cur and (cur_n + n > cap or (first_ids and i == len(first_ids)))
+            if boundary:
+                plan.append((cur, cur_n))
+                cur, cur_n = [], 0
+            cur.append((p, cur_n))
+            cur_n += n
+        plan.append((cur, cur_n))
+        self.flat = [torch.zeros(n, dtype=torch.float32, device=dev) for _, n in plan]
+        self.view, self.bucket_of, self.members = {}, {}, []
+        for b, (items, _) in enumerate(plan):
+            self.members.append(len(items))
+            for p_, off in items:
+                self.view[id(p_)] = self.flat[b][off:off + p_.numel()].view_as(p_)
+                self.bucket_of[id(p_)] = b
+        self.by_ptr = {v.data_ptr(): pid for pid, v in self.view.items()}
+        self.bytes = sum(f.numel() * 4 for f in self.flat)
+
+    def attach(self):
+        for f in self.flat:
+            f.zero_()
+        for p in self.params:
+            p.grad = self.view[id(p)]
+
+
+def flat_grad_buckets(module, params, bucket_bytes=None, first=()):
+    """the module's FlatGradBuckets (built once, rebuilt when the parameter set / device changes)"""
+    params = list(params)
+    fb = module.__dict__.get("_grad_buckets")
+    sig = tuple((id(p), p.numel(), p.device) for p in params)
+    if fb is None or fb.sig != sig or fb.bucket_bytes != (bucket_bytes or BUCKET_BYTES):
+        fb = FlatGradBuckets(params, bucket_bytes or BUCKET_BYTES, first)
+        fb.bucket_bytes = bucket_bytes or BUCKET_BYTES
+        module.__dict__["_grad_buckets"] = fb
+    return fb
+
+
 class BucketedAllReduce:
     """SUM all-reduce of gradients in flat buckets.  A bucket's collective is started asynchronously as soon as
-    the bucket is full (RCCL runs it on its own stream) and the sums are copied back in `finish()`.  Gradients
+    the bucket is complete (RCCL runs it on its own stream); `finish()` waits for all of them.  Gradients
     arrive through `add()`: inside `deferred_param_grads(on_ready=...)` every parameter is handed over the moment its
     time-batched weight-gradient contraction has been enqueued, so a bucket's collective overlaps the contractions of
-    the parameters that follow (NOT the activation backward, which has finished by then).
+    the parameters that follow (NOT the activation backward, which has finished by then) — except fc, whose gradient
+    is final at the start of the backward and whose bucket therefore runs underneath all of it.
+    With `flat` (FlatGradBuckets: `.grad` tensors are views of persistent flat buffers) the collective runs in place on
+    the bucket; without it, finished gradients are packed into a fresh flat buffer and the sums copied back in `finish()`.
     xGMI rings are per-link bound, so buckets are few and large (64 MB)."""
 
-    def __init__(self, group=None, bucket_bytes=None, enabled=True):
+    def __init__(self, group=None, bucket_bytes=None, enabled=True, flat=None):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -63,6 +124,11 @@ class BucketedAllReduce:
         self.bucket, self.size, self.pending, self.seen = [], 0, [], set()
         self.n_buckets = 0
         self.bytes = 0
+        self.flat = flat if self.active else None
+        if self.flat is not None:
+            self.arrived = [0] * len(self.flat.flat)
+            self.launched = [False] * len(self.flat.flat)
+            self.strays = []
 
     def add(self, grad, flush=False):
         """queue one final gradient tensor (each tensor once); flush: start the (partial) bucket's collective now — used
@@ -71,6 +137,16 @@ class BucketedAllReduce:
         if not self.active or grad is None or id(grad) in self.seen:
             return
         self.seen.add(id(grad))
+        if self.flat is not None:
+            pid = self.flat.by_ptr.get(grad.data_ptr())
+            if pid is None:                  # a gradient that does not live in its view (replaced by the caller): pack it the old way
+                self.strays.append(grad)
+                return
+            b = self.flat.bucket_of[pid]
+            self.arrived[b] += 1
+            if self.arrived[b] == self.flat.members[b]:
+                self._launch_flat(b)
+            return
         nbytes = grad.numel() * grad.element_size()
         if self.bucket and self.size + nbytes > self.bucket_bytes:
             self._launch()
@@ -78,6 +154,16 @@ class BucketedAllReduce:
         self.size += nbytes
         if self.size >= self.bucket_bytes or (flush and self.size >= (8 << 20)):
             self._launch()
+
+    def _launch_flat(self, b):
+        if self.launched[b]:
+            return
+        self.launched[b] = True
+        flat = self.flat.flat[b]
+        work = _all_reduce_sum(self.dist, flat, self.group, async_op=True)
+        self.pending.append((work, None, None))
+        self.bytes += flat.numel() * flat.element_size()
+        self.n_buckets += 1
 
     def _launch(self):
         if not self.bucket:
@@ -90,13 +176,21 @@ class BucketedAllReduce:
         self.n_buckets += 1
 
     def finish(self):
-        """launch the last partial bucket, wait for every collective and scatter the sums back; returns #buckets"""
+        """launch what has not been launched, wait for every collective (and scatter the sums back where a bucket was
+        packed); returns #buckets"""
         if not self.active:
             return 0
+        if self.flat is not None:
+            for b in range(len(self.flat.flat)):      # buckets with a member that never announced itself (unused parameter)
+                self._launch_flat(b)
+            for g in self.strays:
+                self.bucket.append(g)
         self._launch()
         for work, flat, bucket in self.pending:
             if work is not None:
                 work.wait()
+            if bucket is None:
+                continue
             off = 0
             for g in bucket:
                 g.copy_(flat[off:off + g.numel()].view_as(g))
@@ -138,25 +232,47 @@ def _global_loss(loss_sum_local, n_glob, group=None):
     return float(t.item()) / max(n_glob, 1)
 
 
+def _token_count(caplens, caplens_host=None):
+    """sum of the decode lengths (caption length - 1) WITHOUT a device->host synchronisation when a host copy of the
+    lengths is at hand (the data loader's tensor before `.to(device)`, editnet.py:560-563)"""
+    src = caplens_host if caplens_host is not None else caplens
+    if torch.is_tensor(src):
+        return int((src.reshape(-1).to("cpu") - 1).sum().item()) if src.is_cuda else int((src.reshape(-1) - 1).sum())
+    return int(sum(int(l) - 1 for l in src))
+
+
+def _begin_backward(module, group, grp_on, first=()):
+    """gradient storage of one backward: data-parallel -> persistent flat buckets with `.grad` as views (zeroed; the
+    backward accumulates into them and every bucket is all-reduced in place); single rank -> `.grad = None` (the fused
+    weight-gradient contractions then write fresh tensors without reading anything)"""
+    params = [p for p in module.parameters() if p.requires_grad]
+    if grp_on and _FLAT_BUCKETS and all(p.is_cuda and p.dtype == torch.float32 for p in params):
+        fb = flat_grad_buckets(module, params, first=first)
+        fb.attach()
+        return BucketedAllReduce(group, enabled=True, flat=fb)
+    for p in module.parameters():
+        p.grad = None
+    return BucketedAllReduce(group, enabled=grp_on)
+
+
 def xe_backward(decoder, image_features, caps, caplens, previous_caption, prev_caplen, use_ss=False, ss_prob=0.0,
-                group=None, reduce=True):
+                group=None, reduce=True, caplens_host=None):
     """Forward + backward + gradient exchange of editnet.py:558-579 on this rank's shard; leaves the SUM-reduced
     gradients of the GLOBAL mean loss in `.grad`.  Returns (global mean loss, local tokens, reducer).
-    `reduce=False` skips every collective (single-rank timing of the same step)."""
+    `reduce=False` skips every collective (single-rank timing of the same step).  `caplens_host`: the caption lengths
+    as the data loader produced them (host tensor / list) — with it the token count costs no device round trip."""
     from .autograd_ops import deferred_param_grads
     grp_on = reduce and _dist_active(group)
     # the token count only depends on the caption lengths: exchange it BEFORE the forward is enqueued so the
     # host never waits on the device between forward and backward
-    n_tok = int((caplens.reshape(-1) - 1).sum().item())
+    n_tok = _token_count(caplens, caplens_host)
     n_glob = global_token_count(n_tok, image_features.device, group) if grp_on else n_tok
     scores, caps_sorted, decode_lengths, _ = decoder(image_features, caps, caplens, previous_caption, prev_caplen, use_ss,
                                                      ss_prob)
     loss_sum, n_chk, _, _ = xe_loss_sum(scores, caps_sorted, decode_lengths)
     assert n_chk == n_tok, (n_chk, n_tok)
     loss = loss_sum / n_glob
-    for p in decoder.parameters():
-        p.grad = None
-    reducer = BucketedAllReduce(group, enabled=grp_on)
+    reducer = _begin_backward(decoder, group, grp_on, first=(decoder.fc.weight, decoder.fc.bias))
     # one weight-gradient contraction per parameter over all timesteps; every finished gradient goes straight
     # into an all-reduce bucket, so the collectives overlap the remaining contractions
     with deferred_param_grads(on_ready=lambda p, eager=False: reducer.add(p.grad, flush=eager)):
@@ -167,30 +283,28 @@ def xe_backward(decoder, image_features, caps, caplens, previous_caption, prev_c
 
 
 def xe_train_step(decoder, optimizer, image_features, caps, caplens, previous_caption, prev_caplen, use_ss=False,
-                  ss_prob=0.0, group=None, reduce=True):
+                  ss_prob=0.0, group=None, reduce=True, caplens_host=None):
     """One step of editnet.py:558-581 on this rank's shard.  Returns (GLOBAL mean loss — identical on every
     rank —, local tokens)."""
     decoder.train()
     loss, n_tok, _ = xe_backward(decoder, image_features, caps, caplens, previous_caption, prev_caplen, use_ss, ss_prob,
-                                 group, reduce)
+                                 group, reduce, caplens_host)
     params = [p for p in decoder.parameters() if p.requires_grad]
     clip_grad_norm_and_step(params, optimizer, GRAD_CLIP)
     return loss, n_tok
 
 
-def dcnet_xe_backward(dae, caps, caplens, previous_caption, prev_caplen, group=None, reduce=True):
+def dcnet_xe_backward(dae, caps, caplens, previous_caption, prev_caplen, group=None, reduce=True, caplens_host=None):
     """DCNet twin of `xe_backward` (dcnet.py:352-400): the denoising auto-encoder has no image input."""
     from .autograd_ops import deferred_param_grads
     grp_on = reduce and _dist_active(group)
-    n_tok = int((caplens.reshape(-1) - 1).sum().item())
+    n_tok = _token_count(caplens, caplens_host)
     n_glob = global_token_count(n_tok, caps.device, group) if grp_on else n_tok
     scores, caps_sorted, decode_lengths, _ = dae(caps, caplens, previous_caption, prev_caplen)
     loss_sum, n_chk, _, _ = xe_loss_sum(scores, caps_sorted, decode_lengths)
     assert n_chk == n_tok, (n_chk, n_tok)
     loss = loss_sum / n_glob
-    for p in dae.parameters():
-        p.grad = None
-    reducer = BucketedAllReduce(group, enabled=grp_on)
+    reducer = _begin_backward(dae, group, grp_on, first=(dae.fc.weight, dae.fc.bias))
     with deferred_param_grads(on_ready=lambda p, eager=False: reducer.add(p.grad, flush=eager)):
         loss.backward()
     params = [p for p in dae.parameters() if p.requires_grad]
@@ -198,11 +312,12 @@ def dcnet_xe_backward(dae, caps, caplens, previous_caption, prev_caplen, group=N
     return (_global_loss(loss_sum, n_glob, group) if grp_on else float(loss_sum.detach()) / max(n_glob, 1)), n_tok, reducer
 
 
-def dcnet_xe_train_step(dae, optimizer, caps, caplens, previous_caption, prev_caplen, group=None, reduce=True):
+def dcnet_xe_train_step(dae, optimizer, caps, caplens, previous_caption, prev_caplen, group=None, reduce=True,
+                        caplens_host=None):
     """One step of dcnet.py:352-402 on this rank's shard; same global-token-count normalisation and gradient
     all-reduce as `xe_train_step`.  Returns (GLOBAL mean loss, local tokens)."""
     dae.train()
-    loss, n_tok, _ = dcnet_xe_backward(dae, caps, caplens, previous_caption, prev_caplen, group, reduce)
+    loss, n_tok, _ = dcnet_xe_backward(dae, caps, caplens, previous_caption, prev_caplen, group, reduce, caplens_host)
     params = [p for p in dae.parameters() if p.requires_grad]
     clip_grad_norm_and_step(params, optimizer, GRAD_CLIP)
     return loss, n_tok
@@ -235,8 +350,8 @@ def _scst_step(model, optimizer, greedy_fn, sample_fn, rep, ground_truth, scorer
     sample), RewardCriterion normalised by the GLOBAL mask count, backward, gradient all-reduce, clip, optimizer."""
     from . import ciderd
     from .autograd_ops import deferred_param_grads
-    for p in model.parameters():
-        p.grad = None
+    core = getattr(model, "dae", model)              # DAEWithAR wraps the DAE whose fc finishes first
+    reducer = _begin_backward(model, group, _dist_active(group), first=(core.fc.weight, core.fc.bias))
     # the greedy baseline (a latency-bound chain of small kernels) and the sampled rollout are independent: the baseline is
     # enqueued on a side stream and runs underneath the rollout's forward (SET_SCST_OVERLAP=0: one after the other)
     cur = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
@@ -250,7 +365,6 @@ def _scst_step(model, optimizer, greedy_fn, sample_fn, rep, ground_truth, scorer
         with torch.no_grad():
             greedy, _ = greedy_fn()
     model.train()
-    reducer = BucketedAllReduce(group)
     with deferred_param_grads(on_ready=lambda p, eager=False: reducer.add(p.grad, flush=eager)):
         seq, logp = sample_fn()
         if side is not None:

@@ -254,3 +254,34 @@ def test_out_of_range_token_ids_are_clamped_with_and_without_token_table():
     with torch.no_grad():
         ref = rl(wm, ok, plen, X, True, False)
     assert torch.equal(ref[0], outs[2][0])
+
+
+def test_persistent_encoder_under_concurrent_streams():
+    """The weights-stationary persistent encoder (csrc/encoder_persistent.hip: one launch, grid barrier per step) while
+    other decodes run on other streams: instances are serialised by the library's event chain, the kernels of the other
+    streams finish on their own, so nothing may hang, no barrier may time out (status word stays 0) and every stream's
+    tokens equal the single-stream decode."""
+    d, xe, rl = editnet_modules("editnet_full_b4")          # (the persistent encoder is the default up to 32 rows)
+    wm = d["wm"]
+    prev, plen, X = to_dev(d["prev"]), to_dev(d["plen"]), to_dev(d["X"])
+    with torch.no_grad():
+        rl(wm, prev, plen, X, True, False)
+        ref, ref_lp = rl(wm, prev, plen, X, True, False)
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream() for _ in range(8)]
+        outs = []
+        for rep in range(4):
+            for s in streams:
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    outs.append(rl(wm, prev, plen, X, True, False))
+        torch.cuda.synchronize()
+    for seq, lp in outs:
+        assert torch.equal(seq, ref)
+        assert float((lp - ref_lp).abs().max()) < 1e-5
+    # the status word behind the barrier words of every workspace that ran the encoder
+    dims = rl._dims(X.shape[0], prev.shape[1], X.shape[1], rl.max_len + 1)
+    for ws in rl._ws_cache.values():
+        rl._ws = ws
+        bar = rl.ws_tensor(dims, "enc_bar", (18 * 32,), dtype=torch.int32)
+        assert int(bar[17 * 32]) == 0, "a grid barrier of the persistent encoder timed out"

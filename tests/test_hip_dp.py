@@ -101,6 +101,28 @@ def test_dp_nccl_two_devices():
     _run("nccl", False, "editnet_small", 64 << 10)
 
 
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
+def test_bench_gpus_two_devices_nccl():
+    """`python bench.py --gpus 2` on two real devices over RCCL: the line must say so (ranks_seen: two distinct devices,
+    backend nccl) and carry the collective's own time next to the exposed part"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "SET_BENCH_ONE_DEVICE", "SET_BENCH_BACKEND"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                          "--repeat", "1", "--no-profile", "--no-cpu-baseline", "--no-secondary", "--train-steps", "2"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    tr = line["train"]
+    assert line["n_gpus"] == 2 and tr["n_gpus"] == 2
+    assert sorted(r["device"] for r in tr["ranks_seen"]) == [0, 1] and all(r["backend"] == "nccl" for r in tr["ranks_seen"])
+    assert tr["allreduce_ms"] > 0 and "allreduce_exposed_ms" in tr
+
+
 def test_bench_gpus_flag_spawns_ranks():
     """`python bench.py --gpus 2` (no torchrun around it) must launch two ranks and report n_gpus = 2 — the command the
     driver uses for its scaling run.  On the one-GPU test box both ranks share cuda:0 over gloo."""
@@ -119,3 +141,5 @@ def test_bench_gpus_flag_spawns_ranks():
     assert line["value"] > 0 and line["config"]["parallelism"].startswith("dp2")
     tr = line["train"]
     assert tr["n_gpus"] == 2 and tr["ms_per_train_step"] > 0 and "allreduce_exposed_ms" in tr
+    assert len(tr["ranks_seen"]) == 2 and all(r["backend"] == "gloo" for r in tr["ranks_seen"])
+    assert tr["allreduce_ms"] > 0 and sum(tr["allreduce_buckets"]) > 300        # 354.7 MB in flat buckets

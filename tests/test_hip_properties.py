@@ -56,6 +56,20 @@ def test_padding_invariance(setup):
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
+def test_padding_invariance_small_batch(setup):
+    """the same property on the small-batch kernels (4 rows: gemv row class, 512-thread attention launch whose two thread
+    halves own FIXED blocks of positions, persistent encoder): bit-identical with six more <pad> columns"""
+    d, xe, rl, X, prev, plen = setup
+    p4, l4, X4 = prev[:4].contiguous(), plen[:4].contiguous(), X[:4].contiguous()
+    a = _greedy(rl, d["wm"], p4, l4, X4)
+    p4b = torch.cat([p4, torch.zeros(4, 6, dtype=prev.dtype, device=prev.device)], 1).contiguous()
+    b = _greedy(rl, d["wm"], p4b, l4, X4)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    full = _greedy(rl, d["wm"], prev, plen, X)            # and the rows agree with their decode inside the full batch
+    same = (full[0][:4] == a[0]).all(1)
+    assert same.all() or np.abs(full[1][:4][same] - a[1][same]).max() < 1e-4
+
+
 def test_sub_batch_consistency(setup):
     """Rows decoded alone (B=32 -> 64x64 GEMM tiles, other split-K plan) agree with the same rows decoded
     inside the full batch to fp32 summation-order noise; tokens bit-exact away from near-ties."""

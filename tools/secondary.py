@@ -131,7 +131,23 @@ def dcnet(dev):
             if B == 4:
                 t, _ = _timed(lambda: er(wm, prev, plen, X, True, False), 10, 3)
                 out["editnet_greedy_b4_ms"] = round(1e3 * t, 3)
+    # BASELINE.json configs[0] (batch 4) is weight-streaming bound (265.7 MB per EditNet timestep incl.
+    # 2.3 MB of activations, 160.6 MB of DCNet weights): bytes / time against the 8 TB/s HBM peak, prologue included in
+    # the time (19 timesteps per decode)
+    out["roofline_b4"] = {
+        "bound": "hbm", "peak": 8000.0, "unit": "GB/s",
+        "editnet": _stream_roof(265.7e6, out["editnet_greedy_b4_ms"]),
+        "dcnet": _stream_roof(160.6e6 + 1.2e6, out["dcnet_greedy_b4_ms"]),
+        "note": "algorithmic bytes per timestep (SURVEY.md 8d) x 19 / decode time incl. the prologue; the token tables fold "
+                "~89 MB (EditNet) of those weights into row gathers, so fewer bytes actually move"}
     return out
+
+
+def _stream_roof(bytes_per_timestep, ms_per_decode):
+    us = 1e3 * ms_per_decode / 19.0
+    gbs = bytes_per_timestep / (us * 1e-6) / 1e9
+    return {"us_per_timestep": round(us, 2), "bound_us_per_timestep": round(bytes_per_timestep / 8e12 * 1e6, 2),
+            "achieved": round(gbs, 1), "frac": round(gbs / 8000.0, 4)}
 
 
 def dcnet_train(dev, batch=128):

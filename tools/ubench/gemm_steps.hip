@@ -128,7 +128,7 @@ int main(int argc, char** argv) {
     plan_ksplit(&big, 1, tgt);
 
     auto flops = [](const GemmProb* p, int n) { double f = 0; for (int i = 0; i < n; ++i) f += 2.0 * p[i].M * p[i].N * p[i].ktiles() * 32.0; return f; };
-    auto wgs = [](const GemmProb* p, int n) { int w = 0; for (int i = 0; i < n; ++i) w += cdiv(p[i].M, tile_m_of(p[0])) * cdiv(p[i].N, tile_n_of(p[0])) * p[i].ksplit; return w; };
+    auto wgs = [](const GemmProb* p, int n) { int w = 0; for (int i = 0; i < n; ++i) w += cdiv(p[i].M, tile_m_of(p[0])) * cdiv(p[i].N, launch_tile_n(p, n)) * p[i].ksplit; return w; };
     hipStream_t st; hipStreamCreate(&st);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     auto run = [&](const char* name, auto fn, double fl, int n_launch) {
