@@ -765,7 +765,18 @@ static int tile_m_of(const GemmProb& p) { return (p.bm_hint == 64 || p.bm_hint =
 // is half as long: att_embed (4608 x 1024: 576 tiles = 3 rounds, as 1152 half-size tiles 5) 203 -> 170 us, features_att
 // (288 tiles = 2 rounds, as 576: 3 half rounds) 75 -> 56 us; the large products of the training step (fc over all
 // timesteps, the all-timestep region projection: >= 11 rounds either way) stay on 128x64.
+// SET_GEMM_BN32=1 (experiment, round 3): decode batches of 65..128 rows on 128x32 tiles — ONE workgroup owns both 64-row
+// halves of a weight block (same workgroup count as two 64x64 tiles, each weight byte fetched once instead of relying on
+// the second row tile's L2 hit; the activation rows are re-read by twice as many workgroups, from L2)
+static bool use_bn32(const GemmProb* probs, int n) {
+    static const int on = env_int("SET_GEMM_BN32", 0);
+    if (!on || n <= 0 || probs[0].bm_hint || gemm_split_mode()) return false;
+    for (int i = 0; i < n; ++i)
+        if (probs[i].M <= 64 || probs[i].M > 128 || gemm_tile_m(probs[i].M) != 64) return false;
+    return true;
+}
 static int launch_tile_m(const GemmProb* probs, int n) {
+    if (use_bn32(probs, n)) return 128;
     // one row-tile class per launch: the largest any problem asks for (the teacher-forced loop merges fc over this step's
     // rows with phase A over the next step's, and the sorted batch may shrink across a class boundary in between)
     int bm = tile_m_of(probs[0]);
@@ -783,6 +794,7 @@ static int launch_tile_m(const GemmProb* probs, int n) {
     return c64 < 0.97 * c128 ? 64 : 128;
 }
 static int launch_tile_n(const GemmProb* probs, int n) {
+    if (use_bn32(probs, n)) return 32;
     const int bm = launch_tile_m(probs, n);
     return (bm == 32 || (bm == 128 && gemm_bn128())) ? 128 : 64;      // (class 16: 4 waves x 16 columns)
 }
@@ -797,7 +809,7 @@ void plan_ksplit(GemmProb* probs, int n, int cap_wgs) {
     static const int pct64 = env_int("SET_GEMM_WGS64_PCT", 150);
     static const int pct32 = env_int("SET_GEMM_WGS32_PCT", 50);
     const int bm_l = n > 0 ? launch_tile_m(probs, n) : 128, bn_l = n > 0 ? launch_tile_n(probs, n) : 64;
-    if (n > 0 && bm_l == 64) cap_wgs = cap_wgs * pct64 / 100;
+    if (n > 0 && (bm_l == 64 || bn_l == 32)) cap_wgs = cap_wgs * pct64 / 100;
     // <= 32 rows: the launch only streams weights; fewer, longer workgroups halve the slab traffic (measured +5 %)
     if (n > 0 && bm_l == 32) cap_wgs = cap_wgs * pct32 / 100;
     // <= 16 rows: 64-column workgroups without LDS, many fit a CU; slabs are a few KB, so split generously for bytes in flight
@@ -895,7 +907,7 @@ int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag
         flops += 2.0 * t.M * t.N * K;
         bytes += 4.0 * ((double)t.M * K + (double)t.N * K + (double)t.M * t.N * t.ksplit);
     }
-    const char* kname = bm == 128 ? "gemm_nt_f32<128,64>" : (bm == 64 ? "gemm_nt_f32<64,64>" : (bm == 32 ? "gemm_nt_f32<32,128>" : "gemv_nt_f32<16,64>"));
+    const char* kname = (bm == 128 && bn == 32) ? "gemm_nt_f32<128,32>" : bm == 128 ? "gemm_nt_f32<128,64>" : (bm == 64 ? "gemm_nt_f32<64,64>" : (bm == 32 ? "gemm_nt_f32<32,128>" : "gemv_nt_f32<16,64>"));
     ProfScope ps(kname, stream, flops, bytes);
     static const bool sites = env_int("SET_PROFILE_SITES", 0) != 0;   // per-call-site breakdown (nested events)
     ProfScope ps2(sites ? (tag ? tag : "gemm:other") : nullptr, stream, flops, bytes);
@@ -916,6 +928,8 @@ int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag
                   w5 = L.t[5].wg_begin;
         if (bm == 16)
             hipLaunchKernelGGL(gemv_nt_f32, grid, block, 0, stream, nt, w1, w2, w3, w4, w5, L);
+        else if (bm == 128 && bn == 32)
+            hipLaunchKernelGGL((gemm_nt_f32<128, 32, 4, 1>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, L);
         else if (bm == 128 && bn == 128)
             hipLaunchKernelGGL((gemm_nt_f32<128, 128, 2, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, L);
         else if (bm == 128 && gemm_dma())

@@ -122,6 +122,25 @@ class _Ops:
 
 
 _ATT1_HOIST_LIVE = 0.75     # all-timestep region projection when at least this fraction of the (t, b) rows is live
+# Overlapped weight gradients (round 3): the time-batched dW contractions (0.4 TFLOP, the chip's full width) only become
+# possible when the back-propagation through time has produced the gradient logs — but the BPTT loop itself is a chain of
+# M = 128 launches and small kernels that leaves most of the matrix pipe idle.  Half way through the loop the rows of the
+# later timesteps are final: their share of every dW is contracted on a side stream underneath the rest of the loop, the
+# earlier timesteps' share is accumulated on top after it.  Measured (B = 128, same box, ABAB): 18.10 / 17.81 ms without,
+# 17.84 / 18.82 ms with — as with every other second-queue experiment on this path the loop's kernels slow down by what the
+# side stream gains.  Correct (the gradient-parity tests pass with it on) but not a win: opt-in, SET_WGRAD_OVERLAP=1.
+_WGRAD_OVERLAP = __import__("os").environ.get("SET_WGRAD_OVERLAP", "0") == "1"
+_side = {}
+
+
+def _side_stream(dev):
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    st = _side.get(key)
+    if st is None:
+        if len(_side) > 16:
+            _side.clear()
+        st = _side[key] = torch.cuda.Stream(dev)
+    return st
 
 
 def _dvalues(alpha, dctx, ops):
@@ -401,6 +420,56 @@ class _XESequence(torch.autograd.Function):
             A.gemm_group([(dy, wv, dy.shape[0], wv.shape[1], dy.shape[1], out, acc) for dy, wv, out, acc in items], False, True)
 
         dlast = dlogp.contiguous() if (cfg.rollout is None and cfg.adaptive and dlogp is not None) else None   # 2nd output (adaptive)
+        pidx = {n: i for i, n in enumerate(PARAM_NAMES)}
+        need = ctx.needs_input_grad[10:]                       # frozen parameters (requires_grad False) get no gradient
+        mid = T // 2 if (_WGRAD_OVERLAP and T >= 6 and dev.type == "cuda") else 0
+        early = None                                           # (side stream, first row of the early share)
+
+        def wgrad_specs(r0, r1):
+            """(parameter name, dy rows, x rows, first column of the block in the weight or None) of the time-batched
+            weight gradients over the log rows [r0, r1) — (t, b) rows, t-major"""
+            TBs = slice(r0, r1)
+            dg1 = DG1.view(T * B, 4 * D)[TBs]
+            dgw = DGW.view(T * B, 4 * D)[TBs]
+            du = DU.view(T * B, D)[TBs]
+            whc = L["WHC"].view(T * B, 3 * D)[TBs]
+            dszt = DSZT.view(T * B, 3 * D)[TBs]
+            h1_all = L["H1"][1:].reshape(T * B, D)[TBs]
+            datt2 = DATT2.view(T * B, 2 * Adim)[TBs]
+            specs = [("al_wih", dg1, L["EMB"].view(T * B, D)[TBs], 0), ("al_wih", dg1, L["H2"][:T].reshape(T * B, D)[TBs], 2 * D),
+                     ("al_whh", dg1, L["H1"][:T].reshape(T * B, D)[TBs], None),
+                     ("cl_x2h_w", dgw, L["X2"].view(T * B, K2)[TBs], None), ("cl_h2h_w", dgw, L["H2"][:T].reshape(T * B, D)[TBs], None),
+                     ("cl_cnew_w", du, L["CNEW"].view(T * B, D)[TBs], None), ("cl_cmem_w", du, L["SEL"].view(T * B, D)[TBs], None),
+                     ("ca_gate_w", dszt[:, D:2 * D], whc, None), ("ca_tc_w", dszt[:, 2 * D:], whc[:, :2 * D], None),
+                     ("ca_sc_w", dszt[:, :D], whc[:, 2 * D:], None),
+                     ("ca_dec_w", datt2[:, Adim:], h1_all, None), ("va_dec_w", datt2[:, :Adim], h1_all, None)]
+            if train:
+                specs.append(("va_fa_w", DATT1.view(T * B * R, Adim)[r0 * R:r1 * R], L["FE"].view(T * B * R, D)[r0 * R:r1 * R], None))
+            return [sp for sp in specs if need[pidx[sp[0]]]]
+
+        def launch_early():
+            """the later timesteps' share of every weight gradient, on the side stream, straight into `.grad`"""
+            cur = torch.cuda.current_stream(dev)
+            side = _side_stream(dev)
+            targets, seen = [], {}
+            for name, dy, x, c0 in wgrad_specs(mid * B, T * B):
+                prm = params[pidx[name]]
+                if id(prm) not in seen:
+                    seen[id(prm)] = prm.grad is None
+                    if prm.grad is None:                           # allocated on the caller's stream, first written on the side one
+                        # (column-block weights keep blocks that only the final pass fills: those start from zero)
+                        prm.grad = torch.zeros_like(prm) if c0 is not None else torch.empty_like(prm)
+                targets.append((prm, dy, x, c0, seen[id(prm)] and c0 is None))
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                for prm, dy, x, c0, overwrite in targets:
+                    Kb = x.shape[1]
+                    out = prm.grad if c0 is None else prm.grad[:, c0:c0 + Kb]
+                    A.gemm(dy, True, x, True, prm.shape[0], Kb, dy.shape[0], out=out, accumulate=not overwrite)
+            return side
+
         for t in range(T - 1, -1, -1):
             bt = bts[t]
             r = lambda x: _rows(x, bt)
@@ -464,6 +533,8 @@ class _XESequence(torch.autograd.Function):
             gg([(dg1, wih[:, :D], r(demb), True), (dg1, wih[:, 2 * D:3 * D], r(DH2), True), (dg1, P["al_whh"], r(DH1), False)])
             # ---- embedding: dropout + ReLU backward; the table rows are scattered once after the loop
             ops.dropout_bwd(demb, L["EMB"][t], DEMBRAW[t], bt, D, sc_emb, False)
+            if mid and t == mid and all(A._is_leaf_param(params[i]) for i in range(len(params)) if need[i]):
+                early = launch_early()
 
         # dH[b, l, :] = sum_t alpha_c[t, b, l] dctx[t, b, :]: one batched (Tc x T)(T x D) product per sample over the logs
         # instead of a read-modify-write of all of dH in every timestep
@@ -476,16 +547,18 @@ class _XESequence(torch.autograd.Function):
         # loop-invariant inputs of the attention LSTM: d final_hidden = (sum_t dgates) . W_ih[:, D:2D]
         sdg1 = DG1.sum(0)
         dFH = A.gemm(sdg1, False, wih[:, D:2 * D], True, B, D, 4 * D)
-        # ---- parameter gradients: one contraction per parameter over all (t, b) rows
-        pidx = {n: i for i, n in enumerate(PARAM_NAMES)}
+        # ---- parameter gradients: one contraction per parameter over all (t, b) rows (over the rows of the earlier timesteps
+        # only, accumulated onto the side stream's share, when that was launched half way through the loop)
         g = [None] * len(PARAM_NAMES)
         TB = T * B
-
-        need = ctx.needs_input_grad[10:]                       # frozen parameters (requires_grad False) get no gradient
+        hi = TB
+        if early is not None:
+            torch.cuda.current_stream(dev).wait_stream(early)
+            hi = mid * B
 
         def W(name, dy, x):
             if need[pidx[name]]:
-                g[pidx[name]] = A._wgrad(params[pidx[name]], dy, x)
+                g[pidx[name]] = A._wgrad(params[pidx[name]], dy[:hi], x[:hi])
 
         def Bg(name, dy):
             if need[pidx[name]]:
@@ -502,7 +575,7 @@ class _XESequence(torch.autograd.Function):
         dg1 = DG1.view(TB, 4 * D)
         if need[pidx["al_wih"]]:           # column blocks [emb | final_hidden | h2 | image_mean]; the invariant ones from sum_t
             g[pidx["al_wih"]] = A._wgrad_blocks(params[pidx["al_wih"]], [
-                (dg1, L["EMB"].view(TB, D), 0), (sdg1, L["FH"], D), (dg1, L["H2"][:T].reshape(TB, D), 2 * D),
+                (dg1[:hi], L["EMB"].view(TB, D)[:hi], 0), (sdg1, L["FH"], D), (dg1[:hi], L["H2"][:T].reshape(TB, D)[:hi], 2 * D),
                 (sdg1, L["MEAN"], 3 * D)])
         W("al_whh", dg1, L["H1"][:T].reshape(TB, D))
         Bg("al_bih", dg1); Bg("al_bhh", dg1)
@@ -531,7 +604,9 @@ class _XESequence(torch.autograd.Function):
         if need[pidx["va_full_b"]]:
             g[pidx["va_full_b"]] = DEV.sum().reshape(1)
         if train:
-            W("va_fa_w", DATT1.view(TB * R, Adim), L["FE"].view(TB * R, D)); Bg("va_fa_b", DATT1.view(TB * R, Adim))
+            if need[pidx["va_fa_w"]]:
+                g[pidx["va_fa_w"]] = A._wgrad(params[pidx["va_fa_w"]], DATT1.view(TB * R, Adim)[:hi * R], L["FE"].view(TB * R, D)[:hi * R])
+            Bg("va_fa_b", DATT1.view(TB * R, Adim))
         ctx.L = None
         # inputs: cfg, X, mean, H, Mem, final_hidden, mask, att1_c, Yin, caps
         return (None, None, None, dH, dMem, dFH, None, datt1c, dYin, None) + tuple(g)

@@ -1,14 +1,16 @@
 #!/bin/bash
 # HBM traffic + issue counters of the dominant kernel over the bench workload: SEPARATE --pmc passes (FETCH_SIZE,
 # WRITE_SIZE, SQ/GRBM) with --kernel-trace only (gpurun refuses --pmc combined with sys/hip/hsa trace domains).
+#   pmc_bench.sh [outdir = gpurun_out/pmc_bench] [kernel substring = "gemm_nt_f32<64, 64"]   (+ any SET_* switches in the env)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/pmc_bench
+OUT=${1:-gpurun_out/pmc_bench}
+KERNEL=${2:-"gemm_nt_f32<64, 64"}
 rm -rf $OUT; mkdir -p $OUT
-BENCH="python bench.py --steps 3 --warmup 1 --repeat 1 --streams 3 --no-cpu-baseline --no-profile --no-train --no-secondary"
+BENCH="python bench.py --steps 3 --warmup 1 --repeat 1 --streams ${PMC_STREAMS:-3} --no-cpu-baseline --no-profile --no-train --no-secondary"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- $BENCH > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- $BENCH > $OUT/write.log 2>&1
+if [ -z "$PMC_NO_SQ" ]; then
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/sq -o sq -- $BENCH > $OUT/sq.log 2>&1
-ls $OUT/*
-python tools/pmc_traffic.py $OUT "gemm_nt_f32<64, 64" $OUT/traffic.json
 python tools/pmc_table.py $OUT/sq sq > $OUT/sq_table.txt 2>&1 || true
-head -40 $OUT/sq_table.txt
+fi
+python tools/pmc_traffic.py $OUT "$KERNEL" $OUT/traffic.json
