@@ -223,7 +223,12 @@ class CiderD:
         first0 = np.where(is0.any(1), is0.argmax(1), L - 1)          # keep the first 0; no 0 -> the whole row
         lens = first0 + 1
         keep = np.arange(L)[None, :] < lens[:, None]
-        flat_refs = [c for refs in ref_sets for c in refs]
+        # references are cut after their first 0 as well (tokens_to_str / array_to_str do the same on the string path;
+        # lists from ground_truth_lists carry no interior 0)
+        def _cut(c):
+            c = list(c)
+            return c[:c.index(0) + 1] if 0 in c else c
+        flat_refs = [_cut(c) for refs in ref_sets for c in refs]
         ref_len = np.fromiter((len(c) for c in flat_refs), dtype=np.int64, count=len(flat_refs))
         ref_flat = np.fromiter((w for c in flat_refs for w in c), dtype=np.int64, count=int(ref_len.sum()))
         max_id = int(max(hyps.max(initial=0), ref_flat.max(initial=0)))

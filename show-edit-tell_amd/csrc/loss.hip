@@ -51,9 +51,10 @@ __global__ void __launch_bounds__(256) xe_loss_fwd_k(const float* scores, long l
 #pragma unroll
         for (int i = 0; i < 4; ++i) ss += red_s[i] * __expf(red_m[i] - mm);
         const float lse = mm + logf(ss);
-        long long tg = targets[b * tb + t * tt];
-        tg = tg < 0 ? 0 : (tg >= V ? V - 1 : tg);
-        rowloss[blockIdx.x] = lse - x[tg];
+        // an id outside [0, V) (corrupted caption, vocabulary mismatch): F.cross_entropy raises; without a host round trip the
+        // loud form available here is a NaN loss — never a silently clamped label
+        const long long tg = targets[b * tb + t * tt];
+        rowloss[blockIdx.x] = (tg < 0 || tg >= V) ? __builtin_nanf("") : lse - x[tg];
         lse_out[blockIdx.x] = lse;
     }
 }
@@ -81,11 +82,11 @@ __global__ void __launch_bounds__(256) xe_loss_bwd_k(const float* scores, long l
     }
     const float* x = scores + b * sb + t * st;
     const float l = lse[blockIdx.x], d = *dloss;
-    long long tg = targets[b * tb + t * tt];
-    tg = tg < 0 ? 0 : (tg >= V ? V - 1 : tg);
+    const long long tg = targets[b * tb + t * tt];
+    const bool bad = tg < 0 || tg >= V;                      // see the forward: the row's gradient is NaN, not a clamped label's
     for (int v = threadIdx.x; v < V4; v += 256) {
         float o = 0.f;
-        if (v < V) o = (__expf(x[v] - l) - (v == (int)tg ? 1.f : 0.f)) * d;
+        if (v < V) o = bad ? __builtin_nanf("") : (__expf(x[v] - l) - (v == (int)tg ? 1.f : 0.f)) * d;
         g[v] = o;
     }
 }

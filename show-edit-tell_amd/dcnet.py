@@ -136,7 +136,8 @@ class DAE(nn.Module):
     def __getstate__(self):
         state = dict(self.__dict__)
         state["_ws"] = state["_ws_key"] = None
-        state.pop("_tok_state", None)
+        for k in ("_tok_state", "_ws_cache", "_fwd_seed", "_grad_buckets"):
+            state.pop(k, None)
         return state
 
     def invalidate_token_table(self):
@@ -159,6 +160,8 @@ class DAE(nn.Module):
 
     def _apply(self, fn, *args, **kwargs):
         self._ws = self._ws_key = None
+        self.__dict__.pop("_ws_cache", None)
+        self.__dict__.pop("_grad_buckets", None)
         self.invalidate_token_table()
         return super()._apply(fn, *args, **kwargs)
 
@@ -220,15 +223,23 @@ class DAE(nn.Module):
         return DcnetDims(B=B, T=T, D=D, A=A, C=Cc, E=E, V=self.vocab_size, maxT=maxT)
 
     def _workspace(self, dims):
+        """One workspace per (dims, device, stream), as DecoderC._workspace: concurrent decodes on different streams (the
+        self-critical step runs the greedy baseline on a side stream underneath the sampled rollout) must not share
+        recurrent state or split-K slabs."""
         lib = _lib.load()
-        key = tuple(getattr(dims, f) for f, _ in DcnetDims._fields_) + (str(self.fc.weight.device),)
-        if self._ws_key != key:
+        dev = self.fc.weight.device
+        key = tuple(getattr(dims, f) for f, _ in DcnetDims._fields_) + (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+        cache = self.__dict__.setdefault("_ws_cache", {})
+        ws = cache.get(key)
+        if ws is None:
             n = lib.set_dcnet_workspace_bytes(C.byref(dims))
             if n == 0:
                 raise _lib.SetError("unsupported DCNet dims %r" % (key,))
-            self._ws = torch.empty(n, dtype=torch.uint8, device=self.fc.weight.device)
-            self._ws_key = key
-        return self._ws
+            if len(cache) >= 8:
+                cache.clear()
+            ws = cache[key] = torch.empty(n, dtype=torch.uint8, device=dev)
+        self._ws, self._ws_key = ws, key
+        return ws
 
     def ws_tensor(self, dims, name, shape, dtype=torch.float32):
         lib = _lib.load()

@@ -137,6 +137,12 @@ class DevicePrefetcher:
         self.device = torch.device(device)
         self.stream = torch.cuda.Stream(self.device)
         self.depth = max(1, depth)
+        # a reader that lends out pinned ring slots (AdaptiveFeatureReader: `depth` slots, one returned per consumed batch)
+        # must keep at least one slot to produce into: staging `depth` batches ahead of a `depth`-slot ring would leave the
+        # producer waiting for a slot and this side waiting for a batch
+        ring = getattr(iterable, "depth", None)
+        if isinstance(ring, int) and ring >= 1:
+            self.depth = max(1, min(self.depth, ring - 1))
         self.queue = []
         self.record_timing = record_timing
         self.timeline = []

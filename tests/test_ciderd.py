@@ -3,6 +3,8 @@ published metric.  The reference's own scorer is an un-vendored external checkou
 NOT pinned to the reference ("parity unpinned")."""
 import math
 
+import pytest
+
 import numpy as np
 
 from show_edit_tell_amd import ciderd
@@ -126,3 +128,19 @@ def test_integer_fast_path_matches_string_path():
     assert fast.shape == (N, L) and np.allclose(fast[:, 0], want, atol=1e-6) and np.allclose(fast, fast[:, :1])
     direct = s.score_token_ids(np.concatenate([sampled, greedy]), np.arange(2 * N) % B, gt)
     assert np.allclose(direct, per, atol=1e-10)
+
+
+def test_token_id_path_cuts_references_after_their_first_zero():
+    """references that were not produced by ground_truth_lists (interior 0 = <end>): the integer path cuts them after the
+    first 0, as tokens_to_str does on the string path"""
+    from show_edit_tell_amd import ciderd
+    refs = [[[5, 6, 7, 0, 9, 9], [5, 6, 8, 0]], [[1, 2, 3, 0, 4]]]
+    cut = [[[5, 6, 7, 0], [5, 6, 8, 0]], [[1, 2, 3, 0]]]
+    df, docs = ciderd.document_frequency([[ciderd.tokens_to_str(c) for c in caps] for caps in cut])
+    s = ciderd.CiderD(df, docs)
+    if not s._native:
+        pytest.skip("native scorer not built")
+    hyps = np.array([[5, 6, 7, 0, 0, 0], [1, 2, 4, 0, 0, 0]], np.int64)
+    a = s.score_token_ids(hyps, np.array([0, 1]), refs)
+    b = s.score_token_ids(hyps, np.array([0, 1]), cut)
+    assert np.array_equal(a, b)

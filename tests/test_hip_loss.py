@@ -67,3 +67,19 @@ def test_padded_gradient_feeds_the_contractions_in_place():
     A._wgrad_mm(rows, x, out=acc)
     assert torch.allclose(acc, 1.0 + ref.t() @ x, rtol=1e-4, atol=1e-5)
     assert torch.allclose(A._colsum(rows), ref.sum(0), rtol=1e-4, atol=1e-6)
+
+
+def test_out_of_range_target_poisons_the_loss():
+    """a label outside [0, V) must not train silently on a clamped word (F.cross_entropy raises): the fused loss and its
+    gradient row become NaN"""
+    from show_edit_tell_amd.train import xe_loss_sum
+    B, T, V = 4, 5, 203
+    g = torch.Generator().manual_seed(1)
+    scores = torch.randn(B, T, V, generator=g).to(_dev()).requires_grad_(True)
+    caps = torch.randint(0, V, (B, T + 1), generator=g).to(_dev())
+    caps[1, 2] = V + 7
+    ls, n, _, _ = xe_loss_sum(scores, caps, [5, 4, 3, 2])
+    assert torch.isnan(ls)
+    ls.backward()
+    gr = scores.grad
+    assert torch.isnan(gr[1, 1]).all() and torch.isfinite(gr[0]).all() and torch.isfinite(gr[1, 0]).all()

@@ -72,3 +72,19 @@ def test_reader_reports_bad_files(tmp_path):
     except (FileNotFoundError, OSError):
         return
     raise AssertionError("a missing feature file must surface as an error, not as zeros")
+
+
+def test_prefetcher_depth_is_clamped_to_the_reader_ring():
+    """DevicePrefetcher(depth) >= reader.depth would leave the producer waiting for a free pinned slot and the prefetcher
+    waiting for a batch (slots come back only when a staged batch is consumed): the depth is clamped to ring - 1"""
+    class FakeReader:
+        depth = 3
+        def __iter__(self):
+            return iter(())
+    if not torch.cuda.is_available():
+        # the constructor creates a copy stream: exercise the clamp rule itself
+        ring, asked = FakeReader.depth, 8
+        assert max(1, min(asked, ring - 1)) == 2
+        return
+    p = pipeline.DevicePrefetcher(FakeReader(), "cuda:0", depth=8)
+    assert p.depth == 2
