@@ -23,6 +23,8 @@ struct DcnetWs {
     int *unfinished, *alive;
     float *sA0, *sA1, *sB0, *sB1, *sC0, *sF0;
     float *hf, *cf, *hb, *cb, *xg_f, *xg_b, *emb_seq, *s_ef, *s_eb, *s_cat, *s_pre;
+    int* enc_order;                   // [perm (B) | nactive (T)] of the length-ordered persistent encoder
+    char* enc_bar;                    // its barrier words
     size_t bytes;
 };
 
@@ -76,6 +78,8 @@ static DcnetWs carve(const SetDcnetDims* d, void* base) {
     w.s_eb = c.take<float>(KS * B * 4 * C);
     w.s_cat = c.take<float>(KS * B * 2 * C);
     w.s_pre = c.take<float>(KS * B * 4 * D);
+    w.enc_order = c.take<int>(B + T);
+    w.enc_bar = c.take<char>(persistent_encoder_bar_bytes());
     w.bytes = c.off;
     return w;
 }
@@ -103,7 +107,30 @@ static int begin_impl(const SetDcnetWeights* w, const SetDcnetDims* d, const int
     SET_TRY(zero_f32(ws.hb, (size_t)B * C, st));
     SET_TRY(zero_f32(ws.cb, (size_t)B * C, st));
     float *hf_cur = ws.hf, *hf_nxt = ws.s_ef, *hb_cur = ws.hb, *hb_nxt = ws.s_eb;   // ping-pong (slab regions are free)
-    for (int t = 0; t < T; ++t) {
+    // both directions as ONE weights-stationary launch with grid barriers (encoder_persistent.hip) when the shape allows it
+    // (small batches by default): 2 T launches of ~14 us become T barrier steps of ~6 us
+    bool persistent = fused && B <= 4096 && persistent_encoder_ok(B, C, T);
+    if (persistent) {
+        int* perm = ws.enc_order; int* nactive = ws.enc_order + B;
+        SET_TRY(encoder_order(prevlen, B, T, perm, nactive, st));
+        PEncDirHost dirs[2];
+        if (tab) {
+            dirs[0] = PEncDirHost{w->enc_whh_f, w->tok_table + 4 * D, w->enc_bhh_f, hf_cur, hf_nxt, 0, 0};
+            dirs[1] = PEncDirHost{w->enc_whh_b, w->tok_table + 4 * D + 4 * C, w->enc_bhh_b, hb_cur, hb_nxt, C, 1};
+        } else {
+            dirs[0] = PEncDirHost{w->enc_whh_f, ws.xg_f, w->enc_bhh_f, hf_cur, hf_nxt, 0, 0};
+            dirs[1] = PEncDirHost{w->enc_whh_b, ws.xg_b, w->enc_bhh_b, hb_cur, hb_nxt, C, 1};
+        }
+        const int rc = tab ? persistent_encoder_dirs(dirs, 2, ldt, 0, prevlen, prev, T, d->V, ws.enc, nullptr, (long long)T * 2 * C,
+                                                     2 * C, perm, nactive, ws.enc_bar, B, C, T, st)
+                           : persistent_encoder_dirs(dirs, 2, (long long)T * 4 * C, 4 * C, prevlen, nullptr, 0, 0, ws.enc, nullptr,
+                                                     (long long)T * 2 * C, 2 * C, perm, nactive, ws.enc_bar, B, C, T, st);
+        if (rc == SET_OK) {
+            if (T & 1) { float* tmp = hf_cur; hf_cur = hf_nxt; hf_nxt = tmp; tmp = hb_cur; hb_cur = hb_nxt; hb_nxt = tmp; }
+        } else if (rc == SET_ERR_UNSUPPORTED) persistent = false;
+        else return rc;
+    }
+    for (int t = 0; t < T && !persistent; ++t) {
         if (fused && tab) {                   // x W_ih^T + b_ih of every word is a row of the token table
             SET_TRY(fused_encoder_step(hf_cur, hf_nxt, ws.cf, w->enc_whh_f, w->tok_table + 4 * D, ldt, 0, w->enc_bhh_f,
                                        prevlen, t, 0, ws.enc, nullptr, (long long)T * 2 * C, 2 * C, 0, B, C, st, prev, T, d->V));

@@ -34,16 +34,23 @@ constexpr int PENC_BAR_STRIDE = 32;                 // unsigned words between tw
 constexpr int PENC_BAR_WORDS = (8 + 1 + 8) * PENC_BAR_STRIDE;
 constexpr unsigned PENC_SPIN_LIMIT = 4000000u;
 
-struct PEncArgs {
+// one recurrence ("direction"): EditNet's encoder has one, DCNet's bidirectional encoder two that share the launch
+struct PEncDir {
     const float* w_hh;               // (4D, D), gate q of unit u at row q*D + u
     const float* xg;                 // hoisted input projection: token table rows (seq != NULL) or (B, T, 4D)
-    long long ld_xg_row, ld_xg_t;
     const float* b_extra;            // (4D) added to xg, or NULL
+    float* hbuf0; float* hbuf1;      // (B, D) ping-pong; hbuf0 = initial state (zeros)
+    int out_col0;                    // first output column of this direction in H / Mem rows
+    int reverse;                     // 1: step t visits position len - 1 - t (nn.LSTM's backward direction on a packed batch)
+};
+struct PEncArgs {
+    PEncDir dir[2];
+    int ndir;
+    long long ld_xg_row, ld_xg_t;
     const int64_t* lens;             // (B)
     const int64_t* seq;              // (B, seq_T) token ids when xg is a token table
     int seq_T, seq_V;
-    float* hbuf0; float* hbuf1;      // (B, D) ping-pong; hbuf0 = initial state (zeros)
-    float* H; float* Mem;            // (B, T, D) outputs (zero-initialised by the caller)
+    float* H; float* Mem;            // (B, T, ld_out_t) outputs (zero-initialised by the caller); Mem may be NULL
     long long ld_out_b, ld_out_t;
     const int* perm; const int* nactive;
     unsigned* bar;                   // PENC_BAR_WORDS zeroed words
@@ -123,7 +130,9 @@ __global__ void __launch_bounds__(256, (NT <= 2 ? 2 : 1)) encoder_persistent_k(c
     const int tid = threadIdx.x, lane = tid & 63, kq = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int D = P.D, B = P.B, K4 = D >> 2;
-    const int unit0 = blockIdx.x * 4;
+    const int per_dir = D >> 2;                      // workgroups per direction
+    const PEncDir& Q = P.dir[(int)blockIdx.x >= per_dir ? 1 : 0];
+    const int unit0 = ((int)blockIdx.x % per_dir) * 4;
     const unsigned G = gridDim.x, ns = G < 8u ? G : 8u;
     const int shard = (int)(blockIdx.x % ns);
     const unsigned pop = G / ns + ((unsigned)shard < G % ns ? 1u : 0u);
@@ -131,7 +140,7 @@ __global__ void __launch_bounds__(256, (NT <= 2 ? 2 : 1)) encoder_persistent_k(c
     // ---- stationary B operands: W_hh[gate row of column r][kq*K4 + 16 kb + 4 g .. +3]
     f32x4 wreg[KB];
     {
-        const float* wrow = P.w_hh + ((long long)(r >> 2) * D + unit0 + (r & 3)) * D + kq * K4 + 4 * g;
+        const float* wrow = Q.w_hh + ((long long)(r >> 2) * D + unit0 + (r & 3)) * D + kq * K4 + 4 * g;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) wreg[kb] = *(gptr4)(wrow + 16 * kb);
     }
@@ -140,8 +149,8 @@ __global__ void __launch_bounds__(256, (NT <= 2 ? 2 : 1)) encoder_persistent_k(c
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) { const int p = 16 * rt + r; aoff[rt] = P.perm[p < B ? p : B - 1] * D * 4; }
     const int hbytes = B * D * 4;
-    const __amdgpu_buffer_rsrc_t hrs0 = __builtin_amdgcn_make_buffer_rsrc((void*)P.hbuf0, 0, hbytes, 0x00027000);
-    const __amdgpu_buffer_rsrc_t hrs1 = __builtin_amdgcn_make_buffer_rsrc((void*)P.hbuf1, 0, hbytes, 0x00027000);
+    const __amdgpu_buffer_rsrc_t hrs0 = __builtin_amdgcn_make_buffer_rsrc((void*)Q.hbuf0, 0, hbytes, 0x00027000);
+    const __amdgpu_buffer_rsrc_t hrs1 = __builtin_amdgcn_make_buffer_rsrc((void*)Q.hbuf1, 0, hbytes, 0x00027000);
     const int koff = (kq * K4 + 4 * g) * 4;
     // (row, unit) pairs of this thread for the cell update: pair p = tid + 256 i -> sorted row p >> 2, unit p & 3
     int prow[PAIRS], plen[PAIRS];
@@ -152,7 +161,7 @@ __global__ void __launch_bounds__(256, (NT <= 2 ? 2 : 1)) encoder_persistent_k(c
         prow[i] = rs < B ? P.perm[rs] : -1;
         plen[i] = rs < B ? (int)P.lens[prow[i]] : 0;
         creg[i] = 0.f;
-        hreg[i] = rs < B ? P.hbuf0[(long long)prow[i] * D + unit0 + ((tid + 256 * i) & 3)] : 0.f;
+        hreg[i] = rs < B ? Q.hbuf0[(long long)prow[i] * D + unit0 + ((tid + 256 * i) & 3)] : 0.f;
     }
 
     // the hoisted input projection of step t for this thread's pairs: it does not depend on the recurrence, so step t + 1's
@@ -164,15 +173,16 @@ __global__ void __launch_bounds__(256, (NT <= 2 ? 2 : 1)) encoder_persistent_k(c
         _Pragma("unroll") for (int q = 0; q < 4; ++q) eg[i][q] = 0.f;                                     \
         if (prow[i] >= 0 && (TT) < plen[i]) {                                                             \
             const float* xr_;                                                                             \
+            const int pos_ = Q.reverse ? plen[i] - 1 - (TT) : (TT);                                       \
             if (P.seq) {                                                                                  \
-                long long tok_ = P.seq[(long long)prow[i] * P.seq_T + (TT)];                              \
+                long long tok_ = P.seq[(long long)prow[i] * P.seq_T + pos_];                              \
                 tok_ = tok_ < 0 ? 0 : (tok_ >= P.seq_V ? P.seq_V - 1 : tok_);   /* same clamp as embed_relu_k */ \
-                xr_ = P.xg + tok_ * P.ld_xg_row;                                                          \
+                xr_ = Q.xg + tok_ * P.ld_xg_row;                                                          \
             } else {                                                                                      \
-                xr_ = P.xg + (long long)prow[i] * P.ld_xg_row + (long long)(TT) * P.ld_xg_t;              \
+                xr_ = Q.xg + (long long)prow[i] * P.ld_xg_row + (long long)pos_ * P.ld_xg_t;              \
             }                                                                                             \
             _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                 \
-                eg[i][q] = xr_[q * D + u_] + (P.b_extra ? P.b_extra[q * D + u_] : 0.f);                   \
+                eg[i][q] = xr_[q * D + u_] + (Q.b_extra ? Q.b_extra[q * D + u_] : 0.f);                   \
         }                                                                                                 \
     }
     PENC_GATHER(0);
@@ -180,7 +190,7 @@ __global__ void __launch_bounds__(256, (NT <= 2 ? 2 : 1)) encoder_persistent_k(c
         const int nact = P.nactive[t];
         const int nt_act = (nact + 15) >> 4;                       // wave-uniform: tiles with at least one live row
         const __amdgpu_buffer_rsrc_t hrs = (t & 1) ? hrs1 : hrs0;
-        float* hout = (t & 1) ? P.hbuf0 : P.hbuf1;
+        float* hout = (t & 1) ? Q.hbuf0 : Q.hbuf1;
         // ---- contraction of the live row tiles against this wave's K quarter (static tile counts: 2, 4, 6, ... NT; the
         // tiles beyond nt_act inside a variant hold finished rows only and their results are never read)
         f32x4 acc[NT];
@@ -234,9 +244,10 @@ __global__ void __launch_bounds__(256, (NT <= 2 ? 2 : 1)) encoder_persistent_k(c
 #pragma unroll
         for (int i = 0; i < PAIRS; ++i)
             if (live_[i]) {
-                const long long o = (long long)prow[i] * P.ld_out_b + (long long)t * P.ld_out_t + unit0 + ((tid + 256 * i) & 3);
+                const int pos = Q.reverse ? plen[i] - 1 - t : t;
+                const long long o = (long long)prow[i] * P.ld_out_b + (long long)pos * P.ld_out_t + Q.out_col0 + unit0 + ((tid + 256 * i) & 3);
                 P.H[o] = hn_[i];
-                P.Mem[o] = cn_[i];
+                if (P.Mem) P.Mem[o] = cn_[i];
             }
         if (more) {
             PENC_GATHER(t + 1);
@@ -265,7 +276,7 @@ bool persistent_encoder_ok(int B, int D, int T) {
 }
 
 template <int NT, int KB>
-static int launch_penc(const PEncArgs& P, hipStream_t s) {
+static int launch_penc(const PEncArgs& P, int grid, hipStream_t s) {
     const int lds = 4 * NT * 256 * (int)sizeof(float);
     static bool configured = false;
     if (!configured) {
@@ -273,24 +284,30 @@ static int launch_penc(const PEncArgs& P, hipStream_t s) {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         configured = true;
     }
-    hipLaunchKernelGGL((encoder_persistent_k<NT, KB>), dim3(P.D / 4), dim3(256), lds, s, P);
+    hipLaunchKernelGGL((encoder_persistent_k<NT, KB>), dim3(grid), dim3(256), lds, s, P);
     SET_LAUNCH_CHECK();
     return SET_OK;
 }
 
-// the whole recurrence; hbuf0 must hold the initial state (zeros), H / Mem must be zero-filled, bar is scratch of
-// persistent_encoder_bar_bytes().  The final state is left in (T & 1) ? hbuf1 : hbuf0.
-int persistent_encoder(const float* w_hh, const float* xg, long long ld_xg_row, long long ld_xg_t, const float* b_extra,
-                       const int64_t* lens, const int64_t* seq, int seq_T, int seq_V, float* hbuf0, float* hbuf1, float* H,
-                       float* Mem, long long ld_out_b, long long ld_out_t, const int* perm, const int* nactive, void* bar,
-                       int B, int D, int T, hipStream_t s) {
-    if (!persistent_encoder_ok(B, D, T) || !perm || !nactive || !bar) return SET_ERR_UNSUPPORTED;
+// the whole recurrence(s); every direction's hbuf0 must hold its initial state (zeros), H / Mem must be zero-filled, bar is
+// scratch of persistent_encoder_bar_bytes().  A direction's final state is left in (T & 1) ? hbuf1 : hbuf0.
+int persistent_encoder_dirs(const PEncDirHost* dirs, int ndir, long long ld_xg_row, long long ld_xg_t, const int64_t* lens,
+                            const int64_t* seq, int seq_T, int seq_V, float* H, float* Mem, long long ld_out_b,
+                            long long ld_out_t, const int* perm, const int* nactive, void* bar, int B, int D, int T,
+                            hipStream_t s) {
+    if (!persistent_encoder_ok(B, D, T) || !perm || !nactive || !bar || ndir < 1 || ndir > 2) return SET_ERR_UNSUPPORTED;
     PEncArgs P{};
-    P.w_hh = w_hh; P.xg = xg; P.ld_xg_row = ld_xg_row; P.ld_xg_t = ld_xg_t; P.b_extra = b_extra; P.lens = lens;
-    P.seq = seq; P.seq_T = seq_T; P.seq_V = seq_V > 0 ? seq_V : 1; P.hbuf0 = hbuf0; P.hbuf1 = hbuf1; P.H = H; P.Mem = Mem;
+    for (int i = 0; i < ndir; ++i) {
+        P.dir[i].w_hh = dirs[i].w_hh; P.dir[i].xg = dirs[i].xg; P.dir[i].b_extra = dirs[i].b_extra;
+        P.dir[i].hbuf0 = dirs[i].hbuf0; P.dir[i].hbuf1 = dirs[i].hbuf1; P.dir[i].out_col0 = dirs[i].out_col0;
+        P.dir[i].reverse = dirs[i].reverse;
+    }
+    if (ndir == 1) P.dir[1] = P.dir[0];
+    P.ndir = ndir; P.ld_xg_row = ld_xg_row; P.ld_xg_t = ld_xg_t; P.lens = lens;
+    P.seq = seq; P.seq_T = seq_T; P.seq_V = seq_V > 0 ? seq_V : 1; P.H = H; P.Mem = Mem;
     P.ld_out_b = ld_out_b; P.ld_out_t = ld_out_t; P.perm = perm; P.nactive = nactive;
     P.bar = (unsigned*)bar; P.status = (unsigned*)bar + PENC_BAR_WORDS; P.B = B; P.D = D; P.T = T;
-    ProfScope ps("persistent_encoder", s, 8.0 * B * D * D * T, 4.0 * (4.0 * D * D + 8.0 * B * D * T));
+    ProfScope ps("persistent_encoder", s, 8.0 * ndir * B * D * D * T, 4.0 * ndir * (4.0 * D * D + 8.0 * B * D * T));
     SET_HIP_TRY(hipMemsetAsync(bar, 0, persistent_encoder_bar_bytes(), s));
     // at most ONE instance of this kernel runs at a time in this process: every launch waits for the previous one's
     // completion event (a no-op when that was on the same stream); see the residency note at the top of the file
@@ -304,12 +321,21 @@ int persistent_encoder(const float* w_hh, const float* xg, long long ld_xg_row, 
         else SET_HIP_TRY(hipStreamWaitEvent(s, g_penc_event[dev], 0));
     }
     int rc;
-    const int nt = (B + 15) / 16;
-    if (D == 1024) rc = nt <= 2 ? launch_penc<2, 16>(P, s) : launch_penc<8, 16>(P, s);
-    else if (D == 512) rc = nt <= 2 ? launch_penc<2, 8>(P, s) : launch_penc<8, 8>(P, s);
-    else rc = nt <= 2 ? launch_penc<2, 1>(P, s) : (nt <= 8 ? launch_penc<8, 1>(P, s) : launch_penc<16, 1>(P, s));
+    const int nt = (B + 15) / 16, grid = ndir * (D / 4);
+    if (D == 1024) rc = nt <= 2 ? launch_penc<2, 16>(P, grid, s) : launch_penc<8, 16>(P, grid, s);
+    else if (D == 512) rc = nt <= 2 ? launch_penc<2, 8>(P, grid, s) : launch_penc<8, 8>(P, grid, s);
+    else rc = nt <= 2 ? launch_penc<2, 1>(P, grid, s) : (nt <= 8 ? launch_penc<8, 1>(P, grid, s) : launch_penc<16, 1>(P, grid, s));
     if (rc == SET_OK && serialise) SET_HIP_TRY(hipEventRecord(g_penc_event[dev], s));
     return rc;
+}
+
+int persistent_encoder(const float* w_hh, const float* xg, long long ld_xg_row, long long ld_xg_t, const float* b_extra,
+                       const int64_t* lens, const int64_t* seq, int seq_T, int seq_V, float* hbuf0, float* hbuf1, float* H,
+                       float* Mem, long long ld_out_b, long long ld_out_t, const int* perm, const int* nactive, void* bar,
+                       int B, int D, int T, hipStream_t s) {
+    PEncDirHost d{w_hh, xg, b_extra, hbuf0, hbuf1, 0, 0};
+    return persistent_encoder_dirs(&d, 1, ld_xg_row, ld_xg_t, lens, seq, seq_T, seq_V, H, Mem, ld_out_b, ld_out_t, perm, nactive,
+                                   bar, B, D, T, s);
 }
 
 }  // namespace set

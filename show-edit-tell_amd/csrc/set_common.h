@@ -117,6 +117,11 @@ int editnet_encoder(const SetEditNetWeights* w, const int64_t* seq, const int64_
 // encoder_persistent.hip: the whole encoder recurrence in one weights-stationary launch with grid barriers
 size_t persistent_encoder_bar_bytes();
 bool persistent_encoder_ok(int B, int D, int T);
+struct PEncDirHost { const float* w_hh; const float* xg; const float* b_extra; float* hbuf0; float* hbuf1; int out_col0; int reverse; };
+int persistent_encoder_dirs(const PEncDirHost* dirs, int ndir, long long ld_xg_row, long long ld_xg_t, const int64_t* lens,
+                            const int64_t* seq, int seq_T, int seq_V, float* H, float* Mem, long long ld_out_b,
+                            long long ld_out_t, const int* perm, const int* nactive, void* bar, int B, int D, int T,
+                            hipStream_t s);
 int persistent_encoder(const float* w_hh, const float* xg, long long ld_xg_row, long long ld_xg_t, const float* b_extra,
                        const int64_t* lens, const int64_t* seq, int seq_T, int seq_V, float* hbuf0, float* hbuf1, float* H,
                        float* Mem, long long ld_out_b, long long ld_out_t, const int* perm, const int* nactive, void* bar,

@@ -235,7 +235,7 @@ class DAE(nn.Module):
             n = lib.set_dcnet_workspace_bytes(C.byref(dims))
             if n == 0:
                 raise _lib.SetError("unsupported DCNet dims %r" % (key,))
-            if len(cache) >= 8:
+            if len(cache) >= 24:
                 cache.clear()
             ws = cache[key] = torch.empty(n, dtype=torch.uint8, device=dev)
         self._ws, self._ws_key = ws, key

@@ -519,7 +519,7 @@ class DecoderC(nn.Module):
             n = lib.set_editnet_workspace_bytes(C.byref(dims))
             if n == 0:
                 raise _lib.SetError("unsupported EditNet dims %r (contraction dims must be multiples of 32)" % (key,))
-            if len(cache) >= 8:
+            if len(cache) >= 24:
                 cache.clear()
             ws = torch.empty(n, dtype=torch.uint8, device=dev)
             cache[key] = ws
