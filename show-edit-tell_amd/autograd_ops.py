@@ -44,6 +44,8 @@ def _scratch(device):
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _gemm_ws.get(key)
     if ws is None:
+        if len(_gemm_ws) >= 16:               # 64 MB each, keyed by (device, stream): bounded
+            _gemm_ws.clear()
         ws = _gemm_ws[key] = torch.empty(_GEMM_WS_BYTES, dtype=torch.uint8, device=device)
     return ws
 

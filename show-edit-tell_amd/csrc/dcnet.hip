@@ -102,10 +102,11 @@ static int begin_impl(const SetDcnetWeights* w, const SetDcnetDims* d, const int
         SET_TRY(gemm_group(p, 2, st, "gemm:enc x2h"));
     }
     SET_TRY(zero_f32(ws.enc, (size_t)B * T * 2 * C, st));
-    SET_TRY(zero_f32(ws.hf, (size_t)B * C, st));
-    SET_TRY(zero_f32(ws.cf, (size_t)B * C, st));
-    SET_TRY(zero_f32(ws.hb, (size_t)B * C, st));
-    SET_TRY(zero_f32(ws.cb, (size_t)B * C, st));
+    {
+        float* zp[4] = {ws.hf, ws.cf, ws.hb, ws.cb};
+        const size_t zn[4] = {(size_t)B * C, (size_t)B * C, (size_t)B * C, (size_t)B * C};
+        SET_TRY(zero_runs(zp, zn, 4, st));
+    }
     float *hf_cur = ws.hf, *hf_nxt = ws.s_ef, *hb_cur = ws.hb, *hb_nxt = ws.s_eb;   // ping-pong (slab regions are free)
     // both directions as ONE weights-stationary launch with grid barriers (encoder_persistent.hip) when the shape allows it
     // (small batches by default): 2 T launches of ~14 us become T barrier steps of ~6 us
@@ -187,10 +188,11 @@ static int begin_impl(const SetDcnetWeights* w, const SetDcnetDims* d, const int
         SET_TRY(gemm_group(&p, 1, st));
         SET_TRY(reduce_bias_act(slabs_of(p), w->al_bih, w->al_bhh, ws.pre1, 4 * D, B, 4 * D, SET_ACT_NONE, st));
     }
-    SET_TRY(zero_f32(ws.h1, (size_t)B * D, st));
-    SET_TRY(zero_f32(ws.c1, (size_t)B * D, st));
-    SET_TRY(zero_f32(ws.h2, (size_t)B * D, st));
-    SET_TRY(zero_f32(ws.c2, (size_t)B * D, st));
+    {
+        float* zp[4] = {ws.h1, ws.c1, ws.h2, ws.c2};
+        const size_t zn[4] = {(size_t)B * D, (size_t)B * D, (size_t)B * D, (size_t)B * D};
+        SET_TRY(zero_runs(zp, zn, 4, st));
+    }
     return SET_OK;
 }
 

@@ -144,6 +144,21 @@ GemmProb direct_prob(float* out, long long ldo, int M, int N, const float* bias,
     return p;
 }
 
+// zero several fp32 buffers with as few fill launches as their placement allows (buffers carved back to back from one
+// workspace need ONE fill; a fill is a ~5 us launch on the chain and the decode prologue had ten of them)
+int zero_runs(float* const* p, const size_t* n, int cnt, hipStream_t st) {
+    int i = 0;
+    while (i < cnt) {
+        float* base = p[i];
+        size_t len = n[i];
+        int j = i + 1;
+        while (j < cnt && p[j] == base + len) { len += n[j]; ++j; }
+        SET_TRY(zero_f32(base, len, st));
+        i = j;
+    }
+    return SET_OK;
+}
+
 // CaptionEncoderC.forward (editnet.py:319-348) without the length sort: rows advance while
 // t < len[b]; H / Mem rows beyond a caption's length stay zero; mask = (Mem.sum(2) != 0).
 int editnet_encoder(const SetEditNetWeights* w, const int64_t* seq, const int64_t* lens, float* H, float* Mem,
@@ -159,10 +174,11 @@ int editnet_encoder(const SetEditNetWeights* w, const int64_t* seq, const int64_
         p.add(emb_seq, D, w->enc_x2h_w, D, D);
         SET_TRY(gemm_group(&p, 1, st, "gemm:enc x2h"));
     }
-    SET_TRY(zero_f32(H, (size_t)B * T * D, st));
-    SET_TRY(zero_f32(Mem, (size_t)B * T * D, st));
-    SET_TRY(zero_f32(enc_h, (size_t)B * D, st));
-    SET_TRY(zero_f32(enc_c, (size_t)B * D, st));
+    {
+        float* zp[4] = {H, Mem, enc_h, enc_c};
+        const size_t zn[4] = {(size_t)B * T * D, (size_t)B * T * D, (size_t)B * D, (size_t)B * D};
+        SET_TRY(zero_runs(zp, zn, 4, st));
+    }
     float* h_cur = enc_h;
     float* h_nxt = s_enc;                         // (B,D) ping-pong partner (the slab region is free in the fused path)
     // visit the rows longest first (device-side ranking, no host sync) so that tiles of finished rows are skipped:
@@ -264,10 +280,11 @@ static int begin_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const
         SET_TRY(gemm_group(&p, 1, st));
         SET_TRY(reduce_bias_act(slabs_of(p), w->al_bih, w->al_bhh, ws.pre1, 4 * D, B, 4 * D, SET_ACT_NONE, st));
     }
-    SET_TRY(zero_f32(ws.h1, (size_t)B * D, st));
-    SET_TRY(zero_f32(ws.c1, (size_t)B * D, st));
-    SET_TRY(zero_f32(ws.h2, (size_t)B * D, st));
-    SET_TRY(zero_f32(ws.c2, (size_t)B * D, st));
+    {
+        float* zp[4] = {ws.h1, ws.c1, ws.h2, ws.c2};
+        const size_t zn[4] = {(size_t)B * D, (size_t)B * D, (size_t)B * D, (size_t)B * D};
+        SET_TRY(zero_runs(zp, zn, 4, st));
+    }
     return SET_OK;
 }
 

@@ -33,6 +33,10 @@ __global__ void __launch_bounds__(256) greedy_pick_k(Slabs logits, const float* 
     __shared__ float s_sum[4];
     __shared__ long long s_tok;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // bookkeeping words of the serial tail (thread 0): requested now, under the row fetch, instead of as a dependent
+    // round trip after the reductions
+    int unf_prev = 1, alive_prev = 1;
+    if (tid == 0 && t > 0) { unf_prev = unfinished[b]; alive_prev = alive[t - 1]; }
     float best = -INFINITY;
     int bi = 0x7fffffff;
     f32x4 x[GP_MAXQ];
@@ -139,9 +143,9 @@ __global__ void __launch_bounds__(256) greedy_pick_k(Slabs logits, const float* 
         const float logp = (best - best) - logf(total);         // log_softmax at the arg-max
         long long it = bi;
         if (it == end_idx) it = 0;
-        int unf = (t == 0) ? (it > 0) : (unfinished[b] && it > 0);
+        int unf = (t == 0) ? (it > 0) : (unf_prev && it > 0);
         it = unf ? it : 0;
-        const bool broken = (t > 0) && (alive[t - 1] == 0);
+        const bool broken = (t > 0) && (alive_prev == 0);
         if (t < max_len && !broken) {
             seq[(long long)b * max_len + t] = it;
             seq_logp[(long long)b * max_len + t] = logp;

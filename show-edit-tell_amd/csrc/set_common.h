@@ -163,6 +163,7 @@ int encoder_pointwise(Slabs hh, const float* xg, long long ld_xg_row, long long 
                       hipStream_t s);
 int rowsum_mask(const float* x, long long ld_row, int rows, int D, float* mask, hipStream_t s);
 int zero_f32(float* p, size_t n, hipStream_t s);
+int zero_runs(float* const* p, const size_t* n, int cnt, hipStream_t st);   // editnet.hip: adjacent buffers share one fill
 
 // attention.hip
 int caption_attention(const float* att1_c, Slabs att2_c, const float* dec_bias, const float* w_full,

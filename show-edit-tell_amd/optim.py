@@ -94,6 +94,8 @@ def clip_grad_norm_and_step(parameters, optimizer, max_norm, scale_grads=False):
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
     ws = _ws.get(key)
     if ws is None or ws.numel() < nbytes:
+        if len(_ws) >= 32:                    # keyed by (device, stream): bounded
+            _ws.clear()
         ws = _ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     norm = torch.empty((), dtype=torch.float32, device=dev)
     check(lib.set_clip_adam_f32(n, P, G, M, V, numel, step, lr, b1, b2, eps, wd, float(max_norm), int(bool(scale_grads)),

@@ -339,6 +339,8 @@ def _side_stream(dev):
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
     s = _side_streams.get(key)
     if s is None:
+        if len(_side_streams) >= 32:          # keyed by the caller's stream: bounded, not a process-lifetime leak
+            _side_streams.clear()
         s = _side_streams[key] = torch.cuda.Stream(dev)
     return s
 
