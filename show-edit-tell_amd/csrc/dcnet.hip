@@ -215,7 +215,7 @@ static void build_phase_a(const SetDcnetWeights* w, const SetDcnetDims* d, Dcnet
 static int step_impl(const SetDcnetWeights* w, const SetDcnetDims* d, int bt, DcnetWs& ws, float* dst, long long ld_dst,
                      Slabs* logits_out, hipStream_t st, const long long* tok_ids = nullptr, long long tok_stride = 1,
                      const GemmProb* a_pre = nullptr, GemmProb* a_next = nullptr, bool* logits_biased = nullptr,
-                     int bt_next = -1) {
+                     int bt_next = -1, bool a_done = false) {
     const int B = d->B, T = d->T, D = d->D, A = d->A, C = d->C, E = d->E, V = d->V;
     const int tgt = gemm_target_wgs();
     const Slabs none{nullptr, 0, 0, 0};
@@ -230,8 +230,9 @@ static int step_impl(const SetDcnetWeights* w, const SetDcnetDims* d, int bt, Dc
         plan_ksplit(a, 2, tgt);
         SET_TRY(gemm_group(a, 2, st, "gemm:A gates1+h2h"));
     }
-    SET_TRY(lstm_pointwise(slabs_of(a[0]), none, none, ws.pre1, 4 * D, nullptr, nullptr, ws.c1, ws.c1, ws.h1, nullptr,
-                           bt, D, st, g_gates));
+    if (!(a_done && a_pre && tab))       // a_done: the previous pick finished this cell (LstmTail, as in csrc/editnet.hip)
+        SET_TRY(lstm_pointwise(slabs_of(a[0]), none, none, ws.pre1, 4 * D, nullptr, nullptr, ws.c1, ws.c1, ws.h1, nullptr,
+                               bt, D, st, g_gates));
     GemmProb b[2];
     b[0] = slab_prob(ws.sB0, bt, A, B);
     b[0].add(ws.h1, D, w->ca_dec_w, D, D);
@@ -353,25 +354,34 @@ static int dcnet_rollout(const SetDcnetWeights* w, const SetDcnetDims* d, const 
     if (emb_needed) SET_TRY(embed_relu(w->embed, (const int64_t*)W.it, 1, W.emb, d->E, B, d->E, d->V, st));
     static const int fa_merge = env_int("SET_FA_MERGE", 1);
     const bool merge = fa_merge && !emb_needed;
+    static const int pick_tail = env_int("SET_PICK_TAIL", 1);    // the pick finishes the next attention-LSTM cell (LstmTail)
     GemmProb a_cur[2], a_nxt[2];
-    bool have_a = false;
+    bool have_a = false, a_done = false;
     for (int t = 0; t <= max_len; ++t) {                                 // dcnet_rl.py:305,315-316
         Slabs lg;
         bool biased = false;
         const bool next_a = merge && t < max_len;
         SET_TRY(step_impl(w, d, B, W, nullptr, 0, &lg, st, W.it, 1, have_a ? a_cur : nullptr, next_a ? a_nxt : nullptr,
-                          &biased));
+                          &biased, -1, a_done));
         have_a = next_a;
         if (next_a) { a_cur[0] = a_nxt[0]; a_cur[1] = a_nxt[1]; }
         if (t == max_len) break;
         const float* pick_bias = biased ? nullptr : w->fc_b;
+        LstmTail tail;
+        a_done = next_a && pick_tail;
+        if (a_done) {
+            tail.g0 = slabs_of(a_nxt[0]);
+            tail.pre = W.pre1; tail.ldpre = 4LL * d->D;
+            tail.tab = w->tok_table; tail.ld_tab = 4LL * d->D + 8LL * d->C; tail.col0 = 0; tail.nrows = d->V;
+            tail.c_in = W.c1; tail.c_out = W.c1; tail.h_out = W.h1; tail.D = d->D;
+        }
         if (sample)
             SET_TRY(sample_pick(lg, pick_bias, d->V, t, max_len, end_idx, (long long*)seq, seq_logp, W.it, W.unfinished,
                                 W.alive, emb_needed ? w->embed : nullptr, W.emb, d->E, B, seed, offset, nullptr, nullptr,
-                                nullptr, st));
+                                nullptr, st, a_done ? &tail : nullptr));
         else
             SET_TRY(greedy_pick(lg, pick_bias, d->V, t, max_len, end_idx, (long long*)seq, seq_logp, W.it, W.unfinished,
-                                W.alive, emb_needed ? w->embed : nullptr, W.emb, d->E, B, st));
+                                W.alive, emb_needed ? w->embed : nullptr, W.emb, d->E, B, st, a_done ? &tail : nullptr));
     }
     return SET_OK;
 }

@@ -313,10 +313,11 @@ static void build_phase_a(const SetEditNetWeights* w, const SetEditNetDims* d, E
 //   a_pre  != NULL: phase A of THIS timestep was launched by the previous one; these are its planned problems
 //   a_next != NULL: launch the NEXT timestep's phase A together with this timestep's fc and return its problems here
 //   *logits_biased: set when the returned logits already include fc.bias (unsplit fc)
+//   a_done: the attention-LSTM cell of this timestep was finished by the previous pick (LstmTail): h1 / c1 are current
 static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X, int bt, EditNetWs& ws,
                      const long long* tok_ids, long long tok_stride, float* dst,
                      long long ld_dst, Slabs* logits_out, hipStream_t st, const GemmProb* a_pre = nullptr,
-                     GemmProb* a_next = nullptr, bool* logits_biased = nullptr, int bt_next = -1) {
+                     GemmProb* a_next = nullptr, bool* logits_biased = nullptr, int bt_next = -1, bool a_done = false) {
     const int B = d->B, T = d->T, R = d->R, F = d->F, D = d->D, A = d->A, V = d->V;
     const int tgt = gemm_target_wgs();
     const long long ld_x2h = 2LL * D + F;
@@ -340,8 +341,9 @@ static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const 
         SET_TRY(gemm_group(a, 2, st, "gemm:A gates1+h2h"));
     }
     const Slabs none{nullptr, 0, 0, 0};
-    SET_TRY(lstm_pointwise(slabs_of(a[0]), none, none, ws.pre1, 4 * D, nullptr, nullptr, ws.c1, ws.c1, ws.h1, nullptr,
-                           bt, D, st, g_gates));
+    if (!(a_done && a_pre && tab))
+        SET_TRY(lstm_pointwise(slabs_of(a[0]), none, none, ws.pre1, 4 * D, nullptr, nullptr, ws.c1, ws.c1, ws.h1, nullptr,
+                               bt, D, st, g_gates));
     // ---- B
     GemmProb b[5];
     b[0] = slab_prob(ws.sB0, bt, A, B);
@@ -510,25 +512,36 @@ static int rollout(const SetEditNetWeights* w, const SetEditNetDims* d, const fl
     // the reference runs max_len + 1 timesteps and discards the last one (editnet_rl.py:503,517-518)
     static const int fa_merge = env_int("SET_FA_MERGE", 1);
     const bool merge = fa_merge && !emb_needed;      // the token table is active: phase A does not see the token
+    // the pick finishes the next timestep's attention-LSTM cell (LstmTail): its gate products ride this timestep's fc
+    // launch and only the token-table row waits for the word (SET_PICK_TAIL=0: separate lstm_pointwise launch)
+    static const int pick_tail = env_int("SET_PICK_TAIL", 1);
     GemmProb a_cur[2], a_nxt[2];
-    bool have_a = false;
+    bool have_a = false, a_done = false;
     for (int t = 0; t <= max_len; ++t) {
         Slabs lg;
         bool biased = false;
         const bool next_a = merge && t < max_len;     // there is a next timestep to pre-launch phase A for
         SET_TRY(step_impl(w, d, X, B, W, W.it, 1, nullptr, 0, &lg, st, have_a ? a_cur : nullptr, next_a ? a_nxt : nullptr,
-                          &biased));
+                          &biased, -1, a_done));
         have_a = next_a;
         if (next_a) { a_cur[0] = a_nxt[0]; a_cur[1] = a_nxt[1]; }
         if (t == max_len) break;
         const float* pick_bias = biased ? nullptr : w->fc_b;
+        LstmTail tail;
+        a_done = next_a && pick_tail;
+        if (a_done) {
+            tail.g0 = slabs_of(a_nxt[0]);
+            tail.pre = W.pre1; tail.ldpre = 4LL * d->D;
+            tail.tab = w->tok_table; tail.ld_tab = 10LL * d->D; tail.col0 = 0; tail.nrows = d->V;
+            tail.c_in = W.c1; tail.c_out = W.c1; tail.h_out = W.h1; tail.D = d->D;
+        }
         if (sample)
             SET_TRY(sample_pick(lg, pick_bias, d->V, t, max_len, end_idx, (long long*)seq, seq_logp, W.it, W.unfinished,
                                 W.alive, emb_needed ? w->embed : nullptr, W.emb, d->D, B, seed, offset, nullptr, nullptr,
-                                nullptr, st));
+                                nullptr, st, a_done ? &tail : nullptr));
         else
             SET_TRY(greedy_pick(lg, pick_bias, d->V, t, max_len, end_idx, (long long*)seq, seq_logp, W.it, W.unfinished,
-                                W.alive, emb_needed ? w->embed : nullptr, W.emb, d->D, B, st));
+                                W.alive, emb_needed ? w->embed : nullptr, W.emb, d->D, B, st, a_done ? &tail : nullptr));
     }
     return SET_OK;
 }

@@ -13,9 +13,10 @@
 //     skip their loads and MFMAs, finished rows carry their state;
 //   * the new h (2 KB per workgroup) is published with write-through (sc1) stores and the steps are separated by a grid
 //     barrier: per-shard arrival counters (blockIdx % 8), a top counter, per-shard generation words polled by ONE lane with
-//     relaxed loads + s_sleep, one agent-scope acquire per workgroup after the match (MI355X_MICROARCH.md, barrier-xcd /
-//     Guideline 16 R1).  Sharding is by block id, not by XCC id: correct for ANY placement; faster when block b runs on
-//     XCD b % 8, which is what the dispatcher does.
+//     relaxed loads + s_sleep.  h is READ with sc1 loads as well (raw buffer loads, aux = sc1), so both sides of the exchange
+//     go to the coherence point and neither an L2 write-back nor an invalidate is needed — only the drain of a wave's own
+//     sc1 stores before it arrives (MI355X_MICROARCH.md, barrier-xcd / Guideline 16).  Sharding is by block id, not by XCC
+//     id: correct for ANY placement; faster when block b runs on XCD b % 8, which is what the dispatcher does.
 // Residency: the barrier needs all G workgroups resident at once.  G <= 256 workgroups of 256 threads, <= 32 KB of LDS; the
 // default small-batch instantiation (B <= 32) stays within 256 registers (__launch_bounds__(256, 2)), so any two instances
 // fit the chip together (two processes sharing one GPU, e.g. the world-size-2 tests, cannot starve each other; the opt-in

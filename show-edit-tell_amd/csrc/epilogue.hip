@@ -16,6 +16,72 @@ __device__ __forceinline__ float logit_at(const Slabs& s, const float* bias, lon
     return bias ? x + bias[v] : x;
 }
 
+// ---- LstmTail (set_common.h): the next timestep's attention-LSTM cell of this row, finished by the workgroup that chose
+// the row's word.  Arithmetic and operand order are lstm_pointwise_k's (slab 0, 1, ..., pre, table row; c' = f c + i g,
+// h' = o tanh c').  tail_fetch requests everything that does not depend on the word (the first two slabs, pre, c) so the
+// latency sits under the logits fetch; tail_finish adds the table row and stores.
+__device__ __forceinline__ float tail_sigm(float x) { return 1.f / (1.f + expf(-x)); }
+struct TailRegs {
+    f32x4 s0[4], s1[4], pre[4], c;
+};
+__device__ __forceinline__ void tail_fetch(const LstmTail& L, int b, int j, TailRegs& r) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const float* p = L.g0.p + (long long)b * L.g0.ld + j;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        r.s0[q] = L.g0.n > 0 ? *reinterpret_cast<const f32x4*>(p + q * L.D) : z;
+        r.s1[q] = L.g0.n > 1 ? *reinterpret_cast<const f32x4*>(p + L.g0.stride + q * L.D) : z;
+        r.pre[q] = L.pre ? *reinterpret_cast<const f32x4*>(L.pre + (long long)b * L.ldpre + q * L.D + j) : z;
+    }
+    r.c = *reinterpret_cast<const f32x4*>(L.c_in + (long long)b * L.D + j);
+}
+struct TailRow {
+    f32x4 xt[4];
+};
+__device__ __forceinline__ void tail_row_fetch(const LstmTail& L, int j, const float* trow, TailRow& w) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w.xt[q] = *reinterpret_cast<const f32x4*>(trow + q * L.D + j);
+}
+__device__ __forceinline__ void tail_finish(const LstmTail& L, int b, int j, const TailRow& w, const TailRegs& r) {
+    f32x4 g[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        g[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (L.g0.n > 0) g[q] += r.s0[q];
+        if (L.g0.n > 1) g[q] += r.s1[q];
+    }
+    for (int i = 2; i < L.g0.n; ++i) {
+        const float* p = L.g0.p + (long long)i * L.g0.stride + (long long)b * L.g0.ld + j;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] += *reinterpret_cast<const f32x4*>(p + q * L.D);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (L.pre) g[q] += r.pre[q];
+        g[q] += w.xt[q];
+    }
+    f32x4 cn, hn;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float ig = tail_sigm(g[0][e]), fg = tail_sigm(g[1][e]), gg = tanhf(g[2][e]);
+        const float og = tail_sigm(g[3][e]);
+        cn[e] = fg * r.c[e] + ig * gg;
+        hn[e] = og * tanhf(cn[e]);
+    }
+    *reinterpret_cast<f32x4*>(L.c_out + (long long)b * L.D + j) = cn;
+    *reinterpret_cast<f32x4*>(L.h_out + (long long)b * L.D + j) = hn;
+}
+__device__ __forceinline__ const float* tail_row(const LstmTail& L, long long tok) {
+    tok = tok < 0 ? 0 : (tok >= L.nrows ? L.nrows - 1 : tok);       // clamped like RowGather::row
+    return L.tab + tok * L.ld_tab + L.col0;
+}
+
+static bool tail_ok(const LstmTail& L) {
+    return L.D > 0 && !(L.D & 3) && L.g0.p && L.g0.n >= 1 && !(L.g0.ld & 3) && !(L.g0.stride & 3) && aligned16(L.g0.p) &&
+           L.tab && !(L.ld_tab & 3) && !(L.col0 & 3) && aligned16(L.tab) && L.nrows > 0 && L.c_in && L.c_out && L.h_out &&
+           aligned16(L.c_in) && aligned16(L.c_out) && aligned16(L.h_out) && (!L.pre || (aligned16(L.pre) && !(L.ldpre & 3)));
+}
+
 // grid = B rows.  alive[t] counts rows still unfinished after step t (zeroed by the caller);
 // once alive[t-1] == 0 the reference has left its loop (`break`, editnet_rl.py:546) and nothing
 // more is written to seq / seq_logp.
@@ -23,11 +89,11 @@ __device__ __forceinline__ float logit_at(const Slabs& s, const float* bias, lon
 // in registers), max / first-argmax and sum-exp are reduced from registers.
 constexpr int GP_MAXQ = 12;
 
-template <bool REG>
+template <bool REG, bool TAIL>
 __global__ void __launch_bounds__(256) greedy_pick_k(Slabs logits, const float* bias, int V, int t, int max_len,
                                                      long long end_idx, long long* seq, float* seq_logp,
                                                      long long* it_buf, int* unfinished, int* alive,
-                                                     const float* table, float* emb_out, int D) {
+                                                     const float* table, float* emb_out, int D, const LstmTail tail) {
     __shared__ float s_val[4];
     __shared__ int s_idx[4];
     __shared__ float s_sum[4];
@@ -36,7 +102,13 @@ __global__ void __launch_bounds__(256) greedy_pick_k(Slabs logits, const float* 
     // bookkeeping words of the serial tail (thread 0): requested now, under the row fetch, instead of as a dependent
     // round trip after the reductions
     int unf_prev = 1, alive_prev = 1;
-    if (tid == 0 && t > 0) { unf_prev = unfinished[b]; alive_prev = alive[t - 1]; }
+    if (t > 0) {
+        if (TAIL || tid == 0) unf_prev = unfinished[b];          // (TAIL: every thread derives the word right after the arg-max)
+        if (tid == 0) alive_prev = alive[t - 1];
+    }
+    TailRegs tr;
+    const bool tail0 = TAIL && tid * 4 < tail.D;
+    if (TAIL) { if (tail0) tail_fetch(tail, b, tid * 4, tr); }
     float best = -INFINITY;
     int bi = 0x7fffffff;
     f32x4 x[GP_MAXQ];
@@ -125,6 +197,16 @@ __global__ void __launch_bounds__(256) greedy_pick_k(Slabs logits, const float* 
 #pragma unroll
     for (int w = 1; w < 4; ++w)
         if (s_val[w] > best || (s_val[w] == best && s_idx[w] < bi)) { best = s_val[w]; bi = s_idx[w]; }
+    // the word follows from the arg-max and the row's latch alone: with a tail, every thread requests its piece of the
+    // token-table row NOW, so that round trip runs under the sum-exp pass instead of after the serial bookkeeping
+    TailRow tw;
+    if (TAIL) {
+        long long it = bi;
+        if (it == end_idx) it = 0;
+        const int unf = (t == 0) ? (it > 0) : (unf_prev && it > 0);
+        it = unf ? it : 0;
+        if (tail0) tail_row_fetch(tail, tid * 4, tail_row(tail, it), tw);
+    }
     float sum = 0.f;
     if (REG) {
 #pragma unroll
@@ -165,21 +247,35 @@ __global__ void __launch_bounds__(256) greedy_pick_k(Slabs logits, const float* 
             *reinterpret_cast<f32x4*>(emb_out + (long long)b * D + d) = v;
         }
     }
+    if (TAIL) {
+        if (tail0) tail_finish(tail, b, tid * 4, tw, tr);
+        const float* trow = tail_row(tail, s_tok);
+        for (int j = tid * 4 + 1024; j < tail.D; j += 1024) {
+            TailRegs r2;
+            TailRow w2;
+            tail_fetch(tail, b, j, r2);
+            tail_row_fetch(tail, j, trow, w2);
+            tail_finish(tail, b, j, w2, r2);
+        }
+    }
 }
 
 int greedy_pick(Slabs logits, const float* bias, int V, int t, int max_len, long long end_idx, long long* seq,
                 float* seq_logp, long long* it, int* unfinished, int* alive, const float* table, float* emb_out,
-                int D, int B, hipStream_t s) {
+                int D, int B, hipStream_t s, const LstmTail* tail) {
     if (B <= 0) return SET_OK;
     if (D & 3) return SET_ERR_UNSUPPORTED;
-    ProfScope ps("greedy_pick", s, 0.0, 4.0 * B * (2.0 * V * logits.n + 2.0 * D));
+    if (tail && !tail_ok(*tail)) return SET_ERR_ARG;
+    const LstmTail tl = tail ? *tail : LstmTail();
+    ProfScope ps("greedy_pick", s, 0.0,
+                 4.0 * B * (2.0 * V * logits.n + 2.0 * D + (tail ? tl.D * (4.0 * (tl.g0.n + 2) + 3.0) : 0.0)));
     const bool reg = V <= 4 * 256 * GP_MAXQ && !(logits.ld & 3) && !(logits.stride & 3) && aligned16(logits.p);
-    if (reg)
-        hipLaunchKernelGGL(greedy_pick_k<true>, dim3(B), dim3(256), 0, s, logits, bias, V, t, max_len, end_idx, seq,
-                           seq_logp, it, unfinished, alive, table, emb_out, D);
-    else
-        hipLaunchKernelGGL(greedy_pick_k<false>, dim3(B), dim3(256), 0, s, logits, bias, V, t, max_len, end_idx, seq,
-                           seq_logp, it, unfinished, alive, table, emb_out, D);
+#define SET_PICK_LAUNCH(REG, TAIL)                                                                                    \
+    hipLaunchKernelGGL((greedy_pick_k<REG, TAIL>), dim3(B), dim3(256), 0, s, logits, bias, V, t, max_len, end_idx, seq, \
+                       seq_logp, it, unfinished, alive, table, emb_out, D, tl)
+    if (reg) { if (tail) SET_PICK_LAUNCH(true, true); else SET_PICK_LAUNCH(true, false); }
+    else { if (tail) SET_PICK_LAUNCH(false, true); else SET_PICK_LAUNCH(false, false); }
+#undef SET_PICK_LAUNCH
     SET_LAUNCH_CHECK();
     return SET_OK;
 }
@@ -226,13 +322,13 @@ struct SampleOut {
     float* step_logp;     // (B) this step's log-prob (0 once the loop has been left)
 };
 
-template <bool REG>
+template <bool REG, bool TAIL>
 __global__ void __launch_bounds__(256) sample_pick_k(Slabs logits, const float* bias, int V, int t, int max_len,
                                                      long long end_idx, long long* seq, float* seq_logp,
                                                      long long* it_buf, int* unfinished, int* alive,
                                                      const float* table, float* emb_out, int D,
                                                      unsigned long long seed, unsigned long long offset,
-                                                     SampleOut so) {
+                                                     SampleOut so, const LstmTail tail) {
     __shared__ float s_red[4];
     __shared__ float s_scan[4];
     __shared__ float s_max;
@@ -381,23 +477,36 @@ __global__ void __launch_bounds__(256) sample_pick_k(Slabs logits, const float* 
             *reinterpret_cast<f32x4*>(emb_out + (long long)b * D + d) = v;
         }
     }
+    if (TAIL) {
+        const float* trow = tail_row(tail, s_tok);
+        for (int j = tid * 4; j < tail.D; j += 1024) {
+            TailRegs r2;
+            TailRow w2;
+            tail_fetch(tail, b, j, r2);
+            tail_row_fetch(tail, j, trow, w2);
+            tail_finish(tail, b, j, w2, r2);
+        }
+    }
 }
 
 int sample_pick(Slabs logits, const float* bias, int V, int t, int max_len, long long end_idx, long long* seq,
                 float* seq_logp, long long* it, int* unfinished, int* alive, const float* table, float* emb_out, int D,
                 int B, unsigned long long seed, unsigned long long offset, long long* raw_ids, float* lse,
-                float* step_logp, hipStream_t s) {
+                float* step_logp, hipStream_t s, const LstmTail* tail) {
     if (B <= 0) return SET_OK;
     if (D & 3) return SET_ERR_UNSUPPORTED;
-    ProfScope ps("sample_pick", s, 0.0, 4.0 * B * (1.0 * V * logits.n + 2.0 * D));
+    if (tail && !tail_ok(*tail)) return SET_ERR_ARG;
+    const LstmTail tl = tail ? *tail : LstmTail();
+    ProfScope ps("sample_pick", s, 0.0,
+                 4.0 * B * (1.0 * V * logits.n + 2.0 * D + (tail ? tl.D * (4.0 * (tl.g0.n + 2) + 3.0) : 0.0)));
     const bool reg = V <= 4 * 256 * GP_MAXQ && !(logits.ld & 3) && !(logits.stride & 3) && aligned16(logits.p);
     SampleOut so{raw_ids, lse, step_logp};
-    if (reg)
-        hipLaunchKernelGGL(sample_pick_k<true>, dim3(B), dim3(256), 0, s, logits, bias, V, t, max_len, end_idx, seq,
-                           seq_logp, it, unfinished, alive, table, emb_out, D, seed, offset, so);
-    else
-        hipLaunchKernelGGL(sample_pick_k<false>, dim3(B), dim3(256), 0, s, logits, bias, V, t, max_len, end_idx, seq,
-                           seq_logp, it, unfinished, alive, table, emb_out, D, seed, offset, so);
+#define SET_PICK_LAUNCH(REG, TAIL)                                                                                    \
+    hipLaunchKernelGGL((sample_pick_k<REG, TAIL>), dim3(B), dim3(256), 0, s, logits, bias, V, t, max_len, end_idx, seq, \
+                       seq_logp, it, unfinished, alive, table, emb_out, D, seed, offset, so, tl)
+    if (reg) { if (tail) SET_PICK_LAUNCH(true, true); else SET_PICK_LAUNCH(true, false); }
+    else { if (tail) SET_PICK_LAUNCH(false, true); else SET_PICK_LAUNCH(false, false); }
+#undef SET_PICK_LAUNCH
     SET_LAUNCH_CHECK();
     return SET_OK;
 }

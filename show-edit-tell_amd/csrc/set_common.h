@@ -209,13 +209,30 @@ int fused_encoder_step(const float* h_in, float* h_out, float* c, const float* w
 int encoder_order(const int64_t* lens, int B, int T, int* perm, int* nactive, hipStream_t s);
 
 // epilogue.hip
+// Optional tail of the pick kernels (free-running loops with the token table): the NEXT timestep's attention-LSTM cell
+// update of the row.  Its gate products [h2 | h1] W were launched together with this timestep's fc; the only operand that
+// waits for the pick is the token-table row, so the workgroup that has just chosen the row's word finishes the cell here
+// and the loop needs no lstm_pointwise launch between the pick and phase B.  Same operand order as lstm_pointwise_k
+// (slabs, pre, table row).
+struct LstmTail {
+    Slabs g0{nullptr, 0, 0, 0};              // gate pre-activation slabs (rows, 4D)
+    const float* pre = nullptr;              // hoisted loop-invariant columns + biases (rows, ldpre)
+    long long ldpre = 0;
+    const float* tab = nullptr;              // token table: row `word`, columns col0 .. col0 + 4D
+    long long ld_tab = 0;
+    int col0 = 0, nrows = 0;
+    const float* c_in = nullptr;
+    float* c_out = nullptr;
+    float* h_out = nullptr;
+    int D = 0;
+};
 int greedy_pick(Slabs logits, const float* bias, int V, int t, int max_len, long long end_idx,
                 long long* seq, float* seq_logp, long long* it, int* unfinished, int* alive,
-                const float* table, float* emb_out, int D, int B, hipStream_t s);
+                const float* table, float* emb_out, int D, int B, hipStream_t s, const LstmTail* tail = nullptr);
 int sample_pick(Slabs logits, const float* bias, int V, int t, int max_len, long long end_idx, long long* seq,
                 float* seq_logp, long long* it, int* unfinished, int* alive, const float* table, float* emb_out, int D,
                 int B, unsigned long long seed, unsigned long long offset, long long* raw_ids, float* lse,
-                float* step_logp, hipStream_t s);
+                float* step_logp, hipStream_t s, const LstmTail* tail = nullptr);
 int sample_logp_bwd(const float* logits, long long ld, const float* lse, const long long* ids, const float* g,
                     float* dlogits, long long ldd, int B, int V, hipStream_t s);
 int philox_fill(uint32_t* out, int n, unsigned long long seed, unsigned long long offset, hipStream_t s);

@@ -138,3 +138,20 @@ def test_gemm_kernel_variants_keep_parity(env_extra):
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout and "failed" not in out.stdout
+
+
+def test_pick_without_the_lstm_tail_keeps_parity():
+    """Free-running loops: the pick kernel finishes the next timestep's attention-LSTM cell by default (LstmTail,
+    csrc/epilogue.hip).  SET_PICK_TAIL=0 restores the separate lstm_pointwise launch; the greedy / sampled rollout tests
+    of both models must pass either way (the default route is what the rest of the suite runs)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, SET_PICK_TAIL="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+           os.path.join(root, "tests", "test_hip_editnet.py"), os.path.join(root, "tests", "test_hip_dcnet.py"),
+           os.path.join(root, "tests", "test_hip_sampling.py"), "-k", "greedy or rollout or sample"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout and "failed" not in out.stdout
