@@ -46,7 +46,8 @@ def _scratch(device):
     if ws is None:
         if len(_gemm_ws) >= 16:               # 64 MB each, keyed by (device, stream): bounded
             _gemm_ws.clear()
-        ws = _gemm_ws[key] = torch.empty(_GEMM_WS_BYTES, dtype=torch.uint8, device=device)
+        # zeroed once: with SET_GEN_COMBINE=1 the library keeps its arrival counters in the tail of this buffer
+        ws = _gemm_ws[key] = torch.zeros(_GEMM_WS_BYTES, dtype=torch.uint8, device=device)
     return ws
 
 

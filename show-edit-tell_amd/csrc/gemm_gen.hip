@@ -21,6 +21,7 @@ namespace set {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const f32x4 __attribute__((address_space(1)))* gptr4;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GEN_MAX_TASKS = 6;
 struct GenTask {
@@ -34,6 +35,9 @@ struct GenTask {
     float* out;
     long long ldo;
     int red_begin;       // first 256-thread block of this task in the grouped reduction launch
+    // in-launch combine (SET_GEN_COMBINE=1): one arrival counter per output tile, zero on entry and on exit; the last of a
+    // tile's ksplit workgroups adds the slabs (in slab order, like slab_reduce_k) and writes `out`
+    unsigned* counters;
 };
 struct GenLaunch {
     GenTask t[GEN_MAX_TASKS];
@@ -208,6 +212,97 @@ __global__ void __launch_bounds__(256) gemm_gen_f32(const GenLaunch L) {
     const bool acc_c = T.accumulate && T.ksplit == 1;
     const int crow0 = m0 + wm * TM * 32 + 4 * kh;
     const int ccol0 = n0 + wn * TN * 32 + frow;
+    if (T.ksplit > 1 && T.counters) {
+        // ---- in-launch combine.  The partial tile goes out write-through (sc1), the workgroup drains its stores and takes a
+        // ticket; the last arrival of the tile reads all slabs back with sc1 loads (both sides at the coherence point: no
+        // L2 write-back, no invalidate — MI355X_MICROARCH.md, Guideline 16 / splitk-seam) and does slab_reduce_k's job.
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)T.C, 0, 0x7ffffff0, 0x00027000);
+        const int sbase = ks * (int)T.slab_stride;                 // floats; slabs of one task stay below 2^29 floats (host)
+        float* sT = &lds[0][0] + wave * 1024;
+        const int trow = lane >> 3, tcol = (lane & 7) * 4;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * TN * 32 + j * 32 + tcol;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (i + j) __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sT[((r & 3) + 8 * (r >> 2) + 4 * kh) * 32 + frow] = acc[i][j][r];
+                __syncthreads();
+                const int rbase = m0 + wm * TM * 32 + i * 32 + trow;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(sT + q * 256 + lane * 4);
+                    const int row = rbase + 8 * q;
+                    if (row < T.M && col < T.N)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), rs,
+                                                               (sbase + row * (int)T.ldc + col) * 4, 0, 16);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* flag = reinterpret_cast<unsigned*>(&lds[1][0]);
+        if (tid == 0) {
+            unsigned* cnt = T.counters + tile;
+            const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool last = old + 1u == (unsigned)T.ksplit;
+            if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = last ? 1u : 0u;
+        }
+        __syncthreads();
+        if (*flag == 0u) return;
+        // BM x 64 tile = BM*16 float4, 256 threads
+        constexpr int PER = BM * BN / 4 / 256;
+        int off[PER];
+        long long oo[PER];
+        bool ok[PER];
+        f32x4 v[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int f = tid + 256 * u, row = m0 + f / (BN / 4), col = n0 + (f % (BN / 4)) * 4;
+            ok[u] = row < T.M && col < T.N;
+            off[u] = ok[u] ? (row * (int)T.ldc + col) * 4 : 0;
+            oo[u] = (long long)row * T.ldo + col;
+            v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        const int sstep = (int)T.slab_stride * 4;
+        // slabs in index order (0 + s0 + s1 + ... is slab_reduce_k's sum bit for bit); PER x 4 loads in flight
+        int sidx = 0;
+        for (; sidx + 4 <= T.ksplit; sidx += 4) {
+            f32x4 w[4][PER];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int u = 0; u < PER; ++u)
+                    w[q][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off[u] + (sidx + q) * sstep, 0, 16));
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int u = 0; u < PER; ++u) v[u] += w[q][u];
+        }
+        for (; sidx < T.ksplit; ++sidx) {
+            f32x4 w[PER];
+#pragma unroll
+            for (int u = 0; u < PER; ++u)
+                w[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off[u] + sidx * sstep, 0, 16));
+#pragma unroll
+            for (int u = 0; u < PER; ++u) v[u] += w[u];
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            if (!ok[u]) continue;
+            float* o = T.out + oo[u];
+            if (T.accumulate) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += v[u][e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = v[u][e];
+            }
+        }
+        return;
+    }
     if (T.vec_store) {
         // 16-byte stores through a per-wave LDS transpose of each 32x32 sub-tile (same epilogue as gemm_nt_f32)
         float* sT = &lds[0][0] + wave * 1024;
@@ -382,6 +477,17 @@ int gemm_gen_group(const SetGemmDesc* d, int n, int a_kminor, int b_kminor, void
             if (wgs <= slots) break;
         }
     }
+    // SET_GEN_COMBINE=1 (experiment): split products are combined inside the launch by each tile's last workgroup instead of
+    // by slab_reduce_k.  The arrival counters live in the last GEN_COUNTER_BYTES of the scratch, which the caller must hand
+    // over ZEROED once (they are left zero by every launch).
+    static const int combine = env_int("SET_GEN_COMBINE", 0);
+    constexpr size_t GEN_COUNTER_BYTES = 64 << 10;
+    unsigned* counters = nullptr;
+    long long counters_used = 0;
+    if (combine && ws && ws_bytes > 4 * GEN_COUNTER_BYTES) {
+        ws_bytes -= GEN_COUNTER_BYTES;
+        counters = reinterpret_cast<unsigned*>((char*)ws + ws_bytes);
+    }
     size_t ws_off = 0;
     int wg = 0, red_blocks = 0;
     double flops = 0.0, bytes = 0.0, red_bytes = 0.0;
@@ -396,13 +502,20 @@ int gemm_gen_group(const SetGemmDesc* d, int n, int a_kminor, int b_kminor, void
         if (ksplit < 2) ksplit = 1;
         T.ksplit = ksplit;
         T.red_begin = 0x7fffffff;
+        T.counters = nullptr;
         if (ksplit == 1) { T.C = T.out; T.ldc = T.ldo; T.slab_stride = 0; }
         else {
             T.C = (float*)((char*)ws + ws_off); T.ldc = T.N; T.slab_stride = (long long)(slab / sizeof(float));
             ws_off += (size_t)ksplit * slab;
-            T.red_begin = red_blocks;
-            red_blocks += (int)(((long long)T.M * (T.N >> 2) + 255) / 256);
-            red_bytes += 4.0 * T.M * T.N * (ksplit + 1.0);
+            if (counters && (counters_used + tiles[i]) * sizeof(unsigned) <= GEN_COUNTER_BYTES &&
+                (size_t)ksplit * slab < ((size_t)1 << 31)) {
+                T.counters = counters + counters_used;
+                counters_used += tiles[i];
+            } else {
+                T.red_begin = red_blocks;
+                red_blocks += (int)(((long long)T.M * (T.N >> 2) + 255) / 256);
+                red_bytes += 4.0 * T.M * T.N * (ksplit + 1.0);
+            }
         }
         static const int vec_epi = env_int("SET_GEMM_VEC_EPILOGUE", 1);
         T.vec_store = vec_epi && !(T.N & 3) && !(T.ldc & 3) && !(T.slab_stride & 3) && aligned16(T.C);
