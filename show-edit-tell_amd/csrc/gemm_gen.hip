@@ -44,7 +44,10 @@ struct GenLaunch {
     int ntasks;
 };
 
-template <int BM, int BN, bool A_KMAJ, bool B_KMAJ>
+// COMBINE: the in-launch split-K combine (experiment, SET_GEN_COMBINE=1) is compiled into its own instantiations — its
+// read-back holds BM/16 x 4 slab pieces per thread, which would otherwise set the register budget (and the occupancy) of
+// the default kernels too
+template <int BM, int BN, bool A_KMAJ, bool B_KMAJ, bool COMBINE = false>
 __global__ void __launch_bounds__(256) gemm_gen_f32(const GenLaunch L) {
     constexpr int TM = BM / 64, TN = BN / 64;            // 2x2 waves
     constexpr int LA = BM / 32, LB = BN / 32;            // float4 loads per thread per k-tile
@@ -212,7 +215,7 @@ __global__ void __launch_bounds__(256) gemm_gen_f32(const GenLaunch L) {
     const bool acc_c = T.accumulate && T.ksplit == 1;
     const int crow0 = m0 + wm * TM * 32 + 4 * kh;
     const int ccol0 = n0 + wn * TN * 32 + frow;
-    if (T.ksplit > 1 && T.counters) {
+    if constexpr (COMBINE) if (T.ksplit > 1 && T.counters) {
         // ---- in-launch combine.  The partial tile goes out write-through (sc1), the workgroup drains its stores and takes a
         // ticket; the last arrival of the tile reads all slabs back with sc1 loads (both sides at the coherence point: no
         // L2 write-back, no invalidate — MI355X_MICROARCH.md, Guideline 16 / splitk-seam) and does slab_reduce_k's job.
@@ -253,52 +256,58 @@ __global__ void __launch_bounds__(256) gemm_gen_f32(const GenLaunch L) {
         __syncthreads();
         if (*flag == 0u) return;
         // BM x 64 tile = BM*16 float4, 256 threads
-        constexpr int PER = BM * BN / 4 / 256;
-        int off[PER];
-        long long oo[PER];
-        bool ok[PER];
-        f32x4 v[PER];
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int f = tid + 256 * u, row = m0 + f / (BN / 4), col = n0 + (f % (BN / 4)) * 4;
-            ok[u] = row < T.M && col < T.N;
-            off[u] = ok[u] ? (row * (int)T.ldc + col) * 4 : 0;
-            oo[u] = (long long)row * T.ldo + col;
-            v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
+        // read-back in groups of 4 output pieces x 2 slabs (8 loads of 16 bytes in flight per thread: the accumulator and
+        // staging registers are dead here, so this fits the k-loop's register budget); slabs in index order, 0 + s0 + s1 + ...
+        // = slab_reduce_k's sum bit for bit
+        constexpr int PER = BM * BN / 4 / 256, GRP = 4;
+        static_assert(PER % GRP == 0, "whole groups");
         const int sstep = (int)T.slab_stride * 4;
-        // slabs in index order (0 + s0 + s1 + ... is slab_reduce_k's sum bit for bit); PER x 4 loads in flight
-        int sidx = 0;
-        for (; sidx + 4 <= T.ksplit; sidx += 4) {
-            f32x4 w[4][PER];
+#pragma unroll 1
+        for (int u0 = 0; u0 < PER; u0 += GRP) {
+            int off[GRP];
+            long long oo[GRP];
+            bool ok[GRP];
+            f32x4 v[GRP];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int u = 0; u < GRP; ++u) {
+                const int f = tid + 256 * (u0 + u), row = m0 + f / (BN / 4), col = n0 + (f % (BN / 4)) * 4;
+                ok[u] = row < T.M && col < T.N;
+                off[u] = ok[u] ? (row * (int)T.ldc + col) * 4 : 0;
+                oo[u] = (long long)row * T.ldo + col;
+                v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            int sidx = 0;
+            for (; sidx + 2 <= T.ksplit; sidx += 2) {
+                f32x4 w[2][GRP];
 #pragma unroll
-                for (int u = 0; u < PER; ++u)
-                    w[q][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off[u] + (sidx + q) * sstep, 0, 16));
+                for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+                    for (int u = 0; u < GRP; ++u)
+                        w[q][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off[u] + (sidx + q) * sstep, 0, 16));
 #pragma unroll
-                for (int u = 0; u < PER; ++u) v[u] += w[q][u];
-        }
-        for (; sidx < T.ksplit; ++sidx) {
-            f32x4 w[PER];
+                for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int u = 0; u < PER; ++u)
-                w[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off[u] + sidx * sstep, 0, 16));
+                    for (int u = 0; u < GRP; ++u) v[u] += w[q][u];
+            }
+            if (sidx < T.ksplit) {
+                f32x4 w[GRP];
 #pragma unroll
-            for (int u = 0; u < PER; ++u) v[u] += w[u];
-        }
+                for (int u = 0; u < GRP; ++u)
+                    w[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off[u] + sidx * sstep, 0, 16));
 #pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            if (!ok[u]) continue;
-            float* o = T.out + oo[u];
-            if (T.accumulate) {
+                for (int u = 0; u < GRP; ++u) v[u] += w[u];
+            }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] += v[u][e];
-            } else {
+            for (int u = 0; u < GRP; ++u) {
+                if (!ok[u]) continue;
+                float* o = T.out + oo[u];
+                if (T.accumulate) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = v[u][e];
+                    for (int e = 0; e < 4; ++e) o[e] += v[u][e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = v[u][e];
+                }
             }
         }
         return;
@@ -374,13 +383,13 @@ __global__ void __launch_bounds__(256) slab_reduce_k(const GenLaunch L) {
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool COMBINE>
 static void launch_gen(const GenLaunch& L, int a_kmaj, int b_kmaj, unsigned wgs, hipStream_t s) {
     dim3 grid(wgs), block(256);
-    if (a_kmaj && b_kmaj) hipLaunchKernelGGL((gemm_gen_f32<BM, BN, true, true>), grid, block, 0, s, L);
-    else if (a_kmaj) hipLaunchKernelGGL((gemm_gen_f32<BM, BN, true, false>), grid, block, 0, s, L);
-    else if (b_kmaj) hipLaunchKernelGGL((gemm_gen_f32<BM, BN, false, true>), grid, block, 0, s, L);
-    else hipLaunchKernelGGL((gemm_gen_f32<BM, BN, false, false>), grid, block, 0, s, L);
+    if (a_kmaj && b_kmaj) hipLaunchKernelGGL((gemm_gen_f32<BM, BN, true, true, COMBINE>), grid, block, 0, s, L);
+    else if (a_kmaj) hipLaunchKernelGGL((gemm_gen_f32<BM, BN, true, false, COMBINE>), grid, block, 0, s, L);
+    else if (b_kmaj) hipLaunchKernelGGL((gemm_gen_f32<BM, BN, false, true, COMBINE>), grid, block, 0, s, L);
+    else hipLaunchKernelGGL((gemm_gen_f32<BM, BN, false, false, COMBINE>), grid, block, 0, s, L);
 }
 
 // n independent problems of the same operand layout in ONE launch (+ one reduction launch when any is split):
@@ -529,8 +538,13 @@ int gemm_gen_group(const SetGemmDesc* d, int n, int a_kminor, int b_kminor, void
         const char* name = a_kminor ? (b_kminor ? "gemm_gen_f32<tn>" : "gemm_gen_f32<tt>")
                                     : (b_kminor ? "gemm_gen_f32<nn>" : "gemm_gen_f32<nt>");
         ProfScope ps(name, s, flops, bytes);
-        if (bm == 128) launch_gen<128, 64>(L, !a_kminor, !b_kminor, (unsigned)wg, s);
-        else launch_gen<64, 64>(L, !a_kminor, !b_kminor, (unsigned)wg, s);
+        if (counters_used > 0) {
+            if (bm == 128) launch_gen<128, 64, true>(L, !a_kminor, !b_kminor, (unsigned)wg, s);
+            else launch_gen<64, 64, true>(L, !a_kminor, !b_kminor, (unsigned)wg, s);
+        } else {
+            if (bm == 128) launch_gen<128, 64, false>(L, !a_kminor, !b_kminor, (unsigned)wg, s);
+            else launch_gen<64, 64, false>(L, !a_kminor, !b_kminor, (unsigned)wg, s);
+        }
         SET_LAUNCH_CHECK();
     }
     if (red_blocks > 0) {
