@@ -20,6 +20,8 @@ SHAPES = [
     (70, 9, 36, 128, 64, 256, 514),
     (130, 20, 5, 64, 64, 64, 9490 // 10),
     (200, 3, 100, 64, 32, 128, 300),
+    (9, 6, 4, 512, 64, 128, 150),          # D = 512: the persistent encoder's third width
+    (16, 4, 3, 2048, 64, 128, 211),        # D > 1024: more than one 1024-column pass per row in the pick's LSTM tail
 ]
 
 
