@@ -118,8 +118,7 @@ class BucketedAllReduce:
         import torch.distributed as dist
         self.dist = dist
         self.group = group
-        self.active = (enabled and dist.is_available() and dist.is_initialized()
-                       and dist.get_world_size(group) > 1)
+        self.active = enabled and _dist_active(group)
         self.bucket_bytes = bucket_bytes or BUCKET_BYTES
         self.bucket, self.size, self.pending, self.seen = [], 0, [], set()
         self.n_buckets = 0
@@ -208,9 +207,14 @@ def allreduce_gradients(params, group=None, bucket_bytes=None, reducer=None):
     return r.finish()
 
 
+# A process group of ONE rank needs no exchange and the collectives are skipped.  Setting this to 1 makes a one-rank group
+# go through them anyway (tests: the only way to run the RCCL calls of the exchange step on a one-GPU box).
+MIN_WORLD_FOR_EXCHANGE = 2
+
+
 def _dist_active(group=None):
     import torch.distributed as dist
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) >= MIN_WORLD_FOR_EXCHANGE
 
 
 def global_token_count(n_local, device, group=None):

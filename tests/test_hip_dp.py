@@ -96,6 +96,53 @@ def test_dp_hip_model_full_size_two_ranks_one_device_gloo():
     assert r[0]["bytes"] > 300e6
 
 
+def _nccl_one_rank_worker(rank, port, ret):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (here, os.path.dirname(here)):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    from hip_adapter import editnet_modules, to_dev
+    from show_edit_tell_amd import train
+    train.BUCKET_BYTES = 64 << 10
+    train.MIN_WORLD_FOR_EXCHANGE = 1                # a one-rank group runs the collectives too
+    d, xe, _ = editnet_modules("editnet_small", "cuda:0")
+    xe.eval()
+    full = tuple(to_dev(d[k], "cuda:0") for k in ("X", "caps", "clen", "prev", "plen"))
+    loss_ref, n_ref, _ = train.xe_backward(xe, *full, reduce=False)
+    ref = _grads_of(xe)
+    loss, n_tok, reducer = train.xe_backward(xe, *full)            # token-count exchange + bucketed all-reduce on RCCL
+    got = _grads_of(xe)
+    # (the flat-bucket backward accumulates into zeroed views where the single-rank one writes fresh tensors: parameters with
+    # several contributions may differ by the order of their additions)
+    scale = max(float(np.abs(r).max()) for r in ref.values())
+    worst = max(float(np.abs(got[k] - ref[k]).max()) for k in ref) / scale
+    ret[0] = dict(worst=worst, loss=loss, loss_ref=loss_ref, n_tok=n_tok, n_ref=n_ref, buckets=reducer.n_buckets,
+                  backend=dist.get_backend())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_exchange_runs_on_rccl_with_one_rank():
+    """The box has one GPU, so a two-rank RCCL group cannot form (RCCL refuses two ranks on one device); a ONE-rank group
+    still goes through the same calls — communicator creation, the int64 token-count all-reduce before the forward, the
+    in-place async all-reduce of every flat gradient bucket on the `nccl` backend, `work.wait()` — and must leave the
+    gradients as they were (SUM over one rank)."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_nccl_one_rank_worker, args=(29650 + (os.getpid() % 300), ret), nprocs=1, join=True)
+    r = ret[0]
+    assert r["backend"] == "nccl" and r["buckets"] >= 2
+    assert r["worst"] < 1e-6, r
+    assert r["n_tok"] == r["n_ref"] and abs(r["loss"] - r["loss_ref"]) < 1e-12
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI)")
 def test_dp_nccl_two_devices():
     _run("nccl", False, "editnet_small", 64 << 10)
