@@ -1,7 +1,7 @@
 """round 3 probe: one B=128 greedy decode as ONE chain vs as 2 / 4 row groups decoded concurrently on side streams
 (same rows, same weights; the groups are independent samples).  Prints ms per complete B=128 decode."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from show_edit_tell_amd import editnet_rl, synth
 
