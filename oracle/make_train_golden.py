@@ -34,6 +34,7 @@ TRAIN_CASES = (
     ("editnet_small", 0x1234_5678_9ABC, 0.0),
     ("editnet_small", 0x0BAD_CAFE_F00D_18, 0.25),          # scheduled sampling (editnet.py:508-520)
     ("editnet_full_b4", 0x2345_6789_ABCD, 0.0),
+    ("editnet_full_b128", 0x6789_ABCD_EF01, 0.0),          # the benchmarked training shape (BASELINE.json configs[1]) in train() mode
     ("editnet_adaptive_small", 0x3456_789A_BCDE, 0.0),
     ("dcnet_small", 0x4567_89AB_CDEF, 0.0),
     ("dcnet_full_b4", 0x5678_9ABC_DEF0, 0.0),
@@ -131,10 +132,22 @@ def make_editnet(name, seed, ss_prob):
     X, prev, plen, caps, clen = (T_(d[k]) for k in ("X", "prev", "plen", "caps", "clen"))
     # the decoder's row order (distinct caption lengths in these cases: the sort is unambiguous)
     clen_s, sort_ind = clen.squeeze(1).sort(dim=0, descending=True)
-    assert len(set(clen_s.tolist())) == B, "train-mode cases need distinct caption lengths"
+    # The dropout streams are addressed by SORTED row.  The reference's sort (editnet.py:488) is unstable — on CPU it
+    # resolves tied lengths in REVERSE input order —, the package's is stable; with distinct lengths both give the same rows,
+    # with ties (B = 128) the two row orders differ by a permutation inside every group of equal lengths.  A timestep's
+    # active prefix holds the same samples either way, so the reference is handed the package's masks row-permuted:
+    # row_map[reference row] = package row of the same sample; scores are stored in the package's row order.
+    sort_stable = clen.squeeze(1).sort(dim=0, descending=True, stable=True)[1]
+    inv_stable = torch.empty_like(sort_stable)
+    inv_stable[sort_stable] = torch.arange(B)
+    row_map = _np(inv_stable[sort_ind])
+    identity = bool((row_map == np.arange(B)).all())
+    assert identity or (ss_prob == 0 and not adaptive), "tied lengths are handled for the plain XE train-mode cases only"
     dl = (clen_s - 1).tolist()
     Tm = max(dl)
     bts = [sum(l > t for l in dl) for t in range(Tm)]
+    for t in range(Tm):
+        assert sorted(row_map[:bts[t]].tolist()) == list(range(bts[t]))
     plen_s = plen[sort_ind]
     enc_perm = _np(plen_s.squeeze(1).sort(dim=0, descending=True)[1])         # the call CaptionEncoderC.forward makes (:322)
     Xs = X[sort_ind]
@@ -144,19 +157,19 @@ def make_editnet(name, seed, ss_prob):
 
     def embed_keep(call, x):
         if call == 0:                       # caption_encoder(previous captions), editnet.py:501
-            return _encoder_keep(seed, PH.SITE_ENC_EMBED, p_emb, _np(plen_s).reshape(-1), x.shape, enc_perm)
+            return _encoder_keep(seed, PH.SITE_ENC_EMBED, p_emb, _np(plen_s).reshape(-1), x.shape, row_map[enc_perm])
         if adaptive and call == 1:          # caption_encoder(ground-truth captions), editnet_adaptive.py:516 (already sorted)
             perm = _np(clen_s.sort(dim=0, descending=True)[1])
             return _encoder_keep(seed, PH.SITE_ENC2_EMBED, p_emb, clen_s.tolist(), x.shape, perm)
         t = call - n_enc
         assert x.shape == (bts[t], D)
-        return PH.dropout_keep(seed, PH.site_offset(PH.SITE_EMBED, t), bts[t], D, p_emb)
+        return PH.dropout_keep(seed, PH.site_offset(PH.SITE_EMBED, t), bts[t], D, p_emb)[row_map[:bts[t]]]
 
     def region_keep(t, x):
         bt = bts[t]
         mine = PH.dropout_keep(seed, PH.site_offset(PH.SITE_REGION, t), bt * R, D, p_reg)
         if not adaptive:
-            return mine.reshape(bt, R, D)
+            return mine.reshape(bt, R, D)[row_map[:bt]]
         # editnet_adaptive.py:440-442: att_embed sees only the packed valid rows; find each packed row's (b, r)
         att_len = (Xs[:bt].sum(2) != 0).sum(1).tolist()
         idx = torch.arange(bt * R, dtype=torch.float32).view(bt, R, 1)
@@ -164,7 +177,7 @@ def make_editnet(name, seed, ss_prob):
         return mine[flat]
 
     def out_keep(t, x):
-        return PH.dropout_keep(seed, PH.site_offset(PH.SITE_OUT, t), bts[t], D, p_out)
+        return PH.dropout_keep(seed, PH.site_offset(PH.SITE_OUT, t), bts[t], D, p_out)[row_map[:bts[t]]]
 
     dec.embed.dropout = InjectedDropout(p_emb, embed_keep)
     dec.visual_attention.att_embed[2] = InjectedDropout(p_reg, region_keep)
@@ -191,8 +204,12 @@ def make_editnet(name, seed, ss_prob):
         loss = loss + nn.MSELoss()(last_h, gd_fh)
     loss.backward()
     pre = "train_ss." if ss_prob > 0 else "train."
-    out = {pre + "seed": np.uint64(seed), pre + "loss": np.float64(loss.item()), pre + "sort_ind": _np(sort_ind)}
-    _store_pred(_np(pred), small, V, out, pre)
+    inv_map = np.empty(B, np.int64)
+    inv_map[row_map] = np.arange(B)
+    out = {pre + "seed": np.uint64(seed), pre + "loss": np.float64(loss.item()), pre + "sort_ind": _np(sort_stable)}
+    if not identity:
+        out[pre + "ref_sort_ind"] = _np(sort_ind)
+    _store_pred(_np(pred)[inv_map], small, V, out, pre)          # package row order (= the reference's unless lengths tie)
     if adaptive:
         out[pre + "gd_final"], out[pre + "last_hidden"] = _np(gd_fh), _np(last_h)
     _grads(dec, small, out, pre)

@@ -33,7 +33,7 @@ typedef const f32x4 __attribute__((address_space(1)))* gptr4;
 
 constexpr int PENC_BAR_STRIDE = 32;                 // unsigned words between two barrier words (128 bytes)
 constexpr int PENC_BAR_WORDS = (8 + 1 + 8) * PENC_BAR_STRIDE;
-constexpr unsigned PENC_SPIN_LIMIT = 4000000u;
+constexpr unsigned PENC_SPIN_LIMIT = 4000000u;     // default bound of one barrier wait (SET_PENC_SPIN_LIMIT overrides it)
 
 // one recurrence ("direction"): EditNet's encoder has one, DCNet's bidirectional encoder two that share the launch
 struct PEncDir {
@@ -56,6 +56,9 @@ struct PEncArgs {
     const int* perm; const int* nactive;
     unsigned* bar;                   // PENC_BAR_WORDS zeroed words
     unsigned* status;                // set to 1 on a barrier timeout
+    unsigned* fault;                 // host-mapped, sticky: a timeout of ANY launch of this process on this device (never cleared by a launch)
+    unsigned spin_limit;             // polls of one barrier wait before it gives up
+    int test_stall;                  // test hook (SET_PENC_TEST_STALL): workgroup 0 never arrives at a barrier
     int B, D, T;
 };
 
@@ -79,7 +82,8 @@ __device__ __forceinline__ void penc_arrive(unsigned* bar, unsigned epoch, int s
         }
     }
 }
-__device__ __forceinline__ void penc_wait(unsigned* bar, unsigned epoch, int shard, unsigned* status) {
+__device__ __forceinline__ void penc_wait(unsigned* bar, unsigned epoch, int shard, unsigned* status, unsigned* fault,
+                                          unsigned limit) {
     if (threadIdx.x == 0) {
         unsigned* gen = bar + (9 + shard) * PENC_BAR_STRIDE;
         unsigned spins = 0;
@@ -87,7 +91,11 @@ __device__ __forceinline__ void penc_wait(unsigned* bar, unsigned epoch, int sha
         while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 1023u) == 0u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-            if (spins > PENC_SPIN_LIMIT) { __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if (spins > limit) {
+                __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // the host reads this one at its next call
+                break;
+            }
         }
     }
     __syncthreads();
@@ -241,7 +249,7 @@ __global__ void __launch_bounds__(256, (NT <= 2 ? 2 : 1)) encoder_persistent_k(c
             __hip_atomic_store(hout + (long long)prow[i] * D + unit0 + u, hreg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const bool more = t + 1 < P.T;
-        if (more) penc_arrive(P.bar, (unsigned)(t + 1), shard, pop, ns);
+        if (more && !(P.test_stall && blockIdx.x == 0)) penc_arrive(P.bar, (unsigned)(t + 1), shard, pop, ns);
 #pragma unroll
         for (int i = 0; i < PAIRS; ++i)
             if (live_[i]) {
@@ -252,14 +260,39 @@ __global__ void __launch_bounds__(256, (NT <= 2 ? 2 : 1)) encoder_persistent_k(c
             }
         if (more) {
             PENC_GATHER(t + 1);
-            penc_wait(P.bar, (unsigned)(t + 1), shard, P.status);
+            penc_wait(P.bar, (unsigned)(t + 1), shard, P.status, P.fault, P.spin_limit);
         }
     }
 #undef PENC_GATHER
+    // ---- a barrier of this launch timed out (not every workgroup was resident, or one was held up beyond the bound): the
+    // recurrence ran on stale h somewhere.  Never hand that out as a result: every workgroup that sees the status word
+    // overwrites its units of both h buffers (-> final_hidden -> every later gate product) and of H / Mem at position 0
+    // with NaN, so the decode that consumes this encoder returns NaN log-probabilities / scores instead of plausible
+    // numbers; the host raises SET_ERR_FAULT at its next call (sticky host-mapped fault word) and stops using this kernel.
+    __shared__ unsigned s_bad;
+    if (tid == 0) s_bad = __hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_bad) {
+        const float qnan = __builtin_nanf("");
+        for (int i = tid; i < B * 4; i += 256) {
+            const int b = i >> 2, u = unit0 + (i & 3);
+            Q.hbuf0[(long long)b * D + u] = qnan;
+            Q.hbuf1[(long long)b * D + u] = qnan;
+            const long long o = (long long)b * P.ld_out_b + Q.out_col0 + u;
+            P.H[o] = qnan;
+            if (P.Mem) P.Mem[o] = qnan;
+        }
+    }
 }
 
 static std::mutex g_penc_mutex;
 static hipEvent_t g_penc_event[64] = {};
+// sticky fault word per device: host-mapped pinned memory the kernel writes on a barrier timeout and the host reads (without
+// any synchronisation) at its next call.  g_penc_disabled: a fault was seen -> the per-step path from then on.
+static unsigned* g_penc_fault_host[64] = {};
+static unsigned* g_penc_fault_dev[64] = {};
+static bool g_penc_disabled[64] = {};
+static int g_penc_capacity[64][9] = {};          // resident workgroups the device admits per kernel instantiation (0 = not asked yet)
 
 size_t persistent_encoder_bar_bytes() { return sizeof(unsigned) * (PENC_BAR_WORDS + PENC_BAR_STRIDE); }
 
@@ -271,13 +304,20 @@ bool persistent_encoder_ok(int B, int D, int T) {
     static const int on = env_int("SET_ENC_PERSISTENT", 1);
     static const int maxb = env_int("SET_ENC_PERSISTENT_MAXB", 32);
     if (B > maxb) return false;
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && g_penc_disabled[dev & 63]) return false;     // a barrier timed out earlier
+    }
     // 16-row tiles held in registers: 8 (B <= 128) fit the 256-register budget of two co-resident instances at D = 512 / 1024;
     // 16 tiles would spill there (only the reduced test dimension takes them)
     return on && B >= 1 && T >= 1 && ((B <= 128 && (D == 512 || D == 1024)) || (B <= 256 && D == 64));
 }
 
+// slot of an instantiation in g_penc_capacity
+template <int NT, int KB> constexpr int penc_slot() { return (NT == 2 ? 0 : NT == 8 ? 1 : 2) * 3 + (KB == 16 ? 0 : KB == 8 ? 1 : 2); }
+
 template <int NT, int KB>
-static int launch_penc(const PEncArgs& P, int grid, hipStream_t s) {
+static int launch_penc(const PEncArgs& P, int grid, hipStream_t s, int dev) {
     const int lds = 4 * NT * 256 * (int)sizeof(float);
     static bool configured = false;
     if (!configured) {
@@ -285,6 +325,24 @@ static int launch_penc(const PEncArgs& P, int grid, hipStream_t s) {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         configured = true;
     }
+    // The grid barrier needs every workgroup resident at once.  Ask the runtime how many workgroups of THIS instantiation one
+    // CU admits (registers, LDS) and how many CUs the device has (a partitioned or smaller part reports fewer); refuse the
+    // launch when the grid does not fit -> the caller takes the per-step kernels.  (MI355X_MICROARCH.md: the API can be one
+    // high per CU only at >= 7 workgroups per CU; these kernels sit at 1-2 by their register budget.)
+    static_assert(penc_slot<NT, KB>() < 9, "capacity table");
+    int& cap = g_penc_capacity[dev][penc_slot<NT, KB>()];
+    if (cap == 0) {
+        int per_cu = 0, cus = 0;
+        SET_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&encoder_persistent_k<NT, KB>),
+                                                                 256, (size_t)lds));
+        SET_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if (per_cu > 8) per_cu = 8;
+        cap = per_cu * cus;
+        if (cap <= 0) cap = -1;
+        const int forced = env_int("SET_PENC_TEST_CAPACITY", 0);      // test hook: pretend the device admits this many
+        if (forced > 0) cap = forced;
+    }
+    if (grid > cap) return SET_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((encoder_persistent_k<NT, KB>), dim3(grid), dim3(256), lds, s, P);
     SET_LAUNCH_CHECK();
     return SET_OK;
@@ -308,14 +366,33 @@ int persistent_encoder_dirs(const PEncDirHost* dirs, int ndir, long long ld_xg_r
     P.seq = seq; P.seq_T = seq_T; P.seq_V = seq_V > 0 ? seq_V : 1; P.H = H; P.Mem = Mem;
     P.ld_out_b = ld_out_b; P.ld_out_t = ld_out_t; P.perm = perm; P.nactive = nactive;
     P.bar = (unsigned*)bar; P.status = (unsigned*)bar + PENC_BAR_WORDS; P.B = B; P.D = D; P.T = T;
-    ProfScope ps("persistent_encoder", s, 8.0 * ndir * B * D * D * T, 4.0 * ndir * (4.0 * D * D + 8.0 * B * D * T));
-    SET_HIP_TRY(hipMemsetAsync(bar, 0, persistent_encoder_bar_bytes(), s));
+    static const int spin_limit = env_int("SET_PENC_SPIN_LIMIT", (int)PENC_SPIN_LIMIT);
+    static const int test_stall = env_int("SET_PENC_TEST_STALL", 0);
+    P.spin_limit = spin_limit > 0 ? (unsigned)spin_limit : PENC_SPIN_LIMIT;
+    P.test_stall = test_stall;
     // at most ONE instance of this kernel runs at a time in this process: every launch waits for the previous one's
     // completion event (a no-op when that was on the same stream); see the residency note at the top of the file
     int dev = 0;
     SET_HIP_TRY(hipGetDevice(&dev));
     dev &= 63;
     std::lock_guard<std::mutex> lk(g_penc_mutex);
+    if (!g_penc_fault_host[dev]) {
+        void* hp = nullptr; void* dp = nullptr;
+        SET_HIP_TRY(hipHostMalloc(&hp, 64, hipHostMallocMapped));
+        *(volatile unsigned*)hp = 0u;
+        SET_HIP_TRY(hipHostGetDevicePointer(&dp, hp, 0));
+        g_penc_fault_host[dev] = (unsigned*)hp; g_penc_fault_dev[dev] = (unsigned*)dp;
+    }
+    if (*(volatile unsigned*)g_penc_fault_host[dev]) {
+        // an earlier launch's barrier timed out (its outputs were poisoned with NaN on the device): say so ONCE, loudly, and
+        // never use this kernel again in this process on this device — the caller's retry runs the per-step kernels
+        *(volatile unsigned*)g_penc_fault_host[dev] = 0u;
+        g_penc_disabled[dev] = true;
+        return SET_ERR_FAULT;
+    }
+    if (g_penc_disabled[dev]) return SET_ERR_UNSUPPORTED;
+    P.fault = g_penc_fault_dev[dev];
+    ProfScope ps("persistent_encoder", s, 8.0 * ndir * B * D * D * T, 4.0 * ndir * (4.0 * D * D + 8.0 * B * D * T));
     static const int serialise = env_int("SET_ENC_PERSISTENT_SERIALISE", 1);
     if (serialise) {
         if (!g_penc_event[dev]) SET_HIP_TRY(hipEventCreateWithFlags(&g_penc_event[dev], hipEventDisableTiming));
@@ -323,9 +400,11 @@ int persistent_encoder_dirs(const PEncDirHost* dirs, int ndir, long long ld_xg_r
     }
     int rc;
     const int nt = (B + 15) / 16, grid = ndir * (D / 4);
-    if (D == 1024) rc = nt <= 2 ? launch_penc<2, 16>(P, grid, s) : launch_penc<8, 16>(P, grid, s);
-    else if (D == 512) rc = nt <= 2 ? launch_penc<2, 8>(P, grid, s) : launch_penc<8, 8>(P, grid, s);
-    else rc = nt <= 2 ? launch_penc<2, 1>(P, grid, s) : (nt <= 8 ? launch_penc<8, 1>(P, grid, s) : launch_penc<16, 1>(P, grid, s));
+    // (the barrier words are cleared on the launch stream right before the launch; a refused launch has touched nothing)
+    SET_HIP_TRY(hipMemsetAsync(bar, 0, persistent_encoder_bar_bytes(), s));
+    if (D == 1024) rc = nt <= 2 ? launch_penc<2, 16>(P, grid, s, dev) : launch_penc<8, 16>(P, grid, s, dev);
+    else if (D == 512) rc = nt <= 2 ? launch_penc<2, 8>(P, grid, s, dev) : launch_penc<8, 8>(P, grid, s, dev);
+    else rc = nt <= 2 ? launch_penc<2, 1>(P, grid, s, dev) : (nt <= 8 ? launch_penc<8, 1>(P, grid, s, dev) : launch_penc<16, 1>(P, grid, s, dev));
     if (rc == SET_OK && serialise) SET_HIP_TRY(hipEventRecord(g_penc_event[dev], s));
     return rc;
 }

@@ -138,9 +138,15 @@ def test_token_id_path_cuts_references_after_their_first_zero():
     cut = [[[5, 6, 7, 0], [5, 6, 8, 0]], [[1, 2, 3, 0]]]
     df, docs = ciderd.document_frequency([[ciderd.tokens_to_str(c) for c in caps] for caps in cut])
     s = ciderd.CiderD(df, docs)
-    if not s._native:
+    if s._handle() is None:                       # (the handle is built lazily: ask for it, do not peek at `_native`)
         pytest.skip("native scorer not built")
     hyps = np.array([[5, 6, 7, 0, 0, 0], [1, 2, 4, 0, 0, 0]], np.int64)
     a = s.score_token_ids(hyps, np.array([0, 1]), refs)
     b = s.score_token_ids(hyps, np.array([0, 1]), cut)
     assert np.array_equal(a, b)
+    # and the cut matters: scoring against the UNCUT token lists through the string route gives something else
+    gts = {i: [" ".join(str(t) for t in c) for c in caps] for i, caps in enumerate(refs)}
+    res = [{"image_id": i, "caption": [ciderd.tokens_to_str(h)]} for i, h in enumerate(hyps)]
+    cut_gts = {i: [ciderd.tokens_to_str(c) for c in caps] for i, caps in enumerate(cut)}
+    _, per_cut = s.compute_score(cut_gts, res)
+    assert np.allclose(a, per_cut, atol=1e-10)

@@ -285,3 +285,55 @@ def test_persistent_encoder_under_concurrent_streams():
         rl._ws = ws
         bar = rl.ws_tensor(dims, "enc_bar", (18 * 32,), dtype=torch.int32)
         assert int(bar[17 * 32]) == 0, "a grid barrier of the persistent encoder timed out"
+
+
+_FAULT_SCRIPT = r"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.getcwd(), "tests")); sys.path.insert(0, os.getcwd())
+import parity
+from hip_adapter import editnet_modules, to_dev
+from show_edit_tell_amd import _lib
+d, xe, rl = editnet_modules("editnet_full_b4")
+g = parity.load("editnet_full_b4")
+args = (d["wm"], to_dev(d["prev"]), to_dev(d["plen"]), to_dev(d["X"]), True, False)
+mode = sys.argv[1]
+with torch.no_grad():
+    if mode == "stall":
+        seq, logp = rl(*args)                      # workgroup 0 never arrives: every barrier wait times out
+        torch.cuda.synchronize()
+        assert torch.isnan(logp).all(), "a timed-out persistent encoder must poison the decode (NaN log-probs)"
+        try:
+            rl(*args)
+            raise SystemExit("the call after a barrier timeout must raise SetError")
+        except _lib.SetError as e:
+            assert "code 5" in str(e), str(e)
+    for _ in range(3):                             # from now on the per-step kernels: parity with the golden
+        seq, logp = rl(*args)
+        torch.cuda.synchronize()
+        parity.check_greedy(seq.cpu().numpy(), logp.cpu().numpy(), g)
+    lib = _lib.load()
+    lib.set_profile_enable(1)
+    rl(*args); torch.cuda.synchronize()
+    names = [r["tag"] for r in _lib.profile_report()]
+    lib.set_profile_enable(0)
+    assert "persistent_encoder" not in names, names
+print("OK", mode)
+"""
+
+
+@pytest.mark.parametrize("mode,env", [("stall", {"SET_PENC_TEST_STALL": "1", "SET_PENC_SPIN_LIMIT": "20000"}),
+                                      ("capacity", {"SET_PENC_TEST_CAPACITY": "100"})])
+def test_persistent_encoder_failure_is_loud(mode, env):
+    """The persistent caption encoder can fail in two ways and neither may be silent (csrc/encoder_persistent.hip):
+    * `capacity`: the device does not admit the whole grid at once (occupancy query x CU count < workgroups; forced here
+      with a test hook) -> the launch is refused up front and the per-step kernels run: results equal the golden;
+    * `stall`: a workgroup never reaches the grid barrier (test hook; stands for a workgroup that is not resident) -> the
+      bounded waits time out, the kernel overwrites its outputs with NaN (the decode returns NaN log-probs, never plausible
+      numbers), the NEXT call raises SetError(SET_ERR_FAULT) once, and the library keeps to the per-step kernels after that."""
+    import subprocess, sys, os
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", _FAULT_SCRIPT, mode], env=e, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and ("OK " + mode) in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
