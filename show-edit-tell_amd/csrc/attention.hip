@@ -60,7 +60,7 @@ __device__ __forceinline__ void block_softmax(float* sc, int n, int tid, int* ar
                 const int oi = __shfl_xor(bi, o);
                 if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
             }
-            if (tid == 0) *argmax_out = bi;
+            if (tid == 0) *argmax_out = bi == 0x7fffffff ? 0 : bi;   // all-NaN weights: a valid row index (the outputs are NaN anyway), never an out-of-range gather
         }
     }
 }
@@ -769,7 +769,7 @@ __global__ void __launch_bounds__(256) select_rows_k(const float* Mem, const flo
             const int oi = __shfl_xor(bi, o);
             if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
         }
-        if (tid == 0) { s_arg = bi; s_val = best; }
+        if (tid == 0) { s_arg = bi == 0x7fffffff ? 0 : bi; s_val = best; }     // (all-NaN alpha: stay in range)
     }
     __syncthreads();
     const float aj = s_val;

@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(256) select_bwd_k(const float* dsel, const flo
             const int oi = __shfl_xor(bi, o);
             if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
         }
-        if (tid == 0) { s_arg = bi; s_val = best; }
+        if (tid == 0) { s_arg = bi == 0x7fffffff ? 0 : bi; s_val = best; }     // (all-NaN alpha: stay in range)
     }
     __syncthreads();
     const int js = s_arg;

@@ -316,8 +316,13 @@ bool persistent_encoder_ok(int B, int D, int T) {
 // slot of an instantiation in g_penc_capacity
 template <int NT, int KB> constexpr int penc_slot() { return (NT == 2 ? 0 : NT == 8 ? 1 : 2) * 3 + (KB == 16 ? 0 : KB == 8 ? 1 : 2); }
 
+// configure the instantiation once and say whether the device admits `grid` workgroups of it at the same time.
+// The grid barrier needs every workgroup resident: ask the runtime how many workgroups of THIS instantiation one CU admits
+// (registers, LDS) and how many CUs the device has (a partitioned or smaller part reports fewer); when the grid does not fit
+// the caller takes the per-step kernels.  (MI355X_MICROARCH.md: the API can be one high per CU only at >= 7 workgroups per
+// CU; these kernels sit at 1-2 by their register budget.)
 template <int NT, int KB>
-static int launch_penc(const PEncArgs& P, int grid, hipStream_t s, int dev) {
+static int penc_fits(int grid, int dev, bool* fits) {
     const int lds = 4 * NT * 256 * (int)sizeof(float);
     static bool configured = false;
     if (!configured) {
@@ -325,10 +330,6 @@ static int launch_penc(const PEncArgs& P, int grid, hipStream_t s, int dev) {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         configured = true;
     }
-    // The grid barrier needs every workgroup resident at once.  Ask the runtime how many workgroups of THIS instantiation one
-    // CU admits (registers, LDS) and how many CUs the device has (a partitioned or smaller part reports fewer); refuse the
-    // launch when the grid does not fit -> the caller takes the per-step kernels.  (MI355X_MICROARCH.md: the API can be one
-    // high per CU only at >= 7 workgroups per CU; these kernels sit at 1-2 by their register budget.)
     static_assert(penc_slot<NT, KB>() < 9, "capacity table");
     int& cap = g_penc_capacity[dev][penc_slot<NT, KB>()];
     if (cap == 0) {
@@ -342,7 +343,13 @@ static int launch_penc(const PEncArgs& P, int grid, hipStream_t s, int dev) {
         const int forced = env_int("SET_PENC_TEST_CAPACITY", 0);      // test hook: pretend the device admits this many
         if (forced > 0) cap = forced;
     }
-    if (grid > cap) return SET_ERR_UNSUPPORTED;
+    *fits = grid <= cap;
+    return SET_OK;
+}
+
+template <int NT, int KB>
+static int launch_penc(const PEncArgs& P, int grid, hipStream_t s) {
+    const int lds = 4 * NT * 256 * (int)sizeof(float);
     hipLaunchKernelGGL((encoder_persistent_k<NT, KB>), dim3(grid), dim3(256), lds, s, P);
     SET_LAUNCH_CHECK();
     return SET_OK;
@@ -392,19 +399,37 @@ int persistent_encoder_dirs(const PEncDirHost* dirs, int ndir, long long ld_xg_r
     }
     if (g_penc_disabled[dev]) return SET_ERR_UNSUPPORTED;
     P.fault = g_penc_fault_dev[dev];
+    const int nt = (B + 15) / 16, grid = ndir * (D / 4);
+    // one of nine instantiations: 0/1/2 = <2,*>/<8,*>/<16,*>, KB by D
+    const int inst = D == 1024 ? (nt <= 2 ? 0 : 1) : D == 512 ? (nt <= 2 ? 2 : 3) : (nt <= 2 ? 4 : (nt <= 8 ? 5 : 6));
+    bool fits = false;
+    switch (inst) {
+        case 0: SET_TRY((penc_fits<2, 16>(grid, dev, &fits))); break;
+        case 1: SET_TRY((penc_fits<8, 16>(grid, dev, &fits))); break;
+        case 2: SET_TRY((penc_fits<2, 8>(grid, dev, &fits))); break;
+        case 3: SET_TRY((penc_fits<8, 8>(grid, dev, &fits))); break;
+        case 4: SET_TRY((penc_fits<2, 1>(grid, dev, &fits))); break;
+        case 5: SET_TRY((penc_fits<8, 1>(grid, dev, &fits))); break;
+        default: SET_TRY((penc_fits<16, 1>(grid, dev, &fits))); break;
+    }
+    if (!fits) return SET_ERR_UNSUPPORTED;          // (nothing has been touched: the caller runs the per-step kernels)
     ProfScope ps("persistent_encoder", s, 8.0 * ndir * B * D * D * T, 4.0 * ndir * (4.0 * D * D + 8.0 * B * D * T));
     static const int serialise = env_int("SET_ENC_PERSISTENT_SERIALISE", 1);
     if (serialise) {
         if (!g_penc_event[dev]) SET_HIP_TRY(hipEventCreateWithFlags(&g_penc_event[dev], hipEventDisableTiming));
         else SET_HIP_TRY(hipStreamWaitEvent(s, g_penc_event[dev], 0));
     }
-    int rc;
-    const int nt = (B + 15) / 16, grid = ndir * (D / 4);
-    // (the barrier words are cleared on the launch stream right before the launch; a refused launch has touched nothing)
     SET_HIP_TRY(hipMemsetAsync(bar, 0, persistent_encoder_bar_bytes(), s));
-    if (D == 1024) rc = nt <= 2 ? launch_penc<2, 16>(P, grid, s, dev) : launch_penc<8, 16>(P, grid, s, dev);
-    else if (D == 512) rc = nt <= 2 ? launch_penc<2, 8>(P, grid, s, dev) : launch_penc<8, 8>(P, grid, s, dev);
-    else rc = nt <= 2 ? launch_penc<2, 1>(P, grid, s, dev) : (nt <= 8 ? launch_penc<8, 1>(P, grid, s, dev) : launch_penc<16, 1>(P, grid, s, dev));
+    int rc;
+    switch (inst) {
+        case 0: rc = launch_penc<2, 16>(P, grid, s); break;
+        case 1: rc = launch_penc<8, 16>(P, grid, s); break;
+        case 2: rc = launch_penc<2, 8>(P, grid, s); break;
+        case 3: rc = launch_penc<8, 8>(P, grid, s); break;
+        case 4: rc = launch_penc<2, 1>(P, grid, s); break;
+        case 5: rc = launch_penc<8, 1>(P, grid, s); break;
+        default: rc = launch_penc<16, 1>(P, grid, s); break;
+    }
     if (rc == SET_OK && serialise) SET_HIP_TRY(hipEventRecord(g_penc_event[dev], s));
     return rc;
 }

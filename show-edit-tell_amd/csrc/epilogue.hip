@@ -197,6 +197,7 @@ __global__ void __launch_bounds__(256) greedy_pick_k(Slabs logits, const float* 
 #pragma unroll
     for (int w = 1; w < 4; ++w)
         if (s_val[w] > best || (s_val[w] == best && s_idx[w] < bi)) { best = s_val[w]; bi = s_idx[w]; }
+    if (bi == 0x7fffffff) { bi = 0; best = __builtin_nanf(""); }   // no comparison succeeded: the row is all NaN.  Word 0 and a NaN log-prob, never an out-of-range gather
     // the word follows from the arg-max and the row's latch alone: with a tail, every thread requests its piece of the
     // token-table row NOW, so that round trip runs under the sum-exp pass instead of after the serial bookkeeping
     TailRow tw;

@@ -290,6 +290,302 @@ __global__ void __launch_bounds__(256 * KG) gemm_nt_f32(const int ntasks, const 
 #undef SET_LSTORE
 
 // ---------------------------------------------------------------------------------------------
+// Round 4: the 64-row class with the WEIGHT operand taken off LDS (`gemm_nt_f32_wreg`, SET_GEMM_WREG).
+//
+// gemm_nt_f32<64,64,2,2> moves 3 LDS "operand words" per MFMA (each wave reads one A and one W value per lane and MFMA
+// from LDS, and the workgroup writes 16 KB per 64 MFMAs into it) and is bound by what the chip sustains for that mix of
+// MFMA + LDS + L2 traffic (clock 2.0 GHz under this load against 2.4 for bare MFMAs).  Here
+//   * the four waves are 2 (column halves of the 64x64 tile) x 2 (K groups): a wave owns a 64 x 32 piece of the output —
+//     TWO 32x32 accumulators that share every weight fragment — over every other k-tile of the workgroup's K slice;
+//   * the weight fragments never see LDS: lane (j = l & 31, h = l >> 5) loads W[n0 + j][8 kk + 4 h .. +3] of its wave's 32
+//     columns straight from global memory as 16-byte pieces — already the B operand of four v_mfma_f32_32x32x2_f32 (K inside
+//     an 8-block permuted exactly as the LDS fragment reads of the activations permute it) — two k-tiles ahead, each piece
+//     re-requested as soon as its MFMAs have issued;
+//   * only the 64 x 32 activation tile of each K group goes through LDS (shared by the group's two waves; same XOR-swizzled
+//     image, same conflict-free ds_write_b128 / ds_read_b128 as above), two register stages + two LDS buffers;
+//   * per MFMA: 1 LDS operand word read (was 2), 0.5 written (was 1), one barrier per 32 MFMAs of a wave (was 16);
+//   * after the loop the two K groups exchange one 32x32 accumulator each through LDS (group 0 keeps rows 0-31, group 1
+//     rows 32-63; sum order group 0 + group 1, fixed), so all four waves store, through the same epilogue.
+// Same task descriptors, K segments, split-K slabs, bias / activation epilogue as gemm_nt_f32.
+// ---------------------------------------------------------------------------------------------
+#ifdef SET_WREG_A2
+#define WR_WAVES_PER_SIMD 2
+#else
+#define WR_WAVES_PER_SIMD 3
+#endif
+__global__ void __launch_bounds__(256, WR_WAVES_PER_SIMD) gemm_nt_f32_wreg(const int ntasks, const int wb1, const int wb2, const int wb3,
+                                                        const int wb4, const int wb5, const GemmLaunch L) {
+    constexpr int BM = 64, BN = 64;
+    constexpr int GROUP_FLOATS = BM * LDS_STRIDE;                  // one K group's activation tile (8 KB)
+    __shared__ __attribute__((aligned(16))) float lds[2][2 * GROUP_FLOATS];
+
+    const int tid = threadIdx.x;
+    // the wave index decides control flow here (K group, tile counts): make it a scalar for the compiler, or every
+    // `j < nt` becomes an exec-mask branch and the segment selects turn into per-lane loads of the kernel arguments
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wk = wave >> 1;                       // column half, K group
+    int ti = 0;
+    {
+        const int bid = (int)blockIdx.x;
+        if (1 < ntasks && bid >= wb1) ti = 1;
+        if (2 < ntasks && bid >= wb2) ti = 2;
+        if (3 < ntasks && bid >= wb3) ti = 3;
+        if (4 < ntasks && bid >= wb4) ti = 4;
+        if (5 < ntasks && bid >= wb5) ti = 5;
+    }
+    const GemmTask& T = L.t[ti];
+    const int local = (int)blockIdx.x - T.wg_begin;
+    const int tm = local / T.tm_stride;
+    const int rem = local - tm * T.tm_stride;
+    if (rem >= T.tiles_n * T.ksplit) return;          // padding slot
+    const int ks = rem % T.ksplit;
+    const int tn = rem / T.ksplit;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kt0 = (int)(((long long)ks * T.ktiles) / T.ksplit);
+    const int kt1 = (int)(((long long)(ks + 1) * T.ktiles) / T.ksplit);
+    // this K group's k-tiles: kt0 + wk, kt0 + wk + 2, ...  (local index j <-> global k-tile kt0 + wk + 2 j)
+    const int nt_wg = kt1 - kt0;
+    const int nt = (nt_wg - wk + 1) >> 1;                          // tiles of this group
+    const int nt_max = (nt_wg + 1) >> 1;                           // tiles of group 0 = barrier rounds of the workgroup
+
+    // ---- activation staging: thread g (0..127 of the group) -> rows g/8 + 16 i, 16-byte column g%8
+    const int tg = tid & 127;
+    const int srow = tg >> 3, scol = (tg & 7) * 4;
+    const int sswz = ((tg & 7) ^ ((srow >> 1) & 7)) * 4;           // rows srow + 16 i share (r >> 1) & 7
+    int arow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int r = m0 + srow + 16 * i; arow[i] = r < T.M ? r : T.M - 1; }
+    // ---- weight fragments: lane -> row n0 + 32 wn + (lane & 31), floats 4 (lane >> 5) + 8 kk of a k-tile
+    const int frow = lane & 31, fh = lane >> 5;
+    int wrow = n0 + 32 * wn + frow;
+    wrow = wrow < T.N ? wrow : T.N - 1;
+
+    // Operand addresses are derived per k-tile from the (wave-uniform) global k-tile index with branch-free selects over the
+    // <= 3 K segments: a dozen SALU + a few 64-bit VALU adds per 32 MFMAs, no running pointers, no seek branches (the seek
+    // code of gemm_nt_f32, instantiated for two streams x two rounds, cost 540 spilled SGPRs here).
+    const long long arow_l[4] = {arow[0], arow[1], arow[2], arow[3]};
+    const int nseg_ = T.nseg, ke0_ = T.kt_end[0], ke1_ = T.kt_end[1];
+    const float *A0_ = T.A[0], *A1_ = T.A[1], *A2_ = T.A[2], *W0_ = T.W[0], *W1_ = T.W[1], *W2_ = T.W[2];
+    const long long la0_ = T.lda[0], la1_ = T.lda[1], la2_ = T.lda[2], lw0_ = T.ldw[0], lw1_ = T.ldw[1], lw2_ = T.ldw[2];
+#define WR_SEG(G)                                                                                       \
+        const int g_ = (G);                                                                             \
+        const bool s1_ = nseg_ > 1 && g_ >= ke0_, s2_ = nseg_ > 2 && g_ >= ke1_;                        \
+        const int kb_ = s2_ ? ke1_ : (s1_ ? ke0_ : 0);                                                  \
+        const long long ko_ = (long long)(g_ - kb_) * GEMM_BK;
+    // Loads are UNCONDITIONAL (a request past the group's last tile repeats that tile: a cache hit whose result is never
+    // used): with a branch around a load the compiler's s_waitcnt placement must assume the path with fewer requests
+    // outstanding and ends up draining the whole queue (vmcnt(0)) in the middle of every round.
+    const int jlast = nt > 0 ? nt - 1 : 0;
+    const int glast = kt1 - 1;
+#define WR_TILE(J) ({ int j_ = (J) < jlast ? (J) : jlast; int g_ = kt0 + wk + 2 * j_; g_ < glast ? g_ : glast; })
+#define WR_STAGE_A(J, RA)                                                                               \
+    {                                                                                                   \
+        WR_SEG(WR_TILE(J))                                                                              \
+        const float* Ab_ = (s2_ ? A2_ : (s1_ ? A1_ : A0_)) + ko_ + scol;                                \
+        const long long lda_ = s2_ ? la2_ : (s1_ ? la1_ : la0_);                                        \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) RA[i] = *(gptr4)(Ab_ + arow_l[i] * lda_);         \
+    }
+#define WR_LSTORE(BUF, RA)                                                                              \
+    {                                                                                                   \
+        float* sA_ = lds[(BUF)] + wk * GROUP_FLOATS;                                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
+            *reinterpret_cast<f32x4*>(sA_ + (srow + 16 * i) * LDS_STRIDE + sswz) = RA[i];               \
+    }
+    // weight stream: one row pointer per tile (WR_W_BEGIN), its four 16-byte pieces are requested one by one
+    const float* pw = nullptr;
+#define WR_W_BEGIN(J)                                                                                   \
+    {                                                                                                   \
+        WR_SEG(WR_TILE(J))                                                                              \
+        const float* Wb_ = (s2_ ? W2_ : (s1_ ? W1_ : W0_)) + ko_ + 4 * fh;                              \
+        const long long ldw_ = s2_ ? lw2_ : (s1_ ? lw1_ : lw0_);                                        \
+        pw = Wb_ + (long long)wrow * ldw_;                                                              \
+    }
+#define WR_W_PIECE(KK, WR) WR[KK] = *(gptr4)(pw + 8 * (KK));
+
+    f32x16 acc2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[i][e] = 0.f;
+    int fo[4];                                                     // swizzled float offset of k-chunk 2 kk + (lane >> 5)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) fo[kk] = (((kk * 2 + fh) ^ ((frow >> 1) & 7)) * 4);
+
+    f32x4 we[4], wo[4];                   // weight fragments of the even / odd local tiles
+#define WR_FRAG(KK, FA)                                                                                  \
+    {                                                                                                   \
+        FA[0] = *reinterpret_cast<const f32x4*>(sA + fo[KK]);                                           \
+        FA[1] = *reinterpret_cast<const f32x4*>(sA + 32 * LDS_STRIDE + fo[KK]);                         \
+    }
+#define WR_MFMA(FA, W4)                                                                                 \
+    {                                                                                                   \
+        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0].x, (W4).x, acc2[0], 0, 0, 0);              \
+        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1].x, (W4).x, acc2[1], 0, 0, 0);              \
+        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0].y, (W4).y, acc2[0], 0, 0, 0);              \
+        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1].y, (W4).y, acc2[1], 0, 0, 0);              \
+        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0].z, (W4).z, acc2[0], 0, 0, 0);              \
+        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1].z, (W4).z, acc2[1], 0, 0, 0);              \
+        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0].w, (W4).w, acc2[0], 0, 0, 0);              \
+        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1].w, (W4).w, acc2[1], 0, 0, 0);              \
+    }
+    // one round: MFMAs of local tile J (activations from lds[BUF], weights from WR); meanwhile the register stage RA (tile
+    // J + 1) goes to lds[BUF ^ 1] and is re-requested with tile J + 3, and every weight piece is re-requested with tile
+    // J + 2's as soon as its MFMAs have issued.  Straight-line code: both K groups run the same `nfull` rounds; the odd
+    // k-tile of a slice, if any, is group 0's and is contracted after the loop (WR_TAIL).
+    // The hand-written order must survive the compiler: MFMAs are pure values to LLVM and get sunk past the weight
+    // re-requests (which then go through temporaries and come back as v_mov copies behind s_waitcnt vmcnt(0)); an IR-level
+    // sched_barrier does not stop that.  An empty volatile asm that "rewrites" both accumulators and clobbers memory does:
+    // every MFMA before it must have issued, every load / LDS access after it stays after it.
+#define WR_SB() asm volatile("" : "+a"(acc2[0]), "+a"(acc2[1]) : : "memory")
+#define WR_ROUND(J, BUF, RA, WR)                                                                        \
+    {                                                                                                   \
+        const float* sA = lds[BUF] + wk * GROUP_FLOATS + frow * LDS_STRIDE;                             \
+        f32x4 fa0[2], fa1[2];                                                                           \
+        WR_FRAG(0, fa0);                                                                                \
+        WR_FRAG(1, fa1);                                                                                \
+        WR_SB();                                                                                        \
+        WR_MFMA(fa0, WR[0]);                                                                            \
+        WR_SB();                                                                                        \
+        WR_W_BEGIN((J) + 2);                                                                            \
+        WR_W_PIECE(0, WR);                                                                              \
+        WR_LSTORE((BUF) ^ 1, RA);                                                                       \
+        WR_STAGE_A((J) + WR_ADIST, RA);                                                                 \
+        WR_FRAG(2, fa0);                                                                                \
+        WR_SB();                                                                                        \
+        WR_MFMA(fa1, WR[1]);                                                                            \
+        WR_SB();                                                                                        \
+        WR_W_PIECE(1, WR);                                                                              \
+        WR_FRAG(3, fa1);                                                                                \
+        WR_SB();                                                                                        \
+        WR_MFMA(fa0, WR[2]);                                                                            \
+        WR_SB();                                                                                        \
+        WR_W_PIECE(2, WR);                                                                              \
+        WR_SB();                                                                                        \
+        WR_MFMA(fa1, WR[3]);                                                                            \
+        WR_SB();                                                                                        \
+        WR_W_PIECE(3, WR);                                                                              \
+        __syncthreads();                                                                                \
+    }
+#define WR_TAIL(BUF, WR)                                                                                \
+    {                                                                                                   \
+        const float* sA = lds[BUF] + frow * LDS_STRIDE;                                                 \
+        f32x4 fa0[2], fa1[2];                                                                           \
+        WR_FRAG(0, fa0);                                                                                \
+        WR_FRAG(1, fa1);                                                                                \
+        WR_MFMA(fa0, WR[0]);                                                                            \
+        WR_FRAG(2, fa0);                                                                                \
+        WR_MFMA(fa1, WR[1]);                                                                            \
+        WR_FRAG(3, fa1);                                                                                \
+        WR_MFMA(fa0, WR[2]);                                                                            \
+        WR_MFMA(fa1, WR[3]);                                                                            \
+    }
+#ifdef SET_WREG_A2
+    // two activation register stages (tile j + 1 landed, tile j + 2 in flight at the top of round j): 16 more registers,
+    // two waves per SIMD
+#define WR_ADIST 3
+    f32x4 ra0[4], ra1[4];
+    {
+        WR_STAGE_A(0, ra0);                  // tile 0
+        WR_W_BEGIN(0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) WR_W_PIECE(kk, we);
+        WR_STAGE_A(1, ra1);                  // tile 1
+        WR_W_BEGIN(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) WR_W_PIECE(kk, wo);
+        WR_LSTORE(0, ra0);
+        WR_STAGE_A(2, ra0);                  // tile 2
+    }
+    __syncthreads();
+#define WR_RA_EVEN ra1
+#define WR_RA_ODD ra0
+#else
+    // one activation register stage: tile j + 1 is requested in round j - 1 (right after the stage went to LDS) and stored
+    // in round j — the activations are a few MB that every workgroup of the launch re-reads, i.e. L2 hits
+#define WR_ADIST 2
+    f32x4 ra0[4];
+    {
+        // requests in the order a round issues them (weight piece 0, the activation tile, pieces 1-3): the queue the first
+        // round finds is then the queue every round finds, and the compiler's vmcnt values at the loop head stay exact
+        WR_W_BEGIN(0);
+        WR_W_PIECE(0, we);
+        WR_STAGE_A(0, ra0);                  // tile 0
+        WR_W_PIECE(1, we);
+        WR_W_PIECE(2, we);
+        WR_W_PIECE(3, we);
+        WR_W_BEGIN(1);
+        WR_W_PIECE(0, wo);
+        WR_LSTORE(0, ra0);
+        WR_STAGE_A(1, ra0);                  // tile 1
+        WR_W_PIECE(1, wo);
+        WR_W_PIECE(2, wo);
+        WR_W_PIECE(3, wo);
+    }
+    __syncthreads();
+#define WR_RA_EVEN ra0
+#define WR_RA_ODD ra0
+#endif
+    // invariant at the top of an even round j: lds[0] = tile j, the register stage(s) hold tile j + 1 (and j + 2), we = W(j),
+    // wo = W(j + 1)
+    const int nfull = nt_wg >> 1;
+    const bool odd_tail = (nt_wg & 1) && wk == 0;        // the slice's odd k-tile is group 0's
+    int j = 0;
+    for (; j + 2 <= nfull; j += 2) {
+        WR_ROUND(j, 0, WR_RA_EVEN, we);
+        WR_ROUND(j + 1, 1, WR_RA_ODD, wo);
+    }
+    if (j < nfull) {                                     // odd number of full rounds: one more on buffer 0
+        WR_ROUND(j, 0, WR_RA_EVEN, we);
+        if (odd_tail) WR_TAIL(1, wo);
+    } else if (odd_tail) {
+        WR_TAIL(0, we);
+    }
+    __syncthreads();                                     // (all fragment reads of the stages are done: the epilogue reuses them)
+#undef WR_ROUND
+#undef WR_ADIST
+#undef WR_RA_EVEN
+#undef WR_RA_ODD
+#undef WR_SB
+#undef WR_TAIL
+#undef WR_MFMA
+#undef WR_FRAG
+#undef WR_W_PIECE
+#undef WR_W_BEGIN
+#undef WR_LSTORE
+#undef WR_STAGE_A
+#undef WR_TILE
+#undef WR_SEG
+    // ---- the two K groups exchange one 32x32 accumulator each (lane-major in lds[1]: conflict-free): group 0 keeps the
+    // tile's rows 0-31, group 1 rows 32-63; every sum is (group 0's partial) + (group 1's partial)
+    {
+        // (static register indices only: `acc2[wk]` with a run-time wk turns into thousands of v_cndmask; the result lands in
+        // acc2[0] for both groups so that no third accumulator is live)
+        float* sX = &lds[1][0] + wave * 1024 + lane;
+        const float* sY = &lds[1][0] + (wave ^ 2) * 1024 + lane;
+        if (wk == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sX[r * 64] = acc2[1][r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sX[r * 64] = acc2[0][r];
+        }
+        __syncthreads();
+        if (wk == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[0][r] = acc2[0][r] + sY[r * 64];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[0][r] = sY[r * 64] + acc2[1][r];
+        }
+    }
+    f32x16 (&acc)[1][1] = *reinterpret_cast<f32x16 (*)[1][1]>(&acc2[0]);
+    constexpr int TM = 1, TN = 1, KG = 1;
+    const int kg = 0, wm = wk;
+    // (the shared epilogue transposes through lds[0], which nobody reads any more: the last round's barrier is behind us)
+#include "gemm_f32_epilogue.inc"
+}
+
+// ---------------------------------------------------------------------------------------------
 // The same grouped GEMM with the operand tiles staged by LDS-DMA (`global_load_lds_dwordx4`): no VGPR round trip and no
 // ds_write pass.  A wave-instruction lands 64 x 16 B = 1 KB = eight 128-byte rows of the stage CONTIGUOUSLY (the LDS
 // destination is wave-uniform base + lane * 16), so the XOR swizzle of the 16-byte chunks is applied on the SOURCE side:
@@ -757,6 +1053,8 @@ int gemm_tile_m(int M) {
     return M <= bm16_upto ? 16 : (M <= bm32_upto ? 32 : (M <= bm64_upto ? 64 : 128));
 }
 static int gemm_dma() { static int v = env_int("SET_GEMM_DMA", 0); return v; }
+int g_gemm_wreg_force = -1;        // tools/ubench: switch kernels inside one process (-1: the environment decides)
+static int gemm_wreg() { static int v = env_int("SET_GEMM_WREG", 0); return g_gemm_wreg_force >= 0 ? g_gemm_wreg_force : v; }
 static int gemm_kgroups() { static int v = env_int("SET_GEMM_KGROUPS", 1); return v; }
 static int gemm_bn128() { static int v = env_int("SET_GEMM_BN128", 0); return v; }
 static int tile_m_of(const GemmProb& p) { return (p.bm_hint == 64 || p.bm_hint == 128) ? p.bm_hint : gemm_tile_m(p.M); }
@@ -936,6 +1234,8 @@ int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag
             hipLaunchKernelGGL((gemm_nt_f32_dma<128, 64, 2, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, L);
         else if (bm == 128)
             hipLaunchKernelGGL((gemm_nt_f32<128, 64, 2, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, L);
+        else if (bm == 64 && gemm_wreg())
+            hipLaunchKernelGGL(gemm_nt_f32_wreg, grid, block, 0, stream, nt, w1, w2, w3, w4, w5, L);
         else if (bm == 64 && gemm_kgroups() == 2)
             hipLaunchKernelGGL((gemm_nt_f32<64, 64, 2, 2, 2>), grid, dim3(512), 0, stream, nt, w1, w2, w3, w4, w5, L);
         else if (bm == 64 && gemm_dma())

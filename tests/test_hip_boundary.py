@@ -302,7 +302,8 @@ with torch.no_grad():
     if mode == "stall":
         seq, logp = rl(*args)                      # workgroup 0 never arrives: every barrier wait times out
         torch.cuda.synchronize()
-        assert torch.isnan(logp).all(), "a timed-out persistent encoder must poison the decode (NaN log-probs)"
+        # every row's first log-prob is NaN and its word 0 (= finished): the reference's break then ends the decode
+        assert torch.isnan(logp[:, 0]).all() and not seq.any(), "a timed-out persistent encoder must poison the decode"
         try:
             rl(*args)
             raise SystemExit("the call after a barrier timeout must raise SetError")

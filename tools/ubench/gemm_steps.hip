@@ -4,6 +4,7 @@
 // Kernel variants are selected with -D flags on the included gemm_f32.hip (same flags as tools/ab.sh).
 #include "../../show-edit-tell_amd/csrc/gemm_f32.hip"
 #include <cstdio>
+#include <cmath>
 #include <vector>
 using namespace set;
 // self-contained: the few host helpers gemm_f32.hip expects from the rest of the library (linking libset_hip.so as well
@@ -78,6 +79,8 @@ static void print_raw_clock(const char* what) {
 
 static float* dev_rand(size_t n, unsigned seed) {
     std::vector<float> h(n);
+    static const bool zero = getenv("ZERO_INPUT") != nullptr;      // power / clock probe: operands that never toggle
+    if (zero) { float* d; hipMalloc(&d, n * sizeof(float)); hipMemset(d, 0, n * sizeof(float)); return d; }
     unsigned s = seed * 2654435761u + 12345u;
     for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; h[i] = ((s >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.1f; }
     float* d; hipMalloc(&d, n * sizeof(float)); hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice);
@@ -192,6 +195,40 @@ int main(int argc, char** argv) {
         }
     }
 #endif
+    if (getenv("CHECK_WREG")) {
+        // parity of gemm_nt_f32_wreg against gemm_nt_f32<64,64>: same problems, slabs summed on the host in index order
+        const GemmProb* groups[3] = {fa, b, &dd}; const int gn[3] = {3, 5, 1}; const char* gname[3] = {"F/A", "B", "D"};
+        for (int g = 0; g < 3; ++g) {
+            std::vector<std::vector<double>> res[2];
+            for (int v = 0; v < 2; ++v) {
+                g_gemm_wreg_force = v;
+                hipMemsetAsync(slabs, 0xff, (size_t)off * 4, st);      // NaN-fill: an unwritten element shows
+                gemm_group(groups[g], gn[g], st, nullptr);
+                hipStreamSynchronize(st);
+                for (int i = 0; i < gn[g]; ++i) {
+                    const GemmProb& p = groups[g][i];
+                    std::vector<double> acc((size_t)p.M * p.N, 0.0);
+                    std::vector<float> h((size_t)p.M * p.ldc);
+                    for (int s2 = 0; s2 < p.ksplit; ++s2) {
+                        hipMemcpy(h.data(), p.C + (size_t)s2 * p.slab_stride, h.size() * 4, hipMemcpyDeviceToHost);
+                        for (int r = 0; r < p.M; ++r) for (int c = 0; c < p.N; ++c) acc[(size_t)r * p.N + c] += h[(size_t)r * p.ldc + c];
+                    }
+                    res[v].push_back(acc);
+                }
+            }
+            g_gemm_wreg_force = -1;
+            for (int i = 0; i < gn[g]; ++i) {
+                double md = 0, mx = 0; size_t bad = 0;
+                for (size_t k = 0; k < res[0][i].size(); ++k) {
+                    const double a = res[0][i][k], c = res[1][i][k];
+                    if (!(a == a) || !(c == c)) { ++bad; continue; }
+                    md = fmax(md, fabs(a - c)); mx = fmax(mx, fabs(a));
+                }
+                printf("check %-4s prob %d (M %d N %d ksplit %d): max |diff| %.3e of max |ref| %.3e, %zu NaN\n", gname[g], i,
+                       groups[g][i].M, groups[g][i].N, groups[g][i].ksplit, md, mx, bad);
+            }
+        }
+    }
     run("F/A  fc+gates1+h2h", [&] { gemm_group(fa, 3, st, nullptr); }, flops(fa, 3), 1);
     run("B    att2,tc,cg,x2h_h1", [&] { gemm_group(b, 5, st, nullptr); }, flops(b, 5), 1);
     run("D    x2h ctx", [&] { gemm_group(&dd, 1, st, nullptr); }, flops(&dd, 1), 1);
