@@ -159,6 +159,16 @@ int set_editnet_greedy(const SetEditNetWeights* w, const SetEditNetDims* d, cons
                        int64_t start_idx, int64_t end_idx, int max_len, int64_t* seq,
                        float* seq_logp, void* ws, size_t ws_bytes, void* stream);
 
+/* The timestep loop of set_editnet_greedy alone (editnet_rl.py:503-547) on a workspace that already holds a completed
+ * set_editnet_begin for the same (X, prev, prevlen): the per-sequence prologue (editnet_rl.py:499-501 and the hoisted
+ * projections) of batch i+1 depends on nothing in the decode of batch i, so a caller that issues one decode after the
+ * other can run set_editnet_begin for the NEXT batch on a second stream / workspace while this loop runs
+ * (pipeline.DevicePrefetcher(begin_ahead=...) does).  The caller orders `stream` after the stream that ran the prologue.
+ * Results are bit-identical to set_editnet_greedy. */
+int set_editnet_greedy_begun(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X, int64_t start_idx,
+                             int64_t end_idx, int max_len, int64_t* seq, float* seq_logp, void* ws,
+                             size_t ws_bytes, void* stream);
+
 /* The same loop with multinomial sampling (editnet_rl.py:521-528, sample_rl=True, eval mode, no gradients):
  * it ~ Categorical(softmax(logits)) drawn on the device with Philox4x32-10 (counter = (row, timestep, offset),
  * key = seed): reproducible for a given (seed, offset), independent streams for different offsets.

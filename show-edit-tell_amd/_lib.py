@@ -164,6 +164,7 @@ PROTOTYPES = {
                                      _P, _Z, _P]),
     "set_editnet_greedy": (_I, [C.POINTER(EditNetWeights), C.POINTER(EditNetDims), _P, _P, _P, _P, _L, _L, _I, _P, _P,
                                 _P, _Z, _P]),
+    "set_editnet_greedy_begun": (_I, [C.POINTER(EditNetWeights), C.POINTER(EditNetDims), _P, _L, _L, _I, _P, _P, _P, _Z, _P]),
     "set_editnet_sample": (_I, [C.POINTER(EditNetWeights), C.POINTER(EditNetDims), _P, _P, _P, _P, _L, _L, _I, _U, _U, _P,
                                 _P, _P, _Z, _P]),
     "set_editnet_xe_forward": (_I, [C.POINTER(EditNetWeights), C.POINTER(EditNetDims), _P, _P, _P, _L,

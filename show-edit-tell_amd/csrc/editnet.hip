@@ -491,17 +491,19 @@ int set_editnet_greedy_pick(const SetEditNetWeights* w, const SetEditNetDims* d,
 }
 
 // free-running decode (editnet_rl.py:485-549): sample == 0 greedy (sample_max), 1 multinomial (sample_rl)
+// `begun`: the workspace already holds a completed set_editnet_begin for these inputs (the per-sequence prologue ran
+// earlier, possibly on another stream that this one has been made to wait for): only the timestep loop runs here
 static int rollout(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X, const float* image_mean,
                    const int64_t* prev, const int64_t* prevlen, int64_t start_idx, int64_t end_idx, int max_len,
                    int sample, uint64_t seed, uint64_t offset, int64_t* seq, float* seq_logp, void* ws, size_t ws_bytes,
-                   void* stream) {
-    if (!w || !X || !prev || !prevlen || !seq || !seq_logp || max_len <= 0) return SET_ERR_ARG;
+                   void* stream, bool begun = false) {
+    if (!w || !X || (!begun && (!prev || !prevlen)) || !seq || !seq_logp || max_len <= 0) return SET_ERR_ARG;
     EditNetWs W;
     SET_TRY(prep(d, ws, ws_bytes, &W));
     if (max_len + 1 > d->maxT + 1 || start_idx < 0 || start_idx >= d->V) return SET_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int B = d->B;
-    SET_TRY(begin_impl(w, d, X, image_mean, prev, prevlen, W, st));
+    if (!begun) SET_TRY(begin_impl(w, d, X, image_mean, prev, prevlen, W, st));
     SET_HIP_TRY(hipMemsetAsync(seq, 0, sizeof(int64_t) * B * max_len, st));
     SET_HIP_TRY(hipMemsetAsync(seq_logp, 0, sizeof(float) * B * max_len, st));
     SET_TRY(set_tokens(W.it, start_idx, W.unfinished, W.alive, d->maxT + 2, B, st));
@@ -551,6 +553,13 @@ int set_editnet_greedy(const SetEditNetWeights* w, const SetEditNetDims* d, cons
                        int64_t* seq, float* seq_logp, void* ws, size_t ws_bytes, void* stream) {
     return rollout(w, d, X, image_mean, prev, prevlen, start_idx, end_idx, max_len, 0, 0, 0, seq, seq_logp, ws, ws_bytes,
                    stream);
+}
+
+int set_editnet_greedy_begun(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X, int64_t start_idx,
+                             int64_t end_idx, int max_len, int64_t* seq, float* seq_logp, void* ws, size_t ws_bytes,
+                             void* stream) {
+    return rollout(w, d, X, nullptr, nullptr, nullptr, start_idx, end_idx, max_len, 0, 0, 0, seq, seq_logp, ws, ws_bytes,
+                   stream, true);
 }
 
 int set_editnet_sample(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X, const float* image_mean,

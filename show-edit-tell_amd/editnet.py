@@ -408,7 +408,8 @@ class DecoderC(nn.Module):
     # ---- runtime state is NOT part of the module's persistent state --------------------------------------
     # The reference checkpoints pickle the whole module (editnet.py:168-175, `'decoder': decoder`) and callers may
     # copy.deepcopy a decoder: GPU workspaces, the derived token table and the last autograd graph must not travel.
-    _RUNTIME_ATTRS = ("_ws", "_ws_key", "_ws_cache", "_tok_state", "_last_hidden", "_fwd_seed", "_fed_tokens", "_grad_buckets")
+    _RUNTIME_ATTRS = ("_ws", "_ws_key", "_ws_cache", "_tok_state", "_last_hidden", "_fwd_seed", "_fed_tokens", "_grad_buckets",
+                      "_ahead", "_ahead_free", "_ahead_hits", "_ahead_busy")
 
     def __getstate__(self):
         state = dict(self.__dict__)
@@ -437,6 +438,8 @@ class DecoderC(nn.Module):
     def _apply(self, fn, *args, **kwargs):
         self.invalidate_token_table()
         self.__dict__.pop("_ws_cache", None)
+        self.__dict__.pop("_ahead", None)
+        self.__dict__.pop("_ahead_free", None)
         self.__dict__.pop("_grad_buckets", None)
         self._ws = self._ws_key = None
         return super()._apply(fn, *args, **kwargs)

@@ -41,10 +41,35 @@ class DecoderC(_DecoderXE):
         B = X.shape[0]
         max_len = self.max_len
         dims = self._dims(B, prev.shape[1], X.shape[1], max_len + 1)
-        ws = self._workspace(dims)
-        w = self._weights(dims)
         seq = torch.empty(B, max_len, dtype=torch.long, device=dev)
         seq_logp = torch.empty(B, max_len, dtype=torch.float32, device=dev)
+        ticket = None if sample_rl else self._take_ahead(X, prev, plen, mean)
+        if ticket is not None and ticket.get("out") is not None:
+            # decode_ahead: the whole decode of this batch already ran (or is running) on another stream
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_event(ticket["event"])
+            out = ticket.pop("out")
+            for t in out:
+                t.record_stream(cur)
+            ticket["inputs"] = None
+            self.__dict__["_ahead_hits"] = self.__dict__.get("_ahead_hits", 0) + 1
+            return out
+        if ticket is not None:
+            # the prologue of this batch already ran (begin_ahead) on another stream into its own workspace: order this
+            # stream after it and run the timestep loop alone
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_event(ticket["event"])
+            w = ticket["weights"]
+            check(lib.set_editnet_greedy_begun(C.byref(w), C.byref(dims), ptr(X), int(word_map['<start>']),
+                                               int(word_map['<end>']), max_len, ptr(seq), ptr(seq_logp), ptr(ticket["ws"]),
+                                               ticket["ws"].numel(), stream_of(dev)), "set_editnet_greedy_begun")
+            ticket["done"].record(cur)                     # the workspace may be begun again once this loop has finished
+            ticket["inputs"] = None
+            self.__dict__.setdefault("_ahead_free", []).append(ticket)
+            self.__dict__["_ahead_hits"] = self.__dict__.get("_ahead_hits", 0) + 1
+            return seq, seq_logp
+        ws = self._workspace(dims)
+        w = self._weights(dims)
         if sample_rl:        # multinomial sampling, eval mode, no gradients: fused device loop with the Philox epilogue
             from . import rng
             seed = rng.next_seed()                                      # torch.manual_seed() makes it reproducible
@@ -57,6 +82,108 @@ class DecoderC(_DecoderXE):
                                      int(word_map['<start>']), int(word_map['<end>']), max_len, ptr(seq),
                                      ptr(seq_logp), ptr(ws), ws.numel(), stream_of(dev)), "set_editnet_greedy")
         return seq, seq_logp
+
+    # ---- prologue-ahead (the reference's callers issue one decode after the other: train(), evaluate()) -------------
+    def begin_ahead(self, encoded_previous_captions, previous_cap_length, image_features, image_mean=None):
+        """Run the per-sequence prologue (caption encoder + hoisted projections, editnet_rl.py:499-501) of a batch that
+        will be decoded LATER, on the CURRENT stream, into a workspace of its own.  The next greedy `forward` that is given
+        these very tensors finds the prologue done and runs only its timestep loop (bit-identical results).  Call it from a
+        side stream while the previous batch decodes — `pipeline.DevicePrefetcher(..., begin_ahead=...)` does that.
+        Eval mode / no-grad only; anything else is ignored (the forward then runs its own prologue)."""
+        if self.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            return False
+        _require_cuda(image_features, "image features")
+        lib = _lib.load()
+        dev = image_features.device
+        X = _f32c(image_features)
+        prev = _i64c(encoded_previous_captions)
+        plen = _i64c(previous_cap_length.reshape(-1))
+        mean = None if image_mean is None else _f32c(image_mean)
+        dims = self._dims(X.shape[0], prev.shape[1], X.shape[1], self.max_len + 1)
+        cur = torch.cuda.current_stream(dev)
+        free = self.__dict__.setdefault("_ahead_free", [])
+        key = tuple(getattr(dims, f) for f, _ in _lib.EditNetDims._fields_) + (str(dev),)
+        ticket = None
+        for i, t in enumerate(free):
+            if t["dims_key"] == key:
+                ticket = free.pop(i)
+                cur.wait_event(ticket["done"])          # its previous decode must have finished with the workspace
+                break
+        if ticket is None:
+            n = lib.set_editnet_workspace_bytes(C.byref(dims))
+            if n == 0:
+                raise _lib.SetError("unsupported EditNet dims %r" % (key,))
+            ticket = {"dims_key": key, "ws": torch.empty(n, dtype=torch.uint8, device=dev),
+                      "event": torch.cuda.Event(), "done": torch.cuda.Event()}
+        w = self._weights(dims)
+        check(lib.set_editnet_begin(C.byref(w), C.byref(dims), ptr(X), ptr(mean), ptr(prev), ptr(plen), ptr(ticket["ws"]),
+                                    ticket["ws"].numel(), stream_of(dev)), "set_editnet_begin")
+        ticket["event"].record(cur)
+        # the decode must see the SAME weights view (token table attached or not) the prologue was built with
+        ticket.update(weights=w, inputs=(X, prev, plen, mean), sig=self._ahead_sig(X, prev, plen, mean),
+                      tab=self.__dict__.get("_tok_state", {}).get("table"), wsig=self._weights_sig())
+        pending = self.__dict__.setdefault("_ahead", [])
+        pending.append(ticket)
+        while len(pending) > 4:                          # prologues nobody came back for: recycle the oldest
+            old = pending.pop(0)
+            old["done"].record(cur)
+            old["inputs"] = None
+            free.append(old)
+        return True
+
+    def _weights_sig(self):
+        from . import optim as _optim
+        return tuple(p._version for p in self.parameters()) + (_optim.weights_epoch(),)
+
+    def decode_ahead(self, word_map, encoded_previous_captions, previous_cap_length, image_features, image_mean=None):
+        """The whole greedy decode of a batch that the caller will ask for LATER, issued now on the CURRENT stream (a side
+        stream of pipeline.DevicePrefetcher): the `forward` call that is given these very tensors — with unchanged
+        weights — returns this result after ordering the caller's stream behind it.  For inference loops (the reference's
+        evaluate(): fixed weights, one batch after the other) this keeps several decodes in flight without the caller
+        managing streams; a weight update in between discards the result and the forward decodes again.  Same kernels,
+        same arithmetic: bit-identical to the plain call."""
+        if self.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            return False
+        pending = self.__dict__.setdefault("_ahead", [])
+        X = _f32c(image_features)
+        prev = _i64c(encoded_previous_captions)
+        plen = _i64c(previous_cap_length.reshape(-1))
+        mean = None if image_mean is None else _f32c(image_mean)
+        self.__dict__["_ahead_busy"] = True              # (the forward below must not look for a ticket itself)
+        try:
+            out = self.forward(word_map, prev, plen, X, True, False, image_mean=mean)
+        finally:
+            self.__dict__["_ahead_busy"] = False
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(X.device))
+        pending.append({"out": out, "event": ev, "inputs": (X, prev, plen, mean), "sig": self._ahead_sig(X, prev, plen, mean),
+                        "tab": self.__dict__.get("_tok_state", {}).get("table"), "wsig": self._weights_sig()})
+        while len(pending) > 8:
+            pending.pop(0)
+        return True
+
+    @staticmethod
+    def _ahead_sig(X, prev, plen, mean):
+        return tuple((t.data_ptr(), tuple(t.shape), t._version) for t in (X, prev, plen)) + \
+            ((mean.data_ptr(), mean._version) if mean is not None else None,)
+
+    def _take_ahead(self, X, prev, plen, mean):
+        pending = self.__dict__.get("_ahead")
+        if not pending or self.__dict__.get("_ahead_busy"):
+            return None
+        sig = self._ahead_sig(X, prev, plen, mean)
+        tab = self.__dict__.get("_tok_state", {}).get("table")
+        for i, t in enumerate(pending):
+            if t["sig"] == sig:
+                pending.pop(i)
+                if t["tab"] is not tab or t["wsig"] != self._weights_sig():
+                    # a weight changed (or the token table appeared / was dropped) in between: the prologue is stale
+                    if "ws" in t:
+                        self.__dict__.setdefault("_ahead_free", []).append(t)
+                        t["done"].record(torch.cuda.current_stream(X.device))
+                    return None
+                return t
+        return None
 
     def _rollout_autograd(self, word_map, encoded_previous_captions, previous_cap_length, image_features, sample_max,
                           sample_rl, image_mean=None):

@@ -132,10 +132,20 @@ class DevicePrefetcher:
     `timeline` (when record_timing=True) collects, per batch, timing events around its H2D copy on the copy stream
     (tests use them to show the copy of batch i+1 running while batch i is being decoded)."""
 
-    def __init__(self, iterable, device, depth: int = 2, record_timing: bool = False):
+    def __init__(self, iterable, device, depth: int = 2, record_timing: bool = False, begin_ahead=None, streams: int = 1):
+        """begin_ahead: optional callable(batch_on_device), run on the copy stream right after a batch's H2D copies — e.g.
+        `lambda b: decoder.begin_ahead(b.prev, b.plen, b.features)` (editnet_rl.DecoderC.begin_ahead): the per-sequence
+        prologue of batch i+1 then runs underneath the timestep loop of batch i, and the `decoder(...)` call for batch i+1
+        finds it done.  What a caller that issues one decode after the other (the reference's train() / evaluate()) gains."""
+        self.begin_ahead = begin_ahead
         self.it = iter(iterable)
         self.device = torch.device(device)
-        self.stream = torch.cuda.Stream(self.device)
+        # `streams` side streams, used round-robin per staged batch (1 = the copy stream alone).  With
+        # begin_ahead = decoder.decode_ahead and streams = depth, `depth` whole decodes are in flight while the caller walks
+        # the batches one by one.
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(max(1, streams))]
+        self.stream = self.streams[0]
+        self._staged = 0
         self.depth = max(1, depth)
         # a reader that lends out pinned ring slots (AdaptiveFeatureReader: `depth` slots, one returned per consumed batch)
         # must keep at least one slot to produce into: staging `depth` batches ahead of a `depth`-slot ring would leave the
@@ -155,11 +165,16 @@ class DevicePrefetcher:
         slot, owner = getattr(batch, "slot", None), getattr(batch, "owner", None)
         if not isinstance(batch, (tuple, list)):
             batch = (batch,)
-        with torch.cuda.stream(self.stream):
+        stream = self.streams[self._staged % len(self.streams)]
+        self._staged += 1
+        if any(torch.is_tensor(t) and t.is_cuda for t in batch):
+            # tensors that already live on the device were produced on the caller's stream: order the side stream after it
+            stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(stream):
             t0 = None
             if self.record_timing:
                 t0 = torch.cuda.Event(enable_timing=True)
-                t0.record(self.stream)
+                t0.record(stream)
             dev = []
             for t in batch:
                 if torch.is_tensor(t):
@@ -168,9 +183,11 @@ class DevicePrefetcher:
                     t = t.to(self.device, non_blocking=True)
                 dev.append(t)
             ev = torch.cuda.Event(enable_timing=self.record_timing)
-            ev.record(self.stream)
+            ev.record(stream)
             if self.record_timing:
                 self.timeline.append((t0, ev))
+            if self.begin_ahead is not None:               # (after `ev`: the consumer's copy dependency stays the copy alone)
+                self.begin_ahead(tuple(dev))
         self.queue.append((tuple(dev), ev, slot, owner))
         return True
 

@@ -338,3 +338,83 @@ def test_persistent_encoder_failure_is_loud(mode, env):
     r = subprocess.run([sys.executable, "-c", _FAULT_SCRIPT, mode], env=e, capture_output=True, text=True, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and ("OK " + mode) in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_begin_ahead_pipelined_decode_is_bit_identical():
+    """One caller, one decode after the other (the reference's evaluate() / train() pattern): DevicePrefetcher(begin_ahead=)
+    runs the prologue of batch i+1 on its copy stream while batch i's timestep loop runs; the decoder call then runs
+    set_editnet_greedy_begun on the prepared workspace.  Token ids and log-probs are bit-identical to the un-pipelined
+    decode (and equal the reference's golden); a batch whose tensors were modified in between, or whose weights changed,
+    is NOT taken from the stale prologue."""
+    from show_edit_tell_amd.pipeline import DevicePrefetcher
+    d, xe, rl = editnet_modules("editnet_full_b128")
+    g = parity.load("editnet_full_b128")
+    wm = d["wm"]
+    X, prev, plen = to_dev(d["X"]), to_dev(d["prev"]), to_dev(d["plen"])
+    perm = torch.from_numpy(np.random.RandomState(1).permutation(X.shape[0])).to(X.device)
+    X2, prev2, plen2 = X[perm].contiguous(), prev[perm].contiguous(), plen[perm].contiguous()
+    with torch.no_grad():
+        for _ in range(3):
+            ref = rl(wm, prev, plen, X, True, False)           # (token table active from the second call on)
+        ref2 = rl(wm, prev2, plen2, X2, True, False)
+        torch.cuda.synchronize()
+        batches = [(X, prev, plen), (X2, prev2, plen2)] * 4
+        pf = DevicePrefetcher(iter(batches), X.device, depth=2, begin_ahead=lambda b: rl.begin_ahead(b[1], b[2], b[0]))
+        hits0 = rl.__dict__.get("_ahead_hits", 0)
+        outs = [rl(wm, b[1], b[2], b[0], True, False) for b in pf]
+        torch.cuda.synchronize()
+        assert rl.__dict__.get("_ahead_hits", 0) - hits0 == len(batches), "every decode must have found its prologue done"
+        assert not rl.__dict__.get("_ahead")
+        for i, (seq, lp) in enumerate(outs):
+            want = ref if i % 2 == 0 else ref2
+            assert torch.equal(seq, want[0]) and torch.equal(lp, want[1]), "pipelined decode %d differs" % i
+        parity.check_greedy(outs[0][0].cpu().numpy(), outs[0][1].cpu().numpy(), g)
+        # stale prologues are not used: inputs modified in place after begin_ahead ...
+        Xc = X.clone()
+        rl.begin_ahead(prev, plen, Xc)
+        Xc.mul_(1.0)                                           # bumps the version
+        hits = rl.__dict__["_ahead_hits"]
+        a = rl(wm, prev, plen, Xc, True, False)
+        assert rl.__dict__["_ahead_hits"] == hits and torch.equal(a[0], ref[0])
+        # ... and a weight update in between (the table is dropped, the decode runs its own prologue)
+        rl.begin_ahead(prev, plen, X)
+        rl.fc.bias.add_(0.0)
+        hits = rl.__dict__["_ahead_hits"]
+        b = rl(wm, prev, plen, X, True, False)
+        assert rl.__dict__["_ahead_hits"] == hits
+        assert torch.equal(b[0], ref[0])
+
+
+def test_decode_ahead_keeps_decodes_in_flight_and_is_bit_identical():
+    """DevicePrefetcher(begin_ahead=decoder.decode_ahead, streams=3): the caller still walks the batches one by one, three
+    whole decodes are in flight on the prefetcher's side streams; every result is bit-identical to the plain call, and a
+    weight update between staging and use makes the forward decode again instead of returning the stale result."""
+    from show_edit_tell_amd.pipeline import DevicePrefetcher
+    d, xe, rl = editnet_modules("editnet_full_b128")
+    wm = d["wm"]
+    X, prev, plen = to_dev(d["X"]), to_dev(d["prev"]), to_dev(d["plen"])
+    perm = torch.from_numpy(np.random.RandomState(2).permutation(X.shape[0])).to(X.device)
+    X2, prev2, plen2 = X[perm].contiguous(), prev[perm].contiguous(), plen[perm].contiguous()
+    with torch.no_grad():
+        for _ in range(3):
+            ref = rl(wm, prev, plen, X, True, False)
+        ref2 = rl(wm, prev2, plen2, X2, True, False)
+        torch.cuda.synchronize()
+        batches = [(X, prev, plen), (X2, prev2, plen2)] * 5
+        pf = DevicePrefetcher(iter(batches), X.device, depth=3, streams=3,
+                              begin_ahead=lambda b: rl.decode_ahead(wm, b[1], b[2], b[0]))
+        hits0 = rl.__dict__.get("_ahead_hits", 0)
+        outs = [rl(wm, b[1], b[2], b[0], True, False) for b in pf]
+        torch.cuda.synchronize()
+        assert rl.__dict__.get("_ahead_hits", 0) - hits0 == len(batches)
+        for i, (seq, lp) in enumerate(outs):
+            want = ref if i % 2 == 0 else ref2
+            assert torch.equal(seq, want[0]) and torch.equal(lp, want[1]), "decode %d differs" % i
+        rl.decode_ahead(wm, prev, plen, X)
+        rl.fc.bias.add_(1.0)                                   # changes the scores: the stale result would be wrong
+        hits = rl.__dict__["_ahead_hits"]
+        fresh = rl(wm, prev, plen, X, True, False)
+        plain = rl(wm, prev, plen, X, True, False)
+        assert rl.__dict__["_ahead_hits"] == hits
+        assert torch.equal(fresh[0], plain[0]) and torch.equal(fresh[1], plain[1])
+        assert not torch.equal(fresh[1], ref[1])
