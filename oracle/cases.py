@@ -27,6 +27,11 @@ EDITNET_CASES = {
     "editnet_full_b128": dict(FULL, V=10000, R=36, T=20, B=128, wseed=14, iseed=25, ragged_caps=True, **SCALES),
 }
 
+# no golden: 24 rows at reduced dimensions for the world-size-8 data-parallel tests (8 ragged shards against one process)
+DP_CASES = {
+    "editnet_small_b24": dict(SMALL, V=203, R=7, T=9, B=24, wseed=11, iseed=41, ragged_caps=True, **SCALES),
+}
+
 ADAPTIVE_CASES = {
     "editnet_adaptive_small": dict(SMALL, V=203, R=12, T=9, B=6, wseed=15, iseed=26, nvalid_lo=3,
                                    ragged_caps=True, **SCALES),
@@ -97,7 +102,7 @@ def _boost_end(sd, c):
 
 
 def build_editnet(name):
-    c = dict(EDITNET_CASES.get(name) or ADAPTIVE_ALL[name])
+    c = dict(EDITNET_CASES.get(name) or DP_CASES.get(name) or ADAPTIVE_ALL[name])
     sd = synth.editnet_state(c["wseed"], c["V"], c["D"], c["A"], c["F"], c["emb_scale"], c["fc_scale"], c["gain"])
     sd = _boost_end(sd, c)
     prev, plen = _prev(c)

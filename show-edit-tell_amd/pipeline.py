@@ -17,8 +17,10 @@ Stages
   2. `DevicePrefetcher`: issues the H2D copies of up to `depth` batches ahead on its own stream, hands a batch to
      the consumer after making the consumer's stream wait on the copy event (no host sync on the compute
      stream), and returns the pinned slot to the reader once the copy has completed.
-The fixed 36-region features of `editnet.py:48-74` live in HDF5 files; h5py is not available in this image, so
-that reader is not built (any iterable of host tensors can be fed to DevicePrefetcher).
+The fixed 36-region features of `editnet.py:24-74` (`train36.hdf5` / `val36.hdf5`, dataset `image_features`
+(I,36,2048)) go through `FixedFeatureReader`: it reads the HDF5 datasets themselves when h5py imports, or `.npy` files
+converted from them once (`FixedFeatureReader.convert_hdf5`; memory-mapped here, h5py is not part of this image), and
+gathers a batch's rows with a thread pool straight into the pinned ring.
 """
 from __future__ import annotations
 
@@ -114,6 +116,125 @@ class AdaptiveFeatureReader:
                 bi, slot, n = item
                 img, mean = self._slots[slot]
                 batch = HostBatch((img[:n], mean[:n]) + tuple(self.extras[bi] if self.extras is not None else ()))
+                batch.slot, batch.owner = slot, self
+                yield batch
+        finally:
+            stop.set()
+
+
+class FixedFeatureReader:
+    """Iterable of `(images (B,R,F) fp32, *extras)` host batches in pinned memory for the fixed-region feature files of the
+    reference's datasets (`COCOTrainDataset.__getitem__`, editnet.py:46-74: `objdet = self.objdet[i // cpi]`; the row
+    `objdet[1]` of `val_features` if `objdet[0] == "v"` else of `train_features`).
+
+    stores      : {"t": path_or_array, "v": path_or_array}: per split an `.npy` file (memory-mapped), an HDF5 file (needs
+                  h5py; dataset `image_features`) or any array-like indexable by row with shape (I,R,F)
+    ref_batches : sequence of batches, each a sequence of `(split, row)` pairs (`split` = "v" -> the "v" store, anything
+                  else -> the "t" store, exactly the reference's test) — i.e. `objdet[:2]` of every sample of the batch
+    extras      : optional per-batch tuples of tensors passed through unchanged (captions, lengths, previous captions:
+                  the reference's other `__getitem__` fields, collated by the caller)
+    A batch's rows are gathered by `workers` threads (the memory-mapped / HDF5 reads and the copies release the GIL) into
+    one slot of a ring of pinned buffers; DevicePrefetcher copies from there and returns the slot."""
+
+    DATASET = "image_features"
+
+    def __init__(self, stores, ref_batches, extras=None, workers=8, depth=4, pin=None):
+        self._files = []
+        self.stores = {k: self._open(v) for k, v in stores.items()}
+        if "t" not in self.stores:
+            raise ValueError('stores needs at least the "t" (train) split')
+        self.ref_batches = [[(str(sp), int(row)) for sp, row in b] for b in ref_batches]
+        self.extras = extras
+        any_store = next(iter(self.stores.values()))
+        self.R, self.F = int(any_store.shape[1]), int(any_store.shape[2])
+        self.workers, self.depth = max(1, workers), max(2, depth)
+        self.pin = torch.cuda.is_available() if pin is None else pin
+        self._slots = None
+        self._free = None
+
+    def _open(self, src):
+        if isinstance(src, (str, os.PathLike)):
+            path = os.fspath(src)
+            if path.endswith(".npy"):
+                return np.load(path, mmap_mode="r")
+            try:
+                import h5py
+            except ImportError as e:
+                raise RuntimeError("%s is an HDF5 file and h5py is not installed: convert it once with "
+                                   "FixedFeatureReader.convert_hdf5(path, path_npy) where h5py is available" % path) from e
+            f = h5py.File(path, "r")
+            self._files.append(f)
+            return f[self.DATASET]
+        return src
+
+    @staticmethod
+    def convert_hdf5(h5_path, npy_path, dataset="image_features", chunk=1024):
+        """one-off: copy `dataset` of an HDF5 feature file into a `.npy` file that this reader memory-maps"""
+        import h5py
+        with h5py.File(h5_path, "r") as f:
+            d = f[dataset]
+            out = np.lib.format.open_memmap(npy_path, mode="w+", dtype=np.float32, shape=tuple(d.shape))
+            for i in range(0, d.shape[0], chunk):
+                out[i:i + chunk] = d[i:i + chunk]
+            out.flush()
+        return npy_path
+
+    def __len__(self):
+        return len(self.ref_batches)
+
+    def release(self, slot):
+        if slot is not None and self._free is not None:
+            self._free.put(slot)
+
+    def _alloc(self):
+        bmax = max(len(b) for b in self.ref_batches)
+        mk = lambda *shape: (torch.empty(*shape, dtype=torch.float32).pin_memory() if self.pin
+                             else torch.empty(*shape, dtype=torch.float32))
+        self._slots = [mk(bmax, self.R, self.F) for _ in range(self.depth)]
+        self._free = queue.Queue()
+        for i in range(self.depth):
+            self._free.put(i)
+
+    def _load_one(self, img_np, i, ref):
+        split, row = ref
+        store = self.stores["v"] if split == "v" else self.stores["t"]        # editnet.py:59-62
+        img_np[i] = store[row]                                                # (R,F) -> fp32 (FloatTensor in the reference)
+
+    def __iter__(self):
+        self._alloc()
+        ready = queue.Queue(maxsize=self.depth)
+        stop = threading.Event()
+
+        def producer():
+            try:
+                with ThreadPoolExecutor(self.workers) as pool:
+                    for bi, refs in enumerate(self.ref_batches):
+                        slot = None
+                        while slot is None and not stop.is_set():
+                            try:
+                                slot = self._free.get(timeout=0.1)
+                            except queue.Empty:
+                                pass
+                        if stop.is_set():
+                            return
+                        img_np = self._slots[slot].numpy()
+                        list(pool.map(lambda a: self._load_one(img_np, *a), enumerate(refs)))
+                        ready.put((bi, slot, len(refs)))
+                ready.put(None)
+            except BaseException as e:
+                ready.put(e)
+
+        th = threading.Thread(target=producer, daemon=True)
+        th.start()
+        try:
+            while True:
+                item = ready.get()
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                bi, slot, n = item
+                batch = HostBatch((self._slots[slot][:n],) + tuple(self.extras[bi] if self.extras is not None else ()))
                 batch.slot, batch.owner = slot, self
                 yield batch
         finally:

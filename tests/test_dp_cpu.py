@@ -22,8 +22,9 @@ def _worker(rank, world, port, ret):
     # big-batch reference (same on every rank)
     loss = torch.nn.functional.cross_entropy(lin(emb(ids)), tgt, reduction="sum") / 12
     ref = torch.autograd.grad(loss, params)
-    # sharded: rank 0 gets 5 rows, rank 1 gets 7 (ragged shards -> mean-of-means would be wrong)
-    sl = slice(0, 5) if rank == 0 else slice(5, 12)
+    # sharded: rank 0 gets 5 rows, rank 1 gets 7 (ragged shards -> mean-of-means would be wrong); eight ranks: 1 or 2 rows each
+    cuts = [0, 5, 12] if world == 2 else [0, 1, 3, 4, 6, 7, 9, 10, 12]
+    sl = slice(cuts[rank], cuts[rank + 1])
     n_glob = global_token_count(sl.stop - sl.start, torch.device("cpu"))
     assert n_glob == 12
     for p in params:
@@ -47,9 +48,13 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_dp_gradient_allreduce_matches_big_batch():
-    world = 2
-    port = 29500 + (os.getpid() % 2000)
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_dp_gradient_allreduce_matches_big_batch(world):
+    """(eight ranks: rank / port / bucket-order mistakes show up at 8, not at 2)"""
+    port = 29500 + (os.getpid() % 2000) + world
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)

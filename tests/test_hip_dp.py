@@ -48,9 +48,19 @@ def _worker(rank, world, port, backend, one_device, name, bucket_bytes, ret):
     # single-process big batch (the reference's semantics)
     loss_ref, n_ref, _ = train.xe_backward(xe, *full, reduce=False)
     ref = _grads_of(xe)
-    # this rank's ragged shard (rank 0 gets fewer rows: mean-of-means would be wrong)
-    cut = max(1, B // 3)
-    sl = slice(0, cut) if rank == 0 else slice(cut, B)
+    # this rank's ragged shard (rank 0 gets fewer rows: mean-of-means would be wrong); more than two ranks: shards of
+    # 1, 2, 3, 1, 2, 3, ... rows scaled to the batch
+    if world == 2:
+        cut = max(1, B // 3)
+        cuts = [0, cut, B]
+    else:
+        w = [1 + (r % 3) for r in range(world)]
+        cuts = [0]
+        for r in range(world):
+            cuts.append(min(B - (world - 1 - r), max(cuts[-1] + 1, round(B * sum(w[:r + 1]) / sum(w)))))
+        cuts[-1] = B
+    sl = slice(cuts[rank], cuts[rank + 1])
+    assert sl.stop > sl.start
     shard = tuple(t[sl].contiguous() for t in full)
     loss, n_tok, reducer = train.xe_backward(xe, *shard)
     got = _grads_of(xe)
@@ -68,19 +78,18 @@ def _worker(rank, world, port, backend, one_device, name, bucket_bytes, ret):
     dist.destroy_process_group()
 
 
-def _run(backend, one_device, name, bucket_bytes):
+def _run(backend, one_device, name, bucket_bytes, world=2):
     import torch.multiprocessing as mp
-    world = 2
-    port = 29700 + (os.getpid() % 2000)
+    port = 29700 + (os.getpid() % 2000) + world
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, backend, one_device, name, bucket_bytes, ret), nprocs=world, join=True)
     assert len(ret) == world
     r0, r1 = ret[0], ret[1]
-    # gradients: summation order differs (two shards vs one batch) -> fp32 rounding only
-    assert max(r0["worst"], r1["worst"]) < 2e-4, dict(ret)
-    assert r0["n_tok"] + r1["n_tok"] == r0["n_ref"]
-    assert abs(r0["loss"] - r1["loss"]) < 1e-12, "the returned loss must be the GLOBAL mean on every rank"
+    # gradients: summation order differs (shards vs one batch) -> fp32 rounding only
+    assert max(ret[r]["worst"] for r in range(world)) < 2e-4, dict(ret)
+    assert sum(ret[r]["n_tok"] for r in range(world)) == r0["n_ref"]
+    assert all(abs(ret[r]["loss"] - r0["loss"]) < 1e-12 for r in range(world)), "the returned loss must be the GLOBAL mean on every rank"
     assert abs(r0["loss"] - r0["loss_ref"]) < 1e-5 * max(1.0, abs(r0["loss_ref"]))
     assert r0["buckets"] >= 2 and r0["bytes"] > 0
     return dict(ret)
@@ -94,6 +103,13 @@ def test_dp_hip_model_full_size_two_ranks_one_device_gloo():
     """BASELINE.json config 2 dims (D=1024, 36x2048, V=10000): 354.7 MB of gradients in 64 MB buckets."""
     r = _run("gloo", True, "editnet_full_b4", 64 << 20)
     assert r[0]["bytes"] > 300e6
+
+
+def test_dp_hip_model_eight_ranks_one_device_gloo():
+    """world size 8 (BASELINE.json configs[2] is an 8-GPU job; the box has one GPU, so the eight ranks share it over gloo):
+    eight ragged shards of a 24-row batch, reduced gradients == the single-process big-batch gradients on EVERY rank."""
+    r = _run("gloo", True, "editnet_small_b24", 16 << 10, world=8)
+    assert len(r) == 8 and all(r[k]["buckets"] >= 2 for k in range(8))
 
 
 def _nccl_one_rank_worker(rank, port, ret):
@@ -190,3 +206,23 @@ def test_bench_gpus_flag_spawns_ranks():
     assert tr["n_gpus"] == 2 and tr["ms_per_train_step"] > 0 and "allreduce_exposed_ms" in tr
     assert len(tr["ranks_seen"]) == 2 and all(r["backend"] == "gloo" for r in tr["ranks_seen"])
     assert tr["allreduce_ms"] > 0 and sum(tr["allreduce_buckets"]) > 300        # 354.7 MB in flat buckets
+
+
+def test_bench_gpus_eight_ranks_one_device_gloo():
+    """`python bench.py --gpus 8` as the driver's scaling run launches it, on the one-GPU box (eight ranks share cuda:0,
+    gloo): eight ranks must rendezvous, decode, run the exchange step and report — n_gpus 8, eight entries in ranks_seen."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SET_BENCH_ONE_DEVICE="1", SET_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                          "--repeat", "1", "--streams", "1", "--no-profile", "--no-cpu-baseline", "--no-secondary",
+                          "--train-steps", "2"], env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["config"]["parallelism"].startswith("dp8") and line["value"] > 0
+    tr = line["train"]
+    assert tr["n_gpus"] == 8 and len(tr["ranks_seen"]) == 8
+    assert sorted(r["rank"] for r in tr["ranks_seen"]) == list(range(8))

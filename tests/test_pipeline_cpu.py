@@ -88,3 +88,74 @@ def test_prefetcher_depth_is_clamped_to_the_reader_ring():
         return
     p = pipeline.DevicePrefetcher(FakeReader(), "cuda:0", depth=8)
     assert p.depth == 2
+
+
+def _fixed_dataset(tmp_path, n_train=17, n_val=9, R=36, F=32, cpi=5, seed=3):
+    rng = np.random.default_rng(seed)
+    tr = np.maximum(rng.standard_normal((n_train, R, F)), 0).astype(np.float32)
+    va = np.maximum(rng.standard_normal((n_val, R, F)), 0).astype(np.float32)
+    tp, vp = os.path.join(str(tmp_path), "train36.npy"), os.path.join(str(tmp_path), "val36.npy")
+    np.save(tp, tr)
+    np.save(vp, va)
+    n_img = 12
+    objdet = [["v" if i % 3 == 0 else "t", int(rng.integers(0, n_val if i % 3 == 0 else n_train))] for i in range(n_img)]
+    names = ["img%03d" % i for i in range(n_img)]
+    captions = [[int(x) for x in rng.integers(1, 50, 20)] for _ in range(n_img * cpi)]
+    caplens = [int(rng.integers(7, 21)) for _ in range(n_img * cpi)]
+    util = {n: {"encoded_previous_caption": [int(x) for x in rng.integers(1, 50, 18)],
+                "previous_caption_length": [int(rng.integers(1, 19))]} for n in names}
+    return dict(tr=tr, va=va, tp=tp, vp=vp, objdet=objdet, names=names, captions=captions, caplens=caplens, util=util, cpi=cpi)
+
+
+def test_fixed_reader_matches_the_reference_getitem(tmp_path):
+    """FixedFeatureReader against COCOTrainDataset.__getitem__ (editnet.py:46-74): the split test on objdet[0], the row
+    objdet[1], fp32 features; when /root/reference is present the reference's OWN __getitem__ (AST-sliced, its HDF5 datasets
+    replaced by the same arrays) produces the expected tuples, otherwise its restatement below does."""
+    from oracle import ref_slice
+    ds = _fixed_dataset(tmp_path)
+    cpi = ds["cpi"]
+    n = len(ds["captions"])
+
+    def restated(i):
+        od = ds["objdet"][i // cpi]
+        return torch.from_numpy((ds["va"] if od[0] == "v" else ds["tr"])[od[1]].copy())
+
+    getitem = restated
+    if ref_slice.have_reference():
+        cls = ref_slice.load_classes("editnet.py", ("COCOTrainDataset",))["COCOTrainDataset"]
+        obj = cls.__new__(cls)
+        obj.train_features, obj.val_features, obj.cpi = ds["tr"], ds["va"], cpi
+        obj.captions, obj.caplens, obj.names = ds["captions"], ds["caplens"], ds["names"]
+        obj.caption_util, obj.objdet, obj.dataset_size = ds["util"], ds["objdet"], n
+        getitem = lambda i: obj[i][0]
+        assert torch.equal(obj[7][0], restated(7))
+    order = np.random.default_rng(0).permutation(n)
+    batches = [order[i:i + 8].tolist() for i in range(0, n, 8)]                     # ragged last batch, > ring depth
+    refs = [[tuple(ds["objdet"][i // cpi][:2]) for i in b] for b in batches]
+    extras = [(torch.tensor([ds["caplens"][i] for i in b]).view(-1, 1),) for b in batches]
+    reader = pipeline.FixedFeatureReader({"t": ds["tp"], "v": ds["vp"]}, refs, extras=extras, workers=3, depth=3, pin=False)
+    assert len(reader) == len(batches) and (reader.R, reader.F) == (36, 32)
+    for k, batch in enumerate(reader):
+        img, caplen = batch
+        assert img.dtype == torch.float32 and img.shape == (len(batches[k]), 36, 32)
+        want = torch.stack([getitem(i) for i in batches[k]])
+        assert torch.equal(img, want)
+        assert torch.equal(caplen, extras[k][0])
+        reader.release(batch.slot)
+    # array-likes are accepted as stores too (an open h5py dataset is one)
+    r2 = pipeline.FixedFeatureReader({"t": ds["tr"], "v": ds["va"]}, refs[:1], pin=False)
+    b0 = next(iter(r2))
+    assert torch.equal(b0[0], torch.stack([getitem(i) for i in batches[0]]))
+
+
+def test_fixed_reader_needs_h5py_for_hdf5(tmp_path):
+    import pytest
+    try:
+        import h5py  # noqa: F401
+        pytest.skip("h5py present")
+    except ImportError:
+        pass
+    p = os.path.join(str(tmp_path), "train36.hdf5")
+    open(p, "wb").write(b"x")
+    with pytest.raises(RuntimeError, match="convert"):
+        pipeline.FixedFeatureReader({"t": p}, [[("t", 0)]], pin=False)
