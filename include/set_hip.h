@@ -159,6 +159,20 @@ int set_editnet_greedy(const SetEditNetWeights* w, const SetEditNetDims* d, cons
                        int64_t start_idx, int64_t end_idx, int max_len, int64_t* seq,
                        float* seq_logp, void* ws, size_t ws_bytes, void* stream);
 
+/* Options of the free-running decode loops (set_*_greedy / set_*_sample) for the CALLING host thread.
+ * skip_finished_rows: 0 (default) — every row is decoded for all max_len + 1 timesteps until the WHOLE batch has finished,
+ *   as the reference does (editnet_rl.py:529-547: a finished row is fed word 0 and its seqLogprobs keep being recorded);
+ *   1 — a row is not computed any more once its caption has ended: token ids, and the log-probs of every position up to and
+ *   including a row's <end>, are bit-identical; the (meaningless, masked by RewardCriterion editnet_rl.py:563-566)
+ *   log-probs behind a row's <end> stay 0.  -1: the environment decides (SET_SKIP_FINISHED).
+ * In both modes every kernel of a timestep returns at once after the reference's `break` (all rows finished). */
+int set_decode_options(int skip_finished_rows);
+
+/* MEASUREMENT HOOK, not part of the path: while `lengths_dev` (B int32 on the device) is set for the calling host thread, the
+ * greedy pick of the free-running loops emits <end> for row b at timestep lengths_dev[b] - 1 whatever the scores say, so that
+ * a random-weight model can be given the finish times of real captions (bench.py secondary.realistic_lengths).  NULL: off. */
+int set_debug_force_lengths(const int* lengths_dev);
+
 /* The timestep loop of set_editnet_greedy alone (editnet_rl.py:503-547) on a workspace that already holds a completed
  * set_editnet_begin for the same (X, prev, prevlen): the per-sequence prologue (editnet_rl.py:499-501 and the hoisted
  * projections) of batch i+1 depends on nothing in the decode of batch i, so a caller that issues one decode after the

@@ -14,9 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libset_hip.so")
 ARCH = "gfx950"
-# per-file flags.  gemm_f32.hip: the six leading scalar kernel arguments (task count + first-workgroup table) are preloaded
+# per-file flags.  gemm_f32.hip: the eight leading scalar kernel arguments (task count + first-workgroup table + the two row-gate pointers) are preloaded
 # into SGPRs by the command processor instead of being fetched from the kernarg segment by every workgroup
-FILE_FLAGS = {"gemm_f32.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=6"]}
+FILE_FLAGS = {"gemm_f32.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=8"]}
 
 
 def sources():

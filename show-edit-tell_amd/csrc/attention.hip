@@ -224,10 +224,11 @@ __device__ __forceinline__ void caption_attention_body(const CapAttArgs& P, int 
     }
 }
 
-__global__ void __launch_bounds__(256) caption_attention_k(const CapAttArgs P) {
+__global__ void __launch_bounds__(256) caption_attention_k(const CapAttArgs P, const RowGate G) {
     __shared__ float sc[ATT_MAX_ROWS];
     __shared__ int s_arg;
     const int dsn = P.dsn > 1 ? P.dsn : 1;
+    if (G.loop_left() || G.row_done(blockIdx.x / dsn)) return;      // decode loops (set_common.h RowGate)
     caption_attention_body(P, blockIdx.x / dsn, sc, &s_arg, blockIdx.x % dsn);
 }
 
@@ -240,7 +241,7 @@ static int cap_dsn(int M, int Dh) {
     return dsn;
 }
 
-__global__ void caption_attention_v2_k(const CapAttArgs C);
+__global__ void caption_attention_v2_k(const CapAttArgs C, const RowGate G);
 
 int caption_attention(const float* att1_c, Slabs att2_c, const float* dec_bias, const float* w_full,
                       const float* b_full, const float* mask, const float* H, const float* Mem, float* ctx,
@@ -255,12 +256,12 @@ int caption_attention(const float* att1_c, Slabs att2_c, const float* dec_bias, 
     static const int v2 = env_int("SET_ATT_V2", 1);
     static const int v2_maxm = env_int("SET_ATT_V2_MAXM", 32);
     if (v2 && M <= v2_maxm && Dh <= 1024) {  // 512 threads per row, all H rows requested before the scoring phase (see v2 below)
-        hipLaunchKernelGGL(caption_attention_v2_k, dim3(M), dim3(512), 0, s, P);
+        hipLaunchKernelGGL(caption_attention_v2_k, dim3(M), dim3(512), 0, s, P, g_row_gate);
         SET_LAUNCH_CHECK();
         return SET_OK;
     }
     P.dsn = cap_dsn(M, Dh); P.dcols = Dh / P.dsn;
-    hipLaunchKernelGGL(caption_attention_k, dim3(M * P.dsn), dim3(256), 0, s, P);
+    hipLaunchKernelGGL(caption_attention_k, dim3(M * P.dsn), dim3(256), 0, s, P, g_row_gate);
     SET_LAUNCH_CHECK();
     return SET_OK;
 }
@@ -371,13 +372,16 @@ __global__ void __launch_bounds__(256) visual_attention_k(const VisAttArgs P) {
 // are independent of each other): workgroups [0, Mv*fsn) stream the image regions, the rest score
 // the previous caption.  Saves one kernel boundary + one ~4.5 us launch floor per timestep and lets
 // the MFMA-free caption attention overlap the HBM-bound region streaming.
-__global__ void __launch_bounds__(256) step_attention_k(const VisAttArgs V, const CapAttArgs C, int nvis) {
+__global__ void __launch_bounds__(256) step_attention_k(const VisAttArgs V, const CapAttArgs C, int nvis, const RowGate G) {
     __shared__ float sc[ATT_MAX_ROWS];
     __shared__ int s_arg;
+    if (G.loop_left()) return;                               // decode loops: the reference has left its loop (set_common.h)
     if ((int)blockIdx.x < nvis) {
+        if (G.row_done(blockIdx.x / V.fsn)) return;          // (opt-in) this row's caption has ended
         visual_attention_body(V, blockIdx.x / V.fsn, blockIdx.x % V.fsn, sc);
     } else {
         const int i = blockIdx.x - nvis, dsn = C.dsn > 1 ? C.dsn : 1;
+        if (G.row_done(i / dsn)) return;
         caption_attention_body(C, i / dsn, sc, &s_arg, i % dsn);
     }
 }
@@ -633,18 +637,21 @@ __device__ __forceinline__ void caption_attention_v2(const CapAttArgs& P, int b,
     }
 }
 
-__global__ void __launch_bounds__(512) step_attention_v2_k(const VisAttArgs V, const CapAttArgs C, int nvis) {
+__global__ void __launch_bounds__(512) step_attention_v2_k(const VisAttArgs V, const CapAttArgs C, int nvis, const RowGate G) {
     __shared__ float sc[ATT_MAX_ROWS];
     __shared__ int s_arg;
     __shared__ f32x4 xch[512];
+    if (G.loop_left()) return;
+    if (G.row_done((int)blockIdx.x < nvis ? (int)blockIdx.x : (int)blockIdx.x - nvis)) return;
     if ((int)blockIdx.x < nvis) visual_attention_v2(V, blockIdx.x, sc, xch);
     else caption_attention_v2(C, blockIdx.x - nvis, sc, &s_arg, xch);
 }
 
-__global__ void __launch_bounds__(512) caption_attention_v2_k(const CapAttArgs C) {
+__global__ void __launch_bounds__(512) caption_attention_v2_k(const CapAttArgs C, const RowGate G) {
     __shared__ float sc[ATT_MAX_ROWS];
     __shared__ int s_arg;
     __shared__ f32x4 xch[512];
+    if (G.loop_left() || G.row_done(blockIdx.x)) return;
     caption_attention_v2(C, blockIdx.x, sc, &s_arg, xch);
 }
 
@@ -693,12 +700,12 @@ int step_attention(const float* att1, Slabs att2, const float* v_dec_bias, const
     static const int v2_maxm = env_int("SET_ATT_V2_MAXM", 32);
     if (v2 && M <= v2_maxm && F <= 2048 && Dh <= 1024) {
         V.fcols = F; V.fsn = 1;
-        hipLaunchKernelGGL(step_attention_v2_k, dim3(2 * M), dim3(512), 0, s, V, C, M);
+        hipLaunchKernelGGL(step_attention_v2_k, dim3(2 * M), dim3(512), 0, s, V, C, M, g_row_gate);
         SET_LAUNCH_CHECK();
         return SET_OK;
     }
     C.dsn = cap_dsn(M, Dh); C.dcols = Dh / C.dsn;
-    hipLaunchKernelGGL(step_attention_k, dim3(M * fsn + M * C.dsn), dim3(256), 0, s, V, C, M * fsn);
+    hipLaunchKernelGGL(step_attention_k, dim3(M * fsn + M * C.dsn), dim3(256), 0, s, V, C, M * fsn, g_row_gate);
     SET_LAUNCH_CHECK();
     return SET_OK;
 }

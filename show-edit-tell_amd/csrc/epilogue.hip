@@ -93,18 +93,23 @@ template <bool REG, bool TAIL>
 __global__ void __launch_bounds__(256) greedy_pick_k(Slabs logits, const float* bias, int V, int t, int max_len,
                                                      long long end_idx, long long* seq, float* seq_logp,
                                                      long long* it_buf, int* unfinished, int* alive,
-                                                     const float* table, float* emb_out, int D, const LstmTail tail) {
+                                                     const float* table, float* emb_out, int D, const LstmTail tail,
+                                                     const int skip_finished, const int* force_len) {
     __shared__ float s_val[4];
     __shared__ int s_idx[4];
     __shared__ float s_sum[4];
     __shared__ long long s_tok;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // bookkeeping words of the serial tail (thread 0): requested now, under the row fetch, instead of as a dependent
-    // round trip after the reductions
+    // bookkeeping words of the row: every thread reads them (one broadcast load each).  Once every row had finished after
+    // step t - 1 the reference has left its loop (editnet_rl.py:546): nothing is written any more, so the workgroup returns
+    // (the words it would have rewritten — unfinished[b] = 0, it[b] = 0, alive[t] = 0 — already hold those values).  With
+    // skip_finished (opt-in, set_common.h RowGate) a row whose caption has ended is not scored either.
     int unf_prev = 1, alive_prev = 1;
     if (t > 0) {
-        if (TAIL || tid == 0) unf_prev = unfinished[b];          // (TAIL: every thread derives the word right after the arg-max)
-        if (tid == 0) alive_prev = alive[t - 1];
+        unf_prev = unfinished[b];
+        alive_prev = alive[t - 1];
+        if (alive_prev == 0) return;
+        if (skip_finished && unf_prev == 0) return;
     }
     TailRegs tr;
     const bool tail0 = TAIL && tid * 4 < tail.D;
@@ -198,6 +203,9 @@ __global__ void __launch_bounds__(256) greedy_pick_k(Slabs logits, const float* 
     for (int w = 1; w < 4; ++w)
         if (s_val[w] > best || (s_val[w] == best && s_idx[w] < bi)) { best = s_val[w]; bi = s_idx[w]; }
     if (bi == 0x7fffffff) { bi = 0; best = __builtin_nanf(""); }   // no comparison succeeded: the row is all NaN.  Word 0 and a NaN log-prob, never an out-of-range gather
+    // measurement hook (set_debug_force_lengths): row b emits <end> at step force_len[b] - 1 whatever its scores say, so that
+    // a random-weight model can be given the finish times of real captions; never set by the product path
+    if (force_len && t + 1 >= force_len[b]) bi = (int)end_idx;
     // the word follows from the arg-max and the row's latch alone: with a tail, every thread requests its piece of the
     // token-table row NOW, so that round trip runs under the sum-exp pass instead of after the serial bookkeeping
     TailRow tw;
@@ -273,7 +281,8 @@ int greedy_pick(Slabs logits, const float* bias, int V, int t, int max_len, long
     const bool reg = V <= 4 * 256 * GP_MAXQ && !(logits.ld & 3) && !(logits.stride & 3) && aligned16(logits.p);
 #define SET_PICK_LAUNCH(REG, TAIL)                                                                                    \
     hipLaunchKernelGGL((greedy_pick_k<REG, TAIL>), dim3(B), dim3(256), 0, s, logits, bias, V, t, max_len, end_idx, seq, \
-                       seq_logp, it, unfinished, alive, table, emb_out, D, tl)
+                       seq_logp, it, unfinished, alive, table, emb_out, D, tl, skip, g_force_len)
+    const int skip = g_row_gate.unfinished != nullptr ? 1 : 0;       // finished rows are skipped when the loop's row gate says so
     if (reg) { if (tail) SET_PICK_LAUNCH(true, true); else SET_PICK_LAUNCH(true, false); }
     else { if (tail) SET_PICK_LAUNCH(false, true); else SET_PICK_LAUNCH(false, false); }
 #undef SET_PICK_LAUNCH
@@ -329,7 +338,7 @@ __global__ void __launch_bounds__(256) sample_pick_k(Slabs logits, const float* 
                                                      long long* it_buf, int* unfinished, int* alive,
                                                      const float* table, float* emb_out, int D,
                                                      unsigned long long seed, unsigned long long offset,
-                                                     SampleOut so, const LstmTail tail) {
+                                                     SampleOut so, const LstmTail tail, const int skip_finished) {
     __shared__ float s_red[4];
     __shared__ float s_scan[4];
     __shared__ float s_max;
@@ -337,6 +346,13 @@ __global__ void __launch_bounds__(256) sample_pick_k(Slabs logits, const float* 
     __shared__ int s_pick;
     __shared__ float s_pick_x;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the fused no-grad loops (no per-step side outputs): nothing to do once the reference has left its loop, and — opt-in —
+    // for a row whose caption has ended (see greedy_pick_k).  The grad-enabled rollout keeps every step (its backward reads
+    // raw_ids / lse of all rows).
+    if (t > 0 && !so.raw_ids && !so.lse && !so.step_logp) {
+        if (alive[t - 1] == 0) return;
+        if (skip_finished && unfinished[b] == 0) return;
+    }
     f32x4 x[GP_MAXQ];
     float best = -INFINITY;
     if (REG) {
@@ -504,7 +520,8 @@ int sample_pick(Slabs logits, const float* bias, int V, int t, int max_len, long
     SampleOut so{raw_ids, lse, step_logp};
 #define SET_PICK_LAUNCH(REG, TAIL)                                                                                    \
     hipLaunchKernelGGL((sample_pick_k<REG, TAIL>), dim3(B), dim3(256), 0, s, logits, bias, V, t, max_len, end_idx, seq, \
-                       seq_logp, it, unfinished, alive, table, emb_out, D, seed, offset, so, tl)
+                       seq_logp, it, unfinished, alive, table, emb_out, D, seed, offset, so, tl, skip)
+    const int skip = g_row_gate.unfinished != nullptr ? 1 : 0;
     if (reg) { if (tail) SET_PICK_LAUNCH(true, true); else SET_PICK_LAUNCH(true, false); }
     else { if (tail) SET_PICK_LAUNCH(false, true); else SET_PICK_LAUNCH(false, false); }
 #undef SET_PICK_LAUNCH
@@ -546,6 +563,44 @@ __global__ void __launch_bounds__(256) set_tokens_k(long long* it, long long val
 int set_tokens(long long* it, long long value, int* unfinished, int* alive, int n_alive, int B, hipStream_t s) {
     const int n = B > n_alive ? B : n_alive;
     hipLaunchKernelGGL(set_tokens_k, dim3(cdiv(n, 256)), dim3(256), 0, s, it, value, unfinished, alive, n_alive, B);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+// rowmap[0 .. n) = the rows with unfinished[row] != 0 in ascending order, *n_rows = n (decode loops, set_common.h RowGate);
+// init != 0: the identity list of all B rows (start of a decode).  One workgroup, B <= 4096.
+__global__ void __launch_bounds__(1024) compact_rows_k(const int* unfinished, int B, int* rowmap, int* n_rows, int init) {
+    __shared__ int s_cnt[16];
+    __shared__ int s_base[17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int flag[4], mine = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                         // thread owns rows 4 tid .. 4 tid + 3 (ascending order is kept)
+        const int r = 4 * tid + i;
+        flag[i] = (r < B) && (init || unfinished[r] != 0);
+        mine += flag[i];
+    }
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    if (lane == 63) s_cnt[wave] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int w = 0; w < 16; ++w) { s_base[w] = acc; acc += s_cnt[w]; }
+        s_base[16] = acc;
+        *n_rows = acc;
+    }
+    __syncthreads();
+    int pos = s_base[wave] + incl - mine;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (flag[i]) rowmap[pos++] = 4 * tid + i;
+}
+
+int compact_rows(const int* unfinished, int B, int* rowmap, int* n_rows, int init, hipStream_t s) {
+    if (B > 4096) return SET_ERR_UNSUPPORTED;
+    ProfScope ps("compact_rows", s, 0.0, 8.0 * B);
+    hipLaunchKernelGGL(compact_rows_k, dim3(1), dim3(1024), 0, s, unfinished, B, rowmap, n_rows, init);
     SET_LAUNCH_CHECK();
     return SET_OK;
 }

@@ -51,6 +51,7 @@ struct GemmTask {
 struct GemmLaunch {
     GemmTask t[GEMM_MAX_TASKS];
     int ntasks;
+    RowGate gate;                    // set_common.h: loop-left test and the compacted row list of the decode loops
 #ifdef SET_EXP_STAMPS
     unsigned long long* stamps;      // debug: 8 wall-clock stamps (10 ns units) per workgroup
 #endif
@@ -78,7 +79,8 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 //         CU and half as many MFMAs between two barriers, which fills more of the matrix pipe's idle slots.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int KG = 1>
 __global__ void __launch_bounds__(256 * KG) gemm_nt_f32(const int ntasks, const int wb1, const int wb2, const int wb3,
-                                                        const int wb4, const int wb5, const GemmLaunch L) {
+                                                        const int wb4, const int wb5, const int* const gate_alive,
+        const int* const gate_nrows, const GemmLaunch L) {
     // ntasks / wb1..wb5 repeat L.ntasks and L.t[1..5].wg_begin as leading scalar arguments: this file is compiled with
     // -mllvm -amdgpu-kernarg-preload-count=6, so they arrive in SGPRs with the wave and the task lookup below needs no
     // memory round trip before the task's own fields can be requested (about 0.5 us of every workgroup's start-up)
@@ -123,13 +125,25 @@ __global__ void __launch_bounds__(256 * KG) gemm_nt_f32(const int ntasks, const 
     const int m0 = tm * BM, n0 = tn * BN;
     const int kt0 = (int)(((long long)ks * T.ktiles) / T.ksplit);
     const int kt1 = (int)(((long long)(ks + 1) * T.ktiles) / T.ksplit);
+    // ---- row gate of the decode loops (set_common.h): nothing to do once the reference has left its loop; with the
+    // compacted row list the launch covers *n_rows rows (tiles beyond return) and row r of a tile is batch row rowmap[r]
+    // (gate_alive / gate_nrows repeat L.gate.alive_prev / L.gate.n_rows as leading, SGPR-preloaded arguments: their values
+    // are requested with the wave's first instructions, next to the task descriptor, not behind it)
+    const int* const rowmap = L.gate.rowmap;
+    int epi_m = T.M;
+    if (gate_alive || gate_nrows) {
+        if (gate_alive && *gate_alive == 0) return;
+        if (gate_nrows) { const int nr = *gate_nrows; epi_m = nr < T.M ? nr : T.M; }
+        if (m0 >= epi_m) return;
+    }
+    auto epi_row = [&](int row) { return rowmap ? rowmap[row] : row; };
 
     // ---- staging assignment: thread -> (row = tid/8 + RP*i, 16-byte column = tid%8)
     const int srow = tid >> 3, scol = (tid & 7) * 4;
     const int sswz = ((tid & 7) ^ ((srow >> 1) & 7)) * 4;          // swizzled chunk (rows srow+RP*i share (r>>1)&7)
     int arow[LA], wrow[LW];
 #pragma unroll
-    for (int i = 0; i < LA; ++i) { int r = m0 + srow + RP * i; arow[i] = r < T.M ? r : T.M - 1; }
+    for (int i = 0; i < LA; ++i) { int r = m0 + srow + RP * i; r = r < epi_m ? r : epi_m - 1; arow[i] = rowmap ? rowmap[r] : r; }
 #pragma unroll
     for (int i = 0; i < LW; ++i) { int r = n0 + srow + RP * i; wrow[i] = r < T.N ? r : T.N - 1; }
 #ifdef SET_EXP_SAMEW
@@ -314,7 +328,8 @@ __global__ void __launch_bounds__(256 * KG) gemm_nt_f32(const int ntasks, const 
 #define WR_WAVES_PER_SIMD 3
 #endif
 __global__ void __launch_bounds__(256, WR_WAVES_PER_SIMD) gemm_nt_f32_wreg(const int ntasks, const int wb1, const int wb2, const int wb3,
-                                                        const int wb4, const int wb5, const GemmLaunch L) {
+                                                        const int wb4, const int wb5, const int* const gate_alive,
+        const int* const gate_nrows, const GemmLaunch L) {
     constexpr int BM = 64, BN = 64;
     constexpr int GROUP_FLOATS = BM * LDS_STRIDE;                  // one K group's activation tile (8 KB)
     __shared__ __attribute__((aligned(16))) float lds[2][2 * GROUP_FLOATS];
@@ -343,6 +358,9 @@ __global__ void __launch_bounds__(256, WR_WAVES_PER_SIMD) gemm_nt_f32_wreg(const
     const int m0 = tm * BM, n0 = tn * BN;
     const int kt0 = (int)(((long long)ks * T.ktiles) / T.ksplit);
     const int kt1 = (int)(((long long)(ks + 1) * T.ktiles) / T.ksplit);
+    if (gate_alive && *gate_alive == 0) return;                    // (the compacted row list is not supported here: gemm_group)
+    const int epi_m = T.M;
+    auto epi_row = [](int row) { return row; };
     // this K group's k-tiles: kt0 + wk, kt0 + wk + 2, ...  (local index j <-> global k-tile kt0 + wk + 2 j)
     const int nt_wg = kt1 - kt0;
     const int nt = (nt_wg - wk + 1) >> 1;                          // tiles of this group
@@ -600,7 +618,8 @@ typedef const __attribute__((address_space(1))) void* glb_vptr;
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ void __launch_bounds__(256) gemm_nt_f32_dma(const int ntasks, const int wb1, const int wb2, const int wb3,
-                                                       const int wb4, const int wb5, const GemmLaunch L) {
+                                                       const int wb4, const int wb5, const int* const gate_alive,
+        const int* const gate_nrows, const GemmLaunch L) {
     static_assert(WAVES_M * WAVES_N == 4, "4 waves");
     constexpr int KG = 1;
     constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
@@ -627,11 +646,14 @@ __global__ void __launch_bounds__(256) gemm_nt_f32_dma(const int ntasks, const i
     const int tm = local / T.tm_stride;
     const int rem = local - tm * T.tm_stride;
     if (rem >= T.tiles_n * T.ksplit) return;          // padding slot
+    if (gate_alive && *gate_alive == 0) return;                    // (the compacted row list is not supported here: gemm_group)
     const int ks = rem % T.ksplit;
     const int tn = rem / T.ksplit;
     const int m0 = tm * BM, n0 = tn * BN;
     const int kt0 = (int)(((long long)ks * T.ktiles) / T.ksplit);
     const int kt1 = (int)(((long long)(ks + 1) * T.ktiles) / T.ksplit);
+    const int epi_m = T.M;
+    auto epi_row = [](int row) { return row; };
 
     // ---- DMA assignment: piece i of this wave fills stage rows [8 * (wave * PIECES + i), +8); lane -> (row, chunk position)
     int prow[PIECES];            // global row (clamped) of this lane's stage row, in A (stage row < BM) or W
@@ -958,7 +980,8 @@ __global__ void __launch_bounds__(256) gemm_nt_split_bf16(const GemmLaunch L) {
 // gemm_nt_f32; workgroup = 4 waves = 64 columns of one task x one K slice, no barrier anywhere.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) gemv_nt_f32(const int ntasks, const int wb1, const int wb2, const int wb3,
-                                                   const int wb4, const int wb5, const GemmLaunch L) {
+                                                   const int wb4, const int wb5, const int* const gate_alive,
+        const int* const gate_nrows, const GemmLaunch L) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     int ti = 0;
@@ -973,6 +996,7 @@ __global__ void __launch_bounds__(256) gemv_nt_f32(const int ntasks, const int w
     const GemmTask& T = L.t[ti];
     const int local = (int)blockIdx.x - T.wg_begin;
     if (local >= T.tiles_n * T.ksplit) return;
+    if (gate_alive && *gate_alive == 0) return;                    // the decode loop has been left (set_common.h RowGate)
     const int ks = local % T.ksplit;
     const int tn = local / T.ksplit;
     const int n0 = tn * 64 + wave * 16;
@@ -1160,6 +1184,7 @@ int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag
     if (n > GEMM_MAX_TASKS) return SET_ERR_ARG;
     GemmLaunch L;
     L.ntasks = n;
+    L.gate = g_row_gate;
 #ifdef SET_EXP_STAMPS
     L.stamps = g_gemm_stamps;
 #endif
@@ -1224,26 +1249,31 @@ int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag
     } else {
         const int nt = L.ntasks, w1 = L.t[1].wg_begin, w2 = L.t[2].wg_begin, w3 = L.t[3].wg_begin, w4 = L.t[4].wg_begin,
                   w5 = L.t[5].wg_begin;
+        // only the register-staged kernels walk the compacted row list (the others compute every row: a superset)
+        const bool rowlist_ok = bm != 16 && !(bm == 64 && gemm_wreg()) && !gemm_dma();
+        if (!rowlist_ok) { L.gate.rowmap = nullptr; L.gate.n_rows = nullptr; }
+        const int* ga = L.gate.alive_prev;
+        const int* gn = L.gate.n_rows;
         if (bm == 16)
-            hipLaunchKernelGGL(gemv_nt_f32, grid, block, 0, stream, nt, w1, w2, w3, w4, w5, L);
+            hipLaunchKernelGGL(gemv_nt_f32, grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
         else if (bm == 128 && bn == 32)
-            hipLaunchKernelGGL((gemm_nt_f32<128, 32, 4, 1>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, L);
+            hipLaunchKernelGGL((gemm_nt_f32<128, 32, 4, 1>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
         else if (bm == 128 && bn == 128)
-            hipLaunchKernelGGL((gemm_nt_f32<128, 128, 2, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, L);
+            hipLaunchKernelGGL((gemm_nt_f32<128, 128, 2, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
         else if (bm == 128 && gemm_dma())
-            hipLaunchKernelGGL((gemm_nt_f32_dma<128, 64, 2, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, L);
+            hipLaunchKernelGGL((gemm_nt_f32_dma<128, 64, 2, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
         else if (bm == 128)
-            hipLaunchKernelGGL((gemm_nt_f32<128, 64, 2, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, L);
+            hipLaunchKernelGGL((gemm_nt_f32<128, 64, 2, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
         else if (bm == 64 && gemm_wreg())
-            hipLaunchKernelGGL(gemm_nt_f32_wreg, grid, block, 0, stream, nt, w1, w2, w3, w4, w5, L);
+            hipLaunchKernelGGL(gemm_nt_f32_wreg, grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
         else if (bm == 64 && gemm_kgroups() == 2)
-            hipLaunchKernelGGL((gemm_nt_f32<64, 64, 2, 2, 2>), grid, dim3(512), 0, stream, nt, w1, w2, w3, w4, w5, L);
+            hipLaunchKernelGGL((gemm_nt_f32<64, 64, 2, 2, 2>), grid, dim3(512), 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
         else if (bm == 64 && gemm_dma())
-            hipLaunchKernelGGL((gemm_nt_f32_dma<64, 64, 2, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, L);
+            hipLaunchKernelGGL((gemm_nt_f32_dma<64, 64, 2, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
         else if (bm == 64)
-            hipLaunchKernelGGL((gemm_nt_f32<64, 64, 2, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, L);
+            hipLaunchKernelGGL((gemm_nt_f32<64, 64, 2, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
         else
-            hipLaunchKernelGGL((gemm_nt_f32<32, 128, 1, 4>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, L);
+            hipLaunchKernelGGL((gemm_nt_f32<32, 128, 1, 4>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
     }
     SET_LAUNCH_CHECK();
     return SET_OK;

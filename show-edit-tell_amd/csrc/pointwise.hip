@@ -75,12 +75,13 @@ __global__ void __launch_bounds__(256) lstm_pointwise_k(Slabs g0, Slabs g1, Slab
                                                         long long ldpre, const float* b0, const float* b1,
                                                         const float* c_in, float* c_out, float* h_out,
                                                         float* ogate_out, int M, int D, RowGather gt,
-                                                        float* gates_out) {
+                                                        float* gates_out, const RowGate G) {
     const int per_row = D >> 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)M * per_row) return;
     const long long m = idx / per_row;
     const int j = (int)(idx - m * per_row) << 2;
+    if (G.loop_left() || G.row_done(m)) return;              // decode loops (set_common.h RowGate)
     // operands that do not depend on the slabs are requested first (the table row needs its token id): their
     // latency overlaps the slab reads; the additions keep the order slabs, pre, table row, b0, b1
     const float* trow = gt.tab ? gt.row(m) : nullptr;
@@ -135,7 +136,7 @@ int lstm_pointwise(Slabs g0, Slabs g1, Slabs g2, const float* pre, long long ldp
     const long long n = (long long)M * (D >> 2);
     ProfScope ps("lstm_pointwise", s, 0.0, 4.0 * M * D * (4.0 * (g0.n + g1.n + g2.n + (pre ? 1 : 0)) + 3.0));
     hipLaunchKernelGGL(lstm_pointwise_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g0, g1, g2, pre,
-                       ldpre, b0, b1, c_in, c_out, h_out, ogate_out, M, D, gt, gates_out);
+                       ldpre, b0, b1, c_in, c_out, h_out, ogate_out, M, D, gt, gates_out, g_row_gate);
     SET_LAUNCH_CHECK();
     return SET_OK;
 }
@@ -190,11 +191,13 @@ int context_gate_pointwise(Slabs cg_a, Slabs cg_b, const float* cg_bias, Slabs s
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) copy_gate_k(Slabs gn, const float* bn, Slabs gm, const float* bm,
                                                    const float* c_new, const float* sel, const float* ogate,
-                                                   float* c_out, float* h_out, int M, int D, float* cg_out) {
+                                                   float* c_out, float* h_out, int M, int D, float* cg_out,
+                                                   const RowGate G) {
     const int per_row = D >> 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)M * per_row) return;
     const long long m = idx / per_row;
+    if (G.loop_left() || G.row_done(m)) return;
     const int j = (int)(idx - m * per_row) << 2;
     // reference order: (gate_cnew(c_new) + b) + (gate_cmem(c_memory) + b)
     f32x4 a = slab_sum4(gn, m, j) + ld4(bn + j);
@@ -220,7 +223,7 @@ int copy_gate_pointwise(Slabs gn, const float* bn, Slabs gm, const float* bm, co
     const long long n = (long long)M * (D >> 2);
     ProfScope ps("copy_gate", s, 0.0, 4.0 * M * D * (gn.n + gm.n + 5.0));
     hipLaunchKernelGGL(copy_gate_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gn, bn, gm, bm, c_new,
-                       sel, ogate, c_out, h_out, M, D, cg_out);
+                       sel, ogate, c_out, h_out, M, D, cg_out, g_row_gate);
     SET_LAUNCH_CHECK();
     return SET_OK;
 }

@@ -30,6 +30,7 @@ class DAE(_DAE_XE):
         dims = self._dims(B, prev.shape[1], max_len + 1)
         ws = self._workspace(dims)
         w = self._weights(dims)
+        lib.set_decode_options(1 if getattr(self, "skip_finished_rows", False) else -1)      # see editnet_rl.DecoderC
         seq = torch.empty(B, max_len, dtype=torch.long, device=dev)
         seq_logp = torch.empty(B, max_len, dtype=torch.float32, device=dev)
         if sample_rl:        # multinomial sampling, eval mode, no gradients: fused device loop, Philox epilogue

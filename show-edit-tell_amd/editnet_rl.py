@@ -25,6 +25,10 @@ class DecoderC(_DecoderXE):
     """reference editnet_rl.py:455-549"""
 
     max_len = 18
+    # Opt-in (include/set_hip.h set_decode_options): in the no-grad greedy / sampled loops a row is not computed any more
+    # once its caption has ended.  Token ids, and the log-probs up to and including every row's <end>, are bit-identical;
+    # the log-probs the reference keeps recording behind a row's <end> (masked by RewardCriterion) stay 0.
+    skip_finished_rows = False
 
     def forward(self, word_map, encoded_previous_captions, previous_cap_length, image_features, sample_max=True,
                 sample_rl=False, image_mean=None):
@@ -33,6 +37,7 @@ class DecoderC(_DecoderXE):
             return self._rollout_autograd(word_map, encoded_previous_captions, previous_cap_length, image_features,
                                           sample_max, sample_rl, image_mean)
         lib = _lib.load()
+        lib.set_decode_options(1 if self.skip_finished_rows else -1)
         dev = image_features.device
         X = _f32c(image_features)
         prev = _i64c(encoded_previous_captions)
