@@ -100,16 +100,20 @@ __global__ void __launch_bounds__(256) greedy_pick_k(Slabs logits, const float* 
     __shared__ float s_sum[4];
     __shared__ long long s_tok;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // bookkeeping words of the row: every thread reads them (one broadcast load each).  Once every row had finished after
-    // step t - 1 the reference has left its loop (editnet_rl.py:546): nothing is written any more, so the workgroup returns
-    // (the words it would have rewritten — unfinished[b] = 0, it[b] = 0, alive[t] = 0 — already hold those values).  With
-    // skip_finished (opt-in, set_common.h RowGate) a row whose caption has ended is not scored either.
+    // bookkeeping words of the serial tail (thread 0): requested now, under the row fetch, instead of as a dependent round
+    // trip after the reductions.  (The loop-left test of set_common.h RowGate is NOT made here: a dependent load at the top of
+    // every 10-us kernel of the chain costs more — 2 % of a single-stream decode when all seven kernels of a timestep make
+    // it — than these short kernels cost after the break; the three GEMM launches and the attention launch make it.)  With
+    // skip_finished (opt-in) a row whose caption has ended is not scored.
     int unf_prev = 1, alive_prev = 1;
     if (t > 0) {
-        unf_prev = unfinished[b];
-        alive_prev = alive[t - 1];
-        if (alive_prev == 0) return;
-        if (skip_finished && unf_prev == 0) return;
+        if (skip_finished) {                                     // opt-in: every thread reads the row's latch (one broadcast load)
+            unf_prev = unfinished[b];
+            if (unf_prev == 0) return;
+        } else if (TAIL || tid == 0) {
+            unf_prev = unfinished[b];                            // (TAIL: every thread derives the word right after the arg-max)
+        }
+        if (tid == 0) alive_prev = alive[t - 1];
     }
     TailRegs tr;
     const bool tail0 = TAIL && tid * 4 < tail.D;
@@ -346,12 +350,10 @@ __global__ void __launch_bounds__(256) sample_pick_k(Slabs logits, const float* 
     __shared__ int s_pick;
     __shared__ float s_pick_x;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // the fused no-grad loops (no per-step side outputs): nothing to do once the reference has left its loop, and — opt-in —
-    // for a row whose caption has ended (see greedy_pick_k).  The grad-enabled rollout keeps every step (its backward reads
-    // raw_ids / lse of all rows).
-    if (t > 0 && !so.raw_ids && !so.lse && !so.step_logp) {
-        if (alive[t - 1] == 0) return;
-        if (skip_finished && unfinished[b] == 0) return;
+    // the fused no-grad loops (no per-step side outputs), opt-in: a row whose caption has ended is not scored (see
+    // greedy_pick_k).  The grad-enabled rollout keeps every step (its backward reads raw_ids / lse of all rows).
+    if (t > 0 && skip_finished && !so.raw_ids && !so.lse && !so.step_logp) {
+        if (unfinished[b] == 0) return;
     }
     f32x4 x[GP_MAXQ];
     float best = -INFINITY;

@@ -71,7 +71,6 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
     constexpr bool ROWLIST = (EPI == EPI_ENCLSTM || EPI == EPI_COPYGATE || EPI == EPI_COPYGATE1);   // rows visited through P.perm
     int Meff = P.M;
     if (EPI == EPI_COPYGATE || EPI == EPI_COPYGATE1) {
-        if (P.alive_prev && *P.alive_prev == 0) return;
         if (P.n_rows) { const int nr = *P.n_rows; Meff = nr < P.M ? nr : P.M; }
         if (m0 >= Meff) return;
     }

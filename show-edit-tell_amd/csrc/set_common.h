@@ -92,7 +92,10 @@ int gemm_tile_m(int M);   // BM the launcher will pick for M rows
 // the device, by every kernel of a timestep:
 //   alive_prev   *alive_prev == 0: every row had finished after the previous timestep — the reference has left its loop
 //                (`if unfinished.sum() == 0: break`); the kernel returns at once.  Outputs are unchanged (nothing was
-//                written after the break before either); always on in the fused loops.
+//                written after the break before either); always on in the fused loops, for the kernels that carry a
+//                timestep's time (the three grouped GEMM launches, which get the pointer as a preloaded scalar argument,
+//                and the attention launch); the short pointwise / pick kernels skip the test (a dependent load at their
+//                top costs more than they do after the break).
 //   unfinished / rowmap / n_rows   opt-in (set_decode_options): rows whose caption has ended are not computed any more.
 //                Row-per-workgroup kernels skip rows with unfinished[row] == 0; the grouped GEMMs run over the compacted
 //                list rowmap[0 .. *n_rows) of unfinished rows (activation rows gathered, output rows scattered through

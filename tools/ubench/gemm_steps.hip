@@ -11,6 +11,7 @@ using namespace set;
 // would register a second copy of the same kernel symbols and the runtime may launch the library's instead of this build's)
 namespace set {
 thread_local int g_last_hip_error = 0;
+thread_local RowGate g_row_gate;
 int env_int(const char* name, int dflt) { const char* v = getenv(name); return (v && *v) ? atoi(v) : dflt; }
 ProfScope::ProfScope(const char*, hipStream_t s, double, double) : idx(-1), st(s) {}
 ProfScope::~ProfScope() {}
