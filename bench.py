@@ -471,7 +471,10 @@ def main():
         "stream_probe_decode_steps_per_sec": stream_probe,
         "repeat": {"windows": len(rates), "steps_per_window": args.steps, "median": round(_median(rates), 2),
                    "min": round(rates[0], 2), "max": round(rates[-1], 2), "timed_region_s": round(elapsed, 4),
-                   "value_is": "median window" if first_elapsed < 0.5 else "first window"},
+                   "value_is": "median window" if first_elapsed < 0.5 else "first window",
+                   # rounds 1-2 reported the FIRST window; kept as a named field so that round-over-round comparisons stay
+                   # like for like
+                   "first_window": round(total_steps / first_elapsed, 2)},
         # SURVEY.md 8d's own bound: 16.88 GFLOP per B=128 timestep against the 157.3 TFLOP/s fp32-MFMA peak (107 us)
         "end_to_end_frac": round(SURVEY_GFLOP_PER_TIMESTEP * 1e9 * (total_steps / elapsed) / n_gpus / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
         "single_stream_end_to_end_frac": None if single is None else round(

@@ -487,8 +487,7 @@ int gemm_gen_group(const SetGemmDesc* d, int n, int a_kminor, int b_kminor, void
         }
     }
     // SET_GEN_COMBINE=1 (experiment): split products are combined inside the launch by each tile's last workgroup instead of
-    // by slab_reduce_k.  The arrival counters live in the last GEN_COUNTER_BYTES of the scratch, which the caller must hand
-    // over ZEROED once (they are left zero by every launch).
+    // by slab_reduce_k.  The arrival counters live in the last GEN_COUNTER_BYTES of the scratch.
     static const int combine = env_int("SET_GEN_COMBINE", 0);
     constexpr size_t GEN_COUNTER_BYTES = 64 << 10;
     unsigned* counters = nullptr;
@@ -496,6 +495,9 @@ int gemm_gen_group(const SetGemmDesc* d, int n, int a_kminor, int b_kminor, void
     if (combine && ws && ws_bytes > 4 * GEN_COUNTER_BYTES) {
         ws_bytes -= GEN_COUNTER_BYTES;
         counters = reinterpret_cast<unsigned*>((char*)ws + ws_bytes);
+        // the arrival counters are cleared on the launch stream before EVERY launch (one 64 KB fill): the scratch is the
+        // caller's — it may hold anything, and a launch that was aborted would leave counts behind
+        SET_HIP_TRY(hipMemsetAsync(counters, 0, GEN_COUNTER_BYTES, s));
     }
     size_t ws_off = 0;
     int wg = 0, red_blocks = 0;

@@ -60,6 +60,7 @@ class FlatGradBuckets:
     def __init__(self, params, bucket_bytes, first=()):
         first_ids = {id(p) for p in first}
         order = [p for p in params if id(p) in first_ids] + [p for p in params if id(p) not in first_ids]
+        n_first = sum(1 for p in params if id(p) in first_ids)       # (`first` parameters that are frozen / absent do not count)
         assert order and all(p.dtype == torch.float32 for p in order)
         self.params = order
         self.sig = tuple((id(p), p.numel(), p.device) for p in params)
@@ -67,7 +68,7 @@ class FlatGradBuckets:
         plan, cur, cur_n, cap = [], [], 0, max(1, bucket_bytes // 4)
         for i, p in enumerate(order):
             n = -(-p.numel() // self.ALIGN) * self.ALIGN
-            boundary = cur and (cur_n + n > cap or (first_ids and i == len(first_ids)))
+            boundary = cur and (cur_n + n > cap or (n_first and i == n_first))
             if boundary:
                 plan.append((cur, cur_n))
                 cur, cur_n = [], 0
@@ -87,8 +88,32 @@ class FlatGradBuckets:
     def attach(self):
         for f in self.flat:
             f.zero_()
+        self.touched = set()
+        if not getattr(self, "_hooked", False):
+            # gradients produced by plain autograd accumulation (not announced through deferred_param_grads) are seen here
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(lambda t, _self=self: _self.touched.add(id(t)))
+            self._hooked = True
         for p in self.params:
             p.grad = self.view[id(p)]
+
+    def touch(self, grad):
+        """the backward announces a parameter whose gradient it wrote (BucketedAllReduce.add)"""
+        pid = self.by_ptr.get(grad.data_ptr())
+        if pid is not None:
+            self.touched.add(pid)
+
+    def release_untouched(self):
+        """A parameter that took no part in this step's graph keeps `.grad = None` in the single-rank path, and
+        torch.optim.Adam / the fused clip + Adam skip it (no step count, no momentum-only or weight-decay update).  Its flat
+        view here is all zeros — needed so that every rank reduces the same buckets —, so once the exchange is done the view
+        is detached again: both paths treat the parameter alike.  (The set is a property of the graph, equal on all ranks.)"""
+        n = 0
+        for p in self.params:
+            if id(p) not in self.touched:
+                p.grad = None
+                n += 1
+        return n
 
 
 def flat_grad_buckets(module, params, bucket_bytes=None, first=()):
@@ -129,7 +154,7 @@ class BucketedAllReduce:
             self.launched = [False] * len(self.flat.flat)
             self.strays = []
 
-    def add(self, grad, flush=False):
+    def add(self, grad, flush=False, from_backward=True):
         """queue one final gradient tensor (each tensor once); flush: start the (partial) bucket's collective now — used
         for gradients that are final long before the rest (fc in the sequence nodes: its all-reduce then runs underneath
         the back-propagation through time)"""
@@ -137,6 +162,8 @@ class BucketedAllReduce:
             return
         self.seen.add(id(grad))
         if self.flat is not None:
+            if from_backward:
+                self.flat.touch(grad)            # (the final sweep of allreduce_gradients announces nothing)
             pid = self.flat.by_ptr.get(grad.data_ptr())
             if pid is None:                  # a gradient that does not live in its view (replaced by the caller): pack it the old way
                 self.strays.append(grad)
@@ -203,8 +230,11 @@ def allreduce_gradients(params, group=None, bucket_bytes=None, reducer=None):
     that already received some gradients during backward, only the remaining ones are added."""
     r = reducer if reducer is not None else BucketedAllReduce(group, bucket_bytes)
     for p in params:
-        r.add(p.grad)
-    return r.finish()
+        r.add(p.grad, from_backward=False)
+    n = r.finish()
+    if r.flat is not None:
+        r.flat.release_untouched()       # parameters outside this step's graph: `.grad = None`, as on a single rank
+    return n
 
 
 # A process group of ONE rank needs no exchange and the collectives are skipped.  Setting this to 1 makes a one-rank group
@@ -286,6 +316,18 @@ def xe_backward(decoder, image_features, caps, caplens, previous_caption, prev_c
     return (_global_loss(loss_sum, n_glob, group) if grp_on else float(loss_sum.detach()) / max(n_glob, 1)), n_tok, reducer
 
 
+def _refuse_non_finite(loss):
+    """The token cross-entropy kernel marks a target id outside [0, V) with a NaN row loss (csrc/loss.hip) and the fused
+    clip + Adam deliberately lets a NaN norm through (as torch.clamp(max=1) does): one corrupted caption would turn every
+    weight and Adam moment NaN for good.  The reference's F.cross_entropy raises before any update (editnet.py:577); so does
+    the train step here, at the host read of the loss that it makes anyway — before the optimizer runs.  (The loss is the
+    GLOBAL mean: every rank raises together.)"""
+    import math
+    if not math.isfinite(loss):
+        raise _lib.SetError("non-finite XE loss (%r): NaN scores, or a target id outside [0, V) (csrc/loss.hip poisons that row); "
+                            "no optimizer step was taken" % (loss,))
+
+
 def xe_train_step(decoder, optimizer, image_features, caps, caplens, previous_caption, prev_caplen, use_ss=False,
                   ss_prob=0.0, group=None, reduce=True, caplens_host=None):
     """One step of editnet.py:558-581 on this rank's shard.  Returns (GLOBAL mean loss — identical on every
@@ -293,6 +335,7 @@ def xe_train_step(decoder, optimizer, image_features, caps, caplens, previous_ca
     decoder.train()
     loss, n_tok, _ = xe_backward(decoder, image_features, caps, caplens, previous_caption, prev_caplen, use_ss, ss_prob,
                                  group, reduce, caplens_host)
+    _refuse_non_finite(loss)
     params = [p for p in decoder.parameters() if p.requires_grad]
     clip_grad_norm_and_step(params, optimizer, GRAD_CLIP)
     return loss, n_tok
@@ -322,6 +365,7 @@ def dcnet_xe_train_step(dae, optimizer, caps, caplens, previous_caption, prev_ca
     all-reduce as `xe_train_step`.  Returns (GLOBAL mean loss, local tokens)."""
     dae.train()
     loss, n_tok, _ = dcnet_xe_backward(dae, caps, caplens, previous_caption, prev_caplen, group, reduce, caplens_host)
+    _refuse_non_finite(loss)
     params = [p for p in dae.parameters() if p.requires_grad]
     clip_grad_norm_and_step(params, optimizer, GRAD_CLIP)
     return loss, n_tok

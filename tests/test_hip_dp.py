@@ -226,3 +226,42 @@ def test_bench_gpus_eight_ranks_one_device_gloo():
     tr = line["train"]
     assert tr["n_gpus"] == 8 and len(tr["ranks_seen"]) == 8
     assert sorted(r["rank"] for r in tr["ranks_seen"]) == list(range(8))
+
+
+def test_flat_buckets_leave_unused_parameters_without_gradient():
+    """with the persistent flat buckets every parameter's `.grad` is a zeroed view, so a parameter that takes no
+    part in a step would look "updated with zeros" to the optimizer (Adam step count, momentum-only / weight-decay update)
+    while the single-rank path leaves `.grad = None` and torch.optim.Adam skips it.  After the exchange the views of such
+    parameters are detached again; and a `first` parameter that is not trainable does not shift the first bucket's boundary."""
+    import torch.distributed as dist
+    from show_edit_tell_amd import train
+    from show_edit_tell_amd.train import BucketedAllReduce, FlatGradBuckets, allreduce_gradients
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(29400 + (os.getpid() % 200))
+    dist.init_process_group("gloo", rank=0, world_size=1)                    # a one-rank group makes the exchange path live
+    old_min, train.MIN_WORLD_FOR_EXCHANGE = train.MIN_WORLD_FOR_EXCHANGE, 1
+    try:
+        _flat_bucket_body(train, BucketedAllReduce, FlatGradBuckets, allreduce_gradients)
+    finally:
+        train.MIN_WORLD_FOR_EXCHANGE = old_min
+        dist.destroy_process_group()
+
+
+def _flat_bucket_body(train, BucketedAllReduce, FlatGradBuckets, allreduce_gradients):
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    a, b, c = (torch.nn.Linear(64, 64).to(dev) for _ in range(3))
+    frozen = torch.nn.Parameter(torch.zeros(8, device=dev), requires_grad=False)
+    params = [p for m in (a, b, c) for p in m.parameters()]
+    fb = FlatGradBuckets(params, 1 << 20, first=(c.weight, frozen))         # `frozen` is not among the parameters
+    assert fb.members[0] == 1 and sum(fb.members) == len(params)
+    fb.attach()
+    x = torch.randn(5, 64, device=dev)
+    c(a(x)).sum().backward()                                                 # b is not part of this step's graph
+    red = BucketedAllReduce(None, enabled=True, flat=fb)
+    allreduce_gradients(params, reducer=red)
+    assert b.weight.grad is None and b.bias.grad is None
+    assert a.weight.grad is not None and c.bias.grad is not None and float(a.weight.grad.abs().sum()) > 0
+    assert a.weight.grad.data_ptr() == fb.view[id(a.weight)].data_ptr()
+    fb.attach()                                                              # the next step starts from views again
+    assert b.weight.grad is not None and not b.weight.grad.any()
