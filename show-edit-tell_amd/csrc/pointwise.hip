@@ -129,13 +129,22 @@ __global__ void __launch_bounds__(256) lstm_pointwise_k(Slabs g0, Slabs g1, Slab
     }
 }
 
+// Threads per workgroup of the row-major pointwise kernels.  A handful of rows (BASELINE.json configs[0]: 4) is one or two
+// thousand threads: as 256-thread workgroups that is 4-8 workgroups, each pulling its slabs through ONE CU (~25-40 GB/s)
+// — 10 us for 1.5 MB of slab reads.  64-thread workgroups spread the same threads over 4x as many CUs.
+static int pointwise_block(long long n_threads) {
+    static const int small = env_int("SET_POINTWISE_SMALL_BLOCKS", 1);
+    return (small && n_threads <= 16384) ? 64 : 256;
+}
+
 int lstm_pointwise(Slabs g0, Slabs g1, Slabs g2, const float* pre, long long ldpre, const float* b0,
                    const float* b1, const float* c_in, float* c_out, float* h_out, float* ogate_out, int M,
                    int D, hipStream_t s, RowGather gt, float* gates_out) {
     if (D & 3) return SET_ERR_UNSUPPORTED;
     const long long n = (long long)M * (D >> 2);
     ProfScope ps("lstm_pointwise", s, 0.0, 4.0 * M * D * (4.0 * (g0.n + g1.n + g2.n + (pre ? 1 : 0)) + 3.0));
-    hipLaunchKernelGGL(lstm_pointwise_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g0, g1, g2, pre,
+    const int blk = pointwise_block(n);
+    hipLaunchKernelGGL(lstm_pointwise_k, dim3((unsigned)((n + blk - 1) / blk)), dim3(blk), 0, s, g0, g1, g2, pre,
                        ldpre, b0, b1, c_in, c_out, h_out, ogate_out, M, D, gt, gates_out, g_row_gate);
     SET_LAUNCH_CHECK();
     return SET_OK;
@@ -222,7 +231,8 @@ int copy_gate_pointwise(Slabs gn, const float* bn, Slabs gm, const float* bm, co
     if (D & 3) return SET_ERR_UNSUPPORTED;
     const long long n = (long long)M * (D >> 2);
     ProfScope ps("copy_gate", s, 0.0, 4.0 * M * D * (gn.n + gm.n + 5.0));
-    hipLaunchKernelGGL(copy_gate_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gn, bn, gm, bm, c_new,
+    const int blk = pointwise_block(n);
+    hipLaunchKernelGGL(copy_gate_k, dim3((unsigned)((n + blk - 1) / blk)), dim3(blk), 0, s, gn, bn, gm, bm, c_new,
                        sel, ogate, c_out, h_out, M, D, cg_out, g_row_gate);
     SET_LAUNCH_CHECK();
     return SET_OK;

@@ -31,11 +31,16 @@ class DecoderC(_DecoderXE):
     skip_finished_rows = False
 
     def forward(self, word_map, encoded_previous_captions, previous_cap_length, image_features, sample_max=True,
-                sample_rl=False, image_mean=None):
+                sample_rl=False, image_mean=None, repeat_images=1):
+        """repeat_images = n (an extension for BASELINE.json configs[4], n sampled rollouts per image): `image_features`
+        holds B images while the captions hold n * B rows, sample-major (row s * B + b belongs to image b)."""
         _require_cuda(image_features, "image features")
         if (self.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))):
             return self._rollout_autograd(word_map, encoded_previous_captions, previous_cap_length, image_features,
-                                          sample_max, sample_rl, image_mean)
+                                          sample_max, sample_rl, image_mean, repeat_images)
+        if repeat_images > 1:
+            image_features = image_features.repeat(repeat_images, 1, 1)
+            image_mean = None if image_mean is None else image_mean.repeat(repeat_images, 1)
         lib = _lib.load()
         lib.set_decode_options(1 if self.skip_finished_rows else -1)
         dev = image_features.device
@@ -191,7 +196,7 @@ class DecoderC(_DecoderXE):
         return None
 
     def _rollout_autograd(self, word_map, encoded_previous_captions, previous_cap_length, image_features, sample_max,
-                          sample_rl, image_mean=None):
+                          sample_rl, image_mean=None, repeat_images=1):
         """The reference loop editnet_rl.py:485-549 over autograd-wrapped HIP operators: used for the
         sampled SCST rollout (train mode, dropout active, gradients flow through seqLogprobs) and for
         the grad-enabled greedy decode.  Sampling runs in the HIP epilogue `set_sample_pick_f32` (Philox draw,
@@ -206,7 +211,9 @@ class DecoderC(_DecoderXE):
         training = self.training
         p_emb, p_reg, p_out = self.embed.dropout.p, self.visual_attention.att_embed[2].p, self.dropout.p
         dev = image_features.device
-        X = _f32c(image_features)
+        X1 = _f32c(image_features)                       # one row per IMAGE
+        rep = (lambda t: t) if repeat_images <= 1 else (lambda t: t.repeat(repeat_images, *([1] * (t.dim() - 1))))
+        X = rep(X1)                                      # one row per ROLLOUT (the region stream of the visual attention)
         B, max_len = X.shape[0], self.max_len
         seq = torch.zeros(B, max_len, dtype=torch.long, device=dev)
         logps = []
@@ -214,12 +221,13 @@ class DecoderC(_DecoderXE):
         h1, c1 = self.init_hidden_state(B)
         h2, c2 = self.init_hidden_state(B)
         H, M, final_hidden, mask = self._encoder_autograd(encoded_previous_captions, previous_cap_length, seed)
-        mean = X.mean(1) if image_mean is None else image_mean
+        mean = rep(X1.mean(1) if image_mean is None else image_mean)
         ca, va, cl, al = self.caption_attention, self.visual_attention, self.copy_lstm, self.attention_lstm
         E = self.embed.embedding.weight
         att1_c_all = A.linear(H, ca.cap_features_att.weight, ca.cap_features_att.bias)
-        # relu(att_embed.0(X)) is loop invariant (only its dropout mask is per step): contracted once, see editnet.py
-        Y = A.linear(X, va.att_embed[0].weight, va.att_embed[0].bias, _lib.ACT_RELU)
+        # relu(att_embed.0(X)) is loop invariant (only its dropout mask is per step): contracted once, see editnet.py — and
+        # once per IMAGE: the rows of the n rollouts of an image are copies (autograd sums their gradients back)
+        Y = rep(A.linear(X1, va.att_embed[0].weight, va.att_embed[0].bias, _lib.ACT_RELU))
         att1_eval = None
         if not self.training:
             att1_eval = A.linear(Y, va.features_att.weight, va.features_att.bias)

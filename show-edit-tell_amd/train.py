@@ -420,9 +420,13 @@ def _scst_step(model, optimizer, greedy_fn, sample_fn, rep, ground_truth, scorer
         if side is not None:
             cur.wait_stream(side)
             greedy.record_stream(cur)
-        rewards = ciderd.self_critical_reward(scorer, seq, rep(greedy), list(ground_truth) * n_samples, cider_weight)
-        num, cnt = reward_loss_sum(logp, seq, torch.from_numpy(rewards).to(dev))
-        n_glob = global_token_count(int(cnt.item()), dev, group)
+        # ONE device->host copy of the sampled ids serves the scorer AND the mask count of RewardCriterion (the shifted
+        # `seq > 0` of editnet_rl.py:563-566 summed): no second round trip (`cnt.item()`) between the rollout and the backward
+        seq_host = seq.cpu().numpy()
+        rewards = ciderd.self_critical_reward(scorer, seq_host, rep(greedy), list(ground_truth) * n_samples, cider_weight)
+        num, _ = reward_loss_sum(logp, seq, torch.from_numpy(rewards).to(dev, non_blocking=True))
+        n_mask = int(seq_host.shape[0] + (seq_host[:, :-1] > 0).sum())
+        n_glob = global_token_count(n_mask, dev, group)
         loss = num / n_glob
         loss.backward()
     reward_mean, loss_val = float(rewards[:, 0].mean()), _global_loss(num, n_glob, group)
@@ -448,8 +452,11 @@ def scst_train_step(decoder, optimizer, word_map, image_features, previous_capti
     return _scst_step(
         decoder, optimizer,
         lambda: decoder(word_map, previous_caption, prev_caplen, image_features, sample_max=True, sample_rl=False),
-        lambda: decoder(word_map, rep(previous_caption), rep(prev_caplen), rep(image_features), sample_max=False,
-                        sample_rl=True),
+        # (the image features go in ONCE with the repeat count: relu(att_embed(X)) has no dropout before it, so it is
+        # contracted for the B images and its rows repeated — not for n_samples * B copies of the same regions, forward and
+        # weight gradient alike; the rollout's region stream still gets its own row per sample)
+        lambda: decoder(word_map, rep(previous_caption), rep(prev_caplen), image_features, sample_max=False,
+                        sample_rl=True, repeat_images=n_samples),
         rep, ground_truth, scorer, n_samples, cider_weight, image_features.device, group)
 
 

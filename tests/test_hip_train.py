@@ -230,6 +230,55 @@ def test_scst_full_size_five_samples():
     assert all(torch.isfinite(p).all() for p in rl.parameters())
 
 
+def test_rollout_with_image_repeat_equals_explicitly_repeated_features():
+    """configs[4]: n sampled rollouts per image.  `repeat_images=n` hands the decoder the B images once — the region
+    embedding relu(att_embed(X)) and its weight gradient are contracted for B images, the rows repeated — and must give the
+    rollout (same Philox streams: same words) and the gradients of the explicit n-fold copy of the features."""
+    from show_edit_tell_amd import rng
+    d, xe, rl = editnet_modules("editnet_full_b4")
+    wm = d["wm"]
+    prev, plen, X = to_dev(d["prev"]), to_dev(d["plen"]), to_dev(d["X"])
+    n = 3
+    rep = lambda t: t.repeat(n, *([1] * (t.dim() - 1)))
+    rl.train()
+    outs = []
+    for explicit in (True, False):
+        rl.zero_grad(set_to_none=True)
+        torch.manual_seed(21)
+        if explicit:
+            seq, logp = rl(wm, rep(prev), rep(plen), rep(X), sample_max=False, sample_rl=True)
+        else:
+            seq, logp = rl(wm, rep(prev), rep(plen), X, sample_max=False, sample_rl=True, repeat_images=n)
+        (logp * (seq > 0).float()).sum().backward()
+        outs.append((seq.clone(), logp.detach().clone(), {k: p.grad.detach().clone() for k, p in rl.named_parameters()
+                                                           if p.grad is not None}))
+    (s0, l0, g0), (s1, l1, g1) = outs
+    assert s0.shape[0] == n * X.shape[0]
+    # the region embedding is the only operand that is produced differently: the same numbers up to the summation order of
+    # another GEMM plan (64 x 36 rows instead of 192 x 36)
+    from show_edit_tell_amd import _lib, autograd_ops as A
+    va = rl.visual_attention
+    with torch.no_grad():
+        y1 = A.linear(X, va.att_embed[0].weight, va.att_embed[0].bias, _lib.ACT_RELU).repeat(n, 1, 1)
+        y2 = A.linear(rep(X), va.att_embed[0].weight, va.att_embed[0].bias, _lib.ACT_RELU)
+    assert float((y1 - y2).abs().max()) < 1e-5
+    # a multinomial draw is a step function of the scores: a 1e-6 difference may move one draw across a CDF boundary, and
+    # that row's trajectory then differs from there on.  All other rows: same words, same log-probs
+    same = (s0 == s1).all(1)
+    assert int((~same).sum()) <= 1, "rollouts differ in %d of %d rows" % (int((~same).sum()), s0.shape[0])
+    assert float((l0 - l1)[same].abs().max()) < 2e-5
+    assert set(g0) == set(g1)
+    if bool(same.all()):
+        for k in g0:
+            scale = float(g0[k].abs().max()) + 1e-12
+            assert float((g0[k] - g1[k]).abs().max()) <= 2e-4 * scale + 1e-7, k
+    else:
+        # (one trajectory differs: its gradient contribution differs too; the weight gradient of the region embedding
+        # still has to be a gradient of the same size)
+        k = "visual_attention.att_embed.0.weight"
+        assert 0.5 < float(g1[k].norm() / g0[k].norm()) < 2.0
+
+
 @pytest.mark.parametrize("seq", [True, False], ids=["sequence-node", "per-operator"])
 def test_adaptive_xe_gradients_vs_reference_autograd(seq, monkeypatch):
     """Adaptive features (10-100 zero-padded regions): gradients of CE + MSE(decoder_last_hidden, gd_final_hidden)
