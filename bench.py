@@ -57,6 +57,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md: v_mfma_f32_32x32x
 PEAK_HBM_GBS = 8000.0
 TRAIN_TFLOP_PER_STEP = 1.23             # contractions of one B=128 XE training step as executed
 SURVEY_GFLOP_PER_TIMESTEP = 16.88       # SURVEY.md 8d, B = 128, eval mode, loop invariants hoisted
+EXECUTED_GFLOP_PER_DECODE = 281.0       # contractions one B = 128 greedy decode executes here (token table active), DESIGN.md 3
 PMC_FILES = ("r03_pmc_bench_traffic.json", "r02_pmc_bench_traffic.json", "r01_pmc_bench_traffic.json")
 
 
@@ -477,6 +478,11 @@ def main():
                    "first_window": round(total_steps / first_elapsed, 2)},
         # SURVEY.md 8d's own bound: 16.88 GFLOP per B=128 timestep against the 157.3 TFLOP/s fp32-MFMA peak (107 us)
         "end_to_end_frac": round(SURVEY_GFLOP_PER_TIMESTEP * 1e9 * (total_steps / elapsed) / n_gpus / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+        # the same with the FLOPs the path actually EXECUTES per decode (207.9 GFLOP of step GEMMs with the token
+        # table, 46.5 prologue GEMMs, 21.5 encoder recurrence, 5.1 copy gate = 281 GFLOP; SURVEY's 16.88 x 19 = 320.7 counts
+        # 5.6 GFLOP per timestep that hoisting removed) / time / peak
+        "executed_frac": round(EXECUTED_GFLOP_PER_DECODE * 1e9 * (total_steps / STEPS_PER_DECODE / elapsed) / n_gpus
+                               / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
         "single_stream_end_to_end_frac": None if single is None else round(
             SURVEY_GFLOP_PER_TIMESTEP * 1e9 * (args.steps * STEPS_PER_DECODE / single) / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
         "config": {"workload": "EditNet greedy decode (editnet_rl.py:485-549): prologue + 19 timesteps per bench step",
