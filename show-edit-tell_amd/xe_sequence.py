@@ -24,6 +24,7 @@ adaptive features (region masks + `decoder_last_hidden`), free-running sampled r
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -121,6 +122,7 @@ class _Ops:
                                       M, N, K, _lib.ACT_NONE, ws.data_ptr(), ws.numel(), self.st), "set_linear_f32")
 
 
+_DEMB_HOIST = os.environ.get("SET_DEMB_HOIST", "1") != "0"     # time-batched d emb products of the backward (round 4)
 _ATT1_HOIST_LIVE = 0.75     # all-timestep region projection when at least this fraction of the (t, b) rows is live
 # Overlapped weight gradients (round 3): the time-batched dW contractions (0.4 TFLOP, the chip's full width) only become
 # possible when the back-propagation through time has produced the gradient logs — but the BPTT loop itself is a chain of
@@ -516,8 +518,11 @@ class _XESequence(torch.autograd.Function):
                                                   L["TT"][t].data_ptr(), dszt[:, D:].data_ptr(), dszt.data_ptr(),
                                                   dszt[:, 2 * D:].data_ptr(), 3 * D, bt, D, st), "set_context_gate_bwd_ld_f32")
             dctx = DCTX[t]
-            gg([(r(dszt)[:, :2 * D], w_ctx, r(dctx), False), (r(dszt)[:, D:], w_word, r(demb), False),
-                (r(dszt)[:, D:], w_h1, r(DH1), True)])
+            if _DEMB_HOIST:                # (d emb feeds no recurrence: its two products run once over all timesteps below)
+                gg([(r(dszt)[:, :2 * D], w_ctx, r(dctx), False), (r(dszt)[:, D:], w_h1, r(DH1), True)])
+            else:
+                gg([(r(dszt)[:, :2 * D], w_ctx, r(dctx), False), (r(dszt)[:, D:], w_word, r(demb), False),
+                    (r(dszt)[:, D:], w_h1, r(DH1), True)])
             check(lib.set_attention_bwd_acc_f32(dctx.data_ptr(), dalc.data_ptr(), L["ALPHAC"][t].data_ptr(), H.data_ptr(),
                                                 att1_c.data_ptr(), L["ATT2C"][t].data_ptr(), ca_full.data_ptr(), datt1c.data_ptr(),
                                                 DATT2[t][:, Adim:].data_ptr(), DWFC[t].data_ptr(), None, DEC[t].data_ptr(), bt, Tc,
@@ -530,9 +535,12 @@ class _XESequence(torch.autograd.Function):
                   "set_lstm_cell_bwd_f32")
             dg1 = r(DG1[t])
             # (the final_hidden / image_mean columns are loop-invariant: their gradients come from sum_t dgates below)
-            gg([(dg1, wih[:, :D], r(demb), True), (dg1, wih[:, 2 * D:3 * D], r(DH2), True), (dg1, P["al_whh"], r(DH1), False)])
-            # ---- embedding: dropout + ReLU backward; the table rows are scattered once after the loop
-            ops.dropout_bwd(demb, L["EMB"][t], DEMBRAW[t], bt, D, sc_emb, False)
+            if _DEMB_HOIST:
+                gg([(dg1, wih[:, 2 * D:3 * D], r(DH2), True), (dg1, P["al_whh"], r(DH1), False)])
+            else:
+                gg([(dg1, wih[:, :D], r(demb), True), (dg1, wih[:, 2 * D:3 * D], r(DH2), True), (dg1, P["al_whh"], r(DH1), False)])
+                # ---- embedding: dropout + ReLU backward; the table rows are scattered once after the loop
+                ops.dropout_bwd(demb, L["EMB"][t], DEMBRAW[t], bt, D, sc_emb, False)
             if mid and t == mid and all(A._is_leaf_param(params[i]) for i in range(len(params)) if need[i]):
                 early = launch_early()
 
@@ -543,6 +551,15 @@ class _XESequence(torch.autograd.Function):
             for t in range(T):
                 ops.dropout_bwd(DFE[t], L["FE"][t].view(B * R, D), dYin.view(B * R, D), bts[t] * R, D, sc_reg, True)
             del DFE
+        if _DEMB_HOIST:
+            # d emb[t] = [dz | dt](t) . [gate_w[:, :D]; tc_w[:, :D]] + dgates1(t) . W_ih[:, :D] is consumed by nothing inside the
+            # loop (the word fed at t + 1 is data, not a function of emb[t]): two products over all T * B rows (rows of finished
+            # sequences are zero in DSZT / DG1) instead of 2 x T products of 128 rows on the critical chain, and ONE dropout +
+            # ReLU backward over the logs
+            DEMB = A.gemm(DSZT.view(T * B, 3 * D)[:, D:], False, w_word, True, T * B, D, 2 * D)
+            A.gemm(DG1.view(T * B, 4 * D), False, wih[:, :D], True, T * B, D, 4 * D, out=DEMB, accumulate=True)
+            ops.dropout_bwd(DEMB, L["EMB"].view(T * B, D), DEMBRAW.view(T * B, D), T * B, D, sc_emb, False)
+            del DEMB
         dH = _dvalues(L["ALPHAC"], DCTX, ops)
         # loop-invariant inputs of the attention LSTM: d final_hidden = (sum_t dgates) . W_ih[:, D:2D]
         sdg1 = DG1.sum(0)
