@@ -309,6 +309,229 @@ __global__ void __launch_bounds__(256 * KG) gemm_nt_f32(const int ntasks, const 
 #undef SET_LSTORE
 
 // ---------------------------------------------------------------------------------------------
+// Round 4: gemm_nt_f32<64,64,2,2> with the pipelined k-loop written by hand (`gemm_nt_f32_asm`, SET_GEMM_ASM).
+//
+// Same tile, same LDS image (XOR-swizzled 128-byte rows), same K permutation, same MFMA order per accumulator — the
+// results are BIT-IDENTICAL to the default kernel — and the same task descriptors, split-K slabs and epilogue.  What the
+// hand-written loop controls and the compiler-scheduled one does not (EXPERIMENTS.md 4.2):
+//   * the waits: a register stage is waited for with `s_waitcnt vmcnt(4)` — exactly "all but the four requests of the
+//     younger stage" — so the prefetch distance is two k-tiles in EVERY round (the compiler's placement merges request
+//     queues at the loop head and waits for vmcnt(0) in every second round: one k-tile);
+//   * no loop-carried copies, no address arithmetic on the vector ALU beyond four 32-bit offset increments per k-tile
+//     (operands are addressed as scalar base + 32-bit lane offset);
+//   * requests past the end of the slice are not issued at all (scalar branches on the number of k-tiles left), so
+//     nothing is in flight when the loop ends.
+// The loop lives in ONE asm statement (prologue included): a compiler-visible loop around asm blocks would get loop-carried
+// phi copies of registers whose loads are still in flight.  Registers v48-v95 are the loop's own (two register stages of
+// four 16-byte pieces, four fragment quads); everything else is an operand.  Restriction (checked by the launcher, which
+// otherwise takes the default kernel): every workgroup's K slice lies inside ONE (activation, weight) segment.
+// ---------------------------------------------------------------------------------------------
+#define ASM_HALF_ROUND(BUF, NBUF, SA0, SA1, SW0, SW1, LBL)                                                        \
+    /* fragments of k-blocks 0 and 1 of the tile in buffer BUF */                                                 \
+    "ds_read_b128 v[80:83], %[rdA0] offset:" BUF "\n"                                                             \
+    "ds_read_b128 v[84:87], %[rdW0] offset:" BUF "\n"                                                             \
+    "ds_read_b128 v[88:91], %[rdA1] offset:" BUF "\n"                                                             \
+    "ds_read_b128 v[92:95], %[rdW1] offset:" BUF "\n"                                                             \
+    "s_waitcnt lgkmcnt(2)\n"                                                                                      \
+    "v_mfma_f32_32x32x2_f32 %[acc], v80, v84, %[acc]\n"                                                           \
+    "v_mfma_f32_32x32x2_f32 %[acc], v81, v85, %[acc]\n"                                                           \
+    "v_mfma_f32_32x32x2_f32 %[acc], v82, v86, %[acc]\n"                                                           \
+    "v_mfma_f32_32x32x2_f32 %[acc], v83, v87, %[acc]\n"                                                           \
+    /* tile kt+1 (if any): its register stage -> the other LDS buffer; the younger stage (tile kt+2) may still fly */ \
+    "s_cmp_lt_i32 %[rem], 2\n"                                                                                    \
+    "s_cbranch_scc1 " LBL "_nostore%=\n"                                                                          \
+    "s_cmp_gt_i32 %[rem], 2\n"                                                                                    \
+    "s_cbranch_scc1 " LBL "_w4%=\n"                                                                               \
+    "s_waitcnt vmcnt(0)\n"                                                                                        \
+    "s_branch " LBL "_wd%=\n"                                                                                     \
+    LBL "_w4%=:\n"                                                                                                \
+    "s_waitcnt vmcnt(4)\n"                                                                                        \
+    LBL "_wd%=:\n"                                                                                                \
+    "ds_write_b128 %[wr], " SA0 " offset:" NBUF "\n"                                                              \
+    "ds_write_b128 %[wr], " SA1 " offset:" NBUF "+4096\n"                                                         \
+    "ds_write_b128 %[wr], " SW0 " offset:" NBUF "+8192\n"                                                         \
+    "ds_write_b128 %[wr], " SW1 " offset:" NBUF "+12288\n"                                                        \
+    /* tile kt+3 (if any) into the stage that has just been stored */                                             \
+    "s_cmp_lt_i32 %[rem], 4\n"                                                                                    \
+    "s_cbranch_scc1 " LBL "_nostore%=\n"                                                                          \
+    "global_load_dwordx4 " SA0 ", %[oA0], %[bA]\n"                                                                \
+    "global_load_dwordx4 " SA1 ", %[oA1], %[bA]\n"                                                                \
+    "global_load_dwordx4 " SW0 ", %[oW0], %[bW]\n"                                                                \
+    "global_load_dwordx4 " SW1 ", %[oW1], %[bW]\n"                                                                \
+    "v_add_u32 %[oA0], 128, %[oA0]\n"                                                                             \
+    "v_add_u32 %[oA1], 128, %[oA1]\n"                                                                             \
+    "v_add_u32 %[oW0], 128, %[oW0]\n"                                                                             \
+    "v_add_u32 %[oW1], 128, %[oW1]\n"                                                                             \
+    LBL "_nostore%=:\n"                                                                                           \
+    "ds_read_b128 v[80:83], %[rdA2] offset:" BUF "\n"                                                             \
+    "ds_read_b128 v[84:87], %[rdW2] offset:" BUF "\n"                                                             \
+    "s_waitcnt lgkmcnt(2)\n"                         /* (LDS operations retire in order: all but the two newest) */ \
+    "v_mfma_f32_32x32x2_f32 %[acc], v88, v92, %[acc]\n"                                                           \
+    "v_mfma_f32_32x32x2_f32 %[acc], v89, v93, %[acc]\n"                                                           \
+    "v_mfma_f32_32x32x2_f32 %[acc], v90, v94, %[acc]\n"                                                           \
+    "v_mfma_f32_32x32x2_f32 %[acc], v91, v95, %[acc]\n"                                                           \
+    "ds_read_b128 v[88:91], %[rdA3] offset:" BUF "\n"                                                             \
+    "ds_read_b128 v[92:95], %[rdW3] offset:" BUF "\n"                                                             \
+    "s_waitcnt lgkmcnt(2)\n"                                                                                      \
+    "v_mfma_f32_32x32x2_f32 %[acc], v80, v84, %[acc]\n"                                                           \
+    "v_mfma_f32_32x32x2_f32 %[acc], v81, v85, %[acc]\n"                                                           \
+    "v_mfma_f32_32x32x2_f32 %[acc], v82, v86, %[acc]\n"                                                           \
+    "v_mfma_f32_32x32x2_f32 %[acc], v83, v87, %[acc]\n"                                                           \
+    "s_waitcnt lgkmcnt(0)\n"                                                                                      \
+    "s_barrier\n"                                                                                                 \
+    "v_mfma_f32_32x32x2_f32 %[acc], v88, v92, %[acc]\n"                                                           \
+    "v_mfma_f32_32x32x2_f32 %[acc], v89, v93, %[acc]\n"                                                           \
+    "v_mfma_f32_32x32x2_f32 %[acc], v90, v94, %[acc]\n"                                                           \
+    "v_mfma_f32_32x32x2_f32 %[acc], v91, v95, %[acc]\n"
+
+template <int GATE>
+__global__ void __launch_bounds__(256) gemm_nt_f32_asm(const int ntasks, const int wb1, const int wb2, const int wb3,
+                                                       const int wb4, const int wb5, const int* const gate_alive,
+        const int* const gate_nrows, const GemmLaunch L) {
+    constexpr int BM = 64, BN = 64, TM = 1, TN = 1, KG = 1;
+    __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * LDS_STRIDE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, kg = 0;
+    const int wm = wave % 2, wn = wave / 2;
+    int ti = 0;
+    {
+        const int bid = (int)blockIdx.x;
+        if (1 < ntasks && bid >= wb1) ti = 1;
+        if (2 < ntasks && bid >= wb2) ti = 2;
+        if (3 < ntasks && bid >= wb3) ti = 3;
+        if (4 < ntasks && bid >= wb4) ti = 4;
+        if (5 < ntasks && bid >= wb5) ti = 5;
+    }
+    const GemmTask& T = L.t[ti];
+    const int local = (int)blockIdx.x - T.wg_begin;
+    const int tm = local / T.tm_stride;
+    const int rem0 = local - tm * T.tm_stride;
+    if (rem0 >= T.tiles_n * T.ksplit) return;          // padding slot
+    if constexpr (GATE >= 1) {
+        if (gate_alive && *gate_alive == 0) return;
+    }
+    (void)gate_nrows;
+    const int ks = rem0 % T.ksplit;
+    const int tn = rem0 / T.ksplit;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kt0 = (int)(((long long)ks * T.ktiles) / T.ksplit);
+    const int kt1 = (int)(((long long)(ks + 1) * T.ktiles) / T.ksplit);
+    const int epi_m = T.M;
+    auto epi_row = [](int row) { return row; };
+
+    // the slice's segment (the launcher guarantees [kt0, kt1) lies inside one)
+    int sg = 0, kbase = 0;
+#pragma unroll
+    for (int i = 0; i < GEMM_MAX_SEG - 1; ++i)
+        if (i + 1 < T.nseg && kt0 >= T.kt_end[i]) { sg = i + 1; kbase = T.kt_end[i]; }
+    const float* Ab = T.A[0];
+    const float* Wb = T.W[0];
+    long long lda = T.lda[0], ldw = T.ldw[0];
+#pragma unroll
+    for (int i = 1; i < GEMM_MAX_SEG; ++i)
+        if (sg == i) { Ab = T.A[i]; Wb = T.W[i]; lda = T.lda[i]; ldw = T.ldw[i]; }
+    Ab += (long long)(kt0 - kbase) * GEMM_BK;
+    Wb += (long long)(kt0 - kbase) * GEMM_BK;
+
+    // staging assignment (as gemm_nt_f32): thread -> rows tid/8 and tid/8 + 32, 16-byte column tid%8
+    const int srow = tid >> 3, scol = (tid & 7) * 4;
+    const int sswz = ((tid & 7) ^ ((srow >> 1) & 7)) * 4;
+    unsigned oA0, oA1, oW0, oW1;                  // byte offsets of this thread's pieces from the scalar bases
+    {
+        int r0 = m0 + srow, r1 = m0 + srow + 32;
+        r0 = r0 < T.M ? r0 : T.M - 1; r1 = r1 < T.M ? r1 : T.M - 1;
+        oA0 = (unsigned)((r0 * lda + scol) * 4); oA1 = (unsigned)((r1 * lda + scol) * 4);
+        int c0 = n0 + srow, c1 = n0 + srow + 32;
+        c0 = c0 < T.N ? c0 : T.N - 1; c1 = c1 < T.N ? c1 : T.N - 1;
+        oW0 = (unsigned)((c0 * ldw + scol) * 4); oW1 = (unsigned)((c1 * ldw + scol) * 4);
+    }
+    typedef __attribute__((address_space(3))) float* lds_fptr;
+    const unsigned lbase = (unsigned)(unsigned long long)(lds_fptr)&lds[0][0];
+    const unsigned wr = lbase + (unsigned)(srow * LDS_STRIDE + sswz) * 4u;
+    const int frow = lane & 31;
+    unsigned rdA[4], rdW[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const unsigned fo = (unsigned)((((kk * 2 + (lane >> 5)) ^ ((frow >> 1) & 7)) * 4));
+        rdA[kk] = lbase + ((unsigned)((wm * 32 + frow) * LDS_STRIDE) + fo) * 4u;
+        rdW[kk] = lbase + ((unsigned)((BM + wn * 32 + frow) * LDS_STRIDE) + fo) * 4u;
+    }
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.f;
+    int rem = kt1 - kt0;                           // k-tiles left, the current one included
+    if (rem > 0) {
+        asm volatile(
+            // ---- prologue: tile 0 -> stage 0 -> buffer 0; tile 1 -> stage 1; tile 2 -> stage 0
+            "global_load_dwordx4 v[48:51], %[oA0], %[bA]\n"
+            "global_load_dwordx4 v[52:55], %[oA1], %[bA]\n"
+            "global_load_dwordx4 v[56:59], %[oW0], %[bW]\n"
+            "global_load_dwordx4 v[60:63], %[oW1], %[bW]\n"
+            "v_add_u32 %[oA0], 128, %[oA0]\n"
+            "v_add_u32 %[oA1], 128, %[oA1]\n"
+            "v_add_u32 %[oW0], 128, %[oW0]\n"
+            "v_add_u32 %[oW1], 128, %[oW1]\n"
+            "s_cmp_lt_i32 %[rem], 2\n"
+            "s_cbranch_scc1 P_one%=\n"
+            "global_load_dwordx4 v[64:67], %[oA0], %[bA]\n"
+            "global_load_dwordx4 v[68:71], %[oA1], %[bA]\n"
+            "global_load_dwordx4 v[72:75], %[oW0], %[bW]\n"
+            "global_load_dwordx4 v[76:79], %[oW1], %[bW]\n"
+            "v_add_u32 %[oA0], 128, %[oA0]\n"
+            "v_add_u32 %[oA1], 128, %[oA1]\n"
+            "v_add_u32 %[oW0], 128, %[oW0]\n"
+            "v_add_u32 %[oW1], 128, %[oW1]\n"
+            "s_waitcnt vmcnt(4)\n"
+            "s_branch P_st%=\n"
+            "P_one%=:\n"
+            "s_waitcnt vmcnt(0)\n"
+            "P_st%=:\n"
+            "ds_write_b128 %[wr], v[48:51]\n"
+            "ds_write_b128 %[wr], v[52:55] offset:4096\n"
+            "ds_write_b128 %[wr], v[56:59] offset:8192\n"
+            "ds_write_b128 %[wr], v[60:63] offset:12288\n"
+            "s_cmp_lt_i32 %[rem], 3\n"
+            "s_cbranch_scc1 P_go%=\n"
+            "global_load_dwordx4 v[48:51], %[oA0], %[bA]\n"
+            "global_load_dwordx4 v[52:55], %[oA1], %[bA]\n"
+            "global_load_dwordx4 v[56:59], %[oW0], %[bW]\n"
+            "global_load_dwordx4 v[60:63], %[oW1], %[bW]\n"
+            "v_add_u32 %[oA0], 128, %[oA0]\n"
+            "v_add_u32 %[oA1], 128, %[oA1]\n"
+            "v_add_u32 %[oW0], 128, %[oW0]\n"
+            "v_add_u32 %[oW1], 128, %[oW1]\n"
+            "P_go%=:\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "s_barrier\n"
+            // ---- the loop: an even round on buffer 0 (stores stage 1), an odd round on buffer 1 (stores stage 0)
+            "L_top%=:\n"
+            ASM_HALF_ROUND("0", "16384", "v[64:67]", "v[68:71]", "v[72:75]", "v[76:79]", "A")
+            "s_sub_i32 %[rem], %[rem], 1\n"
+            "s_cmp_eq_u32 %[rem], 0\n"
+            "s_cbranch_scc1 L_end%=\n"
+            ASM_HALF_ROUND("16384", "0", "v[48:51]", "v[52:55]", "v[56:59]", "v[60:63]", "B")
+            "s_sub_i32 %[rem], %[rem], 1\n"
+            "s_cmp_eq_u32 %[rem], 0\n"
+            "s_cbranch_scc0 L_top%=\n"
+            "L_end%=:\n"
+            // the compiler does not know that this statement ends in MFMAs: a VALU read of the accumulator (the epilogue's
+            // v_accvgpr_read) needs 18+ wait states behind a 16-pass MFMA, which nothing else would insert
+            "s_nop 15\n"
+            "s_nop 7\n"
+            : [acc] "+a"(acc[0][0]), [oA0] "+v"(oA0), [oA1] "+v"(oA1), [oW0] "+v"(oW0), [oW1] "+v"(oW1), [rem] "+s"(rem)
+            : [rdA0] "v"(rdA[0]), [rdA1] "v"(rdA[1]), [rdA2] "v"(rdA[2]), [rdA3] "v"(rdA[3]),
+              [rdW0] "v"(rdW[0]), [rdW1] "v"(rdW[1]), [rdW2] "v"(rdW[2]), [rdW3] "v"(rdW[3]),
+              [wr] "v"(wr), [bA] "s"(Ab), [bW] "s"(Wb)
+            : "memory", "scc",
+              "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63",
+              "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",
+              "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
+    }
+#include "gemm_f32_epilogue.inc"
+}
+#undef ASM_HALF_ROUND
+
+// ---------------------------------------------------------------------------------------------
 // Round 4: the 64-row class with the WEIGHT operand taken off LDS (`gemm_nt_f32_wreg`, SET_GEMM_WREG).
 //
 // gemm_nt_f32<64,64,2,2> moves 3 LDS "operand words" per MFMA (each wave reads one A and one W value per lane and MFMA
@@ -1082,6 +1305,8 @@ int gemm_tile_m(int M) {
     return M <= bm16_upto ? 16 : (M <= bm32_upto ? 32 : (M <= bm64_upto ? 64 : 128));
 }
 static int gemm_dma() { static int v = env_int("SET_GEMM_DMA", 0); return v; }
+int g_gemm_asm_force = -1;         // tools/ubench: switch kernels inside one process (-1: the environment decides)
+static int gemm_asm() { static int v = env_int("SET_GEMM_ASM", 1); return g_gemm_asm_force >= 0 ? g_gemm_asm_force : v; }
 int g_gemm_wreg_force = -1;        // tools/ubench: switch kernels inside one process (-1: the environment decides)
 static int gemm_wreg() { static int v = env_int("SET_GEMM_WREG", 0); return g_gemm_wreg_force >= 0 ? g_gemm_wreg_force : v; }
 static int gemm_kgroups() { static int v = env_int("SET_GEMM_KGROUPS", 1); return v; }
@@ -1184,6 +1409,19 @@ void plan_ksplit(GemmProb* probs, int n, int cap_wgs) {
     }
 }
 
+// every K slice of every task lies inside one (activation, weight) segment (what gemm_nt_f32_asm needs)
+static bool slices_in_one_segment(const GemmLaunch& L) {
+    for (int i = 0; i < L.ntasks; ++i) {
+        const GemmTask& t = L.t[i];
+        for (int ks = 0; ks < t.ksplit; ++ks) {
+            const int a = (int)(((long long)ks * t.ktiles) / t.ksplit), b = (int)(((long long)(ks + 1) * t.ktiles) / t.ksplit);
+            for (int sgi = 0; sgi + 1 < t.nseg; ++sgi)
+                if (a < t.kt_end[sgi] && b > t.kt_end[sgi]) return false;
+        }
+    }
+    return true;
+}
+
 int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag) {
     if (n <= 0) return SET_OK;
     if (n > GEMM_MAX_TASKS) return SET_ERR_ARG;
@@ -1278,6 +1516,9 @@ int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag
             hipLaunchKernelGGL((gemm_nt_f32<64, 64, 2, 2, 2>), grid, dim3(512), 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
         else if (bm == 64 && gemm_dma())
             hipLaunchKernelGGL((gemm_nt_f32_dma<64, 64, 2, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
+        else if (bm == 64 && bn == 64 && gemm_asm() && gate_mode <= 1 && slices_in_one_segment(L))
+            if (gate_mode) hipLaunchKernelGGL((gemm_nt_f32_asm<1>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
+            else hipLaunchKernelGGL((gemm_nt_f32_asm<0>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
         else if (bm == 64 && gate_mode == 2)
             hipLaunchKernelGGL((gemm_nt_f32<64, 64, 2, 2, 1, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
         else if (bm == 64 && gate_mode == 1)

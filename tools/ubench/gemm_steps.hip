@@ -196,13 +196,14 @@ int main(int argc, char** argv) {
         }
     }
 #endif
-    if (getenv("CHECK_WREG")) {
+    if (getenv("CHECK_WREG") || getenv("CHECK_ASM")) {
+        const bool chk_asm = getenv("CHECK_ASM") != nullptr;
         // parity of gemm_nt_f32_wreg against gemm_nt_f32<64,64>: same problems, slabs summed on the host in index order
         const GemmProb* groups[3] = {fa, b, &dd}; const int gn[3] = {3, 5, 1}; const char* gname[3] = {"F/A", "B", "D"};
         for (int g = 0; g < 3; ++g) {
             std::vector<std::vector<double>> res[2];
             for (int v = 0; v < 2; ++v) {
-                g_gemm_wreg_force = v;
+                if (chk_asm) g_gemm_asm_force = v; else g_gemm_wreg_force = v;
                 hipMemsetAsync(slabs, 0xff, (size_t)off * 4, st);      // NaN-fill: an unwritten element shows
                 gemm_group(groups[g], gn[g], st, nullptr);
                 hipStreamSynchronize(st);
@@ -217,7 +218,7 @@ int main(int argc, char** argv) {
                     res[v].push_back(acc);
                 }
             }
-            g_gemm_wreg_force = -1;
+            g_gemm_wreg_force = -1; g_gemm_asm_force = -1;
             for (int i = 0; i < gn[g]; ++i) {
                 double md = 0, mx = 0; size_t bad = 0;
                 for (size_t k = 0; k < res[0][i].size(); ++k) {
