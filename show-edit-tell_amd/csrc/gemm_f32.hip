@@ -1413,6 +1413,10 @@ void plan_ksplit(GemmProb* probs, int n, int cap_wgs) {
 static bool slices_in_one_segment(const GemmLaunch& L) {
     for (int i = 0; i < L.ntasks; ++i) {
         const GemmTask& t = L.t[i];
+        // (the hand-written loop addresses its operands as scalar base + 32-bit byte offset of the lane's row)
+        for (int sgi = 0; sgi < t.nseg; ++sgi)
+            if ((unsigned long long)t.M * (unsigned long long)t.lda[sgi] * 4ull >= (1ull << 32) ||
+                (unsigned long long)t.N * (unsigned long long)t.ldw[sgi] * 4ull >= (1ull << 32)) return false;
         for (int ks = 0; ks < t.ksplit; ++ks) {
             const int a = (int)(((long long)ks * t.ktiles) / t.ksplit), b = (int)(((long long)(ks + 1) * t.ktiles) / t.ksplit);
             for (int sgi = 0; sgi + 1 < t.nseg; ++sgi)
