@@ -1477,7 +1477,8 @@ int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag
         flops += 2.0 * t.M * t.N * K;
         bytes += 4.0 * ((double)t.M * K + (double)t.N * K + (double)t.M * t.N * t.ksplit);
     }
-    const char* kname = (bm == 128 && bn == 32) ? "gemm_nt_f32<128,32>" : bm == 128 ? "gemm_nt_f32<128,64>" : (bm == 64 ? "gemm_nt_f32<64,64>" : (bm == 32 ? "gemm_nt_f32<32,128>" : "gemv_nt_f32<16,64>"));
+    const char* kname = (bm == 64 && bn == 64 && gemm_asm() && !g_row_gate.rowmap && slices_in_one_segment(L)) ? "gemm_nt_f32_asm<64,64>" :
+                        (bm == 128 && bn == 32) ? "gemm_nt_f32<128,32>" : bm == 128 ? "gemm_nt_f32<128,64>" : (bm == 64 ? "gemm_nt_f32<64,64>" : (bm == 32 ? "gemm_nt_f32<32,128>" : "gemv_nt_f32<16,64>"));
     ProfScope ps(kname, stream, flops, bytes);
     static const bool sites = env_int("SET_PROFILE_SITES", 0) != 0;   // per-call-site breakdown (nested events)
     ProfScope ps2(sites ? (tag ? tag : "gemm:other") : nullptr, stream, flops, bytes);

@@ -4,7 +4,7 @@
 #   pmc_bench.sh [outdir = gpurun_out/pmc_bench] [kernel substring = "gemm_nt_f32<64, 64"]   (+ any SET_* switches in the env)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=${1:-gpurun_out/pmc_bench}
-KERNEL=${2:-"gemm_nt_f32<64, 64"}
+KERNEL=${2:-"gemm_nt_f32<64, 64|gemm_nt_f32_asm<"}     # the 64x64 GEMM, compiler-scheduled and hand-written k-loop
 rm -rf $OUT; mkdir -p $OUT
 BENCH="python bench.py --steps 3 --warmup 1 --repeat 1 --streams ${PMC_STREAMS:-3} --no-cpu-baseline --no-profile --no-train --no-secondary"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- $BENCH > $OUT/fetch.log 2>&1

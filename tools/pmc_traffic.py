@@ -14,7 +14,7 @@ def rows(d, prefix, counter, kernel):
     out = defaultdict(lambda: [0.0, 0])
     path = f"{d}/{prefix}/{prefix}_counter_collection.csv"
     for r in csv.DictReader(open(path)):
-        if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
+        if any(k in r["Kernel_Name"] for k in kernel.split("|")) and r["Counter_Name"] == counter:
             g = int(r.get("Grid_Size") or r.get("Grid_Size_X") or 0) // max(1, int(r.get("Workgroup_Size") or r.get("Workgroup_Size_X") or 256))
             e = out[g]
             e[0] += float(r["Counter_Value"]); e[1] += 1
