@@ -26,6 +26,8 @@ struct DcnetWs {
     float *hf, *cf, *hb, *cb, *xg_f, *xg_b, *emb_seq, *s_ef, *s_eb, *s_cat, *s_pre;
     int* enc_order;                   // [perm (B) | nactive (T)] of the length-ordered persistent encoder
     char* enc_bar;                    // its barrier words
+    float* pd_pc;                     // persistent small-batch decode (decode_persistent.hip): hoisted context products ...
+    char* pd_x;                       // ... and its exchange region
     size_t bytes;
 };
 
@@ -83,6 +85,11 @@ static DcnetWs carve(const SetDcnetDims* d, void* base) {
     w.s_pre = c.take<float>(KS * B * 4 * D);
     w.enc_order = c.take<int>(B + T);
     w.enc_bar = c.take<char>(persistent_encoder_bar_bytes());
+    {
+        const size_t pb = B <= (size_t)PDEC_MAXB ? B : 0;            // only small batches take the persistent decode
+        w.pd_pc = c.take<float>(pb * T * 4 * D);
+        w.pd_x = c.take<char>(dcnet_persistent_xbytes((int)B, (int)D, (int)A));
+    }
     w.bytes = c.off;
     return w;
 }
@@ -364,6 +371,17 @@ static int dcnet_rollout(const SetDcnetWeights* w, const SetDcnetDims* d, const 
     static const int loop_gate = env_int("SET_LOOP_GATE", 1);
     static const int compact_every = env_int("SET_COMPACT_EVERY", 2);
     const bool skip_rows = skip_finished_rows() && B <= 4096;
+    // small batches, greedy: the whole loop as ONE persistent launch (decode_persistent.hip).  The context half of
+    // language_lstm's input product is linear in the attention weights: Pc = enc W_ih[:, D:]^T is computed here once
+    if (!sample && !emb_needed && !skip_rows && !g_force_len && dcnet_persistent_ok(d, max_len)) {
+        const int T = d->T, D = d->D, C = d->C, E = d->E;
+        GemmProb p = direct_prob(W.pd_pc, 4LL * D, B * T, 4 * D, nullptr, SET_ACT_NONE);
+        p.add(W.enc, 2 * C, w->ll_wih + D, 2 * E, 2 * C);
+        SET_TRY(gemm_group(&p, 1, st, "gemm:pro ll_ctx hoist"));
+        const int rc = dcnet_persistent_greedy(w, d, W.pre1, W.att1_c, W.mask, W.pd_pc, W.pd_x, W.it, W.unfinished, W.alive,
+                                               start_idx, end_idx, max_len, (long long*)seq, seq_logp, st);
+        if (rc != SET_ERR_UNSUPPORTED) return rc;
+    }
     if (skip_rows) SET_TRY(compact_rows(W.unfinished, B, W.rowmap, W.n_rows, 1, st));
     for (int t = 0; t <= max_len; ++t) {                                 // dcnet_rl.py:305,315-316
         Slabs lg;

@@ -25,15 +25,12 @@
 // their own, and every spin is bounded (a timeout raises the status word instead of hanging the queue).
 #include <mutex>
 #include "set_common.h"
+#include "grid_barrier.h"
 
 namespace set {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const f32x4 __attribute__((address_space(1)))* gptr4;
-
-constexpr int PENC_BAR_STRIDE = 32;                 // unsigned words between two barrier words (128 bytes)
-constexpr int PENC_BAR_WORDS = (8 + 1 + 8) * PENC_BAR_STRIDE;
-constexpr unsigned PENC_SPIN_LIMIT = 4000000u;     // default bound of one barrier wait (SET_PENC_SPIN_LIMIT overrides it)
 
 // one recurrence ("direction"): EditNet's encoder has one, DCNet's bidirectional encoder two that share the launch
 struct PEncDir {
@@ -54,7 +51,7 @@ struct PEncArgs {
     float* H; float* Mem;            // (B, T, ld_out_t) outputs (zero-initialised by the caller); Mem may be NULL
     long long ld_out_b, ld_out_t;
     const int* perm; const int* nactive;
-    unsigned* bar;                   // PENC_BAR_WORDS zeroed words
+    unsigned* bar;                   // GBAR_WORDS zeroed words
     unsigned* status;                // set to 1 on a barrier timeout
     unsigned* fault;                 // host-mapped, sticky: a timeout of ANY launch of this process on this device (never cleared by a launch)
     unsigned spin_limit;             // polls of one barrier wait before it gives up
@@ -63,49 +60,6 @@ struct PEncArgs {
 };
 
 __device__ __forceinline__ float psigm(float x) { return 1.f / (1.f + expf(-x)); }
-
-// grid barrier, epoch = 1, 2, ... within the launch; `pop` = workgroups per shard, `ns` = shards.  Split in two so that work
-// which does not depend on the other workgroups (the H / Mem stores, the next step's input-projection gather) sits
-// between the arrival and the wait.  Data crossing the barrier (h) is stored AND loaded write-through / L1-bypassing (sc1
-// both sides, Guideline 16), so no release or acquire fence is needed: only the drain of this wave's own sc1 stores.
-__device__ __forceinline__ void penc_arrive(unsigned* bar, unsigned epoch, int shard, unsigned pop, unsigned ns) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave: its write-through stores are out
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned* mine = bar + shard * PENC_BAR_STRIDE;
-        const unsigned prev = __hip_atomic_fetch_add(mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (prev + 1u == epoch * pop) {                           // last arrival of this shard
-            const unsigned p2 = __hip_atomic_fetch_add(bar + 8 * PENC_BAR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (p2 + 1u == epoch * ns)                            // last shard: release every shard's pollers
-                for (unsigned s = 0; s < ns; ++s)
-                    __hip_atomic_store(bar + (9 + s) * PENC_BAR_STRIDE, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-__device__ __forceinline__ void penc_wait(unsigned* bar, unsigned epoch, int shard, unsigned* status, unsigned* fault,
-                                          unsigned limit) {
-    if (threadIdx.x == 0) {
-        unsigned* gen = bar + (9 + shard) * PENC_BAR_STRIDE;
-        unsigned spins = 0;
-        // bounded spin; a timeout is sticky (later barriers of this launch do not wait again) and raises the status word
-        while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
-            __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 1023u) == 0u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-            if (spins > limit) {
-                __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // the host reads this one at its next call
-                break;
-            }
-        }
-    }
-    __syncthreads();
-}
-
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-// 16-byte sc1 load (L1 bypassed, served by L2 / memory): the reading side of the write-through h exchange
-__device__ __forceinline__ f32x4 ld_sc1(__amdgpu_buffer_rsrc_t rs, int byte_off) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16));
-}
 
 // acc[0..N) += h tiles (rows arow[rt], this wave's K quarter at hk) x the stationary W operands; loads run one k-block ahead
 template <int NT, int KB, int N>
@@ -249,7 +203,7 @@ __global__ void __launch_bounds__(256, (NT <= 2 ? 2 : 1)) encoder_persistent_k(c
             __hip_atomic_store(hout + (long long)prow[i] * D + unit0 + u, hreg[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const bool more = t + 1 < P.T;
-        if (more && !(P.test_stall && blockIdx.x == 0)) penc_arrive(P.bar, (unsigned)(t + 1), shard, pop, ns);
+        if (more && !(P.test_stall && blockIdx.x == 0)) gbar_arrive(P.bar, (unsigned)(t + 1), shard, pop, ns);
 #pragma unroll
         for (int i = 0; i < PAIRS; ++i)
             if (live_[i]) {
@@ -260,7 +214,7 @@ __global__ void __launch_bounds__(256, (NT <= 2 ? 2 : 1)) encoder_persistent_k(c
             }
         if (more) {
             PENC_GATHER(t + 1);
-            penc_wait(P.bar, (unsigned)(t + 1), shard, P.status, P.fault, P.spin_limit);
+            gbar_wait(P.bar, (unsigned)(t + 1), shard, P.status, P.fault, P.spin_limit);
         }
     }
 #undef PENC_GATHER
@@ -294,7 +248,52 @@ static unsigned* g_penc_fault_dev[64] = {};
 static bool g_penc_disabled[64] = {};
 static int g_penc_capacity[64][9] = {};          // resident workgroups the device admits per kernel instantiation (0 = not asked yet)
 
-size_t persistent_encoder_bar_bytes() { return sizeof(unsigned) * (PENC_BAR_WORDS + PENC_BAR_STRIDE); }
+PersistentGuard::PersistentGuard() : rc(SET_OK), dev(0), fault(nullptr), locked(false) {
+    if (hipGetDevice(&dev) != hipSuccess) { rc = SET_ERR_HIP; return; }
+    dev &= 63;
+    g_penc_mutex.lock();
+    locked = true;
+    if (!g_penc_fault_host[dev]) {
+        void* hp = nullptr; void* dp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess) { rc = SET_ERR_HIP; return; }
+        *(volatile unsigned*)hp = 0u;
+        if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { rc = SET_ERR_HIP; return; }
+        g_penc_fault_host[dev] = (unsigned*)hp; g_penc_fault_dev[dev] = (unsigned*)dp;
+    }
+    if (*(volatile unsigned*)g_penc_fault_host[dev]) {
+        // an earlier launch's barrier timed out (its outputs were poisoned with NaN on the device): say so ONCE, loudly, and
+        // never launch a persistent kernel again in this process on this device — the caller's retry runs the per-step kernels
+        *(volatile unsigned*)g_penc_fault_host[dev] = 0u;
+        g_penc_disabled[dev] = true;
+        rc = SET_ERR_FAULT;
+        return;
+    }
+    if (g_penc_disabled[dev]) { rc = SET_ERR_UNSUPPORTED; return; }
+    fault = g_penc_fault_dev[dev];
+}
+PersistentGuard::~PersistentGuard() { if (locked) g_penc_mutex.unlock(); }
+static int penc_serialise() { static const int v = env_int("SET_ENC_PERSISTENT_SERIALISE", 1); return v; }
+int PersistentGuard::serialise(hipStream_t s) {
+    if (!penc_serialise()) return SET_OK;
+    if (!g_penc_event[dev]) SET_HIP_TRY(hipEventCreateWithFlags(&g_penc_event[dev], hipEventDisableTiming));
+    else SET_HIP_TRY(hipStreamWaitEvent(s, g_penc_event[dev], 0));
+    return SET_OK;
+}
+int PersistentGuard::launched(hipStream_t s) {
+    if (penc_serialise() && g_penc_event[dev]) SET_HIP_TRY(hipEventRecord(g_penc_event[dev], s));
+    return SET_OK;
+}
+unsigned PersistentGuard::spin_limit() const {
+    static const int v = env_int("SET_PENC_SPIN_LIMIT", (int)GBAR_SPIN_LIMIT);
+    return v > 0 ? (unsigned)v : GBAR_SPIN_LIMIT;
+}
+int PersistentGuard::test_stall() const { static const int v = env_int("SET_PENC_TEST_STALL", 0); return v; }
+bool persistent_disabled() {
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess && g_penc_disabled[dev & 63];
+}
+
+size_t persistent_encoder_bar_bytes() { return sizeof(unsigned) * (GBAR_WORDS + GBAR_STRIDE); }
 
 bool persistent_encoder_ok(int B, int D, int T) {
     // default: small batches only (SET_ENC_PERSISTENT_MAXB rows).  Measured (round 3): a step of the dependent chain —
@@ -304,10 +303,7 @@ bool persistent_encoder_ok(int B, int D, int T) {
     static const int on = env_int("SET_ENC_PERSISTENT", 1);
     static const int maxb = env_int("SET_ENC_PERSISTENT_MAXB", 32);
     if (B > maxb) return false;
-    {
-        int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && g_penc_disabled[dev & 63]) return false;     // a barrier timed out earlier
-    }
+    if (persistent_disabled()) return false;                 // a barrier timed out earlier
     // 16-row tiles held in registers: 8 (B <= 128) fit the 256-register budget of two co-resident instances at D = 512 / 1024;
     // 16 tiles would spill there (only the reduced test dimension takes them)
     return on && B >= 1 && T >= 1 && ((B <= 128 && (D == 512 || D == 1024)) || (B <= 256 && D == 64));
@@ -372,33 +368,15 @@ int persistent_encoder_dirs(const PEncDirHost* dirs, int ndir, long long ld_xg_r
     P.ndir = ndir; P.ld_xg_row = ld_xg_row; P.ld_xg_t = ld_xg_t; P.lens = lens;
     P.seq = seq; P.seq_T = seq_T; P.seq_V = seq_V > 0 ? seq_V : 1; P.H = H; P.Mem = Mem;
     P.ld_out_b = ld_out_b; P.ld_out_t = ld_out_t; P.perm = perm; P.nactive = nactive;
-    P.bar = (unsigned*)bar; P.status = (unsigned*)bar + PENC_BAR_WORDS; P.B = B; P.D = D; P.T = T;
-    static const int spin_limit = env_int("SET_PENC_SPIN_LIMIT", (int)PENC_SPIN_LIMIT);
-    static const int test_stall = env_int("SET_PENC_TEST_STALL", 0);
-    P.spin_limit = spin_limit > 0 ? (unsigned)spin_limit : PENC_SPIN_LIMIT;
-    P.test_stall = test_stall;
-    // at most ONE instance of this kernel runs at a time in this process: every launch waits for the previous one's
-    // completion event (a no-op when that was on the same stream); see the residency note at the top of the file
-    int dev = 0;
-    SET_HIP_TRY(hipGetDevice(&dev));
-    dev &= 63;
-    std::lock_guard<std::mutex> lk(g_penc_mutex);
-    if (!g_penc_fault_host[dev]) {
-        void* hp = nullptr; void* dp = nullptr;
-        SET_HIP_TRY(hipHostMalloc(&hp, 64, hipHostMallocMapped));
-        *(volatile unsigned*)hp = 0u;
-        SET_HIP_TRY(hipHostGetDevicePointer(&dp, hp, 0));
-        g_penc_fault_host[dev] = (unsigned*)hp; g_penc_fault_dev[dev] = (unsigned*)dp;
-    }
-    if (*(volatile unsigned*)g_penc_fault_host[dev]) {
-        // an earlier launch's barrier timed out (its outputs were poisoned with NaN on the device): say so ONCE, loudly, and
-        // never use this kernel again in this process on this device — the caller's retry runs the per-step kernels
-        *(volatile unsigned*)g_penc_fault_host[dev] = 0u;
-        g_penc_disabled[dev] = true;
-        return SET_ERR_FAULT;
-    }
-    if (g_penc_disabled[dev]) return SET_ERR_UNSUPPORTED;
-    P.fault = g_penc_fault_dev[dev];
+    P.bar = (unsigned*)bar; P.status = (unsigned*)bar + GBAR_WORDS; P.B = B; P.D = D; P.T = T;
+    // at most ONE persistent kernel runs at a time in this process (grid_barrier.h PersistentGuard: lock, sticky fault word,
+    // event chain); see the residency note at the top of the file
+    PersistentGuard guard;
+    if (guard.rc != SET_OK) return guard.rc;
+    const int dev = guard.dev;
+    P.spin_limit = guard.spin_limit();
+    P.test_stall = guard.test_stall();
+    P.fault = guard.fault;
     const int nt = (B + 15) / 16, grid = ndir * (D / 4);
     // one of nine instantiations: 0/1/2 = <2,*>/<8,*>/<16,*>, KB by D
     const int inst = D == 1024 ? (nt <= 2 ? 0 : 1) : D == 512 ? (nt <= 2 ? 2 : 3) : (nt <= 2 ? 4 : (nt <= 8 ? 5 : 6));
@@ -414,11 +392,7 @@ int persistent_encoder_dirs(const PEncDirHost* dirs, int ndir, long long ld_xg_r
     }
     if (!fits) return SET_ERR_UNSUPPORTED;          // (nothing has been touched: the caller runs the per-step kernels)
     ProfScope ps("persistent_encoder", s, 8.0 * ndir * B * D * D * T, 4.0 * ndir * (4.0 * D * D + 8.0 * B * D * T));
-    static const int serialise = env_int("SET_ENC_PERSISTENT_SERIALISE", 1);
-    if (serialise) {
-        if (!g_penc_event[dev]) SET_HIP_TRY(hipEventCreateWithFlags(&g_penc_event[dev], hipEventDisableTiming));
-        else SET_HIP_TRY(hipStreamWaitEvent(s, g_penc_event[dev], 0));
-    }
+    SET_TRY(guard.serialise(s));
     SET_HIP_TRY(hipMemsetAsync(bar, 0, persistent_encoder_bar_bytes(), s));
     int rc;
     switch (inst) {
@@ -430,7 +404,7 @@ int persistent_encoder_dirs(const PEncDirHost* dirs, int ndir, long long ld_xg_r
         case 5: rc = launch_penc<8, 1>(P, grid, s); break;
         default: rc = launch_penc<16, 1>(P, grid, s); break;
     }
-    if (rc == SET_OK && serialise) SET_HIP_TRY(hipEventRecord(g_penc_event[dev], s));
+    if (rc == SET_OK) SET_TRY(guard.launched(s));
     return rc;
 }
 
