@@ -1,0 +1,103 @@
+// Shared pieces of the persistent small-batch decode kernels (decode_persistent.hip: DCNet, decode_persistent_editnet.hip:
+// EditNet): constants, the MFMA GEMV tile helpers and the diagnostic time stamps.
+#pragma once
+#include <cstdio>
+#include "set_common.h"
+#include "grid_barrier.h"
+
+namespace set {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef const f32x4 __attribute__((address_space(1)))* gptr4;
+
+// (PDEC_MAXB = 16 batch rows, set_common.h: one 16-row MFMA tile)
+constexpr int PDEC_TREG = 20;      // ... of which a wave keeps the hoisted attention rows of ONE batch row in registers (B <= 4)
+constexpr int PDEC_TMAX = 32;      // previous-caption positions held in registers by the Pc gather
+constexpr int PDEC_KB = 16;        // 16-wide k-blocks per wave and gate tile: D = 1024 -> K quarter 256
+constexpr int PDEC_THREADS = 256;
+constexpr int PDEC_FC_TILES = 3;   // 16-row fc tiles per workgroup: up to 48 vocabulary rows
+
+// diagnostic (SET_PDEC_STAMPS=1): 100-MHz time stamps of workgroup SET_PDEC_STAMP_WG, 24 per timestep
+#define PD_STAMP(i) if (P.stamps && blockIdx.x == P.stamp_wg && threadIdx.x == 0) P.stamps[t * 24 + (i)] = __builtin_amdgcn_s_memrealtime()
+constexpr int PD_STAMPS = 24, PD_STAMP_STEPS = 64;
+
+__device__ __forceinline__ float pd_sigm(float x) { return 1.f / (1.f + expf(-x)); }
+// tanh of the attention scores: 1 - 2 / (1 + e^(2x)) on the hardware exp2 / rcp (absolute error ~2e-7; saturates to +-1 for
+// large |x| without a branch).  -DSET_PDEC_TANHF: libm's tanhf, ~10x the instructions (160 per lane and row every timestep)
+__device__ __forceinline__ float pd_tanh(float x) {
+#ifdef SET_PDEC_TANHF
+    return tanhf(x);
+#else
+    const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);      // e^(2x)
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + e);
+#endif
+}
+__device__ __forceinline__ float pd_wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float pd_wmax(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+template <int KB>
+__device__ __forceinline__ void pd_load(f32x4 (&w)[KB], const float* p) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) w[kb] = *(gptr4)(p + 16 * kb);
+}
+template <int KB>
+__device__ __forceinline__ void pd_load_if(f32x4 (&w)[KB], const float* p, bool valid) {
+    if (valid) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) w[kb] = *(gptr4)(p + 16 * kb);
+    } else {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) w[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+}
+// acc (16 batch rows x 16 weight rows) += act[rows, this wave's k range] . W^T; the activation operand comes from LDS
+template <int KB>
+__device__ __forceinline__ void pd_mma(f32x4& acc, const f32x4 (&w)[KB], const float* sact) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(sact + 16 * kb);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], w[kb][j], acc, 0, 0, 0);
+    }
+}
+
+// host side of the stamps: buffer for a launch (or NULL) and the report after it
+inline int pd_stamps_begin(unsigned long long** out, int* wg, hipStream_t s) {
+    static const int on = env_int("SET_PDEC_STAMPS", 0);
+    static unsigned long long* d_stamps = nullptr;
+    *out = nullptr; *wg = 0;
+    if (!on) return SET_OK;
+    if (!d_stamps) SET_HIP_TRY(hipMalloc((void**)&d_stamps, sizeof(unsigned long long) * PD_STAMPS * PD_STAMP_STEPS));
+    SET_HIP_TRY(hipMemsetAsync(d_stamps, 0, sizeof(unsigned long long) * PD_STAMPS * PD_STAMP_STEPS, s));
+    *out = d_stamps; *wg = env_int("SET_PDEC_STAMP_WG", 0);
+    return SET_OK;
+}
+inline int pd_stamps_report(const unsigned long long* d_stamps, int wg, int last, int max_len, hipStream_t s) {
+    if (!d_stamps) return SET_OK;
+    static unsigned long long h[PD_STAMPS * PD_STAMP_STEPS];
+    SET_HIP_TRY(hipStreamSynchronize(s));
+    SET_HIP_TRY(hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost));
+    double acc[PD_STAMPS] = {0}, tot = 0;
+    int n = 0;
+    for (int t = 1; t < max_len && t < PD_STAMP_STEPS && h[t * PD_STAMPS + last]; ++t, ++n) {
+        for (int i = 0; i < last; ++i) acc[i] += (double)(h[t * PD_STAMPS + i + 1] - h[t * PD_STAMPS + i]) * 0.01;
+        tot += (double)(h[t * PD_STAMPS + last] - h[t * PD_STAMPS]) * 0.01;
+    }
+    if (n) {
+        fprintf(stderr, "pdec stamps (us, mean of %d steps, wg %d):", n, wg);
+        for (int i = 0; i < last; ++i) fprintf(stderr, " %d-%d:%.2f", i, i + 1, acc[i] / n);
+        fprintf(stderr, "  step %.2f  (step-to-step %.2f)\n", tot / n, n > 1 ? (double)(h[n * PD_STAMPS] - h[PD_STAMPS]) * 0.01 / (n - 1) : 0.0);
+    }
+    return SET_OK;
+}
+
+}  // namespace set

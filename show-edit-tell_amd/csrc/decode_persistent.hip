@@ -23,22 +23,9 @@
 // into registers) and the hoisted Pc values.
 // Same residency rule, fault word and event chain as the persistent encoder (grid_barrier.h).  A barrier timeout poisons
 // seq_logp with NaN; the host raises SET_ERR_FAULT at its next call.
-#include <cstdio>
-#include "set_common.h"
-#include "grid_barrier.h"
+#include "decode_persistent.h"
 
 namespace set {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef const f32x4 __attribute__((address_space(1)))* gptr4;
-
-// (PDEC_MAXB = 16 batch rows, set_common.h: one 16-row MFMA tile)
-constexpr int PDEC_TREG = 20;      // ... of which a wave keeps the hoisted attention rows of ONE batch row in registers (B <= 4)
-constexpr int PDEC_TMAX = 32;      // previous-caption positions held in registers by the Pc gather
-constexpr int PDEC_KB = 16;        // 16-wide k-blocks per wave and gate tile: D = 1024 -> K quarter 256
-constexpr int PDEC_THREADS = 256;
-constexpr int PDEC_FC_TILES = 3;   // 16-row fc tiles per workgroup: up to 48 vocabulary rows
 
 struct PDecDcnetArgs {
     // weights
@@ -68,55 +55,6 @@ struct PDecDcnetArgs {
     int stamp_wg;
     unsigned long long* stamps;                  // diagnostic (SET_PDEC_STAMPS=1): 100-MHz time stamps of workgroup 0, 16 per timestep
 };
-#define PD_STAMP(i) if (P.stamps && blockIdx.x == P.stamp_wg && threadIdx.x == 0) P.stamps[t * 16 + (i)] = __builtin_amdgcn_s_memrealtime()
-
-__device__ __forceinline__ float pd_sigm(float x) { return 1.f / (1.f + expf(-x)); }
-// tanh of the attention scores: 1 - 2 / (1 + e^(2x)) on the hardware exp2 / rcp (absolute error ~2e-7; saturates to +-1 for
-// large |x| without a branch).  -DSET_PDEC_TANHF: libm's tanhf, ~10x the instructions (160 per lane and row every timestep)
-__device__ __forceinline__ float pd_tanh(float x) {
-#ifdef SET_PDEC_TANHF
-    return tanhf(x);
-#else
-    const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);      // e^(2x)
-    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + e);
-#endif
-}
-__device__ __forceinline__ float pd_wsum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ float pd_wmax(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
-
-template <int KB>
-__device__ __forceinline__ void pd_load(f32x4 (&w)[KB], const float* p) {
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) w[kb] = *(gptr4)(p + 16 * kb);
-}
-template <int KB>
-__device__ __forceinline__ void pd_load_if(f32x4 (&w)[KB], const float* p, bool valid) {
-    if (valid) {
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) w[kb] = *(gptr4)(p + 16 * kb);
-    } else {
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) w[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-}
-// acc (16 batch rows x 16 weight rows) += act[rows, this wave's k range] . W^T; the activation operand comes from LDS
-template <int KB>
-__device__ __forceinline__ void pd_mma(f32x4& acc, const f32x4 (&w)[KB], const float* sact) {
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(sact + 16 * kb);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], w[kb][j], acc, 0, 0, 0);
-    }
-}
 
 // RES: B <= 4 and T <= PDEC_TREG — a wave scores ONE fixed row, whose hoisted cap_features_att rows (loop-invariant, T x A
 // floats = 160 registers per lane) then stay in registers for the whole decode
@@ -526,33 +464,12 @@ int dcnet_persistent_greedy(const SetDcnetWeights* w, const SetDcnetDims* d, con
     ProfScope ps("persistent_decode", s, 2.0 * B * wbytes / 4.0 * max_len, wbytes * max_len);
     SET_TRY(guard.serialise(s));
     SET_HIP_TRY(hipMemsetAsync(xbuf, 0, dcnet_persistent_xbytes(B, D, d->A), s));    // no word of an earlier decode may carry a tag of this one
-    static const int stamps = env_int("SET_PDEC_STAMPS", 0);     // diagnostic: synchronises, prints workgroup SET_PDEC_STAMP_WG's phase times
-    static unsigned long long* d_stamps = nullptr;
-    if (stamps) {
-        if (!d_stamps) SET_HIP_TRY(hipMalloc((void**)&d_stamps, sizeof(unsigned long long) * 16 * 64));
-        SET_HIP_TRY(hipMemsetAsync(d_stamps, 0, sizeof(unsigned long long) * 16 * 64, s));
-        P.stamps = d_stamps;
-        P.stamp_wg = env_int("SET_PDEC_STAMP_WG", 0);
-    }
+    SET_TRY(pd_stamps_begin(&P.stamps, &P.stamp_wg, s));
     if (res) hipLaunchKernelGGL(dcnet_persistent_k<true>, dim3(G), dim3(PDEC_THREADS), lds, s, P);
     else hipLaunchKernelGGL(dcnet_persistent_k<false>, dim3(G), dim3(PDEC_THREADS), lds, s, P);
     SET_LAUNCH_CHECK();
     SET_TRY(guard.launched(s));
-    if (stamps) {
-        static unsigned long long h[16 * 64];
-        SET_HIP_TRY(hipStreamSynchronize(s));
-        SET_HIP_TRY(hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost));
-        double acc[16] = {0};
-        int n = 0;
-        for (int t = 1; t < max_len && t < 64 && h[t * 16 + 13]; ++t, ++n)
-            for (int i = 0; i < 16; ++i) acc[i] += (double)(h[t * 16 + (i + 1) % 16 + ((i == 15) ? 0 : 0)] - h[t * 16 + i]) * 0.01;
-        if (n) {
-            fprintf(stderr, "pdec stamps (us, mean of %d steps, wg %d):", n, P.stamp_wg);
-            for (int i = 0; i < 13; ++i) fprintf(stderr, " %d-%d:%.2f", i, i + 1, acc[i] / n);
-            double tot = 0; for (int t = 1; t <= n; ++t) tot += (double)(h[t * 16 + 13] - h[t * 16]) * 0.01;
-            fprintf(stderr, "  step %.2f  (step-to-step %.2f)\n", tot / n, n > 1 ? (double)(h[n * 16] - h[16]) * 0.01 / (n - 1) : 0.0);
-        }
-    }
+    SET_TRY(pd_stamps_report(P.stamps, P.stamp_wg, 13, max_len, s));
     return SET_OK;
 }
 

@@ -52,6 +52,8 @@ struct EditNetWs {
     float *enc_h, *enc_c, *xg, *emb_seq, *fe, *s_enc, *s_aff, *s_pre;
     int* enc_order;                   // [perm (B) | nactive (T)] of the length-ordered encoder
     char* enc_bar;                    // barrier words of the persistent encoder
+    float* pd_pv;                     // persistent small-batch decode (decode_persistent_editnet.hip): X x2h[:, 2D:]^T (B, R, 4D) ...
+    char* pd_x;                       // ... and its exchange region
     size_t bytes;
 };
 
@@ -125,6 +127,11 @@ static EditNetWs carve(const SetEditNetDims* d, void* base) {
     w.s_pre = c.take<float>(KS * B * 4 * D);
     w.enc_order = c.take<int>(B + T);
     w.enc_bar = c.take<char>(persistent_encoder_bar_bytes());
+    {
+        const size_t pb = B <= (size_t)PDEC_MAXB ? B : 0;            // only small batches take the persistent decode
+        w.pd_pv = c.take<float>(pb * R * 4 * D);
+        w.pd_x = c.take<char>(editnet_persistent_xbytes((int)B, (int)D, (int)A));
+    }
     w.bytes = c.off;
     return w;
 }
@@ -536,6 +543,18 @@ static int rollout(const SetEditNetWeights* w, const SetEditNetDims* d, const fl
     static const int loop_gate = env_int("SET_LOOP_GATE", 1);
     static const int compact_every = env_int("SET_COMPACT_EVERY", 2);
     const bool skip_rows = skip_finished_rows() && B <= 4096;
+    // small batches, greedy: the whole loop as ONE persistent launch (decode_persistent_editnet.hip).  copy_lstm.x2h's region
+    // columns are linear in the visual attention weights: Pv = X x2h[:, 2D:]^T is computed here once per decode
+    if (!sample && !emb_needed && !skip_rows && !g_force_len && editnet_persistent_ok(d, max_len)) {
+        const int R = d->R, F = d->F, D = d->D;
+        GemmProb p = direct_prob(W.pd_pv, 4LL * D, B * R, 4 * D, nullptr, SET_ACT_NONE);
+        p.add(X, F, w->cl_x2h_w + 2 * D, 2LL * D + F, F);
+        SET_TRY(gemm_group(&p, 1, st, "gemm:pro x2h_img hoist"));
+        const int rc = editnet_persistent_greedy(w, d, W.pre1, W.att1, W.att1_c, W.mask, W.cap_proj, W.mem_proj, W.Mem, W.pd_pv,
+                                                 W.pd_x, W.it, W.unfinished, W.alive, start_idx, end_idx, max_len, (long long*)seq,
+                                                 seq_logp, st);
+        if (rc != SET_ERR_UNSUPPORTED) return rc;
+    }
     if (skip_rows) SET_TRY(compact_rows(W.unfinished, B, W.rowmap, W.n_rows, 1, st));
     for (int t = 0; t <= max_len; ++t) {
         Slabs lg;

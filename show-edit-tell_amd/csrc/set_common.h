@@ -174,6 +174,13 @@ int dcnet_persistent_greedy(const SetDcnetWeights* w, const SetDcnetDims* d, con
                             long long start_idx, long long end_idx, int max_len, long long* seq, float* seq_logp,
                             hipStream_t s);
 
+size_t editnet_persistent_xbytes(int B, int D, int A);
+bool editnet_persistent_ok(const SetEditNetDims* d, int max_len);
+int editnet_persistent_greedy(const SetEditNetWeights* w, const SetEditNetDims* d, const float* pre1, const float* att1,
+                              const float* att1_c, const float* mask, const float* capP, const float* memQ, const float* Mem,
+                              const float* pv, void* xbuf, long long* it, int* unfinished, int* alive, long long start_idx,
+                              long long end_idx, int max_len, long long* seq, float* seq_logp, hipStream_t s);
+
 // a per-row gathered addend: value(m, n) = tab[ids[m*id_stride]*ld + col0 + n]   (tab == NULL: none)
 struct RowGather {
     const float* tab = nullptr;

@@ -1,0 +1,168 @@
+"""GPU: the persistent small-batch decode (csrc/decode_persistent.hip — the whole greedy loop as ONE launch, flag-in-data
+exchange between workgroups) against the reference's golden and against the per-step loop it replaces."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import parity
+from hip_adapter import dcnet_modules, to_dev
+from show_edit_tell_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _tags(fn):
+    lib = _lib.load()
+    lib.set_profile_enable(1)
+    fn()
+    torch.cuda.synchronize()
+    names = [r["tag"] for r in _lib.profile_report()]
+    lib.set_profile_enable(0)
+    return names
+
+
+def _random_prev(B, T, seed, V=9000):
+    rs = np.random.RandomState(seed)
+    plen = rs.randint(1, T + 1, size=(B, 1)).astype(np.int64)
+    prev = rs.randint(4, V, size=(B, T)).astype(np.int64)
+    for i in range(B):
+        prev[i, plen[i, 0]:] = 0
+    return to_dev(prev), to_dev(plen)
+
+
+def _with_env(key, val, fn):
+    old = os.environ.get(key)
+    os.environ[key] = val
+    try:
+        return fn()
+    finally:
+        if old is None:
+            del os.environ[key]
+        else:
+            os.environ[key] = old
+
+
+def test_dcnet_persistent_decode_matches_golden_and_per_step():
+    """BASELINE.json configs[0]'s shape (DCNet greedy, B = 4, full dimensions): with the token table active the decode is the
+    persistent launch (profile tag `persistent_decode`); ids / log-probs equal the reference's golden, and ids equal the
+    per-step loop's (SET_DEC_PERSISTENT=0) with log-probs within 1e-5 — the two paths add the same products in a
+    different order."""
+    d, xe, rl = dcnet_modules("dcnet_full_b4")
+    g = parity.load("dcnet_full_b4")
+    prev, plen = to_dev(d["prev"]), to_dev(d["plen"])
+    with torch.no_grad():
+        rl(d["wm"], prev, plen, True, False)
+        rl(d["wm"], prev, plen, True, False)                      # token table from the second call on
+        names = _tags(lambda: rl(d["wm"], prev, plen, True, False))
+        assert "persistent_decode" in names, names
+        seq, logp = rl(d["wm"], prev, plen, True, False)
+        torch.cuda.synchronize()
+        parity.check_greedy(_np(seq), _np(logp), g)
+        ref = _with_env("SET_DEC_PERSISTENT", "0", lambda: rl(d["wm"], prev, plen, True, False))
+        names = _with_env("SET_DEC_PERSISTENT", "0", lambda: _tags(lambda: rl(d["wm"], prev, plen, True, False)))
+        assert "persistent_decode" not in names
+    assert torch.equal(seq, ref[0])
+    assert float((logp - ref[1]).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("B", [1, 3, 5, 8])
+def test_dcnet_persistent_decode_other_batch_sizes(B):
+    """1 .. 8 rows (one 16-row MFMA tile, 1 - 2 rows per wave in the attention phase, ragged previous captions incl. length
+    1): the persistent launch against the per-step loop on the same inputs.  Rows are compared individually: a row of these
+    random-weight decodes may pass a near-tie, where the two summation orders can legitimately pick different words."""
+    d, xe, rl = dcnet_modules("dcnet_full_b4")
+    prev, plen = _random_prev(B, d["prev"].shape[1], 100 + B)
+    with torch.no_grad():
+        for _ in range(2):
+            rl(d["wm"], prev, plen, True, False)
+        names = _tags(lambda: rl(d["wm"], prev, plen, True, False))
+        assert "persistent_decode" in names, names
+        seq, logp = rl(d["wm"], prev, plen, True, False)
+        again = rl(d["wm"], prev, plen, True, False)
+        ref = _with_env("SET_DEC_PERSISTENT", "0", lambda: rl(d["wm"], prev, plen, True, False))
+        torch.cuda.synchronize()
+    assert torch.equal(seq, again[0]) and torch.equal(logp, again[1]), "the persistent decode must be run-to-run deterministic"
+    same = (seq == ref[0]).all(1)
+    assert int(same.sum()) >= B - 1, (seq, ref[0])
+    assert float((logp - ref[1])[same].abs().max()) < 1e-5
+    assert torch.isfinite(logp).all()
+
+
+def test_dcnet_persistent_decode_on_concurrent_streams():
+    """Eight decodes on four streams: the library serialises persistent launches with its event chain (their workgroups
+    must all be resident), nothing hangs, no exchange times out and every result equals the single-stream decode."""
+    d, xe, rl = dcnet_modules("dcnet_full_b4")
+    prev, plen = to_dev(d["prev"]), to_dev(d["plen"])
+    with torch.no_grad():
+        for _ in range(2):
+            rl(d["wm"], prev, plen, True, False)
+        ref = rl(d["wm"], prev, plen, True, False)
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream() for _ in range(4)]
+        outs = []
+        for rep in range(2):
+            for s in streams:
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    outs.append(rl(d["wm"], prev, plen, True, False))
+        torch.cuda.synchronize()
+    for seq, lp in outs:
+        assert torch.equal(seq, ref[0]) and torch.equal(lp, ref[1])
+
+
+_FAULT_SCRIPT = r"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.getcwd(), "tests")); sys.path.insert(0, os.getcwd())
+import parity
+from hip_adapter import dcnet_modules, to_dev
+from show_edit_tell_amd import _lib
+d, xe, rl = dcnet_modules("dcnet_full_b4")
+g = parity.load("dcnet_full_b4")
+args = (d["wm"], to_dev(d["prev"]), to_dev(d["plen"]), True, False)
+mode = sys.argv[1]
+with torch.no_grad():
+    rl(*args)                                      # (no token table yet: the per-step loop)
+    if mode == "stall":
+        seq, logp = rl(*args)                      # workgroup 0 never publishes h1: every poll times out
+        torch.cuda.synchronize()
+        assert torch.isnan(logp).all() and not seq.any(), "a timed-out persistent decode must poison its result"
+        try:
+            rl(*args)
+            raise SystemExit("the call after a timeout must raise SetError")
+        except _lib.SetError as e:
+            assert "code 5" in str(e), str(e)
+    for _ in range(3):                             # from now on the per-step kernels: parity with the golden
+        seq, logp = rl(*args)
+        torch.cuda.synchronize()
+        parity.check_greedy(seq.cpu().numpy(), logp.cpu().numpy(), g)
+    lib = _lib.load()
+    lib.set_profile_enable(1)
+    rl(*args); torch.cuda.synchronize()
+    names = [r["tag"] for r in _lib.profile_report()]
+    lib.set_profile_enable(0)
+    assert "persistent_decode" not in names, names
+print("OK", mode)
+"""
+
+
+@pytest.mark.parametrize("mode,env", [("stall", {"SET_PENC_TEST_STALL": "1", "SET_PENC_SPIN_LIMIT": "20000", "SET_ENC_PERSISTENT": "0"}),
+                                      ("capacity", {"SET_PENC_TEST_CAPACITY": "100"})])
+def test_dcnet_persistent_decode_failure_is_loud(mode, env):
+    """Same two failure modes as the persistent encoder (tests/test_hip_boundary.py): a grid that is not admitted whole is
+    refused up front (per-step loop, golden parity); a workgroup that never publishes makes every bounded poll time out, the
+    kernel overwrites seq_logp with NaN, the NEXT call raises SetError(SET_ERR_FAULT) once and the library keeps to the
+    per-step kernels afterwards."""
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", _FAULT_SCRIPT, mode], env=e, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and ("OK " + mode) in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
