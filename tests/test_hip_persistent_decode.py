@@ -9,7 +9,7 @@ import pytest
 import torch
 
 import parity
-from hip_adapter import dcnet_modules, to_dev
+from hip_adapter import dcnet_modules, editnet_modules, to_dev
 from show_edit_tell_amd import _lib
 
 pytestmark = pytest.mark.gpu
@@ -118,12 +118,81 @@ def test_dcnet_persistent_decode_on_concurrent_streams():
         assert torch.equal(seq, ref[0]) and torch.equal(lp, ref[1])
 
 
+def test_editnet_persistent_decode_matches_golden_and_per_step():
+    """EditNet greedy at B = 4, full dimensions (csrc/decode_persistent_editnet.hip): the persistent launch equals the
+    reference's golden and the per-step loop (ids bit-identical, log-probs within 1e-5)."""
+    d, xe, rl = editnet_modules("editnet_full_b4")
+    g = parity.load("editnet_full_b4")
+    args = (d["wm"], to_dev(d["prev"]), to_dev(d["plen"]), to_dev(d["X"]), True, False)
+    with torch.no_grad():
+        rl(*args)
+        rl(*args)
+        names = _tags(lambda: rl(*args))
+        assert "persistent_decode" in names, names
+        seq, logp = rl(*args)
+        torch.cuda.synchronize()
+        parity.check_greedy(_np(seq), _np(logp), g)
+        ref = _with_env("SET_DEC_PERSISTENT", "0", lambda: rl(*args))
+        names = _with_env("SET_DEC_PERSISTENT", "0", lambda: _tags(lambda: rl(*args)))
+        assert "persistent_decode" not in names
+    assert torch.equal(seq, ref[0])
+    assert float((logp - ref[1]).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 5, 6])
+def test_editnet_persistent_decode_other_batch_sizes(B):
+    """1 .. 6 rows (what the kernel's LDS budget admits), random features and ragged previous captions: the persistent launch
+    against the per-step loop, row by row (see the DCNet twin above), and run-to-run determinism."""
+    d, xe, rl = editnet_modules("editnet_full_b4")
+    prev, plen = _random_prev(B, d["prev"].shape[1], 200 + B)
+    X = to_dev(np.abs(np.random.RandomState(300 + B).randn(B, d["X"].shape[1], d["X"].shape[2])).astype(np.float32))
+    args = (d["wm"], prev, plen, X, True, False)
+    with torch.no_grad():
+        for _ in range(2):
+            rl(*args)
+        names = _tags(lambda: rl(*args))
+        assert "persistent_decode" in names, names
+        seq, logp = rl(*args)
+        again = rl(*args)
+        ref = _with_env("SET_DEC_PERSISTENT", "0", lambda: rl(*args))
+        torch.cuda.synchronize()
+    assert torch.equal(seq, again[0]) and torch.equal(logp, again[1])
+    same = (seq == ref[0]).all(1)
+    assert int(same.sum()) >= B - 1, (seq, ref[0])
+    assert float((logp - ref[1])[same].abs().max()) < 1e-5
+    assert torch.isfinite(logp).all()
+
+
+def test_editnet_persistent_decode_early_finish_and_begun():
+    """Rows that emit <end> early (the `editnet_small_end`-style bookkeeping at full size: fc bias pushed towards <end>):
+    finished rows are fed word 0 and keep emitting zeros, the loop leaves once every row has finished, and the prologue /
+    decode split (`set_editnet_greedy_begun`, DevicePrefetcher begin_ahead) takes the persistent launch too."""
+    d, xe, rl = editnet_modules("editnet_full_b4")
+    args = (d["wm"], to_dev(d["prev"]), to_dev(d["plen"]), to_dev(d["X"]), True, False)
+    end = int(d["wm"]["<end>"])
+    with torch.no_grad():
+        rl.fc.bias[end] += 6.0                                    # captions now end after a few words
+        for _ in range(2):
+            rl(*args)
+        seq, logp = rl(*args)
+        ref = _with_env("SET_DEC_PERSISTENT", "0", lambda: rl(*args))
+        torch.cuda.synchronize()
+        assert torch.equal(seq, ref[0]) and float((logp - ref[1]).abs().max()) < 1e-5
+        assert (seq == 0).any(1).all(), "every row should have finished inside max_len in this set-up"
+        rl.begin_ahead(args[1], args[2], args[3])
+        hits = rl.__dict__.get("_ahead_hits", 0)
+        names = _tags(lambda: rl(*args))
+        assert rl.__dict__.get("_ahead_hits", 0) == hits + 1 and "persistent_decode" in names
+        again = rl(*args)
+        assert torch.equal(again[0], seq)
+
+
 _FAULT_SCRIPT = r"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.getcwd(), "tests")); sys.path.insert(0, os.getcwd())
 import parity
-from hip_adapter import dcnet_modules, to_dev
+from hip_adapter import dcnet_modules, editnet_modules, to_dev
 from show_edit_tell_amd import _lib
 d, xe, rl = dcnet_modules("dcnet_full_b4")
 g = parity.load("dcnet_full_b4")
