@@ -21,6 +21,13 @@ from hip_adapter import dcnet_modules, editnet_modules, to_dev
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _per_step_loop(monkeypatch):
+    """These tests compare the per-step loop with and without row skipping BIT for bit; the persistent small-batch launch
+    (tests/test_hip_persistent_decode.py) adds the same products in another order and never skips rows."""
+    monkeypatch.setenv("SET_DEC_PERSISTENT", "0")
+
+
 def _boosted(rl, wm, boost):
     with torch.no_grad():
         rl.fc.bias[int(wm["<end>"])] += boost
