@@ -1,5 +1,6 @@
-// Persistent free-running decode for small batches (B <= 16): the whole greedy loop of DCNet (dcnet_rl.py:286-346) as ONE
-// launch of D / 4 workgroups separated by grid barriers instead of six launches per timestep.
+// Persistent free-running decode for small batches (B <= 8): the whole greedy loop of DCNet (dcnet_rl.py:286-346) as ONE
+// launch of D / 4 workgroups that exchange activations through flag-in-data words instead of six launches per timestep.
+// (EditNet's twin: decode_persistent_editnet.hip.)
 //
 // At B = 4 a timestep of the per-step path is six dependent launches of 10-25 us that stream 123 MB of weights between
 // them: every launch pays a boundary, a start-up and a tail, and the pointwise kernels between the GEMV launches run at the
@@ -12,17 +13,16 @@
 //   * the context half of language_lstm's input product is hoisted: W_ih[:, D:] ctx = sum_t alpha_t (W_ih[:, D:] enc_t), so
 //     the prologue computes Pc = enc W_ih[:, D:]^T (B, T, 4D) once and a timestep only needs the attention weights —
 //     16 MB of weights per timestep are not streamed at all, and every workgroup computes the (tiny) attention itself
-//     instead of waiting for a context vector;
-//   * cap_decoder_att(h1) (A x D) is the one product whose output every workgroup needs: it is split over all
-//     workgroups (16 rows x K / 8 each), the partial sums cross a barrier as 8 slabs;
-//   * fc: a workgroup scores V / 256 (+) vocabulary rows and publishes (max, first arg-max, sum exp) per batch row; after
-//     the barrier every workgroup combines the 256 triples itself (same word everywhere, no broadcast round), workgroup 0
-//     writes seq / seq_logp and the loop's bookkeeping words.
-// Four barriers per timestep (h1, att2 partials, h2, fc partials).  What does not depend on the other workgroups sits
-// between a barrier's arrival and its wait: the first weight tiles of the next phase (64-128 KB per workgroup, requested
-// into registers) and the hoisted Pc values.
-// Same residency rule, fault word and event chain as the persistent encoder (grid_barrier.h).  A barrier timeout poisons
-// seq_logp with NaN; the host raises SET_ERR_FAULT at its next call.
+//     (its cap_features_att rows stay in registers at B <= 4) instead of waiting for a context vector;
+//   * cap_decoder_att(h1) (A x D) is the one product whose output every workgroup needs: A / 256 = 2 rows per workgroup;
+//   * fc: a workgroup scores V / 256 (+) vocabulary rows and publishes (max, first arg-max, sum exp) per batch row; every
+//     workgroup combines the 256 triples itself (same word everywhere, no broadcast round), workgroup 0 writes seq /
+//     seq_logp and the loop's bookkeeping words.
+// Four exchanges per timestep (h1, the attention projection, h2, the fc triples), each as 8-byte {value, tag} words
+// (grid_barrier.h): a consumer polls the words it needs until they carry the exchange's tag — no counters, no fences.  The
+// weight tiles of the next phase are requested before a poll (two register buffers of 64 KB per workgroup).
+// Same residency rule, fault word and event chain as the persistent encoder (grid_barrier.h PersistentGuard).  A poll that
+// times out poisons seq_logp with NaN; the host raises SET_ERR_FAULT at its next call.
 #include "decode_persistent.h"
 
 namespace set {

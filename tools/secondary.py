@@ -131,6 +131,21 @@ def dcnet(dev):
             if B == 4:
                 t, _ = _timed(lambda: er(wm, prev, plen, X, True, False), 10, 3)
                 out["editnet_greedy_b4_ms"] = round(1e3 * t, 3)
+                # the same two decodes on the per-step loop (round 4: up to 8 rows the greedy loop is ONE persistent launch,
+                # csrc/decode_persistent*.hip; SET_DEC_PERSISTENT=0 is read per call)
+                import os
+                old = os.environ.get("SET_DEC_PERSISTENT")
+                os.environ["SET_DEC_PERSISTENT"] = "0"
+                try:
+                    t, _ = _timed(lambda: dae(wm, prev, plen, True, False), 10, 3)
+                    out["dcnet_greedy_b4_per_step_loop_ms"] = round(1e3 * t, 3)
+                    t, _ = _timed(lambda: er(wm, prev, plen, X, True, False), 10, 3)
+                    out["editnet_greedy_b4_per_step_loop_ms"] = round(1e3 * t, 3)
+                finally:
+                    if old is None:
+                        del os.environ["SET_DEC_PERSISTENT"]
+                    else:
+                        os.environ["SET_DEC_PERSISTENT"] = old
     # BASELINE.json configs[0] (batch 4) is weight-streaming bound (265.7 MB per EditNet timestep incl.
     # 2.3 MB of activations, 160.6 MB of DCNet weights): bytes / time against the 8 TB/s HBM peak, prologue included in
     # the time (19 timesteps per decode)
