@@ -251,6 +251,122 @@ __global__ void __launch_bounds__(256) attention_bwd_k(const float* dctx, const 
     }
 }
 
+// Wide form of attention_bwd_k (round 4): 512 threads per row.  The 256-thread form walks five dependent rounds of
+// value-row loads and six of att1 loads with one workgroup per sample (128 workgroups on 256 CUs): 22-25 us at B = 128
+// whatever the bytes.  Here wave w takes the value rows l = w, w + 8, ... three at a time (24 float4 per lane in flight),
+// and the (L x A) projection block is covered by (A / 4) column groups x 4 row slices, each thread holding ten of its rows
+// before it touches any; the per-column sums over rows are combined across the 4 slices in slice order through LDS.  Same
+// results as attention_bwd_k up to the order of those two sums.
+constexpr int ATTW_RB = 3;       // value rows of a wave in flight
+constexpr int ATTW_SB = 10;      // projection rows of a thread in flight
+template <bool TANH>
+__global__ void __launch_bounds__(512) attention_bwd_wide_k(const float* dctx, const float* dalpha_ext, const float* alpha,
+                                                           const float* Vals, const float* att1, const float* att2,
+                                                           const float* w_full, float* datt1, float* datt2,
+                                                           float* dwfull_part, float* de_out, int L, int Dv, int A,
+                                                           int acc_datt1, long long ld_datt2) {
+    __shared__ float s_da[ATTB_MAX];
+    __shared__ float s_de[ATTB_MAX];
+    __shared__ float s_dot;
+    __shared__ __attribute__((aligned(16))) float s_acc[4 * 128 * 4 * 2];     // [slice][column group][acc2 | accw] float4
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* dc = dctx + (long long)b * Dv;
+    constexpr int NQ = 8;                                   // Dv <= 2048
+    f32x4 dcr[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int d = lane * 4 + 256 * q;
+        dcr[q] = d < Dv ? ldb4(dc + d) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int l0 = wave; l0 < L; l0 += 8 * ATTW_RB) {
+        f32x4 xr[ATTW_RB][NQ];
+#pragma unroll
+        for (int i = 0; i < ATTW_RB; ++i) {
+            const int l = l0 + 8 * i;
+            const float* v = Vals + ((long long)b * L + (l < L ? l : l0)) * Dv;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int d = lane * 4 + 256 * q;
+                xr[i][q] = d < Dv ? ldb4(v + d) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < ATTW_RB; ++i) {
+            const int l = l0 + 8 * i;
+            float s0 = 0.f;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)              // same accumulation order as attention_bwd_k
+                s0 += xr[i][q][0] * dcr[q][0] + xr[i][q][1] * dcr[q][1] + xr[i][q][2] * dcr[q][2] + xr[i][q][3] * dcr[q][3];
+            s0 = wsum(s0);
+            if (lane == 0 && l < L) s_da[l] = s0 + (dalpha_ext ? dalpha_ext[(long long)b * L + l] : 0.f);
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float s = 0.f;
+        for (int l = tid; l < L; l += 64) s += alpha[(long long)b * L + l] * s_da[l];
+        s = wsum(s);
+        if (tid == 0) s_dot = s;
+    }
+    __syncthreads();
+    for (int l = tid; l < L; l += 512) {
+        const float a = alpha[(long long)b * L + l];
+        const float de = a * (s_da[l] - s_dot);
+        s_de[l] = de;
+        if (de_out) de_out[(long long)b * L + l] = de;
+    }
+    __syncthreads();
+    const int ncg = A >> 2, t_cg = tid & 127, t_sl = tid >> 7;       // 128 column groups x 4 row slices per pass
+    for (int c0 = 0; c0 < ncg; c0 += 128) {                  // A <= 512: one pass; A <= 1024: two
+        const int c = c0 + t_cg, a = c * 4;
+        const bool on = c < ncg;
+        f32x4 w = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+        if (on) { w = ldb4(w_full + a); a2 = ldb4(att2 + (long long)b * A + a); }
+        f32x4 acc2 = {0.f, 0.f, 0.f, 0.f}, accw = {0.f, 0.f, 0.f, 0.f};
+        for (int lb = t_sl; lb < L; lb += 4 * ATTW_SB) {
+            f32x4 pr[ATTW_SB];
+#pragma unroll
+            for (int u = 0; u < ATTW_SB; ++u) {
+                const int l = lb + 4 * u;
+                pr[u] = (on && l < L) ? ldb4(att1 + ((long long)b * L + l) * A + a) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < ATTW_SB; ++u) {
+                const int l = lb + 4 * u;
+                if (!on || l >= L) continue;
+                const f32x4 p = pr[u] + a2;
+                const float de = s_de[l];
+                f32x4 dp;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float act, dact;
+                    if (TANH) { act = tanhf(p[e]); dact = 1.f - act * act; }
+                    else { act = p[e] > 0.f ? p[e] : 0.f; dact = p[e] > 0.f ? 1.f : 0.f; }
+                    dp[e] = de * w[e] * dact;
+                    accw[e] += de * act;
+                }
+                acc2 += dp;
+                float* o = datt1 + ((long long)b * L + l) * A + a;
+                stb4(o, acc_datt1 ? ldb4(o) + dp : dp);
+            }
+        }
+        if (c0) __syncthreads();
+        *reinterpret_cast<f32x4*>(s_acc + ((t_sl * 128 + t_cg) * 2 + 0) * 4) = acc2;
+        *reinterpret_cast<f32x4*>(s_acc + ((t_sl * 128 + t_cg) * 2 + 1) * 4) = accw;
+        __syncthreads();
+        if (t_sl == 0 && on) {
+            f32x4 r2 = {0.f, 0.f, 0.f, 0.f}, rw = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                r2 += *reinterpret_cast<const f32x4*>(s_acc + ((s4 * 128 + t_cg) * 2 + 0) * 4);
+                rw += *reinterpret_cast<const f32x4*>(s_acc + ((s4 * 128 + t_cg) * 2 + 1) * 4);
+            }
+            stb4(datt2 + (long long)b * ld_datt2 + a, r2);
+            stb4(dwfull_part + (long long)b * A + a, rw);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // SelectC backward (editnet.py:409-420): sel = w M[j*], w = a + (1 - a_detached)
 //   dM[b, j*] = w dsel ; dalpha[b, j*] = <dsel, M[b, j*]> ; zero elsewhere
@@ -505,6 +621,17 @@ int set_attention_bwd_acc_f32(const float* dctx, const float* dalpha_ext, const 
     if (ld_datt2 <= 0) ld_datt2 = A;
     if (L > ATTB_MAX || (A & 3) || (Dv & 3) || A > 1024 || Dv > 2048 || (ld_datt2 & 3) || ld_datt2 < A) return SET_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+    static const int wide = env_int("SET_ATT_BWD_WIDE", 1);
+    if (wide && !dvalues) {                                  // 512 threads per row, several rows of every operand in flight
+        if (use_tanh)
+            hipLaunchKernelGGL(attention_bwd_wide_k<true>, dim3(M), dim3(512), 0, st, dctx, dalpha_ext, alpha, values, att1, att2,
+                               w_full, datt1, datt2, dwfull_part, de, L, Dv, A, acc_datt1, (long long)ld_datt2);
+        else
+            hipLaunchKernelGGL(attention_bwd_wide_k<false>, dim3(M), dim3(512), 0, st, dctx, dalpha_ext, alpha, values, att1, att2,
+                               w_full, datt1, datt2, dwfull_part, de, L, Dv, A, acc_datt1, (long long)ld_datt2);
+        SET_LAUNCH_CHECK();
+        return SET_OK;
+    }
     if (use_tanh)
         hipLaunchKernelGGL(attention_bwd_k<true>, dim3(M), dim3(256), 0, st, dctx, dalpha_ext, alpha, values, att1, att2,
                            w_full, datt1, datt2, dwfull_part, dvalues, de, L, Dv, A, acc_datt1, acc_dvalues, (long long)ld_datt2);
