@@ -447,6 +447,17 @@ int set_dcnet_xe_forward(const SetDcnetWeights* w, const SetDcnetDims* d, const 
     SET_TRY(begin_impl(w, d, prev, prevlen, W, st));
     SET_HIP_TRY(hipMemsetAsync(predictions, 0, sizeof(float) * (size_t)B * maxT * V, st));
     const bool emb_needed = !table_active(w, d);
+    // small batches: the teacher-forced loop as ONE persistent launch too (decode_persistent.hip, words from caps, scores out)
+    if (!emb_needed && dcnet_persistent_ok(d, maxT)) {
+        const int T = d->T, D = d->D, C = d->C, E = d->E;
+        GemmProb p = direct_prob(W.pd_pc, 4LL * D, B * T, 4 * D, nullptr, SET_ACT_NONE);
+        p.add(W.enc, 2 * C, w->ll_wih + D, 2 * E, 2 * C);
+        SET_TRY(gemm_group(&p, 1, st, "gemm:pro ll_ctx hoist"));
+        const PDecTeacher teach{caps, caps_stride, predictions, host_decode_lengths};
+        const int rc = dcnet_persistent_greedy(w, d, W.pre1, W.att1_c, W.mask, W.pd_pc, W.pd_x, W.it, W.unfinished, W.alive, 0, -1,
+                                               maxT, nullptr, nullptr, st, &teach);
+        if (rc != SET_ERR_UNSUPPORTED) return rc;
+    }
     static const int fa_merge = env_int("SET_FA_MERGE", 1);
     const bool merge = fa_merge && !emb_needed;
     auto rows_at = [&](int t) { int n = 0; while (n < B && host_decode_lengths[n] > t) ++n; return n; };   // dcnet.py:334

@@ -52,6 +52,11 @@ struct PDecDcnetArgs {
     unsigned* status; unsigned* fault; unsigned spin_limit; int test_stall;
     int B, D, T, A, V, max_len, rpw;
     long long start_idx, end_idx;
+    // teacher-forced mode (set_dcnet_xe_forward, dcnet.py:333-348): words from caps, scores of the first bt rows written out,
+    // no pick and no fourth exchange
+    const long long* caps; long long caps_stride;
+    float* predictions; long long ld_pred_b;     // (B, maxT, V)
+    int dlen[PDEC_MAXB];                         // decode lengths, descending (0 = free-running)
     int stamp_wg;
     unsigned long long* stamps;                  // diagnostic (SET_PDEC_STAMPS=1): 100-MHz time stamps of workgroup 0, 16 per timestep
 };
@@ -152,8 +157,14 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
         // ================= S1: attention_lstm cell (h1), language_lstm W_hh h2
         PD_STAMP(0);
         float tg[4] = {0.f, 0.f, 0.f, 0.f};
+        int bt = B;                                              // teacher-forced: rows whose caption is still running (sorted batch)
+        if (P.caps) {
+            bt = 0;
+            for (int b = 0; b < B; ++b) bt += P.dlen[b] > t ? 1 : 0;
+            if (bt == 0) break;
+        }
         if (pair) {
-            long long tok = sTok[pb];
+            long long tok = P.caps ? P.caps[(long long)pb * P.caps_stride + t] : sTok[pb];
             tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);          // same clamp as embed_relu_k
             const float* trow = P.tok_table + tok * P.ld_tab + u0 + pu;
 #pragma unroll
@@ -294,6 +305,20 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
             sRed[(kq * 3 + 2) * 256 + (4 * g + e) * 16 + r] = accf2[e];
         }
         __syncthreads();
+        if (P.caps) {
+            // teacher-forced: the scores themselves, rows 0 .. bt - 1 (dcnet.py:347: predictions[:batch_size_t, t, :] = preds)
+            for (int b = kq; b < bt; b += 4) {
+                const int j = lane >> 4, rr = lane & 15, row = row0 + lane;
+                if (lane < 16 * PDEC_FC_TILES && lane < P.rpw && row < V) {
+                    const int o = j * 256 + b * 16 + rr;
+                    P.predictions[(long long)b * P.ld_pred_b + (long long)t * V + row] =
+                        (((sRed[o] + sRed[3 * 256 + o]) + sRed[6 * 256 + o]) + sRed[9 * 256 + o]) + P.fc_b[row];
+                }
+            }
+            if (t + 1 < P.max_len) { pd_load(wa, pT0); pd_load(wb, pT1); }
+            __syncthreads();                                     // sRed is rewritten by the next timestep's S1
+            continue;
+        }
         ++tag;                                                   // X4: (max, arg-max, sum exp) of every workgroup's rows
         for (int b = kq; b < B; b += 4) {
             const int j = lane >> 4, rr = lane & 15, row = row0 + lane;
@@ -380,7 +405,11 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
     __syncthreads();
     if (s_bad && wg == 0) {
         const float qnan = __builtin_nanf("");
-        for (int i = tid; i < B * P.max_len; i += 256) { P.seq_logp[i] = qnan; P.seq[i] = 0; }
+        if (P.caps) {                                              // teacher-forced: the first timestep's scores of every row
+            for (int i = tid; i < B * V; i += 256) P.predictions[(long long)(i / V) * P.ld_pred_b + i % V] = qnan;
+        } else {
+            for (int i = tid; i < B * P.max_len; i += 256) { P.seq_logp[i] = qnan; P.seq[i] = 0; }
+        }
     }
 }
 
@@ -411,7 +440,7 @@ size_t dcnet_persistent_xbytes(int B, int D, int A) {
 int dcnet_persistent_greedy(const SetDcnetWeights* w, const SetDcnetDims* d, const float* pre1, const float* att1_c,
                             const float* mask, const float* pc, void* xbuf, long long* it, int* unfinished, int* alive,
                             long long start_idx, long long end_idx, int max_len, long long* seq, float* seq_logp,
-                            hipStream_t s) {
+                            hipStream_t s, const PDecTeacher* teach) {
     if (!dcnet_persistent_ok(d, max_len)) return SET_ERR_UNSUPPORTED;
     const int B = d->B, D = d->D, E = d->E, C = d->C, G = D / 4;
     PDecDcnetArgs P{};
@@ -432,6 +461,11 @@ int dcnet_persistent_greedy(const SetDcnetWeights* w, const SetDcnetDims* d, con
     P.it = it; P.unfinished = unfinished; P.alive = alive; P.seq = seq; P.seq_logp = seq_logp;
     P.B = B; P.D = D; P.T = d->T; P.A = d->A; P.V = d->V; P.max_len = max_len; P.rpw = (d->V + G - 1) / G;
     P.start_idx = start_idx; P.end_idx = end_idx;
+    if (teach) {
+        P.caps = (const long long*)teach->caps; P.caps_stride = teach->caps_stride;
+        P.predictions = teach->predictions; P.ld_pred_b = (long long)max_len * d->V;
+        for (int b = 0; b < B; ++b) P.dlen[b] = teach->host_decode_lengths[b];
+    }
     const int lds = pdec_lds_floats(B, D, d->A) * (int)sizeof(float);
     PersistentGuard guard;
     if (guard.rc != SET_OK) return guard.rc;

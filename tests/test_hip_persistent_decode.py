@@ -118,6 +118,28 @@ def test_dcnet_persistent_decode_on_concurrent_streams():
         assert torch.equal(seq, ref[0]) and torch.equal(lp, ref[1])
 
 
+def test_dcnet_persistent_xe_forward_matches_golden_and_per_step():
+    """BASELINE.json configs[0] names the teacher-forced forward too: with the token table active `DAE.forward` under no_grad
+    at B <= 8 is the same persistent launch in teacher-forced mode (words from the captions, the scores of the first
+    batch_size_t rows written per timestep, dcnet.py:333-348).  Against the golden, against the per-step loop (same scores
+    within 2e-5, identical zero pattern behind each caption's length), ragged lengths included."""
+    d, xe, rl = dcnet_modules("dcnet_full_b4")
+    c, g = d["case"], parity.load("dcnet_full_b4")
+    prev, plen, caps, clen = (to_dev(d[k]) for k in ("prev", "plen", "caps", "clen"))
+    with torch.no_grad():
+        xe(caps, clen, prev, plen)
+        xe(caps, clen, prev, plen)
+        names = _tags(lambda: xe(caps, clen, prev, plen))
+        assert "persistent_decode" in names, names
+        pred, caps_s, dl, sort_ind = xe(caps, clen, prev, plen)
+        parity.check_xe(_np(pred), dl, _np(sort_ind), g, c["V"], small=False)
+        ref = _with_env("SET_DEC_PERSISTENT", "0", lambda: xe(caps, clen, prev, plen))
+        torch.cuda.synchronize()
+    assert dl == ref[2] and torch.equal(sort_ind, ref[3])
+    assert torch.equal(pred == 0, ref[0] == 0), "rows behind a caption's length stay zero in both paths"
+    assert float((pred - ref[0]).abs().max()) < 2e-5 * max(1.0, float(ref[0].abs().max()))
+
+
 def test_editnet_persistent_decode_matches_golden_and_per_step():
     """EditNet greedy at B = 4, full dimensions (csrc/decode_persistent_editnet.hip): the persistent launch equals the
     reference's golden and the per-step loop (ids bit-identical, log-probs within 1e-5)."""

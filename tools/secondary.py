@@ -123,6 +123,13 @@ def dcnet(dev):
     with torch.no_grad():
         dae = _dcnet(dcnet_rl.DAE, dev, wm).eval()
         er = _editnet(editnet_rl.DecoderC, dev, wm).eval()
+        # BASELINE.json configs[0] verbatim: DCNet XE (teacher-forced) forward, batch 4, captions of 20 words
+        from show_edit_tell_amd import dcnet as dcnet_xe
+        dxe = _dcnet(dcnet_xe.DAE, dev, wm).eval()
+        prev, plen = (torch.from_numpy(x).to(dev) for x in synth.prev_captions(3, 4, T, V, 5))
+        caps, clen = (torch.from_numpy(x).to(dev) for x in synth.captions(3, 4, V, 20, 20))
+        t, _ = _timed(lambda: dxe(caps, clen, prev, plen), 10, 3)
+        out["dcnet_xe_forward_b4_ms"] = round(1e3 * t, 3)
         for B in (4, 128):
             prev, plen = (torch.from_numpy(x).to(dev) for x in synth.prev_captions(3, B, T, V, 5))
             X = torch.from_numpy(synth.features(3, B, R, F)).to(dev)
@@ -139,6 +146,8 @@ def dcnet(dev):
                 try:
                     t, _ = _timed(lambda: dae(wm, prev, plen, True, False), 10, 3)
                     out["dcnet_greedy_b4_per_step_loop_ms"] = round(1e3 * t, 3)
+                    t, _ = _timed(lambda: dxe(caps, clen, prev, plen), 10, 3)
+                    out["dcnet_xe_forward_b4_per_step_loop_ms"] = round(1e3 * t, 3)
                     t, _ = _timed(lambda: er(wm, prev, plen, X, True, False), 10, 3)
                     out["editnet_greedy_b4_per_step_loop_ms"] = round(1e3 * t, 3)
                 finally:
