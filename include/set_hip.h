@@ -34,9 +34,10 @@ extern "C" {
 #define SET_ERR_UNSUPPORTED 2  /* dimension not supported by the kernels (see alignment rules) */
 #define SET_ERR_HIP 3          /* a HIP runtime call failed: see set_last_hip_error() */
 #define SET_ERR_WORKSPACE 4    /* workspace too small */
-#define SET_ERR_FAULT 5        /* an EARLIER call's persistent caption-encoder launch timed out at its grid barrier: that call's
-                                  outputs were overwritten with NaN on the device; reported once, at the next call that would
-                                  have used the kernel; the library uses the per-step kernels from then on (retry succeeds) */
+#define SET_ERR_FAULT 5        /* an EARLIER call's persistent launch (caption encoder, small-batch decode loop) timed out
+                                  waiting for its workgroups: that call's outputs were overwritten with NaN on the device;
+                                  reported once, at the next call that would have used such a kernel; the library uses the
+                                  per-step kernels from then on (retry succeeds) */
 
 #define SET_ACT_NONE 0
 #define SET_ACT_RELU 1

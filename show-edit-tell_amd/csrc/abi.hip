@@ -12,7 +12,7 @@ const char* set_error_string(int code) {
         case SET_ERR_UNSUPPORTED: return "dimension not supported by the gfx950 kernels";
         case SET_ERR_HIP: return "HIP runtime error (see set_last_hip_error_string)";
         case SET_ERR_WORKSPACE: return "workspace too small";
-        case SET_ERR_FAULT: return "an earlier persistent-encoder launch timed out at its grid barrier (its outputs were poisoned with NaN); per-step kernels from now on";
+        case SET_ERR_FAULT: return "an earlier persistent launch (caption encoder / small-batch decode loop) timed out waiting for its workgroups (its outputs were poisoned with NaN); per-step kernels from now on";
         default: return "unknown error";
     }
 }
