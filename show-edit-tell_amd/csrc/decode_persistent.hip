@@ -192,13 +192,12 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
             ll_put(h1rs, pb * D + u0 + pu, ao * tanhf(c1), tag);
         }
         PD_STAMP(2);
-        // (a wave's loads return in order: only what the next phase starts with is requested before the poll)
         pd_load(wb, pT3);
         pd_load_if(wd, pT4, vD);
+        pd_load_if(wa, pF[0], vF[0]);
         PD_STAMP(3);
         ll_stage<256, 8>(h1rs, sH1, B, D, LDH, tag, watch, tid);
         __syncthreads();
-        pd_load_if(wa, pF[0], vF[0]);                            // fc's first tile streams under S2 and the attention
         // ================= S2: language_lstm W_ih[:, :D] h1, this workgroup's rows of cap_decoder_att(h1)
         PD_STAMP(4);
         pd_mma(acc2, wb, aH1);
@@ -221,10 +220,10 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
             }
             g2 = ((sRed[2 * 256 + o] + sRed[5 * 256 + o]) + sRed[8 * 256 + o]) + sRed[11 * 256 + o];
         }
+        pd_load_if(wb, pF[1], vF[1]);
         PD_STAMP(6);
         ll_stage<256, 8>(a2rs, sA2, B, A, A, tag, watch, tid);
         __syncthreads();
-        pd_load_if(wb, pF[1], vF[1]);                            // ... the second under the attention's arithmetic
         // ================= S3: caption attention of every row, in every workgroup (dcnet.py:261-268)
         for (int b = kq; b < B; b += 4) {
             const int a_lo = lane * 4, a_hi = lane * 4 + 256;

@@ -237,13 +237,11 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_k(const PD
             if (crr < 8) sM[cb * 8 + crr] = v;
             else ll_put(a2rs, cb * 2 * A + wg * 4 + crr - 8, v, tag);
         }
+        pd_load(wb, pT5);
+        pd_load_if(wa, pT6, v6);
         PD_STAMP(5);
         ll_stage<256, 8>(a2rs, sA2, B, 2 * A, 2 * A, tag, watch, tid);
         __syncthreads();
-        // (a wave's loads return in order: requested here, S4's and S5's tiles stream under the attention's arithmetic instead
-        // of delaying the poll above)
-        pd_load(wb, pT5);
-        pd_load_if(wa, pT6, v6);
         PD_STAMP(6);
         // ================= S3: caption attention of every row (editnet.py:370-376), SelectC's arg-max (:409-416) ...
         for (int b = kq; b < B; b += 4) {
