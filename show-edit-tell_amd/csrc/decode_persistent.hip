@@ -79,6 +79,8 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
     float* sG = sAl + PDEC_MAXB * PDEC_TMAX;             // (B, 16) gate pre-activations of language_lstm
     float* sA2 = sG + PDEC_MAXB * 16;                    // (B, A) cap_decoder_att(h1) of every row
     float* sF = sA2 + B * A;                             // (B, G, 4) fc triples of every workgroup
+    float* sCon = sF + B * G * 4;                        // [cap_decoder_att.bias | cap_full_att.weight] (2, A): loop-invariant
+    float* sPc = sCon + 2 * A;                           // (B, 16, TMAX) hoisted context products of the owned gate rows
     const LLWatch watch{P.status, P.fault, P.spin_limit};
     // exchange buffers (grid_barrier.h, flag-in-data words)
     const __amdgpu_buffer_rsrc_t h1rs = __builtin_amdgcn_make_buffer_rsrc((void*)P.x_h1, 0, B * D * 8, 0x00027000);
@@ -88,6 +90,8 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
 
     // ---- initial state: h1 = h2 = 0, every row is fed <start>
     for (int i = tid; i < 2 * B * LDH; i += PDEC_THREADS) smem[i] = 0.f;
+    for (int i = tid; i < A; i += PDEC_THREADS) { sCon[i] = P.ca_dec_b[i]; sCon[A + i] = P.ca_full_w[i]; }
+    const float bf = P.ca_full_b[0];
     if (tid < B) { sTok[tid] = P.start_idx; sUnf[tid] = 1; }
     __syncthreads();
 
@@ -111,6 +115,7 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
         vF[j] = (16 * j + r < P.rpw) && row < V;
         pF[j] = P.fc_w + (long long)(vF[j] ? row : 0) * D + kcol;
     }
+    const float fcb_lane = (lane < 16 * PDEC_FC_TILES && lane < P.rpw && row0 + lane < V) ? P.fc_b[row0 + lane] : 0.f;   // fc.bias of the row lane l scores
     const int arow = (r < B ? r : B - 1) * LDH;          // rows >= B repeat the last one: their outputs are never read
     const float* aH1 = sH1 + arow + kcol;
     const float* aH2 = sH2 + arow + kcol;
@@ -129,21 +134,21 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
     }
     if (gcol) b2 = P.ll_bih[ccol] + P.ll_bhh[ccol];
 
-    // weight tiles rotate through two register buffers; every tile but S1's third and fc's third is requested while the
-    // previous exchange is still in flight:  S1 wa=T0 wb=T1 (wa<-T2) | X1: wb<-T3 wd<-T4 wa<-F0 | X2: wb<-F1 | S5 (wa<-F2) |
-    // X4: wa<-T0' wb<-T1'
-    f32x4 wa[PDEC_KB], wb[PDEC_KB], wd[PDEC_KB];
+    // weight tiles rotate through two register buffers; every tile but S1's third and fc's third is requested while an
+    // exchange is in flight:  S1 wa=T0 wb=T1 (wa<-T2) | X1: wb<-T3 wa<-T4 | S2 (wb<-F1, wa<-F0) | S5 (wa<-F2) | X4: wa<-T0' wb<-T1'
+    f32x4 wa[PDEC_KB], wb[PDEC_KB];
     pd_load(wa, pT0);
     pd_load(wb, pT1);
     // loop-invariant operands of the attention phase: the hoisted context products of this thread's gate row ...
-    float pcv[PDEC_TMAX];
-#pragma unroll
-    for (int tt = 0; tt < PDEC_TMAX; ++tt)
-        pcv[tt] = (gcol && tt < T) ? P.pc[((long long)cb * T + tt) * 4 * D + ccol] : 0.f;
+    if (gcol)
+        for (int tt = 0; tt < PDEC_TMAX; ++tt) sPc[tid * PDEC_TMAX + tt] = tt < T ? P.pc[((long long)cb * T + tt) * 4 * D + ccol] : 0.f;
+    __syncthreads();
     // ... and (RES) this wave's row of cap_features_att
     f32x4 a1r[RES ? PDEC_TREG : 1][2];
+    float mk_res = 1.f;                                  // (RES) ... and its mask word
     if constexpr (RES) {
         const int brow = kq < B ? kq : B - 1;
+        if (lane < T) mk_res = P.mask[(long long)brow * T + lane];
 #pragma unroll
         for (int tt = 0; tt < PDEC_TREG; ++tt) {
             const int t2 = tt < T ? tt : T - 1;
@@ -193,16 +198,17 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
         }
         PD_STAMP(2);
         pd_load(wb, pT3);
-        pd_load_if(wd, pT4, vD);
-        pd_load_if(wa, pF[0], vF[0]);
+        pd_load_if(wa, pT4, vD);
         PD_STAMP(3);
         ll_stage<256, 8>(h1rs, sH1, B, D, LDH, tag, watch, tid);
         __syncthreads();
         // ================= S2: language_lstm W_ih[:, :D] h1, this workgroup's rows of cap_decoder_att(h1)
         PD_STAMP(4);
         pd_mma(acc2, wb, aH1);
+        pd_load_if(wb, pF[1], vF[1]);
         f32x4 accd = zero4;
-        pd_mma(accd, wd, aH1);
+        pd_mma(accd, wa, aH1);
+        pd_load_if(wa, pF[0], vF[0]);
         PD_STAMP(5);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -220,7 +226,6 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
             }
             g2 = ((sRed[2 * 256 + o] + sRed[5 * 256 + o]) + sRed[8 * 256 + o]) + sRed[11 * 256 + o];
         }
-        pd_load_if(wb, pF[1], vF[1]);
         PD_STAMP(6);
         ll_stage<256, 8>(a2rs, sA2, B, A, A, tag, watch, tid);
         __syncthreads();
@@ -230,10 +235,9 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
             f32x4 a2[2], wf[2];
             a2[0] = *reinterpret_cast<const f32x4*>(sA2 + b * A + a_lo);
             a2[1] = *reinterpret_cast<const f32x4*>(sA2 + b * A + a_hi);
-            const float mk = lane < T ? P.mask[(long long)b * T + lane] : 1.f;
-            a2[0] += *reinterpret_cast<const f32x4*>(P.ca_dec_b + a_lo); a2[1] += *reinterpret_cast<const f32x4*>(P.ca_dec_b + a_hi);
-            wf[0] = *reinterpret_cast<const f32x4*>(P.ca_full_w + a_lo); wf[1] = *reinterpret_cast<const f32x4*>(P.ca_full_w + a_hi);
-            const float bf = P.ca_full_b[0];
+            const float mk = RES ? mk_res : (lane < T ? P.mask[(long long)b * T + lane] : 1.f);
+            a2[0] += *reinterpret_cast<const f32x4*>(sCon + a_lo); a2[1] += *reinterpret_cast<const f32x4*>(sCon + a_hi);
+            wf[0] = *reinterpret_cast<const f32x4*>(sCon + A + a_lo); wf[1] = *reinterpret_cast<const f32x4*>(sCon + A + a_hi);
             constexpr int RB = 10;
             float mine = 0.f;                                   // lane tt keeps the score of position tt
             const float* a1 = P.att1_c + (long long)b * T * A;
@@ -274,9 +278,7 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
         PD_STAMP(7);
         if (gcol) {
             float s = 0.f;
-#pragma unroll
-            for (int tt = 0; tt < PDEC_TMAX; ++tt)
-                if (tt < T) s += sAl[cb * PDEC_TMAX + tt] * pcv[tt];
+            for (int tt = 0; tt < T; ++tt) s += sAl[cb * PDEC_TMAX + tt] * sPc[tid * PDEC_TMAX + tt];
             sG[cb * 16 + crr] = (g2 + s) + b2;
         }
         __syncthreads();
@@ -312,7 +314,7 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
                 if (lane < 16 * PDEC_FC_TILES && lane < P.rpw && row < V) {
                     const int o = j * 256 + b * 16 + rr;
                     P.predictions[(long long)b * P.ld_pred_b + (long long)t * V + row] =
-                        (((sRed[o] + sRed[3 * 256 + o]) + sRed[6 * 256 + o]) + sRed[9 * 256 + o]) + P.fc_b[row];
+                        (((sRed[o] + sRed[3 * 256 + o]) + sRed[6 * 256 + o]) + sRed[9 * 256 + o]) + fcb_lane;
                 }
             }
             if (t + 1 < P.max_len) { pd_load(wa, pT0); pd_load(wb, pT1); }
@@ -326,7 +328,7 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
             float x = -INFINITY;
             if (ok) {
                 const int o = j * 256 + b * 16 + rr;
-                x = (((sRed[o] + sRed[3 * 256 + o]) + sRed[6 * 256 + o]) + sRed[9 * 256 + o]) + P.fc_b[row];
+                x = (((sRed[o] + sRed[3 * 256 + o]) + sRed[6 * 256 + o]) + sRed[9 * 256 + o]) + fcb_lane;
             }
             float best = -INFINITY;
             int bi = 0x7fffffff;
@@ -415,7 +417,7 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
 
 static int g_pdec_capacity[64][2] = {};
 static int pdec_lds_floats(int B, int D, int A) {
-    return 2 * B * (D + 4) + 4 * 3 * 256 + PDEC_MAXB * PDEC_TMAX + PDEC_MAXB * 16 + B * A + B * (D / 4) * 4;
+    return 2 * B * (D + 4) + 4 * 3 * 256 + PDEC_MAXB * PDEC_TMAX + PDEC_MAXB * 16 + B * A + B * (D / 4) * 4 + 2 * A + B * 16 * PDEC_TMAX;
 }
 
 

@@ -112,6 +112,7 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_k(const PD
         vF[j] = (16 * j + r < P.rpw) && row < V;
         pF[j] = P.fc_w + (long long)(vF[j] ? row : 0) * D + kcol;
     }
+    const float fcb_lane = (lane < 16 * PDEC_FC_TILES && lane < P.rpw && row0 + lane < V) ? P.fc_b[row0 + lane] : 0.f;   // fc.bias of the row lane l scores
     const int arow = (r < B ? r : B - 1) * LDH;
     const float* aX = sX + arow + kcol;
     const float* aH2 = sH2 + arow + kcol;
@@ -152,8 +153,10 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_k(const PD
     const f32x4 va1_1 = *reinterpret_cast<const f32x4*>(P.att1 + ((long long)vs_b * R + vs_r) * A + a_hi);
     // ... and (RES) this wave's row of cap_features_att
     f32x4 a1r[RES ? PDEC_TREG : 1][2];
+    float mk_res = 1.f;                                  // (RES) ... and its mask word
     if constexpr (RES) {
         const int brow = kq < B ? kq : B - 1;
+        if (lane < T) mk_res = P.mask[(long long)brow * T + lane];
 #pragma unroll
         for (int tt = 0; tt < PDEC_TREG; ++tt) {
             const int t2 = tt < T ? tt : T - 1;
@@ -249,7 +252,7 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_k(const PD
             a2[0] = *reinterpret_cast<const f32x4*>(sA2 + b * 2 * A + a_lo) + *reinterpret_cast<const f32x4*>(sCon + a_lo);
             a2[1] = *reinterpret_cast<const f32x4*>(sA2 + b * 2 * A + a_hi) + *reinterpret_cast<const f32x4*>(sCon + a_hi);
             const f32x4 cfw0 = *reinterpret_cast<const f32x4*>(sCon + A + a_lo), cfw1 = *reinterpret_cast<const f32x4*>(sCon + A + a_hi);
-            const float mk = lane < T ? P.mask[(long long)b * T + lane] : 1.f;
+            const float mk = RES ? mk_res : (lane < T ? P.mask[(long long)b * T + lane] : 1.f);
             float mine = 0.f;
             if constexpr (RES) {
 #pragma unroll
@@ -413,7 +416,7 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_k(const PD
             float x = -INFINITY;
             if (ok) {
                 const int o = j * 256 + b * 16 + rr;
-                x = (((sRed[o] + sRed[3 * 256 + o]) + sRed[6 * 256 + o]) + sRed[9 * 256 + o]) + P.fc_b[row];
+                x = (((sRed[o] + sRed[3 * 256 + o]) + sRed[6 * 256 + o]) + sRed[9 * 256 + o]) + fcb_lane;
             }
             float best = -INFINITY;
             int bi = 0x7fffffff;

@@ -1,6 +1,6 @@
 # one gpurun call that regenerates everything under profiles/r04_* : bench lines, rocprofv3 kernel stats of the bench and of the
 # training step, PMC traffic per launch shape, the GEMM step microbenchmark for the default kernel and the round-4
-# weights-to-registers variant with SQ counters of both, small-batch profiles
+# weights-to-registers variant with SQ counters of both, small-batch profiles, the persistent small-batch decode
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r04f
 mkdir -p $O
@@ -30,5 +30,7 @@ for v in 0 1 asm; do
 done
 unset SET_GEMM_ASM SET_GEMM_WREG
 ( for b in 4 16 128; do python tools/profile_small_batch.py $b 2>&1 | grep -v amdgpu.ids; done ) > $O/small_batch.txt 2>&1
+bash tools/profile_persistent_decode.sh $O/pdec > /dev/null 2>&1
+cp $O/pdec/persistent_decode.txt $O/persistent_decode.txt; cp $O/pdec/persistent_decode_kernel_stats.txt $O/persistent_decode_kernel_stats.txt; rm -rf $O/pdec
 rm -rf $O/prof_bench $O/prof_train gpurun_out/pmc_bench/fetch gpurun_out/pmc_bench/write gpurun_out/pmc_bench/sq
 ls -la $O
