@@ -140,11 +140,14 @@ def test_dcnet_persistent_xe_forward_matches_golden_and_per_step():
     assert float((pred - ref[0]).abs().max()) < 2e-5 * max(1.0, float(ref[0].abs().max()))
 
 
-def test_editnet_persistent_decode_matches_golden_and_per_step():
-    """EditNet greedy at B = 4, full dimensions (csrc/decode_persistent_editnet.hip): the persistent launch equals the
-    reference's golden and the per-step loop (ids bit-identical, log-probs within 1e-5)."""
-    d, xe, rl = editnet_modules("editnet_full_b4")
-    g = parity.load("editnet_full_b4")
+@pytest.mark.parametrize("name", ["editnet_full_b4", "editnet_full_v9490"])
+def test_editnet_persistent_decode_matches_golden_and_per_step(name):
+    """EditNet greedy at full dimensions (csrc/decode_persistent_editnet.hip): B = 4 (one row per wave, its attention rows
+    resident in registers) and the B = 5 / V = 9490 fixture (two rows on one wave, streamed attention rows, a vocabulary that is
+    no multiple of the 256 workgroups): the persistent launch equals the reference's golden and the per-step loop (ids
+    bit-identical, log-probs within 1e-5)."""
+    d, xe, rl = editnet_modules(name)
+    g = parity.load(name)
     args = (d["wm"], to_dev(d["prev"]), to_dev(d["plen"]), to_dev(d["X"]), True, False)
     with torch.no_grad():
         rl(*args)
