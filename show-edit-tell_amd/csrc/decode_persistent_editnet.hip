@@ -54,6 +54,11 @@ struct PDecEditArgs {
     unsigned* status; unsigned* fault; unsigned spin_limit; int test_stall;
     int B, D, T, R, A, V, max_len, rpw;
     long long start_idx, end_idx;
+    // teacher-forced mode (set_editnet_xe_forward, editnet.py:505-546): words from caps, scores of the first bt rows written
+    // out, no pick and no sixth exchange
+    const long long* caps; long long caps_stride;
+    float* predictions; long long ld_pred_b;     // (B, maxT, V)
+    int dlen[PDEC_MAXB];                         // decode lengths, descending
     int stamp_wg;
     unsigned long long* stamps;
 };
@@ -189,8 +194,14 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_k(const PD
         // ================= S1: attention_lstm cell (h1); copy_lstm.h2h h2
         PD_STAMP(0);
         float tg[4] = {0.f, 0.f, 0.f, 0.f}, ttc = 0.f, tcg = 0.f;
+        int bt = B;                                              // teacher-forced: rows whose caption is still running (sorted batch)
+        if (P.caps) {
+            bt = 0;
+            for (int b = 0; b < B; ++b) bt += P.dlen[b] > t ? 1 : 0;
+            if (bt == 0) break;
+        }
         if (pair) {
-            long long tok = sTok[pb];
+            long long tok = P.caps ? P.caps[(long long)pb * P.caps_stride + t] : sTok[pb];
             tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
             const float* trow = P.tok_table + tok * P.ld_tab + pd;
 #pragma unroll
@@ -409,6 +420,20 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_k(const PD
             sRed[(kq * 3 + 2) * 256 + (4 * g + e) * 16 + r] = accf2[e];
         }
         __syncthreads();
+        if (P.caps) {
+            // teacher-forced: the scores themselves, rows 0 .. bt - 1 (editnet.py:546: predictions[:batch_size_t, t, :] = preds)
+            for (int b = kq; b < bt; b += 4) {
+                const int j = lane >> 4, rr = lane & 15, row = row0 + lane;
+                if (lane < 16 * PDEC_FC_TILES && lane < P.rpw && row < V) {
+                    const int o = j * 256 + b * 16 + rr;
+                    P.predictions[(long long)b * P.ld_pred_b + (long long)t * V + row] =
+                        (((sRed[o] + sRed[3 * 256 + o]) + sRed[6 * 256 + o]) + sRed[9 * 256 + o]) + fcb_lane;
+                }
+            }
+            if (t + 1 < P.max_len) { pd_load(wa, pT0); pd_load(wb, pT1); }
+            __syncthreads();                                     // sRed is rewritten by the next timestep's S1
+            continue;
+        }
         ++tag;                                                   // X6: triples
         for (int b = kq; b < B; b += 4) {
             const int j = lane >> 4, rr = lane & 15, row = row0 + lane;
@@ -493,7 +518,11 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_k(const PD
     __syncthreads();
     if (s_bad && wg == 0) {                                       // an exchange timed out: never hand this out as a decode
         const float qnan = __builtin_nanf("");
-        for (int i = tid; i < B * P.max_len; i += PDEC_THREADS) { P.seq_logp[i] = qnan; P.seq[i] = 0; }
+        if (P.caps) {                                              // teacher-forced: the first timestep's scores of every row
+            for (int i = tid; i < B * V; i += PDEC_THREADS) P.predictions[(long long)(i / V) * P.ld_pred_b + i % V] = qnan;
+        } else {
+            for (int i = tid; i < B * P.max_len; i += PDEC_THREADS) { P.seq_logp[i] = qnan; P.seq[i] = 0; }
+        }
     }
 }
 
@@ -527,7 +556,8 @@ bool editnet_persistent_ok(const SetEditNetDims* d, int max_len) {
 int editnet_persistent_greedy(const SetEditNetWeights* w, const SetEditNetDims* d, const float* pre1, const float* att1,
                               const float* att1_c, const float* mask, const float* capP, const float* memQ, const float* Mem,
                               const float* pv, void* xbuf, long long* it, int* unfinished, int* alive, long long start_idx,
-                              long long end_idx, int max_len, long long* seq, float* seq_logp, hipStream_t s) {
+                              long long end_idx, int max_len, long long* seq, float* seq_logp, hipStream_t s,
+                              const PDecTeacher* teach) {
     if (!editnet_persistent_ok(d, max_len)) return SET_ERR_UNSUPPORTED;
     const int B = d->B, D = d->D, A = d->A, F = d->F, G = D / 4;
     PDecEditArgs P{};
@@ -553,6 +583,11 @@ int editnet_persistent_greedy(const SetEditNetWeights* w, const SetEditNetDims* 
     P.it = it; P.unfinished = unfinished; P.alive = alive; P.seq = seq; P.seq_logp = seq_logp;
     P.B = B; P.D = D; P.T = d->T; P.R = d->R; P.A = A; P.V = d->V; P.max_len = max_len; P.rpw = (d->V + G - 1) / G;
     P.start_idx = start_idx; P.end_idx = end_idx;
+    if (teach) {
+        P.caps = (const long long*)teach->caps; P.caps_stride = teach->caps_stride;
+        P.predictions = teach->predictions; P.ld_pred_b = (long long)max_len * d->V;
+        for (int b = 0; b < B; ++b) P.dlen[b] = teach->host_decode_lengths[b];
+    }
     const int lds = pedit_lds_floats(B, D, A) * (int)sizeof(float);
     PersistentGuard guard;
     if (guard.rc != SET_OK) return guard.rc;

@@ -644,6 +644,17 @@ int set_editnet_xe_forward(const SetEditNetWeights* w, const SetEditNetDims* d, 
     // fc(h2_t) and the phase-A products of t+1 (over the rows still in the batch then) ride one launch, as in the
     // free-running loop
     const bool emb_needed = !(w->tok_table && (d->D % 64 == 0) && env_int("SET_NO_FUSED", 0) == 0);
+    // small batches: the teacher-forced loop as ONE persistent launch too (decode_persistent_editnet.hip)
+    if (!emb_needed && editnet_persistent_ok(d, maxT)) {
+        const int R = d->R, F = d->F, D = d->D;
+        GemmProb p = direct_prob(W.pd_pv, 4LL * D, B * R, 4 * D, nullptr, SET_ACT_NONE);
+        p.add(X, F, w->cl_x2h_w + 2 * D, 2LL * D + F, F);
+        SET_TRY(gemm_group(&p, 1, st, "gemm:pro x2h_img hoist"));
+        const PDecTeacher teach{caps, caps_stride, predictions, host_decode_lengths};
+        const int rc = editnet_persistent_greedy(w, d, W.pre1, W.att1, W.att1_c, W.mask, W.cap_proj, W.mem_proj, W.Mem, W.pd_pv,
+                                                 W.pd_x, W.it, W.unfinished, W.alive, 0, -1, maxT, nullptr, nullptr, st, &teach);
+        if (rc != SET_ERR_UNSUPPORTED) return rc;
+    }
     static const int fa_merge = env_int("SET_FA_MERGE", 1);
     const bool merge = fa_merge && !emb_needed;
     auto rows_at = [&](int t) { int n = 0; while (n < B && host_decode_lengths[n] > t) ++n; return n; };   // editnet.py:506

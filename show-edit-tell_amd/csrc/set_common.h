@@ -165,9 +165,9 @@ int persistent_encoder(const float* w_hh, const float* xg, long long ld_xg_row, 
                        float* Mem, long long ld_out_b, long long ld_out_t, const int* perm, const int* nactive, void* bar,
                        int B, int D, int T, hipStream_t s);
 
+struct PDecTeacher { const int64_t* caps; long long caps_stride; float* predictions; const int* host_decode_lengths; };   // teacher-forced mode
 // decode_persistent.hip: the greedy loop of a small batch as one launch with grid barriers
 constexpr int PDEC_MAXB = 8;
-struct PDecTeacher { const int64_t* caps; long long caps_stride; float* predictions; const int* host_decode_lengths; };   // teacher-forced mode
 size_t dcnet_persistent_xbytes(int B, int D, int A);
 bool dcnet_persistent_ok(const SetDcnetDims* d, int max_len);
 int dcnet_persistent_greedy(const SetDcnetWeights* w, const SetDcnetDims* d, const float* pre1, const float* att1_c,
@@ -180,7 +180,8 @@ bool editnet_persistent_ok(const SetEditNetDims* d, int max_len);
 int editnet_persistent_greedy(const SetEditNetWeights* w, const SetEditNetDims* d, const float* pre1, const float* att1,
                               const float* att1_c, const float* mask, const float* capP, const float* memQ, const float* Mem,
                               const float* pv, void* xbuf, long long* it, int* unfinished, int* alive, long long start_idx,
-                              long long end_idx, int max_len, long long* seq, float* seq_logp, hipStream_t s);
+                              long long end_idx, int max_len, long long* seq, float* seq_logp, hipStream_t s,
+                              const PDecTeacher* teach = nullptr);
 
 // a per-row gathered addend: value(m, n) = tab[ids[m*id_stride]*ld + col0 + n]   (tab == NULL: none)
 struct RowGather {

@@ -164,6 +164,26 @@ def test_editnet_persistent_decode_matches_golden_and_per_step(name):
     assert float((logp - ref[1]).abs().max()) < 1e-5
 
 
+def test_editnet_persistent_xe_forward_matches_golden_and_per_step():
+    """The teacher-forced forward of EditNet under no_grad at B <= 6 (editnet.py:505-546) on the persistent launch: golden,
+    per-step loop (scores within 2e-5, the same zero pattern behind each caption's length)."""
+    d, xe, rl = editnet_modules("editnet_full_b4")
+    c, g = d["case"], parity.load("editnet_full_b4")
+    args = (to_dev(d["X"]), to_dev(d["caps"]), to_dev(d["clen"]), to_dev(d["prev"]), to_dev(d["plen"]), False, 0.0)
+    with torch.no_grad():
+        xe(*args)
+        xe(*args)
+        names = _tags(lambda: xe(*args))
+        assert "persistent_decode" in names, names
+        pred, caps_s, dl, sort_ind = xe(*args)
+        parity.check_xe(_np(pred), dl, _np(sort_ind), g, c["V"], small=False)
+        ref = _with_env("SET_DEC_PERSISTENT", "0", lambda: xe(*args))
+        torch.cuda.synchronize()
+    assert dl == ref[2] and torch.equal(sort_ind, ref[3])
+    assert torch.equal(pred == 0, ref[0] == 0)
+    assert float((pred - ref[0]).abs().max()) < 2e-5 * max(1.0, float(ref[0].abs().max()))
+
+
 @pytest.mark.parametrize("B", [1, 2, 3, 5, 6])
 def test_editnet_persistent_decode_other_batch_sizes(B):
     """1 .. 6 rows (what the kernel's LDS budget admits), random features and ragged previous captions: the persistent launch
