@@ -134,11 +134,9 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
     }
     if (gcol) b2 = P.ll_bih[ccol] + P.ll_bhh[ccol];
 
-    // weight tiles rotate through two register buffers; every tile but S1's third and fc's third is requested while an
-    // exchange is in flight:  S1 wa=T0 wb=T1 (wa<-T2) | X1: wb<-T3 wa<-T4 | S2 (wb<-F1, wa<-F0) | S5 (wa<-F2) | X4: wa<-T0' wb<-T1'
+    // weight tiles rotate through two register buffers:  X1: wb<-T3 wa<-T4 | S2 (wb<-F1, wa<-F0) | S5 (wa<-F2, wb<-T0', wa<-T1')
+    // | S1' (wb<-T2')
     f32x4 wa[PDEC_KB], wb[PDEC_KB];
-    pd_load(wa, pT0);
-    pd_load(wb, pT1);
     // loop-invariant operands of the attention phase: the hoisted context products of this thread's gate row ...
     if (gcol)
         for (int tt = 0; tt < PDEC_TMAX; ++tt) sPc[tid * PDEC_TMAX + tt] = tt < T ? P.pc[((long long)cb * T + tt) * 4 * D + ccol] : 0.f;
@@ -158,8 +156,11 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
     }
     unsigned tag = 0;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // the h-dependent gate products of timestep t do not depend on the word chosen at t - 1: they are contracted at the END
+    // of timestep t - 1, while its fc triples travel (S1' below; the F/A merge of the per-step loop).  t = 0: h1 = h2 = 0.
+    f32x4 acc1 = zero4, acc2 = zero4;
     for (int t = 0; t < P.max_len; ++t) {
-        // ================= S1: attention_lstm cell (h1), language_lstm W_hh h2
+        // ================= S1: attention_lstm cell (h1) from the products of S1'
         PD_STAMP(0);
         float tg[4] = {0.f, 0.f, 0.f, 0.f};
         int bt = B;                                              // teacher-forced: rows whose caption is still running (sorted batch)
@@ -175,11 +176,6 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
 #pragma unroll
             for (int q = 0; q < 4; ++q) tg[q] = trow[(long long)q * D];
         }
-        f32x4 acc1 = zero4, acc2 = zero4;
-        pd_mma(acc1, wa, aH2);
-        pd_load(wa, pT2);
-        pd_mma(acc1, wb, aH1);
-        pd_mma(acc2, wa, aH2);
         PD_STAMP(1);
 #pragma unroll
         for (int e = 0; e < 4; ++e) sRed[(kq * 3 + 0) * 256 + (4 * g + e) * 16 + r] = acc1[e];
@@ -294,11 +290,14 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
         __syncthreads();
         PD_STAMP(9);
         // ================= S5: fc over this workgroup's vocabulary rows, local (max, first arg-max, sum exp) per batch row
+        const bool more = t + 1 < P.max_len;
         f32x4 accf0 = zero4, accf1 = zero4, accf2 = zero4;
         pd_mma(accf0, wa, aH2);
         pd_load_if(wa, pF[2], vF[2]);
         pd_mma(accf1, wb, aH2);
+        if (more) pd_load(wb, pT0);
         pd_mma(accf2, wa, aH2);
+        if (more) pd_load(wa, pT1);
         PD_STAMP(10);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -317,7 +316,13 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
                         (((sRed[o] + sRed[3 * 256 + o]) + sRed[6 * 256 + o]) + sRed[9 * 256 + o]) + fcb_lane;
                 }
             }
-            if (t + 1 < P.max_len) { pd_load(wa, pT0); pd_load(wb, pT1); }
+            if (more) {                                          // S1' (see below)
+                acc1 = zero4; acc2 = zero4;
+                pd_mma(acc1, wb, aH2);
+                pd_load(wb, pT2);
+                pd_mma(acc1, wa, aH1);
+                pd_mma(acc2, wb, aH2);
+            }
             __syncthreads();                                     // sRed is rewritten by the next timestep's S1
             continue;
         }
@@ -346,7 +351,15 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
             if (lane < 4) ll_put(fcrs, (b * G + wg) * 4 + lane, lane == 0 ? best : (lane == 1 ? __int_as_float(bi) : (lane == 2 ? se : 0.f)), tag);
         }
         PD_STAMP(11);
-        if (t + 1 < P.max_len) { pd_load(wa, pT0); pd_load(wb, pT1); }
+        // ================= S1': [W_ih[:, h2] | W_hh] of attention_lstm and language_lstm.W_hh for timestep t + 1, while the
+        // triples travel: nothing here waits for the word
+        if (more) {
+            acc1 = zero4; acc2 = zero4;
+            pd_mma(acc1, wb, aH2);
+            pd_load(wb, pT2);
+            pd_mma(acc1, wa, aH1);
+            pd_mma(acc2, wb, aH2);
+        }
         PD_STAMP(12);
         ll_stage<256, 8>(fcrs, sF, B * G, 4, 4, tag, watch, tid);
         __syncthreads();

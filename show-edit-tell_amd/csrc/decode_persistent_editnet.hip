@@ -183,13 +183,14 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_k(const PD
     if (tid < B) { sTok[tid] = P.start_idx; sUnf[tid] = 1; }
     __syncthreads();
 
-    // weight tiles rotate through two register buffers: S1 wa=T0 wb=T1 (wa<-T2) | X1: wb<-T3 wa<-T4 | X2: wb<-T5 wa<-T6 |
-    // S4 (wb<-F0) | S5 (wa<-F1) | S6 (wb<-F2) | X6: wa<-T0' wb<-T1'
+    // weight tiles rotate through two register buffers: X1: wb<-T3 wa<-T4 | X2: wb<-T5 wa<-T6 | S4 (wb<-F0) | S5 (wa<-F1) |
+    // S6 (wb<-F2, wa<-T0', wb<-T1') | S1' (wa<-T2')
     f32x4 wa[PDEC_KB], wb[PDEC_KB];
-    pd_load(wa, pT0);
-    pd_load(wb, pT1);
     unsigned tag = 0;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // the h-dependent gate products of timestep t do not depend on the word chosen at t - 1: they are contracted at the END
+    // of timestep t - 1, while its fc triples travel (S1' below; the F/A merge of the per-step loop).  t = 0: h1 = h2 = 0.
+    f32x4 acc1 = zero4, acc2 = zero4;
     for (int t = 0; t < P.max_len; ++t) {
         // ================= S1: attention_lstm cell (h1); copy_lstm.h2h h2
         PD_STAMP(0);
@@ -209,11 +210,6 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_k(const PD
             ttc = trow[4LL * D];
             tcg = trow[5LL * D];
         }
-        f32x4 acc1 = zero4, acc2 = zero4;
-        pd_mma(acc1, wa, aH2);
-        pd_load(wa, pT2);
-        pd_mma(acc1, wb, aH1);
-        pd_mma(acc2, wa, aH2);
         PD_STAMP(1);
 #pragma unroll
         for (int e = 0; e < 4; ++e) sRed[(kq * 3 + 0) * 256 + (4 * g + e) * 16 + r] = acc1[e];
@@ -408,10 +404,13 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_k(const PD
         PD_STAMP(14);
         // ================= S6: fc over this workgroup's vocabulary rows, local (max, first arg-max, sum exp) per batch row
         f32x4 accf0 = zero4, accf1 = zero4, accf2 = zero4;
+        const bool more = t + 1 < P.max_len;
         pd_mma(accf0, wb, aH2);
         pd_load_if(wb, pF[2], vF[2]);
         pd_mma(accf1, wa, aH2);
+        if (more) pd_load(wa, pT0);
         pd_mma(accf2, wb, aH2);
+        if (more) pd_load(wb, pT1);
         PD_STAMP(15);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -430,7 +429,13 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_k(const PD
                         (((sRed[o] + sRed[3 * 256 + o]) + sRed[6 * 256 + o]) + sRed[9 * 256 + o]) + fcb_lane;
                 }
             }
-            if (t + 1 < P.max_len) { pd_load(wa, pT0); pd_load(wb, pT1); }
+            if (more) {                                          // S1' (see below)
+                acc1 = zero4; acc2 = zero4;
+                pd_mma(acc1, wa, aH2);
+                pd_load(wa, pT2);
+                pd_mma(acc1, wb, aH1);
+                pd_mma(acc2, wa, aH2);
+            }
             __syncthreads();                                     // sRed is rewritten by the next timestep's S1
             continue;
         }
@@ -457,7 +462,15 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_k(const PD
             se = pd_wsum(se);
             if (lane < 4) ll_put(fcrs, (b * G + wg) * 4 + lane, lane == 0 ? best : (lane == 1 ? __int_as_float(bi) : (lane == 2 ? se : 0.f)), tag);
         }
-        if (t + 1 < P.max_len) { pd_load(wa, pT0); pd_load(wb, pT1); }
+        // ================= S1': attention_lstm's [W_ih[:, h2] | W_hh] and copy_lstm.h2h for timestep t + 1, while the triples
+        // travel: nothing here waits for the word
+        if (more) {
+            acc1 = zero4; acc2 = zero4;
+            pd_mma(acc1, wa, aH2);
+            pd_load(wa, pT2);
+            pd_mma(acc1, wb, aH1);
+            pd_mma(acc2, wa, aH2);
+        }
         PD_STAMP(16);
         ll_stage<256, 8>(fcrs, sF, B * G, 4, 4, tag, watch, tid);
         __syncthreads();
