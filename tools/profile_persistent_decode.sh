@@ -8,11 +8,11 @@ echo "== DCNet greedy (BASELINE.json configs[0]: B = 4), persistent launch vs pe
 PROBE_BS=4,1,2,3,8 python tools/pdec_probe.py 2>&1 | grep "B=\|golden"
 echo "== EditNet greedy"
 PROBE_BS=4,1,2,3,5,6 python tools/pdec_probe_editnet.py 2>&1 | grep "B=\|golden"
-echo "== phase stamps of workgroup 0 (100-MHz clock), DCNet B = 4: 0 S1 | 1 reduce+cell1+put h1 | 2 request next tiles | 3 poll h1 |"
-echo "   4 S2 | 5 put projection | 6 poll + attention | 7 gates + cell2 + put h2 | 8 poll h2 | 9 fc | 10 stats + put | 11 request | 12 poll + combine"
+echo "== phase stamps of workgroup 0 (100-MHz clock), DCNet B = 4: 0 token gather | 1 reduce+cell1+put h1 | 2 request next tiles | 3 poll h1 |"
+echo "   4 S2 | 5 put projection | 6 poll + attention | 7 gates + cell2 + put h2 | 8 poll h2 | 9 fc | 10 stats + put | 11 S1' (next timestep's gate products) | 12 poll + combine"
 PROBE_BS=4 SET_PDEC_STAMPS=1 python tools/pdec_probe.py 2>&1 | grep stamps | tail -1
-echo "== phase stamps, EditNet B = 4: 0 S1 | 1 cell1+put | 2 poll h1 | 3 S2 | 4 put proj | 5 poll | 6 caption attention + visual score | 7 context gate + put |"
-echo "   8 poll | 9 S4 + visual softmax | 10 c_new put | 11 poll | 12 S5 + copy gate + put h2 | 13 poll | 14 fc | 15 stats + put | 16 poll | 17 combine"
+echo "== phase stamps, EditNet B = 4: 0 token gather | 1 cell1+put | 2 poll h1 | 3 S2 | 4 put proj | 5 poll | 6 caption attention + visual score | 7 context gate + put |"
+echo "   8 poll | 9 S4 + visual softmax | 10 c_new put | 11 poll | 12 S5 + copy gate + put h2 | 13 poll | 14 fc | 15 stats + put + S1' (next timestep's gate products) | 16 poll | 17 combine"
 PROBE_BS=4 SET_PDEC_STAMPS=1 python tools/pdec_probe_editnet.py 2>&1 | grep stamps | tail -1
 echo "== per-kernel breakdown, EditNet B = 4 (persistent launch)"
 python tools/profile_small_batch.py 4
