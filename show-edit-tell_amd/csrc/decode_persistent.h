@@ -95,6 +95,14 @@ inline int pd_stamps_report(const unsigned long long* d_stamps, int wg, int last
     if (n) {
         fprintf(stderr, "pdec stamps (us, mean of %d steps, wg %d):", n, wg);
         for (int i = 0; i < last; ++i) fprintf(stderr, " %d-%d:%.2f", i, i + 1, acc[i] / n);
+        if (env_int("SET_PDEC_STAMPS", 0) > 1) {                 // 2: also every stamp relative to the timestep's first one
+            fprintf(stderr, "  | at:");
+            for (int i = 1; i <= last; ++i) {
+                double a = 0;
+                for (int t = 1; t <= n; ++t) a += (double)(h[t * PD_STAMPS + i] - h[t * PD_STAMPS]) * 0.01;
+                fprintf(stderr, " %d=%.2f", i, a / n);
+            }
+        }
         fprintf(stderr, "  step %.2f  (step-to-step %.2f)\n", tot / n, n > 1 ? (double)(h[n * PD_STAMPS] - h[PD_STAMPS]) * 0.01 / (n - 1) : 0.0);
     }
     return SET_OK;

@@ -201,10 +201,8 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
         // ================= S2: language_lstm W_ih[:, :D] h1, this workgroup's rows of cap_decoder_att(h1)
         PD_STAMP(4);
         pd_mma(acc2, wb, aH1);
-        pd_load_if(wb, pF[1], vF[1]);
         f32x4 accd = zero4;
         pd_mma(accd, wa, aH1);
-        pd_load_if(wa, pF[0], vF[0]);
         PD_STAMP(5);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -225,8 +223,11 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
         PD_STAMP(6);
         ll_stage<256, 8>(a2rs, sA2, B, A, A, tag, watch, tid);
         __syncthreads();
+        pd_load_if(wa, pF[0], vF[0]);                            // fc's first tile streams under the attention's arithmetic ...
         // ================= S3: caption attention of every row, in every workgroup (dcnet.py:261-268)
-        for (int b = kq; b < B; b += 4) {
+        // (RES: one row per wave and no loop around it — the compiler drains every outstanding request at a loop header, and
+        // fc's tiles are meant to stream under this arithmetic)
+        auto attend = [&](const int b) {
             const int a_lo = lane * 4, a_hi = lane * 4 + 256;
             f32x4 a2[2], wf[2];
             a2[0] = *reinterpret_cast<const f32x4*>(sA2 + b * A + a_lo);
@@ -269,7 +270,10 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
             const float ex = lane < T ? expf(sc - m) : 0.f;
             const float sum = pd_wsum(ex);
             if (lane < T) sAl[b * PDEC_TMAX + lane] = ex / sum;
-        }
+        };
+        if constexpr (RES) { if (kq < B) attend(kq); }
+        else { for (int b = kq; b < B; b += 4) attend(b); }
+        pd_load_if(wb, pF[1], vF[1]);                            // ... the second under the cell update and the h2 exchange
         __syncthreads();
         PD_STAMP(7);
         if (gcol) {
