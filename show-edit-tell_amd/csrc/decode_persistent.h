@@ -33,6 +33,30 @@ __device__ __forceinline__ float pd_tanh(float x) {
     return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + e);
 #endif
 }
+// this lane's share of one attention score: sum over its 8 columns of w * tanh(x), two columns per packed instruction
+// (v_pk_mul / v_pk_add / v_pk_fma; the exp2 / rcp pairs stay scalar).  -DSET_PDEC_TANHF: the libm form, column by column.
+typedef float pd_f32x2 __attribute__((ext_vector_type(2)));
+typedef float pd_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float pd_score8(const pd_f32x4& x0, const pd_f32x4& x1, const pd_f32x4& w0, const pd_f32x4& w1) {
+#ifdef SET_PDEC_TANHF
+    float s = w0[0] * tanhf(x0[0]) + w0[1] * tanhf(x0[1]) + w0[2] * tanhf(x0[2]) + w0[3] * tanhf(x0[3]);
+    s += w1[0] * tanhf(x1[0]) + w1[1] * tanhf(x1[1]) + w1[2] * tanhf(x1[2]) + w1[3] * tanhf(x1[3]);
+    return s;
+#else
+    const pd_f32x2 c2 = {2.885390081777927f, 2.885390081777927f}, one = {1.f, 1.f}, mtwo = {-2.f, -2.f};
+    pd_f32x2 acc = {0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const pd_f32x2 x = p < 2 ? (pd_f32x2){x0[2 * p], x0[2 * p + 1]} : (pd_f32x2){x1[2 * p - 4], x1[2 * p - 3]};
+        const pd_f32x2 w = p < 2 ? (pd_f32x2){w0[2 * p], w0[2 * p + 1]} : (pd_f32x2){w1[2 * p - 4], w1[2 * p - 3]};
+        const pd_f32x2 a = x * c2;
+        const pd_f32x2 d = (pd_f32x2){__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)} + one;      // 1 + e^(2x)
+        const pd_f32x2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+        acc += w * (r * mtwo + one);                                                                      // w * tanh(x)
+    }
+    return acc.x + acc.y;
+#endif
+}
 __device__ __forceinline__ float pd_wsum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -237,6 +237,7 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
             wf[0] = *reinterpret_cast<const f32x4*>(sCon + A + a_lo); wf[1] = *reinterpret_cast<const f32x4*>(sCon + A + a_hi);
             constexpr int RB = 10;
             float mine = 0.f;                                   // lane tt keeps the score of position tt
+            const unsigned long long live = __ballot(lane < T && mk != 0.f);
             const float* a1 = P.att1_c + (long long)b * T * A;
             for (int t0 = 0; t0 < (RES ? PDEC_TREG : T); t0 += RB) {
                 f32x4 v[RB][2];
@@ -254,13 +255,10 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
 #pragma unroll
                 for (int u = 0; u < RB; ++u) {
                     const int tt = t0 + u;
-                    float sc = 0.f;
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const f32x4 x = v[u][q] + a2[q];
-                        sc += wf[q][0] * pd_tanh(x[0]) + wf[q][1] * pd_tanh(x[1]) + wf[q][2] * pd_tanh(x[2]) + wf[q][3] * pd_tanh(x[3]);
-                    }
-                    sc = pd_wsum(sc);
+                    // masked position (or past T): its score is -1e10 whatever it is.  Not in the resident variant: a branch here makes
+                    // the compiler wait for fc's tile (requested above to stream under this arithmetic) before the first score
+                    if (!RES && !((live >> tt) & 1ull)) continue;
+                    const float sc = pd_wsum(pd_score8(v[u][0] + a2[0], v[u][1] + a2[1], wf[0], wf[1]));
                     if (lane == tt) mine = sc;
                 }
             }

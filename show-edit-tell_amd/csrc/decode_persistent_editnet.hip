@@ -261,13 +261,12 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_k(const PD
             const f32x4 cfw0 = *reinterpret_cast<const f32x4*>(sCon + A + a_lo), cfw1 = *reinterpret_cast<const f32x4*>(sCon + A + a_hi);
             const float mk = RES ? mk_res : (lane < T ? P.mask[(long long)b * T + lane] : 1.f);
             float mine = 0.f;
+            const unsigned long long live = __ballot(lane < T && mk != 0.f);
             if constexpr (RES) {
 #pragma unroll
                 for (int tt = 0; tt < PDEC_TREG; ++tt) {
-                    const f32x4 x0 = a1r[tt][0] + a2[0], x1 = a1r[tt][1] + a2[1];
-                    float sc = cfw0[0] * pd_tanh(x0[0]) + cfw0[1] * pd_tanh(x0[1]) + cfw0[2] * pd_tanh(x0[2]) + cfw0[3] * pd_tanh(x0[3]);
-                    sc += cfw1[0] * pd_tanh(x1[0]) + cfw1[1] * pd_tanh(x1[1]) + cfw1[2] * pd_tanh(x1[2]) + cfw1[3] * pd_tanh(x1[3]);
-                    sc = pd_wsum(sc);
+                    if (!((live >> tt) & 1ull)) continue;       // masked position (or past T): its score is -1e10 whatever it is
+                    const float sc = pd_wsum(pd_score8(a1r[tt][0] + a2[0], a1r[tt][1] + a2[1], cfw0, cfw1));
                     if (lane == tt) mine = sc;
                 }
             } else {
@@ -283,10 +282,8 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_k(const PD
                     }
 #pragma unroll
                     for (int u = 0; u < RB; ++u) {
-                        const f32x4 x0 = v[u][0] + a2[0], x1 = v[u][1] + a2[1];
-                        float sc = cfw0[0] * pd_tanh(x0[0]) + cfw0[1] * pd_tanh(x0[1]) + cfw0[2] * pd_tanh(x0[2]) + cfw0[3] * pd_tanh(x0[3]);
-                        sc += cfw1[0] * pd_tanh(x1[0]) + cfw1[1] * pd_tanh(x1[1]) + cfw1[2] * pd_tanh(x1[2]) + cfw1[3] * pd_tanh(x1[3]);
-                        sc = pd_wsum(sc);
+                        if (!((live >> (t0 + u)) & 1ull)) continue;
+                        const float sc = pd_wsum(pd_score8(v[u][0] + a2[0], v[u][1] + a2[1], cfw0, cfw1));
                         if (lane == t0 + u) mine = sc;
                     }
                 }
