@@ -247,14 +247,15 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_k(const PD
             if (crr < 8) sM[cb * 8 + crr] = v;
             else ll_put(a2rs, cb * 2 * A + wg * 4 + crr - 8, v, tag);
         }
-        pd_load(wb, pT5);
-        pd_load_if(wa, pT6, v6);
         PD_STAMP(5);
         ll_stage<256, 8>(a2rs, sA2, B, 2 * A, 2 * A, tag, watch, tid);
         __syncthreads();
+        pd_load(wb, pT5);                                        // S4's tile streams under the attention's arithmetic
         PD_STAMP(6);
         // ================= S3: caption attention of every row (editnet.py:370-376), SelectC's arg-max (:409-416) ...
-        for (int b = kq; b < B; b += 4) {
+        // (RES: one row per wave, no loop and no branch around the scores — S4's weight tile, requested just above, streams
+        // under this arithmetic; the compiler would drain it at a loop header or a branch join)
+        auto attend = [&](const int b) {
             f32x4 a2[2];
             a2[0] = *reinterpret_cast<const f32x4*>(sA2 + b * 2 * A + a_lo) + *reinterpret_cast<const f32x4*>(sCon + a_lo);
             a2[1] = *reinterpret_cast<const f32x4*>(sA2 + b * 2 * A + a_hi) + *reinterpret_cast<const f32x4*>(sCon + a_hi);
@@ -265,7 +266,6 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_k(const PD
             if constexpr (RES) {
 #pragma unroll
                 for (int tt = 0; tt < PDEC_TREG; ++tt) {
-                    if (!((live >> tt) & 1ull)) continue;       // masked position (or past T): its score is -1e10 whatever it is
                     const float sc = pd_wsum(pd_score8(a1r[tt][0] + a2[0], a1r[tt][1] + a2[1], cfw0, cfw1));
                     if (lane == tt) mine = sc;
                 }
@@ -307,7 +307,10 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_k(const PD
             const int js = bi == 0x7fffffff ? 0 : bi;          // all-NaN weights: a valid row index (the outputs are NaN anyway)
             const float aj = __shfl(al, js);
             if (lane == 0) { sJs[b] = js; sWj[b] = aj * 1.f + (1.f - aj); }   // the reference's fp32 expression (editnet.py:417-418)
-        }
+        };
+        if constexpr (RES) { if (kq < B) attend(kq); }
+        else { for (int b = kq; b < B; b += 4) attend(b); }
+        pd_load_if(wa, pT6, v6);                                 // S5's (short) tile: under the context gate and the exchange
         // ... and this wave's visual score e[b, r] = w . relu(att1[b, r] + decoder_att(h1) + bias) + b (editnet.py:443-445)
         ++tag;                                                   // X3: attend_cap columns + visual scores
         if (vs_on) {
