@@ -329,28 +329,32 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
             continue;
         }
         ++tag;                                                   // X4: (max, arg-max, sum exp) of every workgroup's rows
-        for (int b = kq; b < B; b += 4) {
-            const int j = lane >> 4, rr = lane & 15, row = row0 + lane;
-            const bool ok = lane < 16 * PDEC_FC_TILES && lane < P.rpw && row < V;
-            float x = -INFINITY;
-            if (ok) {
-                const int o = j * 256 + b * 16 + rr;
-                x = (((sRed[o] + sRed[3 * 256 + o]) + sRed[6 * 256 + o]) + sRed[9 * 256 + o]) + fcb_lane;
-            }
-            float best = -INFINITY;
-            int bi = 0x7fffffff;
-            if (x > best) { best = x; bi = row; }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ob = __shfl_xor(best, o);
-                const int oi = __shfl_xor(bi, o);
-                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-            }
-            // (a NaN score never wins a comparison: it reaches the sum instead and the row's log-prob is NaN)
-            float se = ok ? expf(x - best) : 0.f;
-            if (best == -INFINITY) se = ok ? x : 0.f;            // no finite score here: 0 for an empty range, NaN for NaN scores
-            se = pd_wsum(se);
-            if (lane < 4) ll_put(fcrs, (b * G + wg) * 4 + lane, lane == 0 ? best : (lane == 1 ? __int_as_float(bi) : (lane == 2 ? se : 0.f)), tag);
+        {   // (resident variant: one row per wave, no loop — see the attention phase)
+            auto row_work = [&](const int b) {
+                const int j = lane >> 4, rr = lane & 15, row = row0 + lane;
+                const bool ok = lane < 16 * PDEC_FC_TILES && lane < P.rpw && row < V;
+                float x = -INFINITY;
+                if (ok) {
+                    const int o = j * 256 + b * 16 + rr;
+                    x = (((sRed[o] + sRed[3 * 256 + o]) + sRed[6 * 256 + o]) + sRed[9 * 256 + o]) + fcb_lane;
+                }
+                float best = -INFINITY;
+                int bi = 0x7fffffff;
+                if (x > best) { best = x; bi = row; }
+    #pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ob = __shfl_xor(best, o);
+                    const int oi = __shfl_xor(bi, o);
+                    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+                }
+                // (a NaN score never wins a comparison: it reaches the sum instead and the row's log-prob is NaN)
+                float se = ok ? expf(x - best) : 0.f;
+                if (best == -INFINITY) se = ok ? x : 0.f;            // no finite score here: 0 for an empty range, NaN for NaN scores
+                se = pd_wsum(se);
+                if (lane < 4) ll_put(fcrs, (b * G + wg) * 4 + lane, lane == 0 ? best : (lane == 1 ? __int_as_float(bi) : (lane == 2 ? se : 0.f)), tag);
+            };
+            if constexpr (RES) { if (kq < B) row_work(kq); }
+            else { for (int b = kq; b < B; b += 4) row_work(b); }
         }
         PD_STAMP(11);
         // ================= S1': [W_ih[:, h2] | W_hh] of attention_lstm and language_lstm.W_hh for timestep t + 1, while the
@@ -366,48 +370,52 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
         ll_stage<256, 8>(fcrs, sF, B * G, 4, 4, tag, watch, tid);
         __syncthreads();
         // ================= S6: every workgroup combines the G triples of every row: same word everywhere
-        for (int b = kq; b < B; b += 4) {
-            float best = -INFINITY, tot = 0.f;
-            int bi = 0x7fffffff;
-            float pm[4], ps[4];
-            int pi[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int wi = lane + 64 * i;
-                const bool have = wi < G;
-                const f32x4 e4 = have ? *reinterpret_cast<const f32x4*>(sF + (b * G + wi) * 4) : zero4;
-                pm[i] = have ? e4[0] : -INFINITY;
-                pi[i] = have ? __float_as_int(e4[1]) : 0x7fffffff;
-                ps[i] = have ? e4[2] : 0.f;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (pm[i] > best || (pm[i] == best && pi[i] < bi)) { best = pm[i]; bi = pi[i]; }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ob = __shfl_xor(best, o);
-                const int oi = __shfl_xor(bi, o);
-                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) tot += (pm[i] == -INFINITY) ? ps[i] : ps[i] * expf(pm[i] - best);
-            tot = pd_wsum(tot);
-            if (lane == 0) {
-                float logp = (best - best) - logf(tot);           // log_softmax at the arg-max, as greedy_pick_k writes it
-                if (bi == 0x7fffffff) { bi = 0; logp = __builtin_nanf(""); }   // all-NaN row: word 0 and a NaN log-prob
-                long long it = bi;
-                if (it == P.end_idx) it = 0;
-                const int unf = (t == 0) ? (it > 0) : (sUnf[b] && it > 0);
-                it = unf ? it : 0;
-                if (wg == 0) {
-                    P.seq[(long long)b * P.max_len + t] = it;
-                    P.seq_logp[(long long)b * P.max_len + t] = logp;
-                    P.unfinished[b] = unf;
-                    P.it[b] = it;
+        {   // (resident variant: one row per wave, no loop — see the attention phase)
+            auto row_work = [&](const int b) {
+                float best = -INFINITY, tot = 0.f;
+                int bi = 0x7fffffff;
+                float pm[4], ps[4];
+                int pi[4];
+    #pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int wi = lane + 64 * i;
+                    const bool have = wi < G;
+                    const f32x4 e4 = have ? *reinterpret_cast<const f32x4*>(sF + (b * G + wi) * 4) : zero4;
+                    pm[i] = have ? e4[0] : -INFINITY;
+                    pi[i] = have ? __float_as_int(e4[1]) : 0x7fffffff;
+                    ps[i] = have ? e4[2] : 0.f;
                 }
-                sTok[b] = it;
-                sUnf[b] = unf;
-            }
+    #pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (pm[i] > best || (pm[i] == best && pi[i] < bi)) { best = pm[i]; bi = pi[i]; }
+    #pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ob = __shfl_xor(best, o);
+                    const int oi = __shfl_xor(bi, o);
+                    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+                }
+    #pragma unroll
+                for (int i = 0; i < 4; ++i) tot += (pm[i] == -INFINITY) ? ps[i] : ps[i] * expf(pm[i] - best);
+                tot = pd_wsum(tot);
+                if (lane == 0) {
+                    float logp = (best - best) - logf(tot);           // log_softmax at the arg-max, as greedy_pick_k writes it
+                    if (bi == 0x7fffffff) { bi = 0; logp = __builtin_nanf(""); }   // all-NaN row: word 0 and a NaN log-prob
+                    long long it = bi;
+                    if (it == P.end_idx) it = 0;
+                    const int unf = (t == 0) ? (it > 0) : (sUnf[b] && it > 0);
+                    it = unf ? it : 0;
+                    if (wg == 0) {
+                        P.seq[(long long)b * P.max_len + t] = it;
+                        P.seq_logp[(long long)b * P.max_len + t] = logp;
+                        P.unfinished[b] = unf;
+                        P.it[b] = it;
+                    }
+                    sTok[b] = it;
+                    sUnf[b] = unf;
+                }
+            };
+            if constexpr (RES) { if (kq < B) row_work(kq); }
+            else { for (int b = kq; b < B; b += 4) row_work(b); }
         }
         __syncthreads();
         PD_STAMP(13);
