@@ -73,9 +73,9 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_k(const PD
     const int B = P.B, D = P.D, T = P.T, R = P.R, A = P.A, V = P.V;
     const int KQ = D >> 2, LDH = D + 4;
     const int wg = (int)blockIdx.x, u0 = wg * 4, G = (int)gridDim.x;
-    float* sX = smem;                                    // (B, LDH): attend_cap, then c_new (one K operand at a time)
-    float* sH2 = sX + B * LDH;
-    float* sH1 = sH2 + B * LDH;                          // h1 lives until the NEXT timestep's attention_lstm
+    float* sH2 = smem;                                   // (B, LDH): h2 from its exchange to the end of the timestep (fc, S1') ...
+    float* sX = sH2;                                     // ... and before that attend_cap, then c_new (one K operand at a time)
+    float* sH1 = sH2 + B * LDH;                          // h1: from its exchange to S1' at the end of the timestep
     float* sRed = sH1 + B * LDH;                         // [4 waves][3 tiles][16][16]
     float* sAlc = sRed + 4 * 3 * 256;                    // (B, TMAX) caption attention weights
     float* sAlv = sAlc + PDEC_MAXB * PDEC_TMAX;          // (B, 64) visual scores -> weights
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_k(const PD
     const __amdgpu_buffer_rsrc_t fcrs = __builtin_amdgcn_make_buffer_rsrc(P.x_fc, 0, B * G * 32, 0x00027000);
 
     // ---- initial state (init_hidden_state, editnet.py:494-495): zeros; every row is fed <start>
-    for (int i = tid; i < 3 * B * LDH; i += PDEC_THREADS) smem[i] = 0.f;
+    for (int i = tid; i < 2 * B * LDH; i += PDEC_THREADS) smem[i] = 0.f;
     if (tid < B) { sTok[tid] = P.start_idx; sUnf[tid] = 1; }
     __syncthreads();
 
@@ -553,7 +553,7 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_k(const PD
 
 static int g_pedit_capacity[64][2] = {};
 static int pedit_lds_floats(int B, int D, int A) {
-    return 3 * B * (D + 4) + 4 * 3 * 256 + PDEC_MAXB * (PDEC_TMAX + 64 + 16 + 8 + 8) + B * 2 * A +
+    return 2 * B * (D + 4) + 4 * 3 * 256 + PDEC_MAXB * (PDEC_TMAX + 64 + 16 + 8 + 8) + B * 2 * A +
            B * 16 * PDEC_RREG + B * 8 * PDEC_TMAX + 4 * A;
 }
 
