@@ -187,9 +187,17 @@ static int begin_impl(const SetDcnetWeights* w, const SetDcnetDims* d, const int
     }
     SET_TRY(rowsum_mask(ws.enc, 2 * C, B * T, 2 * C, ws.mask, st));                    // dcnet.py:239
     {
-        GemmProb p = direct_prob(ws.att1_c, A, B * T, A, w->ca_feat_b, SET_ACT_NONE);   // dcnet.py:261
-        p.add(ws.enc, 2 * C, w->ca_feat_w, 2 * C, 2 * C);
-        SET_TRY(gemm_group(&p, 1, st, "gemm:pro cap_features_att"));
+        // small batches (persistent decode, decode_persistent.hip): the context half of language_lstm's input product is
+        // linear in the attention weights — Pc = enc W_ih[:, D:]^T (B, T, 4D) rides this launch (same operand enc)
+        GemmProb p[2];
+        p[0] = direct_prob(ws.att1_c, A, B * T, A, w->ca_feat_b, SET_ACT_NONE);            // dcnet.py:261
+        p[0].add(ws.enc, 2 * C, w->ca_feat_w, 2 * C, 2 * C);
+        const bool pc = dcnet_persistent_ok(d, 1);
+        if (pc) {
+            p[1] = direct_prob(ws.pd_pc, 4LL * D, B * T, 4 * D, nullptr, SET_ACT_NONE);
+            p[1].add(ws.enc, 2 * C, w->ll_wih + D, 2 * E, 2 * C);
+        }
+        SET_TRY(gemm_group(p, pc ? 2 : 1, st, "gemm:pro cap_features_att"));
     }
     {
         GemmProb p = slab_prob(ws.s_pre, B, 4 * D, B);                 // final_hidden columns of attention_lstm
@@ -374,10 +382,6 @@ static int dcnet_rollout(const SetDcnetWeights* w, const SetDcnetDims* d, const 
     // small batches, greedy: the whole loop as ONE persistent launch (decode_persistent.hip).  The context half of
     // language_lstm's input product is linear in the attention weights: Pc = enc W_ih[:, D:]^T is computed here once
     if (!sample && !emb_needed && !skip_rows && !g_force_len && dcnet_persistent_ok(d, max_len)) {
-        const int T = d->T, D = d->D, C = d->C, E = d->E;
-        GemmProb p = direct_prob(W.pd_pc, 4LL * D, B * T, 4 * D, nullptr, SET_ACT_NONE);
-        p.add(W.enc, 2 * C, w->ll_wih + D, 2 * E, 2 * C);
-        SET_TRY(gemm_group(&p, 1, st, "gemm:pro ll_ctx hoist"));
         const int rc = dcnet_persistent_greedy(w, d, W.pre1, W.att1_c, W.mask, W.pd_pc, W.pd_x, W.it, W.unfinished, W.alive,
                                                start_idx, end_idx, max_len, (long long*)seq, seq_logp, st);
         if (rc != SET_ERR_UNSUPPORTED) return rc;
@@ -449,10 +453,6 @@ int set_dcnet_xe_forward(const SetDcnetWeights* w, const SetDcnetDims* d, const 
     const bool emb_needed = !table_active(w, d);
     // small batches: the teacher-forced loop as ONE persistent launch too (decode_persistent.hip, words from caps, scores out)
     if (!emb_needed && dcnet_persistent_ok(d, maxT)) {
-        const int T = d->T, D = d->D, C = d->C, E = d->E;
-        GemmProb p = direct_prob(W.pd_pc, 4LL * D, B * T, 4 * D, nullptr, SET_ACT_NONE);
-        p.add(W.enc, 2 * C, w->ll_wih + D, 2 * E, 2 * C);
-        SET_TRY(gemm_group(&p, 1, st, "gemm:pro ll_ctx hoist"));
         const PDecTeacher teach{caps, caps_stride, predictions, host_decode_lengths};
         const int rc = dcnet_persistent_greedy(w, d, W.pre1, W.att1_c, W.mask, W.pd_pc, W.pd_x, W.it, W.unfinished, W.alive, 0, -1,
                                                maxT, nullptr, nullptr, st, &teach);

@@ -275,9 +275,17 @@ static int begin_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const
         SET_TRY(gemm_group(p, 4, st, "gemm:pro cap projections"));
     }
     {
-        GemmProb p = direct_prob(ws.fe, D, B * R, D, w->va_emb_b, SET_ACT_RELU);          // editnet.py:441
-        p.add(X, F, w->va_emb_w, F, F);
-        SET_TRY(gemm_group(&p, 1, st, "gemm:pro att_embed"));
+        // small batches (persistent decode, decode_persistent_editnet.hip): the region half of copy_lstm.x2h is linear in the
+        // visual attention weights — Pv = X x2h[:, 2D:]^T (B, R, 4D) rides the att_embed launch (same operand X)
+        GemmProb p[2];
+        p[0] = direct_prob(ws.fe, D, B * R, D, w->va_emb_b, SET_ACT_RELU);                // editnet.py:441
+        p[0].add(X, F, w->va_emb_w, F, F);
+        const bool pv = editnet_persistent_ok(d, 1);
+        if (pv) {
+            p[1] = direct_prob(ws.pd_pv, 4LL * D, B * R, 4 * D, nullptr, SET_ACT_NONE);
+            p[1].add(X, F, w->cl_x2h_w + 2 * D, 2LL * D + F, F);
+        }
+        SET_TRY(gemm_group(p, pv ? 2 : 1, st, "gemm:pro att_embed"));
         GemmProb q = direct_prob(ws.att1, A, B * R, A, w->va_feat_b, SET_ACT_NONE);       // editnet.py:442
         q.add(ws.fe, D, w->va_feat_w, D, D);
         SET_TRY(gemm_group(&q, 1, st, "gemm:pro features_att"));
@@ -524,10 +532,10 @@ static int rollout(const SetEditNetWeights* w, const SetEditNetDims* d, const fl
     SET_HIP_TRY(hipMemsetAsync(seq, 0, sizeof(int64_t) * B * max_len, st));
     SET_HIP_TRY(hipMemsetAsync(seq_logp, 0, sizeof(float) * B * max_len, st));
     SET_TRY(set_tokens(W.it, start_idx, W.unfinished, W.alive, d->maxT + 2, B, st));
-    SET_TRY(embed_relu(w->embed, (const int64_t*)W.it, 1, W.emb, d->D, B, d->D, d->V, st));
     // with the token table the step never reads relu(E[it]) (all its consumers gather the folded products),
-    // so the epilogue skips the embedding gather
+    // so neither the loop's first timestep nor the epilogue gathers the embedding
     const bool emb_needed = !(w->tok_table && (d->D % 64 == 0) && env_int("SET_NO_FUSED", 0) == 0);
+    if (emb_needed) SET_TRY(embed_relu(w->embed, (const int64_t*)W.it, 1, W.emb, d->D, B, d->D, d->V, st));
     // the reference runs max_len + 1 timesteps and discards the last one (editnet_rl.py:503,517-518)
     static const int fa_merge = env_int("SET_FA_MERGE", 1);
     const bool merge = fa_merge && !emb_needed;      // the token table is active: phase A does not see the token
@@ -546,10 +554,12 @@ static int rollout(const SetEditNetWeights* w, const SetEditNetDims* d, const fl
     // small batches, greedy: the whole loop as ONE persistent launch (decode_persistent_editnet.hip).  copy_lstm.x2h's region
     // columns are linear in the visual attention weights: Pv = X x2h[:, 2D:]^T is computed here once per decode
     if (!sample && !emb_needed && !skip_rows && !g_force_len && editnet_persistent_ok(d, max_len)) {
-        const int R = d->R, F = d->F, D = d->D;
-        GemmProb p = direct_prob(W.pd_pv, 4LL * D, B * R, 4 * D, nullptr, SET_ACT_NONE);
-        p.add(X, F, w->cl_x2h_w + 2 * D, 2LL * D + F, F);
-        SET_TRY(gemm_group(&p, 1, st, "gemm:pro x2h_img hoist"));
+        if (begun) {     // the prologue ran in an earlier call (begin_ahead), possibly under other switches: Pv is not taken on trust
+            const int R = d->R, F = d->F, D = d->D;
+            GemmProb p = direct_prob(W.pd_pv, 4LL * D, B * R, 4 * D, nullptr, SET_ACT_NONE);
+            p.add(X, F, w->cl_x2h_w + 2 * D, 2LL * D + F, F);
+            SET_TRY(gemm_group(&p, 1, st, "gemm:pro x2h_img hoist"));
+        }
         const int rc = editnet_persistent_greedy(w, d, W.pre1, W.att1, W.att1_c, W.mask, W.cap_proj, W.mem_proj, W.Mem, W.pd_pv,
                                                  W.pd_x, W.it, W.unfinished, W.alive, start_idx, end_idx, max_len, (long long*)seq,
                                                  seq_logp, st);
@@ -646,10 +656,6 @@ int set_editnet_xe_forward(const SetEditNetWeights* w, const SetEditNetDims* d, 
     const bool emb_needed = !(w->tok_table && (d->D % 64 == 0) && env_int("SET_NO_FUSED", 0) == 0);
     // small batches: the teacher-forced loop as ONE persistent launch too (decode_persistent_editnet.hip)
     if (!emb_needed && editnet_persistent_ok(d, maxT)) {
-        const int R = d->R, F = d->F, D = d->D;
-        GemmProb p = direct_prob(W.pd_pv, 4LL * D, B * R, 4 * D, nullptr, SET_ACT_NONE);
-        p.add(X, F, w->cl_x2h_w + 2 * D, 2LL * D + F, F);
-        SET_TRY(gemm_group(&p, 1, st, "gemm:pro x2h_img hoist"));
         const PDecTeacher teach{caps, caps_stride, predictions, host_decode_lengths};
         const int rc = editnet_persistent_greedy(w, d, W.pre1, W.att1, W.att1_c, W.mask, W.cap_proj, W.mem_proj, W.Mem, W.pd_pv,
                                                  W.pd_x, W.it, W.unfinished, W.alive, 0, -1, maxT, nullptr, nullptr, st, &teach);
