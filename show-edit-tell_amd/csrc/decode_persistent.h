@@ -19,8 +19,8 @@ constexpr int PDEC_THREADS = 256;
 constexpr int PDEC_FC_TILES = 3;   // 16-row fc tiles per workgroup: up to 48 vocabulary rows
 
 // diagnostic (SET_PDEC_STAMPS=1): 100-MHz time stamps of workgroup SET_PDEC_STAMP_WG, 24 per timestep
-#define PD_STAMP(i) if (P.stamps && (int)blockIdx.x == P.stamp_wg && threadIdx.x == 0) P.stamps[t * 24 + (i)] = __builtin_amdgcn_s_memrealtime()
 constexpr int PD_STAMPS = 24, PD_STAMP_STEPS = 64;
+#define PD_STAMP(i) if (P.stamps && t < PD_STAMP_STEPS && (int)blockIdx.x == P.stamp_wg && threadIdx.x == 0) P.stamps[t * PD_STAMPS + (i)] = __builtin_amdgcn_s_memrealtime()
 
 __device__ __forceinline__ float pd_sigm(float x) { return 1.f / (1.f + expf(-x)); }
 // tanh of the attention scores: 1 - 2 / (1 + e^(2x)) on the hardware exp2 / rcp (absolute error ~2e-7; saturates to +-1 for
