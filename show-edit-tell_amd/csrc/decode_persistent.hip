@@ -19,8 +19,14 @@
 //     workgroup combines the 256 triples itself (same word everywhere, no broadcast round), workgroup 0 writes seq /
 //     seq_logp and the loop's bookkeeping words.
 // Four exchanges per timestep (h1, the attention projection, h2, the fc triples), each as 8-byte {value, tag} words
-// (grid_barrier.h): a consumer polls the words it needs until they carry the exchange's tag — no counters, no fences.  The
-// weight tiles of the next phase are requested before a poll (two register buffers of 64 KB per workgroup).
+// (grid_barrier.h): a consumer polls the words it needs until they carry the exchange's tag — no counters, no fences.
+// Weight tiles rotate through two register buffers of 64 KB per workgroup.  Where their requests sit matters: a wave's loads
+// return in order (a poll waits for every tile requested before it), a saturated request queue blocks the wave at the next
+// load, and the compiler drains outstanding requests at a loop header or branch join — so a tile is requested right before
+// arithmetic that does not need it (fc's tiles around the attention scores), the h-dependent gate products of timestep t + 1
+// are contracted while the fc triples of timestep t travel (S1'), and the B <= 4 variant has no loop around its per-row work.
+// Teacher-forced mode (set_dcnet_xe_forward): words from the captions, scores written by the owners of the vocabulary rows,
+// three exchanges.
 // Same residency rule, fault word and event chain as the persistent encoder (grid_barrier.h PersistentGuard).  A poll that
 // times out poisons seq_logp with NaN; the host raises SET_ERR_FAULT at its next call.
 #include "decode_persistent.h"

@@ -4,7 +4,8 @@
 // stage itself; what other workgroups need travels as flag-in-data words (grid_barrier.h).
 //
 // Per timestep (eval mode, token table):
-//   S1  attention_lstm gates [W_ih[:, h2] | W_hh] + copy_lstm.h2h                         -> h1            X1 (B, D)
+//   S1  attention_lstm cell from the gate products [W_ih[:, h2] | W_hh] (and copy_lstm.h2h), which were contracted at the
+//       END of the previous timestep (S1', while its fc triples travelled: they do not depend on the word) -> h1  X1 (B, D)
 //   S2  copy_lstm.x2h[:, :D] h1, and one mixed tile: 4 rows of context_gate.W[:, D:2D], 4 rows of tc_affine.W[:, D:],
 //       4 rows of [cap_decoder_att ; decoder_att] (2A = 4 x 256 rows)                     -> projections   X2 (B, 2A)
 //   S3  caption attention of every row in every workgroup (its cap_features_att rows stay in registers at B <= 4) ->
@@ -15,8 +16,10 @@
 //       prologue: the 33 MB of x2h's region columns are never streamed, attend_img is never formed) -> c_new  X4 (B, D)
 //   S5  gate_cnew rows of the owned units, copy gate                                       -> h2            X5 (B, D)
 //   S6  fc rows of this workgroup, (max, first arg-max, sum exp) per batch row             -> triples       X6 (B, G)
+//   S1' the next timestep's h-dependent gate products, between publishing the triples and polling them
 //   S7  every workgroup combines the G triples: same word everywhere; workgroup 0 writes seq / seq_logp
-// 139 MB of weights per timestep instead of 263 MB, six exchanges instead of seven launches.
+// 139 MB of weights per timestep instead of 263 MB, six exchanges instead of seven launches.  Request placement, the
+// loop-free B <= 4 variant and the teacher-forced mode (set_editnet_xe_forward): as in decode_persistent.hip.
 #include "decode_persistent.h"
 
 namespace set {
