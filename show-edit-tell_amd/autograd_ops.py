@@ -262,13 +262,19 @@ def deferred_param_grads(on_ready=None):
                 cat_cache[key] = torch.cat(ts, 0)
             return cat_cache[key]
 
+        colsums = {}       # two biases fed by the SAME output gradients (nn.LSTMCell's bias_ih / bias_hh, the x2h / h2h pair of
+                           # the copy cell, gate_cnew / gate_cmem) share one column sum
         for param, (dys, xs) in pending.values():
             dy = cat(dys)
             if xs is None:
+                key = tuple(id(t) for t in dys)
+                g = colsums.get(key)
+                if g is None:
+                    g = colsums[key] = _colsum(dy)
                 if param.grad is None:
-                    param.grad = _colsum(dy).reshape(param.shape)
+                    param.grad = g.reshape(param.shape).clone()
                 else:
-                    _colsum(dy, out=param.grad)
+                    param.grad.add_(g.reshape(param.shape))
             else:
                 x = cat(xs)
                 if param.grad is None:
