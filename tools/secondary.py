@@ -163,7 +163,10 @@ def dcnet(dev):
         "editnet": _stream_roof(265.7e6, out["editnet_greedy_b4_ms"]),
         "dcnet": _stream_roof(160.6e6 + 1.2e6, out["dcnet_greedy_b4_ms"]),
         "note": "algorithmic bytes per timestep (SURVEY.md 8d) x 19 / decode time incl. the prologue; the token tables fold "
-                "~89 MB (EditNet) of those weights into row gathers, so fewer bytes actually move"}
+                "~89 MB (EditNet) of those weights into row gathers and the persistent launch hoists 33.5 / 16 MB more, so "
+                "fewer bytes actually move: `executed` = the bytes the kernels stream per timestep (PMC: "
+                "profiles/r04_persistent_decode_pmc.txt) on the same clock",
+        "executed": {"editnet": _stream_roof(139e6, out["editnet_greedy_b4_ms"]), "dcnet": _stream_roof(107e6, out["dcnet_greedy_b4_ms"])}}
     return out
 
 
