@@ -254,7 +254,7 @@ class DevicePrefetcher:
     (tests use them to show the copy of batch i+1 running while batch i is being decoded)."""
 
     def __init__(self, iterable, device, depth: int = 2, record_timing: bool = False, begin_ahead=None, streams: int = 1,
-                 stream_priority=None):
+                 stream_priority=None, side_streams=None):
         """begin_ahead: optional callable(batch_on_device), run on the copy stream right after a batch's H2D copies — e.g.
         `lambda b: decoder.begin_ahead(b.prev, b.plen, b.features)` (editnet_rl.DecoderC.begin_ahead): the per-sequence
         prologue of batch i+1 then runs underneath the timestep loop of batch i, and the `decoder(...)` call for batch i+1
@@ -266,8 +266,9 @@ class DevicePrefetcher:
         # begin_ahead = decoder.decode_ahead and streams = depth, `depth` whole decodes are in flight while the caller walks
         # the batches one by one.
         # stream_priority: priority of the side streams (torch.cuda.Stream: lower = more urgent; None = default)
+        # side_streams: the caller's own stream objects instead (e.g. torch.cuda.ExternalStream of a CU-masked HIP stream)
         kw = {} if stream_priority is None else {"priority": int(stream_priority)}
-        self.streams = [torch.cuda.Stream(self.device, **kw) for _ in range(max(1, streams))]
+        self.streams = list(side_streams) if side_streams else [torch.cuda.Stream(self.device, **kw) for _ in range(max(1, streams))]
         self.stream = self.streams[0]
         self._staged = 0
         self.depth = max(1, depth)
