@@ -15,7 +15,17 @@
  *     the caller supplies a workspace sized by the matching *_workspace_bytes() query
  *   - all work is enqueued on `stream` (a hipStream_t); functions never synchronise
  *   - return value: SET_OK or an error code; nothing throws across the ABI
- *   - re-entrant per (workspace, stream) pair; no global mutable state
+ *   - re-entrant per (workspace, stream) pair.  State outside the caller's workspace, all of it listed here:
+ *       thread-local (per calling host thread): the last hipError_t (set_last_hip_error), the row-limit pointer
+ *         (set_decode_row_limits), the loop gate the decode loops set around each timestep for their own launchers, the
+ *         opt-in profiler's records (set_profile_enable);
+ *       process-wide, per device: one mutex + completion-event chain that admits ONE persistent launch at a time (caption
+ *         encoder, small-batch decode loop: their workgroups must all be resident), the sticky host-mapped fault word and
+ *         "persistent kernels disabled" flag behind SET_ERR_FAULT, cached answers of occupancy / LDS-limit queries and of
+ *         "dynamic-LDS cap raised for kernel X on device d";
+ *       environment: SET_* switches are read once per process, except SET_DEC_PERSISTENT / SET_DEC_PERSISTENT_MAXB, which
+ *         the small-batch decode reads per call (tests flip them inside one process).
+ *     None of it carries results between calls: outputs depend on the arguments only.
  *   - alignment: base pointers 16-byte aligned, leading strides and K multiples of 4 floats;
  *     every contraction length (D, A, F, 2D, ...) must be a multiple of 32 (SET_ERR_UNSUPPORTED)
  */
@@ -160,19 +170,15 @@ int set_editnet_greedy(const SetEditNetWeights* w, const SetEditNetDims* d, cons
                        int64_t start_idx, int64_t end_idx, int max_len, int64_t* seq,
                        float* seq_logp, void* ws, size_t ws_bytes, void* stream);
 
-/* Options of the free-running decode loops (set_*_greedy / set_*_sample) for the CALLING host thread.
- * skip_finished_rows: 0 (default) — every row is decoded for all max_len + 1 timesteps until the WHOLE batch has finished,
- *   as the reference does (editnet_rl.py:529-547: a finished row is fed word 0 and its seqLogprobs keep being recorded);
- *   1 — a row is not computed any more once its caption has ended: token ids, and the log-probs of every position up to and
- *   including a row's <end>, are bit-identical; the (meaningless, masked by RewardCriterion editnet_rl.py:563-566)
- *   log-probs behind a row's <end> stay 0.  -1: the environment decides (SET_SKIP_FINISHED).
- * In both modes every kernel of a timestep returns at once after the reference's `break` (all rows finished). */
-int set_decode_options(int skip_finished_rows);
-
-/* MEASUREMENT HOOK, not part of the path: while `lengths_dev` (B int32 on the device) is set for the calling host thread, the
- * greedy pick of the free-running loops emits <end> for row b at timestep lengths_dev[b] - 1 whatever the scores say, so that
- * a random-weight model can be given the finish times of real captions (bench.py secondary.realistic_lengths).  NULL: off. */
-int set_debug_force_lengths(const int* lengths_dev);
+/* Per-row cap on the caption length of the free-running GREEDY loops (set_*_greedy) for the CALLING host thread: while
+ * `row_limit_dev` (B int32 on the device; the pointer is read by the launches of later calls, keep it alive) is set, the
+ * pick of timestep t takes <end> for every row b with t + 1 >= row_limit_dev[b] whatever the scores say — row b's caption has
+ * at most row_limit_dev[b] words (the recorded log-prob of that step stays the arg-max's; every other row and every earlier
+ * position is untouched, tests/test_hip_finished_rows.py).  NULL (default): off = the reference's loop (editnet_rl.py:503-547,
+ * one global max_len).  While set, small batches take the per-step kernels (the persistent launch has no cap).  Also how
+ * bench.py gives a random-weight model the finish times of real captions (secondary.realistic_lengths).
+ * In every mode the GEMM / attention kernels of a timestep return at once after the reference's `break` (all rows finished). */
+int set_decode_row_limits(const int* row_limit_dev);
 
 /* The timestep loop of set_editnet_greedy alone (editnet_rl.py:503-547) on a workspace that already holds a completed
  * set_editnet_begin for the same (X, prev, prevlen): the per-sequence prologue (editnet_rl.py:499-501 and the hoisted

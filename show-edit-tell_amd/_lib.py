@@ -164,8 +164,7 @@ PROTOTYPES = {
                                      _P, _Z, _P]),
     "set_editnet_greedy": (_I, [C.POINTER(EditNetWeights), C.POINTER(EditNetDims), _P, _P, _P, _P, _L, _L, _I, _P, _P,
                                 _P, _Z, _P]),
-    "set_decode_options": (_I, [_I]),
-    "set_debug_force_lengths": (_I, [_P]),
+    "set_decode_row_limits": (_I, [_P]),
     "set_editnet_greedy_begun": (_I, [C.POINTER(EditNetWeights), C.POINTER(EditNetDims), _P, _L, _L, _I, _P, _P, _P, _Z, _P]),
     "set_editnet_sample": (_I, [C.POINTER(EditNetWeights), C.POINTER(EditNetDims), _P, _P, _P, _P, _L, _L, _I, _U, _U, _P,
                                 _P, _P, _Z, _P]),

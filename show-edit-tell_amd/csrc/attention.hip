@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(256) caption_attention_k(const CapAttArgs P, c
     __shared__ float sc[ATT_MAX_ROWS];
     __shared__ int s_arg;
     const int dsn = P.dsn > 1 ? P.dsn : 1;
-    if (G.loop_left() || G.row_done(blockIdx.x / dsn)) return;      // decode loops (set_common.h RowGate)
+    if (G.loop_left()) return;      // decode loops (set_common.h RowGate)
     caption_attention_body(P, blockIdx.x / dsn, sc, &s_arg, blockIdx.x % dsn);
 }
 
@@ -377,11 +377,9 @@ __global__ void __launch_bounds__(256) step_attention_k(const VisAttArgs V, cons
     __shared__ int s_arg;
     if (G.loop_left()) return;                               // decode loops: the reference has left its loop (set_common.h)
     if ((int)blockIdx.x < nvis) {
-        if (G.row_done(blockIdx.x / V.fsn)) return;          // (opt-in) this row's caption has ended
         visual_attention_body(V, blockIdx.x / V.fsn, blockIdx.x % V.fsn, sc);
     } else {
         const int i = blockIdx.x - nvis, dsn = C.dsn > 1 ? C.dsn : 1;
-        if (G.row_done(i / dsn)) return;
         caption_attention_body(C, i / dsn, sc, &s_arg, i % dsn);
     }
 }
@@ -642,7 +640,6 @@ __global__ void __launch_bounds__(512) step_attention_v2_k(const VisAttArgs V, c
     __shared__ int s_arg;
     __shared__ f32x4 xch[512];
     if (G.loop_left()) return;
-    if (G.row_done((int)blockIdx.x < nvis ? (int)blockIdx.x : (int)blockIdx.x - nvis)) return;
     if ((int)blockIdx.x < nvis) visual_attention_v2(V, blockIdx.x, sc, xch);
     else caption_attention_v2(C, blockIdx.x - nvis, sc, &s_arg, xch);
 }
@@ -651,7 +648,7 @@ __global__ void __launch_bounds__(512) caption_attention_v2_k(const CapAttArgs C
     __shared__ float sc[ATT_MAX_ROWS];
     __shared__ int s_arg;
     __shared__ f32x4 xch[512];
-    if (G.loop_left() || G.row_done(blockIdx.x)) return;
+    if (G.loop_left()) return;
     caption_attention_v2(C, blockIdx.x, sc, &s_arg, xch);
 }
 

@@ -21,7 +21,6 @@ struct DcnetWs {
     float *h1, *c1, *h2, *c2, *emb, *attend_cap, *alpha_c, *logits;
     long long* it;
     int *unfinished, *alive;
-    int *rowmap, *n_rows;             // compacted list of unfinished rows (set_common.h RowGate)
     float *sA0, *sA1, *sB0, *sB1, *sC0, *sF0;
     float *hf, *cf, *hb, *cb, *xg_f, *xg_b, *emb_seq, *s_ef, *s_eb, *s_cat, *s_pre;
     int* enc_order;                   // [perm (B) | nactive (T)] of the length-ordered persistent encoder
@@ -64,8 +63,6 @@ static DcnetWs carve(const SetDcnetDims* d, void* base) {
     w.it = c.take<long long>(B);
     w.unfinished = c.take<int>(B);
     w.alive = c.take<int>(d->maxT + 2);
-    w.rowmap = c.take<int>(d->B);
-    w.n_rows = c.take<int>(1);
     w.sA0 = c.take<float>(KS * B * 4 * D);
     w.sA1 = c.take<float>(KS * B * 4 * D);
     w.sB0 = c.take<float>(KS * B * A);
@@ -377,23 +374,19 @@ static int dcnet_rollout(const SetDcnetWeights* w, const SetDcnetDims* d, const 
     bool have_a = false, a_done = false;
     // row gate of the loop (set_common.h RowGate; same policy as the EditNet loop, editnet.hip rollout)
     static const int loop_gate = env_int("SET_LOOP_GATE", 1);
-    static const int compact_every = env_int("SET_COMPACT_EVERY", 2);
-    const bool skip_rows = skip_finished_rows() && B <= 4096;
     // small batches, greedy: the whole loop as ONE persistent launch (decode_persistent.hip).  The context half of
     // language_lstm's input product is linear in the attention weights: Pc = enc W_ih[:, D:]^T is computed here once
-    if (!sample && !emb_needed && !skip_rows && !g_force_len && dcnet_persistent_ok(d, max_len)) {
+    if (!sample && !emb_needed && !g_row_limit && dcnet_persistent_ok(d, max_len)) {
         const int rc = dcnet_persistent_greedy(w, d, W.pre1, W.att1_c, W.mask, W.pd_pc, W.pd_x, W.it, W.unfinished, W.alive,
                                                start_idx, end_idx, max_len, (long long*)seq, seq_logp, st);
         if (rc != SET_ERR_UNSUPPORTED) return rc;
     }
-    if (skip_rows) SET_TRY(compact_rows(W.unfinished, B, W.rowmap, W.n_rows, 1, st));
     for (int t = 0; t <= max_len; ++t) {                                 // dcnet_rl.py:305,315-316
         Slabs lg;
         bool biased = false;
         const bool next_a = merge && t < max_len;
         RowGate gate;
         if (loop_gate && t > 0) gate.alive_prev = W.alive + (t - 1);
-        if (skip_rows && t > 0) { gate.unfinished = W.unfinished; gate.rowmap = W.rowmap; gate.n_rows = W.n_rows; }
         RowGateScope gate_scope(gate);
         SET_TRY(step_impl(w, d, B, W, nullptr, 0, &lg, st, W.it, 1, have_a ? a_cur : nullptr, next_a ? a_nxt : nullptr,
                           &biased, -1, a_done));
@@ -416,8 +409,6 @@ static int dcnet_rollout(const SetDcnetWeights* w, const SetDcnetDims* d, const 
         else
             SET_TRY(greedy_pick(lg, pick_bias, d->V, t, max_len, end_idx, (long long*)seq, seq_logp, W.it, W.unfinished,
                                 W.alive, emb_needed ? w->embed : nullptr, W.emb, d->E, B, st, a_done ? &tail : nullptr));
-        if (skip_rows && t < max_len && (t + 1) % compact_every == 0)
-            SET_TRY(compact_rows(W.unfinished, B, W.rowmap, W.n_rows, 0, st));
     }
     return SET_OK;
 }

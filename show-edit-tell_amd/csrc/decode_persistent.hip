@@ -434,17 +434,24 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
     __shared__ unsigned s_bad;
     if (tid == 0) s_bad = __hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (s_bad && wg == 0) {
+    if (s_bad) {
         const float qnan = __builtin_nanf("");
-        if (P.caps) {                                              // teacher-forced: the first timestep's scores of every row
-            for (int i = tid; i < B * V; i += 256) P.predictions[(long long)(i / V) * P.ld_pred_b + i % V] = qnan;
-        } else {
-            for (int i = tid; i < B * P.max_len; i += 256) { P.seq_logp[i] = qnan; P.seq[i] = 0; }
+        if (P.caps) {
+            // teacher-forced: EVERY score this workgroup wrote (its vocabulary rows, all rows and timesteps) — each workgroup
+            // poisons its own region after its own loop, so no later store of another workgroup can undo it
+            const int row0 = wg * P.rpw;
+            for (int i = tid; i < B * P.max_len * P.rpw; i += PDEC_THREADS) {
+                const int row = row0 + i % P.rpw, bt_ = i / P.rpw;
+                if (row < V) P.predictions[(long long)(bt_ / P.max_len) * P.ld_pred_b + (long long)(bt_ % P.max_len) * V + row] = qnan;
+            }
+        } else if (wg == 0) {
+            for (int i = tid; i < B * P.max_len; i += PDEC_THREADS) { P.seq_logp[i] = qnan; P.seq[i] = 0; }
         }
     }
 }
 
 static int g_pdec_capacity[64][2] = {};
+static int g_pdec_capacity_lds[64][2] = {};
 static int pdec_lds_floats(int B, int D, int A) {
     return 2 * B * (D + 4) + 4 * 3 * 256 + PDEC_MAXB * PDEC_TMAX + PDEC_MAXB * 16 + B * A + B * (D / 4) * 4 + 2 * A + B * 16 * PDEC_TMAX;
 }
@@ -457,6 +464,7 @@ bool dcnet_persistent_ok(const SetDcnetDims* d, int max_len) {
     if (d->D != 64 * PDEC_KB || d->E != d->D || 2 * d->C != d->D || d->A != 512 || d->T > PDEC_TMAX) return false;   // A = 2 rows of cap_decoder_att per workgroup, 512 scores per wave pass
     const int G = d->D / 4;
     if ((d->V + G - 1) / G > 16 * PDEC_FC_TILES) return false;
+    if (pdec_lds_floats(PDEC_MAXB, d->D, d->A) * (int)sizeof(float) > persistent_lds_limit()) return false;   // (a 64-KB-LDS device)
     return !persistent_disabled();
 }
 
@@ -501,25 +509,31 @@ int dcnet_persistent_greedy(const SetDcnetWeights* w, const SetDcnetDims* d, con
     PersistentGuard guard;
     if (guard.rc != SET_OK) return guard.rc;
     const int dev = guard.dev;
-    P.spin_limit = guard.spin_limit() / 4 + 1;      // a poll here is a memory round trip, not a cached flag read
+    P.spin_limit = guard.spin_limit();              // bound of one wait, ticks of the 100-MHz counter
     P.test_stall = guard.test_stall(); P.fault = guard.fault;
     // residency: every workgroup must be on the chip at once (see encoder_persistent.hip penc_fits)
-    static bool configured = false;
-    if (!configured) {
-        const int lds_max = pdec_lds_floats(PDEC_MAXB, D, d->A) * (int)sizeof(float);
-        SET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&dcnet_persistent_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-        SET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&dcnet_persistent_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-        configured = true;
-    }
+    // (function attributes are per device; a device whose LDS limit is below the request, e.g. a 64-KB part, is answered with
+    // SET_ERR_UNSUPPORTED — the caller's per-step loop — never with a HIP error)
+    static bool configured[2][64] = {};
+    const int lds_max = pdec_lds_floats(PDEC_MAXB, D, d->A) * (int)sizeof(float);
+    if (guard.set_lds(reinterpret_cast<const void*>(&dcnet_persistent_k<true>), lds_max, configured[0]) != SET_OK ||
+        guard.set_lds(reinterpret_cast<const void*>(&dcnet_persistent_k<false>), lds_max, configured[1]) != SET_OK)
+        return SET_ERR_UNSUPPORTED;
     const bool res = B <= 4 && d->T <= PDEC_TREG;
+    // resident workgroups the device admits, asked with the LDS size of THIS batch (re-asked when a larger one comes along)
     int& cap = g_pdec_capacity[dev][res ? 1 : 0];
-    if (cap == 0) {
+    int& cap_lds = g_pdec_capacity_lds[dev][res ? 1 : 0];
+    if (cap == 0 || lds > cap_lds) {
         int per_cu = 0, cus = 0;
-        SET_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, res ? reinterpret_cast<const void*>(&dcnet_persistent_k<true>)
-                                                                              : reinterpret_cast<const void*>(&dcnet_persistent_k<false>), PDEC_THREADS,
-                                                                 (size_t)lds));
-        SET_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, res ? reinterpret_cast<const void*>(&dcnet_persistent_k<true>)
+                                                                       : reinterpret_cast<const void*>(&dcnet_persistent_k<false>), PDEC_THREADS,
+                                                         (size_t)lds) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+            (void)hipGetLastError();
+            return SET_ERR_UNSUPPORTED;
+        }
         cap = per_cu * cus;
+        cap_lds = lds;
         if (cap <= 0) cap = -1;
         const int forced = env_int("SET_PENC_TEST_CAPACITY", 0);
         if (forced > 0) cap = forced;

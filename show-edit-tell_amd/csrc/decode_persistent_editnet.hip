@@ -544,17 +544,22 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_k(const PD
     __shared__ unsigned s_bad;
     if (tid == 0) s_bad = __hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (s_bad && wg == 0) {                                       // an exchange timed out: never hand this out as a decode
+    if (s_bad) {                                                  // an exchange timed out: never hand this out as a decode
         const float qnan = __builtin_nanf("");
-        if (P.caps) {                                              // teacher-forced: the first timestep's scores of every row
-            for (int i = tid; i < B * V; i += PDEC_THREADS) P.predictions[(long long)(i / V) * P.ld_pred_b + i % V] = qnan;
-        } else {
+        if (P.caps) {                                              // teacher-forced: every score this workgroup wrote (see decode_persistent.hip)
+            const int row0 = wg * P.rpw;
+            for (int i = tid; i < B * P.max_len * P.rpw; i += PDEC_THREADS) {
+                const int row = row0 + i % P.rpw, bt_ = i / P.rpw;
+                if (row < V) P.predictions[(long long)(bt_ / P.max_len) * P.ld_pred_b + (long long)(bt_ % P.max_len) * V + row] = qnan;
+            }
+        } else if (wg == 0) {
             for (int i = tid; i < B * P.max_len; i += PDEC_THREADS) { P.seq_logp[i] = qnan; P.seq[i] = 0; }
         }
     }
 }
 
 static int g_pedit_capacity[64][2] = {};
+static int g_pedit_capacity_lds[64][2] = {};
 static int pedit_lds_floats(int B, int D, int A) {
     return 2 * B * (D + 4) + 4 * 3 * 256 + PDEC_MAXB * (PDEC_TMAX + 64 + 16 + 8 + 8) + B * 2 * A +
            B * 16 * PDEC_RREG + B * 8 * PDEC_TMAX + 4 * A;
@@ -576,6 +581,7 @@ bool editnet_persistent_ok(const SetEditNetDims* d, int max_len) {
     if ((d->V + G - 1) / G > 16 * PDEC_FC_TILES) return false;
     if (d->B * d->R > 4 * G) return false;                           // one visual score per wave
     if (pedit_lds_floats(d->B, d->D, d->A) * (int)sizeof(float) > 156 * 1024) return false;      // (160 KB per CU, a little of it static)
+    if (pedit_lds_floats(d->B, d->D, d->A) * (int)sizeof(float) + 4096 > persistent_lds_limit()) return false;   // the DEVICE's limit (a 64-KB-LDS part)
     return !persistent_disabled();
 }
 
@@ -620,25 +626,28 @@ int editnet_persistent_greedy(const SetEditNetWeights* w, const SetEditNetDims* 
     PersistentGuard guard;
     if (guard.rc != SET_OK) return guard.rc;
     const int dev = guard.dev;
-    P.spin_limit = guard.spin_limit() / 4 + 1;
+    P.spin_limit = guard.spin_limit();
     P.test_stall = guard.test_stall(); P.fault = guard.fault;
-    static bool configured = false;
-    if (!configured) {
-        int lds_max = pedit_lds_floats(PDEC_MAXB, D, A) * (int)sizeof(float);
-        if (lds_max > 156 * 1024) lds_max = 156 * 1024;         // (editnet_persistent_ok refuses batches that need more)
-        SET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&editnet_persistent_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-        SET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&editnet_persistent_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-        configured = true;
-    }
+    static bool configured[2][64] = {};
+    int lds_max = pedit_lds_floats(PDEC_MAXB, D, A) * (int)sizeof(float);
+    if (lds_max > 156 * 1024) lds_max = 156 * 1024;             // (editnet_persistent_ok refuses batches that need more)
+    if (guard.set_lds(reinterpret_cast<const void*>(&editnet_persistent_k<true>), lds_max, configured[0]) != SET_OK ||
+        guard.set_lds(reinterpret_cast<const void*>(&editnet_persistent_k<false>), lds_max, configured[1]) != SET_OK)
+        return SET_ERR_UNSUPPORTED;
     const bool res = B <= 4 && d->T <= PDEC_TREG;
     int& cap = g_pedit_capacity[dev][res ? 1 : 0];
-    if (cap == 0) {
+    int& cap_lds = g_pedit_capacity_lds[dev][res ? 1 : 0];
+    if (cap == 0 || lds > cap_lds) {
         int per_cu = 0, cus = 0;
-        SET_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, res ? reinterpret_cast<const void*>(&editnet_persistent_k<true>)
-                                                                              : reinterpret_cast<const void*>(&editnet_persistent_k<false>),
-                                                                 PDEC_THREADS, (size_t)lds));
-        SET_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, res ? reinterpret_cast<const void*>(&editnet_persistent_k<true>)
+                                                                       : reinterpret_cast<const void*>(&editnet_persistent_k<false>),
+                                                         PDEC_THREADS, (size_t)lds) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+            (void)hipGetLastError();
+            return SET_ERR_UNSUPPORTED;
+        }
         cap = per_cu * cus;
+        cap_lds = lds;
         if (cap <= 0) cap = -1;
         const int forced = env_int("SET_PENC_TEST_CAPACITY", 0);
         if (forced > 0) cap = forced;

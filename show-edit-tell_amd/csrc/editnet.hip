@@ -25,12 +25,7 @@ int env_int(const char* name, int dflt) {
     return v && *v ? atoi(v) : dflt;
 }
 thread_local RowGate g_row_gate;
-thread_local int g_skip_finished = -1;          // -1: SET_SKIP_FINISHED decides (default off)
-thread_local const int* g_force_len = nullptr;
-bool skip_finished_rows() {
-    static const int env = env_int("SET_SKIP_FINISHED", 0);
-    return (g_skip_finished >= 0 ? g_skip_finished : env) != 0;
-}
+thread_local const int* g_row_limit = nullptr;
 int gemm_target_wgs() {
     static int v = env_int("SET_GEMM_TARGET_WGS", 512);
     return v;
@@ -45,7 +40,6 @@ struct EditNetWs {
     float* logits;
     long long* it;
     int *unfinished, *alive;
-    int *rowmap, *n_rows;             // compacted list of unfinished rows of the free-running loops (set_common.h RowGate)
     // split-K slabs, one region per GEMM of the step
     float *sA0, *sA1, *sB0, *sB1, *sB2, *sB3, *sB4, *sC0, *sC1, *sC2, *sD0, *sE0, *sF0;
     // prologue scratch
@@ -101,8 +95,6 @@ static EditNetWs carve(const SetEditNetDims* d, void* base) {
     w.it = c.take<long long>(B);
     w.unfinished = c.take<int>(B);
     w.alive = c.take<int>(d->maxT + 2);
-    w.rowmap = c.take<int>(B);
-    w.n_rows = c.take<int>(1);
     w.sA0 = c.take<float>(KS * B * 4 * D);
     w.sA1 = c.take<float>(KS * B * 4 * D);
     w.sB0 = c.take<float>(KS * B * A);
@@ -545,15 +537,11 @@ static int rollout(const SetEditNetWeights* w, const SetEditNetDims* d, const fl
     GemmProb a_cur[2], a_nxt[2];
     bool have_a = false, a_done = false;
     // Row gate (set_common.h): every kernel of timestep t returns at once when alive[t - 1] == 0 — the reference's `break`
-    // (editnet_rl.py:546) in TIME, not only in the outputs (SET_LOOP_GATE=0: as before, outputs only).  Opt-in
-    // (set_decode_options / SET_SKIP_FINISHED): rows whose caption has ended are not computed either — row kernels test
-    // unfinished[row], the GEMMs walk the compacted list of unfinished rows, rebuilt every SET_COMPACT_EVERY timesteps.
+    // (editnet_rl.py:546) in TIME, not only in the outputs (SET_LOOP_GATE=0: as before, outputs only).
     static const int loop_gate = env_int("SET_LOOP_GATE", 1);
-    static const int compact_every = env_int("SET_COMPACT_EVERY", 2);
-    const bool skip_rows = skip_finished_rows() && B <= 4096;
     // small batches, greedy: the whole loop as ONE persistent launch (decode_persistent_editnet.hip).  copy_lstm.x2h's region
     // columns are linear in the visual attention weights: Pv = X x2h[:, 2D:]^T is computed here once per decode
-    if (!sample && !emb_needed && !skip_rows && !g_force_len && editnet_persistent_ok(d, max_len)) {
+    if (!sample && !emb_needed && !g_row_limit && editnet_persistent_ok(d, max_len)) {
         if (begun) {     // the prologue ran in an earlier call (begin_ahead), possibly under other switches: Pv is not taken on trust
             const int R = d->R, F = d->F, D = d->D;
             GemmProb p = direct_prob(W.pd_pv, 4LL * D, B * R, 4 * D, nullptr, SET_ACT_NONE);
@@ -565,14 +553,12 @@ static int rollout(const SetEditNetWeights* w, const SetEditNetDims* d, const fl
                                                  seq_logp, st);
         if (rc != SET_ERR_UNSUPPORTED) return rc;
     }
-    if (skip_rows) SET_TRY(compact_rows(W.unfinished, B, W.rowmap, W.n_rows, 1, st));
     for (int t = 0; t <= max_len; ++t) {
         Slabs lg;
         bool biased = false;
         const bool next_a = merge && t < max_len;     // there is a next timestep to pre-launch phase A for
         RowGate gate;
         if (loop_gate && t > 0) gate.alive_prev = W.alive + (t - 1);
-        if (skip_rows && t > 0) { gate.unfinished = W.unfinished; gate.rowmap = W.rowmap; gate.n_rows = W.n_rows; }
         RowGateScope gate_scope(gate);
         SET_TRY(step_impl(w, d, X, B, W, W.it, 1, nullptr, 0, &lg, st, have_a ? a_cur : nullptr, next_a ? a_nxt : nullptr,
                           &biased, -1, a_done));
@@ -595,20 +581,12 @@ static int rollout(const SetEditNetWeights* w, const SetEditNetDims* d, const fl
         else
             SET_TRY(greedy_pick(lg, pick_bias, d->V, t, max_len, end_idx, (long long*)seq, seq_logp, W.it, W.unfinished,
                                 W.alive, emb_needed ? w->embed : nullptr, W.emb, d->D, B, st, a_done ? &tail : nullptr));
-        // (the list may only shrink: a row that finishes between two rebuilds stays in it and is computed in vain)
-        if (skip_rows && t < max_len && (t + 1) % compact_every == 0)
-            SET_TRY(compact_rows(W.unfinished, B, W.rowmap, W.n_rows, 0, st));
     }
     return SET_OK;
 }
 
-int set_debug_force_lengths(const int* lengths_dev) {
-    g_force_len = lengths_dev;
-    return SET_OK;
-}
-
-int set_decode_options(int skip_finished_rows_) {
-    g_skip_finished = skip_finished_rows_ < 0 ? -1 : (skip_finished_rows_ ? 1 : 0);
+int set_decode_row_limits(const int* row_limit_dev) {
+    g_row_limit = row_limit_dev;
     return SET_OK;
 }
 
@@ -725,7 +703,7 @@ void* set_editnet_ws_tensor(const SetEditNetDims* d, void* ws, const char* name)
         {"attend_cap", W.attend_cap}, {"attend_img", W.attend_img}, {"sel", W.sel}, {"c_new", W.c_new},
         {"alpha_c", W.alpha_c}, {"alpha", W.alpha}, {"logits", W.logits}, {"it", W.it},
         {"cap_proj", W.cap_proj}, {"mem_proj", W.mem_proj}, {"enc_bar", W.enc_bar},
-        {"unfinished", W.unfinished}, {"alive", W.alive}, {"rowmap", W.rowmap}, {"n_rows", W.n_rows}};
+        {"unfinished", W.unfinished}, {"alive", W.alive}};
     for (auto& e : tab)
         if (!strcmp(e.n, name)) return e.p;
     return nullptr;

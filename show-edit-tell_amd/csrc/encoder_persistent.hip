@@ -284,8 +284,31 @@ int PersistentGuard::launched(hipStream_t s) {
     return SET_OK;
 }
 unsigned PersistentGuard::spin_limit() const {
-    static const int v = env_int("SET_PENC_SPIN_LIMIT", (int)GBAR_SPIN_LIMIT);
-    return v > 0 ? (unsigned)v : GBAR_SPIN_LIMIT;
+    static const int us = env_int("SET_PENC_TIMEOUT_US", (int)GBAR_TIMEOUT_US);
+    const unsigned v = us > 0 ? (unsigned)us : GBAR_TIMEOUT_US;
+    return v > 40000000u ? 4000000000u : v * 100u;             // ticks of the 100-MHz counter
+}
+int persistent_lds_limit() {
+    static int limit[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    dev &= 63;
+    if (limit[dev] == 0) {
+        int v = 0;
+        limit[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0) ? v : -1;
+    }
+    return limit[dev] > 0 ? limit[dev] : 0;
+}
+int PersistentGuard::set_lds(const void* kernel, int bytes, bool (&done)[64]) {
+    if (done[dev]) return SET_OK;
+    const int lim = persistent_lds_limit();
+    if (lim <= 0 || bytes > lim) return SET_ERR_UNSUPPORTED;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return SET_ERR_UNSUPPORTED;
+    }
+    done[dev] = true;
+    return SET_OK;
 }
 int PersistentGuard::test_stall() const { static const int v = env_int("SET_PENC_TEST_STALL", 0); return v; }
 bool persistent_disabled() {
@@ -318,14 +341,11 @@ template <int NT, int KB> constexpr int penc_slot() { return (NT == 2 ? 0 : NT =
 // the caller takes the per-step kernels.  (MI355X_MICROARCH.md: the API can be one high per CU only at >= 7 workgroups per
 // CU; these kernels sit at 1-2 by their register budget.)
 template <int NT, int KB>
-static int penc_fits(int grid, int dev, bool* fits) {
+static int penc_fits(PersistentGuard& guard, int grid, int dev, bool* fits) {
     const int lds = 4 * NT * 256 * (int)sizeof(float);
-    static bool configured = false;
-    if (!configured) {
-        SET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&encoder_persistent_k<NT, KB>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        configured = true;
-    }
+    static bool configured[64] = {};
+    *fits = false;
+    if (guard.set_lds(reinterpret_cast<const void*>(&encoder_persistent_k<NT, KB>), lds, configured) != SET_OK) return SET_OK;
     static_assert(penc_slot<NT, KB>() < 9, "capacity table");
     int& cap = g_penc_capacity[dev][penc_slot<NT, KB>()];
     if (cap == 0) {
@@ -382,13 +402,13 @@ int persistent_encoder_dirs(const PEncDirHost* dirs, int ndir, long long ld_xg_r
     const int inst = D == 1024 ? (nt <= 2 ? 0 : 1) : D == 512 ? (nt <= 2 ? 2 : 3) : (nt <= 2 ? 4 : (nt <= 8 ? 5 : 6));
     bool fits = false;
     switch (inst) {
-        case 0: SET_TRY((penc_fits<2, 16>(grid, dev, &fits))); break;
-        case 1: SET_TRY((penc_fits<8, 16>(grid, dev, &fits))); break;
-        case 2: SET_TRY((penc_fits<2, 8>(grid, dev, &fits))); break;
-        case 3: SET_TRY((penc_fits<8, 8>(grid, dev, &fits))); break;
-        case 4: SET_TRY((penc_fits<2, 1>(grid, dev, &fits))); break;
-        case 5: SET_TRY((penc_fits<8, 1>(grid, dev, &fits))); break;
-        default: SET_TRY((penc_fits<16, 1>(grid, dev, &fits))); break;
+        case 0: SET_TRY((penc_fits<2, 16>(guard, grid, dev, &fits))); break;
+        case 1: SET_TRY((penc_fits<8, 16>(guard, grid, dev, &fits))); break;
+        case 2: SET_TRY((penc_fits<2, 8>(guard, grid, dev, &fits))); break;
+        case 3: SET_TRY((penc_fits<8, 8>(guard, grid, dev, &fits))); break;
+        case 4: SET_TRY((penc_fits<2, 1>(guard, grid, dev, &fits))); break;
+        case 5: SET_TRY((penc_fits<8, 1>(guard, grid, dev, &fits))); break;
+        default: SET_TRY((penc_fits<16, 1>(guard, grid, dev, &fits))); break;
     }
     if (!fits) return SET_ERR_UNSUPPORTED;          // (nothing has been touched: the caller runs the per-step kernels)
     ProfScope ps("persistent_encoder", s, 8.0 * ndir * B * D * D * T, 4.0 * ndir * (4.0 * D * D + 8.0 * B * D * T));

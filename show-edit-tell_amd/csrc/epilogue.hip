@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256) greedy_pick_k(Slabs logits, const float* 
                                                      long long end_idx, long long* seq, float* seq_logp,
                                                      long long* it_buf, int* unfinished, int* alive,
                                                      const float* table, float* emb_out, int D, const LstmTail tail,
-                                                     const int skip_finished, const int* force_len) {
+                                                     const int* row_limit) {
     __shared__ float s_val[4];
     __shared__ int s_idx[4];
     __shared__ float s_sum[4];
@@ -103,16 +103,10 @@ __global__ void __launch_bounds__(256) greedy_pick_k(Slabs logits, const float* 
     // bookkeeping words of the serial tail (thread 0): requested now, under the row fetch, instead of as a dependent round
     // trip after the reductions.  (The loop-left test of set_common.h RowGate is NOT made here: a dependent load at the top of
     // every 10-us kernel of the chain costs more — 2 % of a single-stream decode when all seven kernels of a timestep make
-    // it — than these short kernels cost after the break; the three GEMM launches and the attention launch make it.)  With
-    // skip_finished (opt-in) a row whose caption has ended is not scored.
+    // it — than these short kernels cost after the break; the three GEMM launches and the attention launch make it.)
     int unf_prev = 1, alive_prev = 1;
     if (t > 0) {
-        if (skip_finished) {                                     // opt-in: every thread reads the row's latch (one broadcast load)
-            unf_prev = unfinished[b];
-            if (unf_prev == 0) return;
-        } else if (TAIL || tid == 0) {
-            unf_prev = unfinished[b];                            // (TAIL: every thread derives the word right after the arg-max)
-        }
+        if (TAIL || tid == 0) unf_prev = unfinished[b];          // (TAIL: every thread derives the word right after the arg-max)
         if (tid == 0) alive_prev = alive[t - 1];
     }
     TailRegs tr;
@@ -207,9 +201,9 @@ __global__ void __launch_bounds__(256) greedy_pick_k(Slabs logits, const float* 
     for (int w = 1; w < 4; ++w)
         if (s_val[w] > best || (s_val[w] == best && s_idx[w] < bi)) { best = s_val[w]; bi = s_idx[w]; }
     if (bi == 0x7fffffff) { bi = 0; best = __builtin_nanf(""); }   // no comparison succeeded: the row is all NaN.  Word 0 and a NaN log-prob, never an out-of-range gather
-    // measurement hook (set_debug_force_lengths): row b emits <end> at step force_len[b] - 1 whatever its scores say, so that
-    // a random-weight model can be given the finish times of real captions; never set by the product path
-    if (force_len && t + 1 >= force_len[b]) bi = (int)end_idx;
+    // set_decode_row_limits: row b's caption is at most row_limit[b] words long — at that timestep the loop ends it (<end> is
+    // taken whatever the scores say; the recorded log-prob stays the arg-max's)
+    if (row_limit && t + 1 >= row_limit[b]) bi = (int)end_idx;
     // the word follows from the arg-max and the row's latch alone: with a tail, every thread requests its piece of the
     // token-table row NOW, so that round trip runs under the sum-exp pass instead of after the serial bookkeeping
     TailRow tw;
@@ -285,8 +279,7 @@ int greedy_pick(Slabs logits, const float* bias, int V, int t, int max_len, long
     const bool reg = V <= 4 * 256 * GP_MAXQ && !(logits.ld & 3) && !(logits.stride & 3) && aligned16(logits.p);
 #define SET_PICK_LAUNCH(REG, TAIL)                                                                                    \
     hipLaunchKernelGGL((greedy_pick_k<REG, TAIL>), dim3(B), dim3(256), 0, s, logits, bias, V, t, max_len, end_idx, seq, \
-                       seq_logp, it, unfinished, alive, table, emb_out, D, tl, skip, g_force_len)
-    const int skip = g_row_gate.unfinished != nullptr ? 1 : 0;       // finished rows are skipped when the loop's row gate says so
+                       seq_logp, it, unfinished, alive, table, emb_out, D, tl, g_row_limit)
     if (reg) { if (tail) SET_PICK_LAUNCH(true, true); else SET_PICK_LAUNCH(true, false); }
     else { if (tail) SET_PICK_LAUNCH(false, true); else SET_PICK_LAUNCH(false, false); }
 #undef SET_PICK_LAUNCH
@@ -342,7 +335,7 @@ __global__ void __launch_bounds__(256) sample_pick_k(Slabs logits, const float* 
                                                      long long* it_buf, int* unfinished, int* alive,
                                                      const float* table, float* emb_out, int D,
                                                      unsigned long long seed, unsigned long long offset,
-                                                     SampleOut so, const LstmTail tail, const int skip_finished) {
+                                                     SampleOut so, const LstmTail tail) {
     __shared__ float s_red[4];
     __shared__ float s_scan[4];
     __shared__ float s_max;
@@ -350,11 +343,6 @@ __global__ void __launch_bounds__(256) sample_pick_k(Slabs logits, const float* 
     __shared__ int s_pick;
     __shared__ float s_pick_x;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // the fused no-grad loops (no per-step side outputs), opt-in: a row whose caption has ended is not scored (see
-    // greedy_pick_k).  The grad-enabled rollout keeps every step (its backward reads raw_ids / lse of all rows).
-    if (t > 0 && skip_finished && !so.raw_ids && !so.lse && !so.step_logp) {
-        if (unfinished[b] == 0) return;
-    }
     f32x4 x[GP_MAXQ];
     float best = -INFINITY;
     if (REG) {
@@ -522,8 +510,7 @@ int sample_pick(Slabs logits, const float* bias, int V, int t, int max_len, long
     SampleOut so{raw_ids, lse, step_logp};
 #define SET_PICK_LAUNCH(REG, TAIL)                                                                                    \
     hipLaunchKernelGGL((sample_pick_k<REG, TAIL>), dim3(B), dim3(256), 0, s, logits, bias, V, t, max_len, end_idx, seq, \
-                       seq_logp, it, unfinished, alive, table, emb_out, D, seed, offset, so, tl, skip)
-    const int skip = g_row_gate.unfinished != nullptr ? 1 : 0;
+                       seq_logp, it, unfinished, alive, table, emb_out, D, seed, offset, so, tl)
     if (reg) { if (tail) SET_PICK_LAUNCH(true, true); else SET_PICK_LAUNCH(true, false); }
     else { if (tail) SET_PICK_LAUNCH(false, true); else SET_PICK_LAUNCH(false, false); }
 #undef SET_PICK_LAUNCH
@@ -569,43 +556,6 @@ int set_tokens(long long* it, long long value, int* unfinished, int* alive, int 
     return SET_OK;
 }
 
-// rowmap[0 .. n) = the rows with unfinished[row] != 0 in ascending order, *n_rows = n (decode loops, set_common.h RowGate);
-// init != 0: the identity list of all B rows (start of a decode).  One workgroup, B <= 4096.
-__global__ void __launch_bounds__(1024) compact_rows_k(const int* unfinished, int B, int* rowmap, int* n_rows, int init) {
-    __shared__ int s_cnt[16];
-    __shared__ int s_base[17];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int flag[4], mine = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {                         // thread owns rows 4 tid .. 4 tid + 3 (ascending order is kept)
-        const int r = 4 * tid + i;
-        flag[i] = (r < B) && (init || unfinished[r] != 0);
-        mine += flag[i];
-    }
-    int incl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-    if (lane == 63) s_cnt[wave] = incl;
-    __syncthreads();
-    if (tid == 0) {
-        int acc = 0;
-        for (int w = 0; w < 16; ++w) { s_base[w] = acc; acc += s_cnt[w]; }
-        s_base[16] = acc;
-        *n_rows = acc;
-    }
-    __syncthreads();
-    int pos = s_base[wave] + incl - mine;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) if (flag[i]) rowmap[pos++] = 4 * tid + i;
-}
-
-int compact_rows(const int* unfinished, int B, int* rowmap, int* n_rows, int init, hipStream_t s) {
-    if (B > 4096) return SET_ERR_UNSUPPORTED;
-    ProfScope ps("compact_rows", s, 0.0, 8.0 * B);
-    hipLaunchKernelGGL(compact_rows_k, dim3(1), dim3(1024), 0, s, unfinished, B, rowmap, n_rows, init);
-    SET_LAUNCH_CHECK();
-    return SET_OK;
-}
 
 __global__ void __launch_bounds__(256) iota_i64_k(long long* p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -78,8 +78,8 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 //         LDS stages and slab plan as KG = 1, but six instead of three resident waves per SIMD at three workgroups per
 //         CU and half as many MFMAs between two barriers, which fills more of the matrix pipe's idle slots.
 // GATE (row gate of the decode loops, set_common.h): 0 = none (prologue, training, every other caller: no gate code at all),
-// 1 = loop-left test, 2 = loop-left test + compacted row list.  Separate instantiations: the ungated kernel keeps the
-// round-3 instruction stream (the gate's branches and the row indirection cost 0.4-0.5 us per launch when compiled in).
+// 1 = loop-left test.  Separate instantiations: the ungated kernel keeps the round-3 instruction stream (the gate's branch
+// costs 0.4-0.5 us per launch when compiled in).
 template <int BM, int BN, int WAVES_M, int WAVES_N, int KG = 1, int GATE = 0>
 __global__ void __launch_bounds__(256 * KG) gemm_nt_f32(const int ntasks, const int wb1, const int wb2, const int wb3,
                                                         const int wb4, const int wb5, const int* const gate_alive,
@@ -128,27 +128,21 @@ __global__ void __launch_bounds__(256 * KG) gemm_nt_f32(const int ntasks, const 
     const int m0 = tm * BM, n0 = tn * BN;
     const int kt0 = (int)(((long long)ks * T.ktiles) / T.ksplit);
     const int kt1 = (int)(((long long)(ks + 1) * T.ktiles) / T.ksplit);
-    // ---- row gate of the decode loops (set_common.h): nothing to do once the reference has left its loop; with the
-    // compacted row list the launch covers *n_rows rows (tiles beyond return) and row r of a tile is batch row rowmap[r]
-    // (gate_alive / gate_nrows repeat L.gate.alive_prev / L.gate.n_rows as leading, SGPR-preloaded arguments: their values
-    // are requested with the wave's first instructions, next to the task descriptor, not behind it)
-    const int* const rowmap = GATE == 2 ? L.gate.rowmap : nullptr;
-    int epi_m = T.M;
+    // ---- row gate of the decode loops (set_common.h): nothing to do once the reference has left its loop
+    // (gate_alive repeats L.gate.alive_prev as a leading, SGPR-preloaded argument: its value is requested with the wave's
+    // first instructions, next to the task descriptor, not behind it; gate_nrows is an unused slot of the preloaded block)
+    const int epi_m = T.M;
     if constexpr (GATE >= 1) {
         if (gate_alive && *gate_alive == 0) return;
     }
-    if constexpr (GATE == 2) {
-        if (gate_nrows) { const int nr = *gate_nrows; epi_m = nr < T.M ? nr : T.M; }
-        if (m0 >= epi_m) return;
-    }
-    auto epi_row = [&](int row) { return (GATE == 2 && rowmap) ? rowmap[row] : row; };
+    auto epi_row = [&](int row) { return row; };
 
     // ---- staging assignment: thread -> (row = tid/8 + RP*i, 16-byte column = tid%8)
     const int srow = tid >> 3, scol = (tid & 7) * 4;
     const int sswz = ((tid & 7) ^ ((srow >> 1) & 7)) * 4;          // swizzled chunk (rows srow+RP*i share (r>>1)&7)
     int arow[LA], wrow[LW];
 #pragma unroll
-    for (int i = 0; i < LA; ++i) { int r = m0 + srow + RP * i; r = r < epi_m ? r : epi_m - 1; arow[i] = (GATE == 2 && rowmap) ? rowmap[r] : r; }
+    for (int i = 0; i < LA; ++i) { int r = m0 + srow + RP * i; r = r < epi_m ? r : epi_m - 1; arow[i] = r; }
 #pragma unroll
     for (int i = 0; i < LW; ++i) { int r = n0 + srow + RP * i; wrow[i] = r < T.N ? r : T.N - 1; }
 #ifdef SET_EXP_SAMEW
@@ -1477,7 +1471,7 @@ int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag
         flops += 2.0 * t.M * t.N * K;
         bytes += 4.0 * ((double)t.M * K + (double)t.N * K + (double)t.M * t.N * t.ksplit);
     }
-    const char* kname = (bm == 64 && bn == 64 && gemm_asm() && !g_row_gate.rowmap && slices_in_one_segment(L)) ? "gemm_nt_f32_asm<64,64>" :
+    const char* kname = (bm == 64 && bn == 64 && gemm_asm() && slices_in_one_segment(L)) ? "gemm_nt_f32_asm<64,64>" :
                         (bm == 128 && bn == 32) ? "gemm_nt_f32<128,32>" : bm == 128 ? "gemm_nt_f32<128,64>" : (bm == 64 ? "gemm_nt_f32<64,64>" : (bm == 32 ? "gemm_nt_f32<32,128>" : "gemv_nt_f32<16,64>"));
     ProfScope ps(kname, stream, flops, bytes);
     static const bool sites = env_int("SET_PROFILE_SITES", 0) != 0;   // per-call-site breakdown (nested events)
@@ -1497,12 +1491,9 @@ int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag
     } else {
         const int nt = L.ntasks, w1 = L.t[1].wg_begin, w2 = L.t[2].wg_begin, w3 = L.t[3].wg_begin, w4 = L.t[4].wg_begin,
                   w5 = L.t[5].wg_begin;
-        // only the register-staged kernels walk the compacted row list (the others compute every row: a superset)
-        const bool rowlist_ok = bm == 64 && bn == 64 && !gemm_wreg() && !gemm_dma() && gemm_kgroups() != 2;
-        if (!rowlist_ok) { L.gate.rowmap = nullptr; L.gate.n_rows = nullptr; }
         const int* ga = L.gate.alive_prev;
-        const int* gn = L.gate.n_rows;
-        const int gate_mode = (gn && L.gate.rowmap) ? 2 : (ga ? 1 : 0);
+        const int* gn = nullptr;                 // (unused slot of the preloaded argument block)
+        const int gate_mode = ga ? 1 : 0;
         if (bm == 16)
             hipLaunchKernelGGL(gemv_nt_f32, grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
         else if (bm == 128 && bn == 32)
@@ -1521,11 +1512,9 @@ int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag
             hipLaunchKernelGGL((gemm_nt_f32<64, 64, 2, 2, 2>), grid, dim3(512), 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
         else if (bm == 64 && gemm_dma())
             hipLaunchKernelGGL((gemm_nt_f32_dma<64, 64, 2, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
-        else if (bm == 64 && bn == 64 && gemm_asm() && gate_mode <= 1 && slices_in_one_segment(L))
+        else if (bm == 64 && bn == 64 && gemm_asm() && slices_in_one_segment(L))
             if (gate_mode) hipLaunchKernelGGL((gemm_nt_f32_asm<1>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
             else hipLaunchKernelGGL((gemm_nt_f32_asm<0>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
-        else if (bm == 64 && gate_mode == 2)
-            hipLaunchKernelGGL((gemm_nt_f32<64, 64, 2, 2, 1, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
         else if (bm == 64 && gate_mode == 1)
             hipLaunchKernelGGL((gemm_nt_f32<64, 64, 2, 2, 1, 1>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
         else if (bm == 64)

@@ -46,9 +46,8 @@ struct FusedArgs {
     // backward needs both), the post-activation gates (i, f, g, o) go to gates[b, q*N + unit], the incoming h to hprev
     // (same indexing as H), and finished rows store zeros to H / Mem / gates and carry h and c
     const float* c_in; float* gates; float* hprev;
-    // decode loops (set_common.h RowGate): COPYGATE*: `perm` = the compacted row list, `n_rows` its length (row tiles
-    // beyond it return), `alive_prev` the loop-left test
-    const int* n_rows; const int* alive_prev;
+    // decode loops (set_common.h RowGate): COPYGATE*: `alive_prev` = the loop-left test
+    const int* alive_prev;
 };
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
@@ -68,12 +67,8 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
     const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
     const int m0 = tm * 32;
     const int n0 = (EPI == EPI_ENCLSTM) ? tn * 8 : tn * 32;
-    constexpr bool ROWLIST = (EPI == EPI_ENCLSTM || EPI == EPI_COPYGATE || EPI == EPI_COPYGATE1);   // rows visited through P.perm
-    int Meff = P.M;
-    if (EPI == EPI_COPYGATE || EPI == EPI_COPYGATE1) {
-        if (P.n_rows) { const int nr = *P.n_rows; Meff = nr < P.M ? nr : P.M; }
-        if (m0 >= Meff) return;
-    }
+    constexpr bool ROWLIST = (EPI == EPI_ENCLSTM);          // rows visited through P.perm
+    const int Meff = P.M;
 
     // staging: thread -> row (tid / (BK/4)) .. covers 32 rows x BK floats with LPT float4 per thread
     constexpr int TPR = BK / 4;                             // threads per row
@@ -352,7 +347,7 @@ int fused_copy_gate(const float* c_new, const float* sel, const float* ogate, co
     P.W[0] = w_cnew; P.W[1] = w_cmem; P.ldw[0] = P.ldw[1] = D;
     P.K = D; P.M = M; P.N = D;
     P.b0 = b_cnew; P.b1 = b_cmem; P.e0 = c_new; P.e1 = sel; P.e2 = ogate; P.o0 = c_out; P.o1 = h_out;
-    P.perm = g_row_gate.rowmap; P.n_rows = g_row_gate.n_rows; P.alive_prev = g_row_gate.alive_prev;
+    P.alive_prev = g_row_gate.alive_prev;
     const int grid = cdiv(M, 32) * cdiv(D, 32);
     ProfScope ps("fused_copy_gate", s, 4.0 * M * D * D, 4.0 * (2.0 * D * D + 6.0 * M * D));
     return launch_fused<2, false, 64, EPI_COPYGATE>(P, grid, s);
@@ -367,7 +362,7 @@ int fused_copy_gate_pre(const float* c_new, const float* sel, const float* cmem_
     P.A[0] = c_new; P.lda[0] = D; P.W[0] = w_cnew; P.ldw[0] = D;
     P.K = D; P.M = M; P.N = D;
     P.b0 = b_cnew; P.b1 = b_cmem; P.e0 = c_new; P.e1 = sel; P.e2 = ogate; P.e3 = cmem_pre; P.o0 = c_out; P.o1 = h_out;
-    P.perm = g_row_gate.rowmap; P.n_rows = g_row_gate.n_rows; P.alive_prev = g_row_gate.alive_prev;
+    P.alive_prev = g_row_gate.alive_prev;
     const int grid = cdiv(M, 32) * cdiv(D, 32);
     ProfScope ps("fused_copy_gate", s, 2.0 * M * D * D, 4.0 * (1.0 * D * D + 7.0 * M * D));
     static const int bk128 = env_int("SET_COPYGATE_BK128", 1);

@@ -15,7 +15,10 @@ namespace set {
 
 constexpr int GBAR_STRIDE = 32;                     // unsigned words between two barrier words (128 bytes)
 constexpr int GBAR_WORDS = (8 + 1 + 8) * GBAR_STRIDE;
-constexpr unsigned GBAR_SPIN_LIMIT = 4000000u;      // default bound of one barrier wait (SET_PENC_SPIN_LIMIT overrides it)
+// Every wait is bounded in WALL-CLOCK time (s_memrealtime, the constant 100-MHz counter), not in poll iterations: a poll is a
+// memory round trip whose duration depends on what else runs, a bound in iterations is not a bound.
+constexpr unsigned GBAR_TIMEOUT_US = 1000000u;      // default bound of one wait: 1 s (SET_PENC_TIMEOUT_US overrides it)
+__device__ __forceinline__ unsigned long long gb_now() { return __builtin_amdgcn_s_memrealtime(); }
 inline size_t grid_barrier_bytes() { return sizeof(unsigned) * (GBAR_WORDS + GBAR_STRIDE); }   // + the status word's line
 
 typedef float gb_f32x4 __attribute__((ext_vector_type(4)));
@@ -42,11 +45,14 @@ __device__ __forceinline__ void gbar_wait(unsigned* bar, unsigned epoch, int sha
     if (threadIdx.x == 0) {
         unsigned* gen = bar + (9 + shard) * GBAR_STRIDE;
         unsigned spins = 0;
-        // bounded spin; a timeout is sticky (later barriers of this launch do not wait again) and raises the status word
+        unsigned long long t0 = 0;
+        // bounded spin (`limit` = ticks of the 100-MHz counter); a timeout is sticky (later barriers of this launch do not wait
+        // again) and raises the status word
         while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
             __builtin_amdgcn_s_sleep(1);
+            if (spins == 0u) t0 = gb_now();
             if ((++spins & 1023u) == 0u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-            if (spins > limit) {
+            if ((spins & 63u) == 0u && gb_now() - t0 > (unsigned long long)limit) {
                 __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // the host reads this one at its next call
                 break;
@@ -85,12 +91,14 @@ __device__ __forceinline__ gb_u32x4 ll_req2(__amdgpu_buffer_rsrc_t rs, int idx) 
     return __builtin_amdgcn_raw_buffer_load_b128(rs, idx * 8, 0, 16);
 }
 __device__ __forceinline__ bool ll_ok2(const gb_u32x4& w, unsigned tag) { return w.y == tag && w.w == tag; }
-// after a failed poll: back off; true = give up (this wait or an earlier one of the launch timed out)
-__device__ __forceinline__ bool ll_giveup(unsigned& spins, const LLWatch& f) {
+// after a failed poll: back off; true = give up (this wait or an earlier one of the launch timed out).  f.limit = ticks of the
+// 100-MHz counter one wait may take; t0 = the time of the wait's first failed poll
+__device__ __forceinline__ bool ll_giveup(unsigned& spins, unsigned long long& t0, const LLWatch& f) {
     __builtin_amdgcn_s_sleep(2);
+    if (spins == 0u) t0 = gb_now();
     ++spins;
     if ((spins & 255u) == 0u && __hip_atomic_load(f.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return true;
-    if (spins > f.limit) {
+    if ((spins & 31u) == 0u && gb_now() - t0 > (unsigned long long)f.limit) {
         __hip_atomic_store(f.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(f.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return true;
@@ -106,6 +114,7 @@ __device__ __forceinline__ void ll_stage(__amdgpu_buffer_rsrc_t rs, float* lds, 
     for (int c0 = tid; c0 < n2; c0 += NT * U) {
         gb_u32x4 w[U];
         unsigned spins = 0;
+        unsigned long long t0 = 0;
         for (;;) {
             bool ok = true;
             asm volatile("" ::: "memory");                        // a poll re-reads memory: nothing may be hoisted out of the loop
@@ -119,7 +128,7 @@ __device__ __forceinline__ void ll_stage(__amdgpu_buffer_rsrc_t rs, float* lds, 
                 const int i2 = c0 + NT * u;
                 if (i2 < n2) ok = ok && ll_ok2(w[u], tag);
             }
-            if (ok || ll_giveup(spins, f)) break;
+            if (ok || ll_giveup(spins, t0, f)) break;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -149,11 +158,16 @@ struct PersistentGuard {
     ~PersistentGuard();
     int serialise(hipStream_t s);         // wait for the previous persistent launch's completion event
     int launched(hipStream_t s);          // record this launch's completion event
-    unsigned spin_limit() const;
+    unsigned spin_limit() const;          // bound of one wait in ticks of the 100-MHz counter (SET_PENC_TIMEOUT_US)
     int test_stall() const;
+    // raise a kernel's dynamic-LDS cap to `bytes` on THIS device (function attributes are per device; `done` = the caller's
+    // per-device flags).  SET_ERR_UNSUPPORTED when the device's LDS limit is below `bytes` or the runtime refuses: the caller
+    // takes the per-step kernels, no HIP error leaves the library
+    int set_lds(const void* kernel, int bytes, bool (&done)[64]);
   private:
     bool locked;
 };
 bool persistent_disabled();               // a barrier timed out earlier on the current device
+int persistent_lds_limit();               // hipDeviceAttributeMaxSharedMemoryPerBlock of the current device (cached; 0 = unknown)
 
 }  // namespace set

@@ -81,7 +81,6 @@ __global__ void __launch_bounds__(256) lstm_pointwise_k(Slabs g0, Slabs g1, Slab
     if (idx >= (long long)M * per_row) return;
     const long long m = idx / per_row;
     const int j = (int)(idx - m * per_row) << 2;
-    if (G.row_done(m)) return;                               // decode loops, opt-in row skipping (set_common.h RowGate)
     // operands that do not depend on the slabs are requested first (the table row needs its token id): their
     // latency overlaps the slab reads; the additions keep the order slabs, pre, table row, b0, b1
     const float* trow = gt.tab ? gt.row(m) : nullptr;
@@ -206,7 +205,6 @@ __global__ void __launch_bounds__(256) copy_gate_k(Slabs gn, const float* bn, Sl
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)M * per_row) return;
     const long long m = idx / per_row;
-    if (G.row_done(m)) return;
     const int j = (int)(idx - m * per_row) << 2;
     // reference order: (gate_cnew(c_new) + b) + (gate_cmem(c_memory) + b)
     f32x4 a = slab_sum4(gn, m, j) + ld4(bn + j);

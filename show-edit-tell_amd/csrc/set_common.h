@@ -88,31 +88,19 @@ int gemm_tile_m(int M);   // BM the launcher will pick for M rows
 
 // ---------------------------------------------------------------------------------------------
 // Row gate of the free-running decode loops (editnet_rl.py:529-547, dcnet_rl.py:326-344).  The host enqueues all
-// max_len + 1 timesteps without ever reading the device, so the two ways the reference stops doing work are decided ON
-// the device, by every kernel of a timestep:
+// max_len + 1 timesteps without ever reading the device, so the way the reference stops doing work is decided ON
+// the device, by the kernels of a timestep:
 //   alive_prev   *alive_prev == 0: every row had finished after the previous timestep — the reference has left its loop
 //                (`if unfinished.sum() == 0: break`); the kernel returns at once.  Outputs are unchanged (nothing was
 //                written after the break before either); always on in the fused loops, for the kernels that carry a
 //                timestep's time (the three grouped GEMM launches, which get the pointer as a preloaded scalar argument,
 //                and the attention launch); the short pointwise / pick kernels skip the test (a dependent load at their
 //                top costs more than they do after the break).
-//   unfinished / rowmap / n_rows   opt-in (set_decode_options): rows whose caption has ended are not computed any more.
-//                Row-per-workgroup kernels skip rows with unfinished[row] == 0; the grouped GEMMs run over the compacted
-//                list rowmap[0 .. *n_rows) of unfinished rows (activation rows gathered, output rows scattered through
-//                it: all state stays in original row order) and drop the row tiles beyond it.  The list is rebuilt every
-//                few timesteps (a row that finished since then is still in it: computed, never consumed).  Token ids
-//                and the log-probs of every position the reference's RewardCriterion looks at are bit-identical; the
-//                log-probs the reference keeps computing for rows that already emitted <end> (it feeds them word 0 until
-//                the whole batch is done) stay 0 instead.
 // The launchers read the current gate from a thread-local that the loop sets around each timestep (RowGateScope).
 // ---------------------------------------------------------------------------------------------
 struct RowGate {
     const int* alive_prev = nullptr;
-    const int* unfinished = nullptr;
-    const int* rowmap = nullptr;
-    const int* n_rows = nullptr;
     __device__ __forceinline__ bool loop_left() const { return alive_prev && *alive_prev == 0; }
-    __device__ __forceinline__ bool row_done(long long m) const { return unfinished && unfinished[m] == 0; }
 };
 extern thread_local RowGate g_row_gate;
 struct RowGateScope {
@@ -120,9 +108,7 @@ struct RowGateScope {
     explicit RowGateScope(const RowGate& g) : prev(g_row_gate) { g_row_gate = g; }
     ~RowGateScope() { g_row_gate = prev; }
 };
-extern thread_local int g_skip_finished;      // set_decode_options(): opt-in finished-row skipping for this host thread
-bool skip_finished_rows();                    // editnet.hip: that option, or SET_SKIP_FINISHED
-extern thread_local const int* g_force_len;   // measurement hook: per-row step at which the greedy pick emits <end> (or NULL)
+extern thread_local const int* g_row_limit;   // set_decode_row_limits(): per-row cap on the caption length of the greedy loops (or NULL)
 
 // ---------------------------------------------------------------------------------------------
 // slab views consumed by the pointwise kernels: value(m,n) = sum_s p[s*stride + m*ld + n]
@@ -295,6 +281,5 @@ int philox_fill(uint32_t* out, int n, unsigned long long seed, unsigned long lon
 int iota_i64(long long* p, int n, hipStream_t s);
 int set_tokens(long long* it, long long value, int* unfinished, int* alive, int n_alive, int B,
                hipStream_t s);
-int compact_rows(const int* unfinished, int B, int* rowmap, int* n_rows, int init, hipStream_t s);
 
 }  // namespace set

@@ -30,7 +30,12 @@ class DAE(_DAE_XE):
         dims = self._dims(B, prev.shape[1], max_len + 1)
         ws = self._workspace(dims)
         w = self._weights(dims)
-        lib.set_decode_options(1 if getattr(self, "skip_finished_rows", False) else -1)      # see editnet_rl.DecoderC
+        limits = getattr(self, "row_limits", None)             # see editnet_rl.DecoderC.row_limits
+        if limits is not None:
+            if limits.dtype != torch.int32 or not limits.is_cuda or limits.numel() != B:
+                raise _lib.SetError("row_limits must be an int32 device tensor with one entry per row")
+            limits = limits.contiguous()
+        lib.set_decode_row_limits(ptr(limits) if limits is not None else None)
         seq = torch.empty(B, max_len, dtype=torch.long, device=dev)
         seq_logp = torch.empty(B, max_len, dtype=torch.float32, device=dev)
         if sample_rl:        # multinomial sampling, eval mode, no gradients: fused device loop, Philox epilogue

@@ -25,10 +25,9 @@ class DecoderC(_DecoderXE):
     """reference editnet_rl.py:455-549"""
 
     max_len = 18
-    # Opt-in (include/set_hip.h set_decode_options): in the no-grad greedy / sampled loops a row is not computed any more
-    # once its caption has ended.  Token ids, and the log-probs up to and including every row's <end>, are bit-identical;
-    # the log-probs the reference keeps recording behind a row's <end> (masked by RewardCriterion) stay 0.
-    skip_finished_rows = False
+    # Optional per-row cap on the caption length of the no-grad greedy loop (include/set_hip.h set_decode_row_limits): an
+    # int32 device tensor of B entries, or None.  Row b is ended by the loop after at most row_limits[b] words.
+    row_limits = None
 
     def forward(self, word_map, encoded_previous_captions, previous_cap_length, image_features, sample_max=True,
                 sample_rl=False, image_mean=None, repeat_images=1):
@@ -42,7 +41,12 @@ class DecoderC(_DecoderXE):
             image_features = image_features.repeat(repeat_images, 1, 1)
             image_mean = None if image_mean is None else image_mean.repeat(repeat_images, 1)
         lib = _lib.load()
-        lib.set_decode_options(1 if self.skip_finished_rows else -1)
+        limits = self.row_limits
+        if limits is not None:
+            if limits.dtype != torch.int32 or not limits.is_cuda or limits.numel() != image_features.shape[0]:
+                raise _lib.SetError("row_limits must be an int32 device tensor with one entry per row")
+            limits = limits.contiguous()
+        lib.set_decode_row_limits(_lib.ptr(limits) if limits is not None else None)
         dev = image_features.device
         X = _f32c(image_features)
         prev = _i64c(encoded_previous_captions)

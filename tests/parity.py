@@ -141,3 +141,46 @@ def _greedy_top2(g):
     if "greedy_logits" in g:
         return np.argsort(-g["greedy_logits"].astype(np.float64), axis=2, kind="stable")[:, :, :2]
     return None
+
+
+def oracle_greedy_reference(model, sd, wm, prev, plen, X=None, max_len=18):
+    """The numpy oracle's greedy trajectory on arbitrary inputs, with what check_greedy_rows needs to judge a differing row:
+    (seq, logp, margins (S,B), top2 (S,B,2)) — margins / candidates from the oracle's own per-step logits (its trace).  Rows
+    whose margin stays >= MARGIN_MIN must then match bit for bit; a differing row must be a DEMONSTRATED near-tie."""
+    from oracle import dcnet_np as DN, editnet_np as EN
+    tr = []
+    if model == "editnet":
+        P = EN.cast_params(sd)
+        seq, logp = EN.greedy_decode(P, wm["<start>"], wm["<end>"], prev, plen, X, max_len=max_len, trace=tr)
+    else:
+        P = DN.cast_params(sd)
+        seq, logp = DN.greedy_decode(P, wm["<start>"], wm["<end>"], prev, plen, max_len=max_len, trace=tr)
+    logits = np.stack([s["logits"] for s in tr], 0).astype(np.float64)           # (S, B, V)
+    top2 = np.argsort(-logits, axis=2, kind="stable")[:, :, :2]
+    tv = np.take_along_axis(logits, top2, 2)
+    margins = tv[:, :, 0] - tv[:, :, 1]
+    # behind a row's <end> every implementation feeds word 0 whatever the arg-max says (editnet_rl.py:531-540): a near-tie
+    # there cannot make trajectories diverge (the recorded max log-prob moves by less than the margin)
+    for b in range(seq.shape[0]):
+        z = np.nonzero(seq[b] == 0)[0]
+        if len(z):
+            margins[z[0] + 1:, b] = np.inf
+    return seq, logp, margins, top2
+
+
+def check_two_paths_rows(seq_a, logp_a, seq_b, logp_b, margins, tol=1e-5, margin_min=MARGIN_MIN):
+    """Two implementations of the same decode (e.g. the persistent launch and the per-step loop): on every row that never
+    passes a near-tie of the reference trajectory (`margins` (S,B)) ids are bit-identical and log-probs within `tol`; a
+    near-tie row must agree up to its first near-tie step.  Returns the number of near-tie rows."""
+    amb = (margins < margin_min).any(0)
+    ok = ~amb
+    assert np.array_equal(seq_a[ok], seq_b[ok]), "ids differ on rows without a near-tie"
+    if ok.any():
+        assert np.abs(logp_a[ok] - logp_b[ok]).max() < tol
+    for b in np.nonzero(amb)[0]:
+        t_star = int(np.argmax(margins[:, b] < margin_min))
+        n = min(t_star, seq_a.shape[1])
+        assert np.array_equal(seq_a[b, :n], seq_b[b, :n]), "near-tie row %d differs before its near-tie step %d" % (b, t_star)
+        if n:
+            assert np.abs(logp_a[b, :n] - logp_b[b, :n]).max() < tol
+    return int(amb.sum())

@@ -323,7 +323,7 @@ print("OK", mode)
 """
 
 
-@pytest.mark.parametrize("mode,env", [("stall", {"SET_PENC_TEST_STALL": "1", "SET_PENC_SPIN_LIMIT": "20000"}),
+@pytest.mark.parametrize("mode,env", [("stall", {"SET_PENC_TEST_STALL": "1", "SET_PENC_TIMEOUT_US": "20000"}),
                                       ("capacity", {"SET_PENC_TEST_CAPACITY": "100"})])
 def test_persistent_encoder_failure_is_loud(mode, env):
     """The persistent caption encoder can fail in two ways and neither may be silent (csrc/encoder_persistent.hip):

@@ -73,11 +73,25 @@ def test_dcnet_persistent_decode_matches_golden_and_per_step():
     assert float((logp - ref[1]).abs().max()) < 1e-5
 
 
-@pytest.mark.parametrize("B", [1, 3, 5, 8])
+def _check_against_oracle_and_per_step(model, d, prev, plen, X, got, ref):
+    """`got` = the persistent launch, `ref` = the per-step loop, both (seq, logp) device tensors.  The numpy oracle decodes the
+    same inputs on the host (its per-step logits give every row's top-1 / top-2 margin): rows without a near-tie must be
+    bit-identical to the oracle AND between the two HIP paths; a differing row must be a demonstrated near-tie whose token is
+    one of the oracle's two best candidates (parity.check_greedy_rows)."""
+    seq_o, logp_o, margins, top2 = parity.oracle_greedy_reference(model, d["sd"], d["wm"], _np(prev), _np(plen),
+                                                                  None if X is None else _np(X))
+    end = int(d["wm"]["<end>"])
+    n_amb = parity.check_greedy_rows(_np(got[0]), _np(got[1]), seq_o, logp_o, margins, top2, end)
+    parity.check_greedy_rows(_np(ref[0]), _np(ref[1]), seq_o, logp_o, margins, top2, end)
+    parity.check_two_paths_rows(_np(got[0]), _np(got[1]), _np(ref[0]), _np(ref[1]), margins)
+    return n_amb
+
+
+@pytest.mark.parametrize("B", [1, 3, 5, 6, 7, 8])
 def test_dcnet_persistent_decode_other_batch_sizes(B):
     """1 .. 8 rows (one 16-row MFMA tile, 1 - 2 rows per wave in the attention phase, ragged previous captions incl. length
-    1): the persistent launch against the per-step loop on the same inputs.  Rows are compared individually: a row of these
-    random-weight decodes may pass a near-tie, where the two summation orders can legitimately pick different words."""
+    1), all T = 19 timesteps: the persistent launch against the NUMPY ORACLE and the per-step loop on the same inputs.  No
+    row is excused without evidence: rows whose oracle margins stay >= 2.5e-4 are bit-identical everywhere."""
     d, xe, rl = dcnet_modules("dcnet_full_b4")
     prev, plen = _random_prev(B, d["prev"].shape[1], 100 + B)
     with torch.no_grad():
@@ -90,41 +104,37 @@ def test_dcnet_persistent_decode_other_batch_sizes(B):
         ref = _with_env("SET_DEC_PERSISTENT", "0", lambda: rl(d["wm"], prev, plen, True, False))
         torch.cuda.synchronize()
     assert torch.equal(seq, again[0]) and torch.equal(logp, again[1]), "the persistent decode must be run-to-run deterministic"
-    same = (seq == ref[0]).all(1)
-    assert int(same.sum()) >= B - 1, (seq, ref[0])
-    assert float((logp - ref[1])[same].abs().max()) < 1e-5
+    _check_against_oracle_and_per_step("dcnet", d, prev, plen, None, (seq, logp), ref)
     assert torch.isfinite(logp).all()
 
 
 @pytest.mark.parametrize("model", ["dcnet", "editnet"])
 def test_persistent_decode_many_random_inputs(model):
     """64 rows of random inputs (16 batches of 4): the persistent launch scores the attention with tanh = 1 - 2 / (1 + e^2x)
-    on the hardware exp2 / rcp and adds every product in another order than the per-step loop — greedy ids must still be
-    identical on (all but at most one near-tie of) the rows, log-probs within 1e-5."""
+    on the hardware exp2 / rcp and adds every product in another order than the per-step loop.  Every batch is decoded by the
+    numpy oracle too: greedy ids identical on every row without a demonstrated near-tie (oracle margins), log-probs within
+    1e-5 between the two HIP paths and 1e-4 against the oracle; near-tie rows stay a small minority."""
     if model == "dcnet":
         d, xe, rl = dcnet_modules("dcnet_full_b4")
     else:
         d, xe, rl = editnet_modules("editnet_full_b4")
     T = d["prev"].shape[1]
-    equal = total = 0
-    worst = 0.0
+    n_amb = 0
     with torch.no_grad():
         for i in range(16):
             prev, plen = _random_prev(4, T, 1000 + i)
+            X = None
             if model == "dcnet":
                 args = (d["wm"], prev, plen, True, False)
             else:
                 X = to_dev(np.abs(np.random.RandomState(2000 + i).randn(4, d["X"].shape[1], d["X"].shape[2])).astype(np.float32))
                 args = (d["wm"], prev, plen, X, True, False)
             rl(*args)                                              # (first call: builds / keeps the token table)
-            seq, logp = rl(*args)
+            got = rl(*args)
             ref = _with_env("SET_DEC_PERSISTENT", "0", lambda: rl(*args))
-            same = (seq == ref[0]).all(1)
-            equal += int(same.sum()); total += 4
-            if same.any():
-                worst = max(worst, float((logp - ref[1])[same].abs().max()))
-    assert equal >= total - 1, (equal, total)
-    assert worst < 1e-5, worst
+            torch.cuda.synchronize()
+            n_amb += _check_against_oracle_and_per_step(model, d, prev, plen, X, got, ref)
+    assert n_amb <= 3, "near-tie rows should be rare among 64 random rows: %d" % n_amb
 
 
 def test_dcnet_persistent_decode_on_concurrent_streams():
@@ -215,10 +225,11 @@ def test_editnet_persistent_xe_forward_matches_golden_and_per_step():
     assert float((pred - ref[0]).abs().max()) < 2e-5 * max(1.0, float(ref[0].abs().max()))
 
 
-@pytest.mark.parametrize("B", [1, 2, 3, 5, 6, 8])
+@pytest.mark.parametrize("B", [1, 2, 3, 5, 6, 7, 8])
 def test_editnet_persistent_decode_other_batch_sizes(B):
-    """1 .. 8 rows, random features and ragged previous captions: the persistent launch
-    against the per-step loop, row by row (see the DCNet twin above), and run-to-run determinism."""
+    """1 .. 8 rows, random features and ragged previous captions, all T = 19 timesteps: the persistent launch against the NUMPY
+    ORACLE and the per-step loop, row by row with the oracle's margins (see the DCNet twin above), and run-to-run
+    determinism."""
     d, xe, rl = editnet_modules("editnet_full_b4")
     prev, plen = _random_prev(B, d["prev"].shape[1], 200 + B)
     X = to_dev(np.abs(np.random.RandomState(300 + B).randn(B, d["X"].shape[1], d["X"].shape[2])).astype(np.float32))
@@ -233,9 +244,7 @@ def test_editnet_persistent_decode_other_batch_sizes(B):
         ref = _with_env("SET_DEC_PERSISTENT", "0", lambda: rl(*args))
         torch.cuda.synchronize()
     assert torch.equal(seq, again[0]) and torch.equal(logp, again[1])
-    same = (seq == ref[0]).all(1)
-    assert int(same.sum()) >= B - 1, (seq, ref[0])
-    assert float((logp - ref[1])[same].abs().max()) < 1e-5
+    _check_against_oracle_and_per_step("editnet", d, prev, plen, X, (seq, logp), ref)
     assert torch.isfinite(logp).all()
 
 
@@ -299,7 +308,7 @@ print("OK", mode)
 """
 
 
-@pytest.mark.parametrize("mode,env", [("stall", {"SET_PENC_TEST_STALL": "1", "SET_PENC_SPIN_LIMIT": "20000", "SET_ENC_PERSISTENT": "0"}),
+@pytest.mark.parametrize("mode,env", [("stall", {"SET_PENC_TEST_STALL": "1", "SET_PENC_TIMEOUT_US": "20000", "SET_ENC_PERSISTENT": "0"}),
                                       ("capacity", {"SET_PENC_TEST_CAPACITY": "100"})])
 def test_dcnet_persistent_decode_failure_is_loud(mode, env):
     """Same two failure modes as the persistent encoder (tests/test_hip_boundary.py): a grid that is not admitted whole is
