@@ -31,6 +31,7 @@ struct GenTask {
     long long lda, ldb, ldc, slab_stride;
     int M, N, K, ktiles, ksplit, tiles_n, accumulate, wg_begin;
     int vec_store;       // 16-byte epilogue stores allowed (N, ldc, slab stride multiples of 4 floats, C 16-byte aligned)
+    unsigned ext_a, ext_b;   // HWB kernels: readable bytes of A / B (the buffer resource's range: loads beyond it return zeros)
     // reduction pass (ksplit > 1): out (+)= sum of slabs
     float* out;
     long long ldo;
@@ -47,7 +48,13 @@ struct GenLaunch {
 // COMBINE: the in-launch split-K combine (experiment, SET_GEN_COMBINE=1) is compiled into its own instantiations — its
 // read-back holds BM/16 x 4 slab pieces per thread, which would otherwise set the register budget (and the occupancy) of
 // the default kernels too
-template <int BM, int BN, bool A_KMAJ, bool B_KMAJ, bool COMBINE = false>
+// HWB (round 5, the default): operands are read with raw buffer loads whose range check does the kernel's bounds work in
+// hardware — a k-minor operand's rows k >= K lie beyond the resource's range and read as zeros, a load that must not happen
+// (k >= K inside a k-major row, a k-tile beyond this workgroup's slice) is given an offset beyond the range — so the
+// pipelined k-loop has NO branch besides its back edge: the compiler keeps two register stages in flight with partial
+// vmcnt waits instead of draining every outstanding request at the join of a predicated load (six exec-mask branches per
+// k-tile before).  HWB = false: global loads + predicates, for operands whose extent does not fit a 31-bit byte offset.
+template <int BM, int BN, bool A_KMAJ, bool B_KMAJ, bool COMBINE = false, bool HWB = false>
 __global__ void __launch_bounds__(256) gemm_gen_f32(const GenLaunch L) {
     constexpr int TM = BM / 64, TN = BN / 64;            // 2x2 waves
     constexpr int LA = BM / 32, LB = BN / 32;            // float4 loads per thread per k-tile
@@ -75,6 +82,7 @@ __global__ void __launch_bounds__(256) gemm_gen_f32(const GenLaunch L) {
     const int sswz = ((tid & 7) ^ ((srow >> 1) & 7)) * 4;
     const float* pa[LA];
     const float* pb[LB];
+    unsigned va[LA], vb[LB];         // HWB: byte offsets of the loads inside A / B
     int ka[LA], kb[LB];              // the k index this thread's load i covers inside a k-tile
     int sa[LA], sb[LB];              // LDS float offset of the store
     long long stepa, stepb;          // pointer advance per k-tile
@@ -83,12 +91,14 @@ __global__ void __launch_bounds__(256) gemm_gen_f32(const GenLaunch L) {
         if constexpr (A_KMAJ) {
             int r = m0 + srow + 32 * i; r = r < T.M ? r : T.M - 1;
             pa[i] = T.A + (long long)r * T.lda + scol;
+            va[i] = (unsigned)(((long long)r * T.lda + scol) * 4);
             ka[i] = scol; sa[i] = (srow + 32 * i) * 32 + sswz;
         } else {
             const int f = tid + 256 * i, kr = f / (BM / 4), c4 = (f % (BM / 4)) * 4;
             const int Mr = (T.M + 3) & ~3;       // a ragged M is accepted when the rows are readable up to Mr (host check)
             int c = m0 + c4; c = c + 4 <= Mr ? c : Mr - 4;
             pa[i] = T.A + (long long)kr * T.lda + c;
+            va[i] = (unsigned)(((long long)kr * T.lda + c) * 4);
             ka[i] = kr; sa[i] = kr * BM + c4;
         }
     }
@@ -97,24 +107,30 @@ __global__ void __launch_bounds__(256) gemm_gen_f32(const GenLaunch L) {
         if constexpr (B_KMAJ) {
             int r = n0 + srow + 32 * i; r = r < T.N ? r : T.N - 1;
             pb[i] = T.B + (long long)r * T.ldb + scol;
+            vb[i] = (unsigned)(((long long)r * T.ldb + scol) * 4);
             kb[i] = scol; sb[i] = (srow + 32 * i) * 32 + sswz;
         } else {
             const int f = tid + 256 * i, kr = f / (BN / 4), c4 = (f % (BN / 4)) * 4;
             int c = n0 + c4; c = c + 4 <= T.N ? c : T.N - 4;
             pb[i] = T.B + (long long)kr * T.ldb + c;
+            vb[i] = (unsigned)(((long long)kr * T.ldb + c) * 4);
             kb[i] = kr; sb[i] = kr * BN + c4;
         }
     }
     stepa = A_KMAJ ? 32 : 32 * T.lda;
     stepb = B_KMAJ ? 32 : 32 * T.ldb;
 #pragma unroll
-    for (int i = 0; i < LA; ++i) pa[i] += (long long)kt0 * stepa;
+    for (int i = 0; i < LA; ++i) { pa[i] += (long long)kt0 * stepa; va[i] += (unsigned)(kt0 * stepa * 4); }
 #pragma unroll
-    for (int i = 0; i < LB; ++i) pb[i] += (long long)kt0 * stepb;
+    for (int i = 0; i < LB; ++i) { pb[i] += (long long)kt0 * stepb; vb[i] += (unsigned)(kt0 * stepb * 4); }
+    const unsigned vstepa = (unsigned)(stepa * 4), vstepb = (unsigned)(stepb * 4);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)T.A, 0, HWB ? T.ext_a : 0u, 0x00027000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)T.B, 0, HWB ? T.ext_b : 0u, 0x00027000);
+    constexpr unsigned GEN_OOB = 0x80000000u;    // beyond every resource's range (host: extents < 2^31 bytes): reads as zeros
 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     // loads of k-tile KT; contraction indices >= K contribute zeros (K need not be a multiple of 32)
-#define GEN_GLOAD(KT, RA, RB)                                                                           \
+#define GEN_GLOAD_PTR(KT, RA, RB)                                                                       \
     {                                                                                                   \
         const int kbase_ = (KT) * 32;                                                                   \
         _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                \
@@ -126,7 +142,25 @@ __global__ void __launch_bounds__(256) gemm_gen_f32(const GenLaunch L) {
             pb[i] += stepb;                                                                             \
         }                                                                                               \
     }
-#define GEN_STAGE(KT, RA, RB) if ((KT) < kt1) GEN_GLOAD(KT, RA, RB)
+    // HWB: every load is issued; what must not be read gets an out-of-range offset (a select, not a branch).  k-minor rows
+    // k >= K are out of range by themselves (the resource ends with row K - 1)
+#define GEN_GLOAD_BUF(KT, RA, RB)                                                                       \
+    {                                                                                                   \
+        const int kbase_ = (KT) * 32;                                                                   \
+        const bool live_ = (KT) < kt1;                                                                  \
+        _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                \
+            const bool ok_ = A_KMAJ ? (live_ && kbase_ + ka[i] < T.K) : live_;                          \
+            RA[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ok_ ? va[i] : GEN_OOB, 0, 0)); \
+            va[i] += vstepa;                                                                            \
+        }                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < LB; ++i) {                                                \
+            const bool ok_ = B_KMAJ ? (live_ && kbase_ + kb[i] < T.K) : live_;                          \
+            RB[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, ok_ ? vb[i] : GEN_OOB, 0, 0)); \
+            vb[i] += vstepb;                                                                            \
+        }                                                                                               \
+    }
+#define GEN_GLOAD(KT, RA, RB) { if constexpr (HWB) GEN_GLOAD_BUF(KT, RA, RB) else GEN_GLOAD_PTR(KT, RA, RB) }
+#define GEN_STAGE(KT, RA, RB) { if constexpr (HWB) GEN_GLOAD_BUF(KT, RA, RB) else if ((KT) < kt1) GEN_GLOAD_PTR(KT, RA, RB) }
 #define GEN_LSTORE(BUF, RA, RB)                                                                         \
     {                                                                                                   \
         float* sA_ = lds[(BUF)];                                                                        \
@@ -178,7 +212,7 @@ __global__ void __launch_bounds__(256) gemm_gen_f32(const GenLaunch L) {
         GEN_FRAG_LOAD(0, fa0, fb0);                                                                     \
         GEN_FRAG_LOAD(1, fa1, fb1);                                                                     \
         GEN_FRAG_MFMA(fa0, fb0);                                                                        \
-        if ((KT) + 1 < kt1) {                                                                           \
+        if (HWB || (KT) + 1 < kt1) {      /* HWB: unconditional (behind the slice: zeros into the idle buffer) */ \
             GEN_LSTORE((BUF) ^ 1, RA, RB);                                                              \
             GEN_STAGE((KT) + 3, RA, RB);                                                                \
         }                                                                                               \
@@ -209,6 +243,8 @@ __global__ void __launch_bounds__(256) gemm_gen_f32(const GenLaunch L) {
 #undef GEN_LSTORE
 #undef GEN_STAGE
 #undef GEN_GLOAD
+#undef GEN_GLOAD_BUF
+#undef GEN_GLOAD_PTR
 
     // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* Cs = T.C + (long long)ks * T.slab_stride;
@@ -383,13 +419,13 @@ __global__ void __launch_bounds__(256) slab_reduce_k(const GenLaunch L) {
     }
 }
 
-template <int BM, int BN, bool COMBINE>
+template <int BM, int BN, bool COMBINE, bool HWB>
 static void launch_gen(const GenLaunch& L, int a_kmaj, int b_kmaj, unsigned wgs, hipStream_t s) {
     dim3 grid(wgs), block(256);
-    if (a_kmaj && b_kmaj) hipLaunchKernelGGL((gemm_gen_f32<BM, BN, true, true, COMBINE>), grid, block, 0, s, L);
-    else if (a_kmaj) hipLaunchKernelGGL((gemm_gen_f32<BM, BN, true, false, COMBINE>), grid, block, 0, s, L);
-    else if (b_kmaj) hipLaunchKernelGGL((gemm_gen_f32<BM, BN, false, true, COMBINE>), grid, block, 0, s, L);
-    else hipLaunchKernelGGL((gemm_gen_f32<BM, BN, false, false, COMBINE>), grid, block, 0, s, L);
+    if (a_kmaj && b_kmaj) hipLaunchKernelGGL((gemm_gen_f32<BM, BN, true, true, COMBINE, HWB>), grid, block, 0, s, L);
+    else if (a_kmaj) hipLaunchKernelGGL((gemm_gen_f32<BM, BN, true, false, COMBINE, HWB>), grid, block, 0, s, L);
+    else if (b_kmaj) hipLaunchKernelGGL((gemm_gen_f32<BM, BN, false, true, COMBINE, HWB>), grid, block, 0, s, L);
+    else hipLaunchKernelGGL((gemm_gen_f32<BM, BN, false, false, COMBINE, HWB>), grid, block, 0, s, L);
 }
 
 // n independent problems of the same operand layout in ONE launch (+ one reduction launch when any is split):
@@ -401,6 +437,8 @@ int gemm_gen_group(const SetGemmDesc* d, int n, int a_kminor, int b_kminor, void
     static const int bm64_upto = env_int("SET_GEMM_GEN_BM64_UPTO", 512);    // same finding as the forward kernel
     GenLaunch L;
     L.ntasks = n;
+    static const int hwb_on = env_int("SET_GEMM_GEN_HWB", 1);
+    bool hwb = hwb_on != 0;
     int bm = 0;
     long long tiles[GEN_MAX_TASKS], tiles_total = 0;
     int max_kt = 1;
@@ -428,6 +466,16 @@ int gemm_gen_group(const SetGemmDesc* d, int n, int a_kminor, int b_kminor, void
         T.M = p.M; T.N = p.N; T.K = p.K; T.ktiles = cdiv(p.K, GEMM_BK); T.tiles_n = cdiv(p.N, 64);
         T.accumulate = p.accumulate; T.out = p.C; T.ldo = p.ldc;
         if (T.ktiles > max_kt) max_kt = T.ktiles;
+        // readable extent of each operand = the range of its buffer resource (HWB kernels).  k-major: M (N) rows of K4 floats;
+        // k-minor: K rows, the last one read up to the (4-padded) row / column count.  The furthest offset a load may carry
+        // (32 rows past the last k-tile) must stay below 2^31 as well
+        const long long K4 = ((long long)p.K + 3) & ~3LL, M4 = ((long long)p.M + 3) & ~3LL, Kt = (long long)T.ktiles * 32 + 64;
+        const long long ea = 4 * (a_kminor ? ((long long)(p.K - 1) * p.lda + M4) : ((long long)(p.M - 1) * p.lda + K4));
+        const long long eb = 4 * (b_kminor ? ((long long)(p.K - 1) * p.ldb + p.N) : ((long long)(p.N - 1) * p.ldb + K4));
+        const long long fa = 4 * (a_kminor ? Kt * p.lda + M4 : (long long)(p.M - 1) * p.lda + Kt);
+        const long long fb = 4 * (b_kminor ? Kt * p.ldb + p.N : (long long)(p.N - 1) * p.ldb + Kt);
+        if (ea >= 0x7fffffffLL || eb >= 0x7fffffffLL || fa >= 0x7fffffffLL || fb >= 0x7fffffffLL) hwb = false;
+        T.ext_a = (unsigned)(ea < 0x7fffffffLL ? ea : 0); T.ext_b = (unsigned)(eb < 0x7fffffffLL ? eb : 0);
     }
     static const int plan_model = env_int("SET_GEMM_GEN_PLAN", 1);
     // Split depth (and, above 512 rows, the row-tile class).  Cost model, measured with tools/bench_gen_split.py:
@@ -541,11 +589,14 @@ int gemm_gen_group(const SetGemmDesc* d, int n, int a_kminor, int b_kminor, void
                                     : (b_kminor ? "gemm_gen_f32<nn>" : "gemm_gen_f32<nt>");
         ProfScope ps(name, s, flops, bytes);
         if (counters_used > 0) {
-            if (bm == 128) launch_gen<128, 64, true>(L, !a_kminor, !b_kminor, (unsigned)wg, s);
-            else launch_gen<64, 64, true>(L, !a_kminor, !b_kminor, (unsigned)wg, s);
+            if (bm == 128) launch_gen<128, 64, true, false>(L, !a_kminor, !b_kminor, (unsigned)wg, s);
+            else launch_gen<64, 64, true, false>(L, !a_kminor, !b_kminor, (unsigned)wg, s);
+        } else if (hwb) {
+            if (bm == 128) launch_gen<128, 64, false, true>(L, !a_kminor, !b_kminor, (unsigned)wg, s);
+            else launch_gen<64, 64, false, true>(L, !a_kminor, !b_kminor, (unsigned)wg, s);
         } else {
-            if (bm == 128) launch_gen<128, 64, false>(L, !a_kminor, !b_kminor, (unsigned)wg, s);
-            else launch_gen<64, 64, false>(L, !a_kminor, !b_kminor, (unsigned)wg, s);
+            if (bm == 128) launch_gen<128, 64, false, false>(L, !a_kminor, !b_kminor, (unsigned)wg, s);
+            else launch_gen<64, 64, false, false>(L, !a_kminor, !b_kminor, (unsigned)wg, s);
         }
         SET_LAUNCH_CHECK();
     }

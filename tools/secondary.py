@@ -240,10 +240,42 @@ def realistic_lengths(dev, batch=128, mean_len=10.5, std_len=2.4):
                     "finished-row skipping (+0.9 % beyond the gate) was removed in round 5"}
 
 
+def batch_sweep(dev, batches=(1, 4, 8, 16, 32, 64, 128)):
+    """EditNet greedy decode (editnet_rl.py:485-549: prologue + 19 timesteps, token table active) per batch size, one decode at
+    a time: ms per decode and the fraction of the binding roofline of SURVEY.md §8(d) — per timestep max(t_HBM, t_fp32) with
+    263.4 MB of weights + 0.573 MB of activations per row at 8 TB/s, 0.1319 GFLOP per row at 157.3 TFLOP/s — that 19
+    timesteps would take.  `path` = which loop ran (one persistent launch / the per-step kernels)."""
+    from show_edit_tell_amd import _lib, editnet_rl, synth
+    wm = synth.word_map(V)
+    dec = _editnet(editnet_rl.DecoderC, dev, wm).eval()
+    lib = _lib.load()
+    rows = []
+    for Bn in batches:
+        X = torch.from_numpy(synth.features(25, Bn, R, F)).to(dev)
+        prev, plen = (torch.from_numpy(x).to(dev) for x in synth.prev_captions(25, Bn, T, V, 5))
+        with torch.no_grad():
+            fn = lambda: dec(wm, prev, plen, X, True, False)
+            t, _ = _timed(fn, 20, 4)
+            lib.set_profile_enable(1)
+            fn()
+            torch.cuda.synchronize()
+            tags = [r["tag"] for r in _lib.profile_report()]
+            lib.set_profile_enable(0)
+        t_hbm = (263.4e6 + 0.573e6 * Bn) / 8e12
+        t_mma = 0.1319e9 * Bn / 157.3e12
+        bound = 19 * max(t_hbm, t_mma)
+        rows.append({"batch": Bn, "ms_per_decode": round(1e3 * t, 3), "decode_steps_per_sec": round(19 / t, 1),
+                     "us_per_timestep_incl_prologue": round(1e6 * t / 19, 1), "bound": "hbm" if t_hbm >= t_mma else "mfma",
+                     "roofline_ms": round(1e3 * bound, 3), "frac_of_roofline": round(bound / t, 3),
+                     "path": "persistent" if "persistent_decode" in tags else "per-step"})
+    return {"workload": "EditNet greedy decode, one batch at a time, B in %s (36x2048 feats, prev len 20, V=10000)" % (list(batches),),
+            "rows": rows}
+
+
 def all_secondary(dev):
     out = {}
     for name, fn in (("scst", scst), ("adaptive", adaptive), ("dcnet", dcnet), ("dcnet_train", dcnet_train), ("beam", beam),
-                     ("realistic_lengths", realistic_lengths)):
+                     ("realistic_lengths", realistic_lengths), ("batch_sweep", batch_sweep)):
         try:
             out[name] = fn(dev)
         except Exception as e:              # a secondary figure must never break the bench line
