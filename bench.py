@@ -191,22 +191,6 @@ def cpu_baseline(budget_s=float(os.environ.get("SET_CPU_BASELINE_BUDGET", "10"))
                 variants=variants)
 
 
-def experimental_split(args):
-    """Secondary, NOT the headline, opt-in (--experimental): the same bench with SET_GEMM_SPLIT=1 (fp32 operands
-    split exactly into 3 bf16, 6 partial products, fp32 accumulation) in a child process."""
-    env = dict(os.environ, SET_GEMM_SPLIT="1")
-    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--streams", str(args.streams), "--no-cpu-baseline", "--no-profile", "--no-train", "--no-secondary", "--repeat", "1"]
-    try:
-        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
-        d = json.loads(out.stdout.strip().splitlines()[-1])
-        return {"split_bf16x3_gemm": {"decode_steps_per_sec": d["value"],
-                                      "single_stream_decode_steps_per_sec": d["single_stream_decode_steps_per_sec"],
-                                      "switch": "SET_GEMM_SPLIT=1 (off by default)"}}
-    except Exception as e:          # never let the experiment break the bench line
-        return {"split_bf16x3_gemm": {"error": repr(e)[:200]}}
-
-
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -242,8 +226,6 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the 'secondary' object (SCST step, adaptive features, DCNet / B=4 greedy, batched beam search)")
     ap.add_argument("--train-steps", type=int, default=6)
-    ap.add_argument("--experimental", action="store_true",
-                    help="also report the opt-in split-precision (bf16x3) GEMM figure under 'experimental'")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("SET_BENCH_STREAMS", "0")),
                     help="independent batches in flight per GPU (each on its own HIP stream + workspace)")
     args = ap.parse_args()
@@ -531,12 +513,6 @@ def main():
         line["kernels"] = {p["tag"]: _kernel(p) for p in prof}
     if train is not None:
         line["train"] = train
-    split_env = os.environ.get("SET_GEMM_SPLIT", "0") not in ("", "0")
-    if split_env:      # opt-in experimental kernel: say so in the line, never pass it off as the fp32-MFMA figure
-        line["dtype"] = "f32 emulated as bf16x3 (6 partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulate)"
-        line.pop("roofline", None)
-    if n_gpus == 1 and args.experimental and not split_env:
-        line["experimental"] = experimental_split(args)
     if not args.no_secondary and n_gpus == 1:
         from tools import secondary
         line["secondary"] = secondary.all_secondary(dev)
@@ -612,6 +588,24 @@ def train_leg(args, dec, wm, X, caps, clen, prev, plen, dev, dist, rank, world, 
         seen = [None] * world
         dist.all_gather_object(seen, {"rank": rank, "device": torch.cuda.current_device(),
                                       "name": torch.cuda.get_device_name(), "backend": dist.get_backend()})
+        # the collective library and the fabric the ranks talk over (rank 0's view; best effort, never fatal)
+        fabric = {}
+        if rank == 0:
+            try:
+                fabric["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:
+                fabric["rccl_version"] = "unavailable: %r" % (e,)
+            for key in ("NCCL_DEBUG", "RCCL_MSCCL_ENABLE", "NCCL_ALGO", "NCCL_PROTO", "HSA_ENABLE_IPC_MODE_LEGACY"):
+                if key in os.environ:
+                    fabric[key] = os.environ[key]
+            try:
+                topo = subprocess.run(["rocm-smi", "--showtopo"], capture_output=True, text=True, timeout=60).stdout
+                # keep the link-type and hop tables, drop banners
+                keep = [ln for ln in topo.splitlines() if ln.strip() and not set(ln.strip()) <= set("=-")]
+                fabric["rocm_smi_showtopo"] = keep[:80]
+            except Exception as e:
+                fabric["rocm_smi_showtopo"] = "unavailable: %r" % (e,)
+        out["fabric"] = fabric
         out.update(ms_per_train_step_no_allreduce=round(1e3 * t_local / K, 3),
                    allreduce_exposed_ms=round(1e3 * (t_dp - t_local) / K, 3), allreduce_ms=ar_ms,
                    allreduce_buckets=None if fb is None else [round(f.numel() * 4 / 1e6, 1) for f in fb.flat],

@@ -27,7 +27,7 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + [os.path.join(HERE, "..", "include", "set_hip.h")]
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + glob.glob(os.path.join(CSRC, "experimental", "*.inc")) + [os.path.join(HERE, "..", "include", "set_hip.h")]
     return any(os.path.getmtime(p) > t for p in deps)
 
 

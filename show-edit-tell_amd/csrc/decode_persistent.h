@@ -94,6 +94,55 @@ __device__ __forceinline__ void pd_mma(f32x4& acc, const f32x4 (&w)[KB], const f
     }
 }
 
+// ---- EditNet: arguments shared by decode_persistent_editnet.hip (<= 8 rows) and decode_persistent_wide.hip (<= 16 rows)
+constexpr int PDEC_RREG = 36;      // image regions whose hoisted x2h products a thread keeps in registers
+
+struct PDecEditArgs {
+    // weights (nn.Linear layout, used in place)
+    const float* al_wih; long long ld_ih;        // attention_lstm.weight_ih (4D, 3D + F): columns [2D, 3D) = h2
+    const float* al_whh;
+    const float* cl_h2h_w;
+    const float* cl_x2h_w; long long ld_x2h;     // copy_lstm.x2h (4D, 2D + F): [0, D) h1, [D, 2D) attend_cap
+    const float *cl_x2h_b, *cl_h2h_b;
+    const float *ca_gate_w, *ca_gate_b;          // (D, 3D): columns [D, 2D) = h1
+    const float *ca_tc_w, *ca_tc_b;              // (D, 2D): columns [D, 2D) = h1
+    const float* ca_sc_b;
+    const float *ca_dec_w, *ca_dec_b, *ca_full_w, *ca_full_b;
+    const float *va_dec_w, *va_dec_b, *va_full_w, *va_full_b;
+    const float *cl_cnew_w, *cl_cnew_b, *cl_cmem_b;
+    const float *fc_w, *fc_b;
+    const float* tok_table; long long ld_tab;    // (V, 10D): [0, 4D) gates, [4D, 5D) tc_affine, [5D, 6D) context_gate
+    // per sequence (prologue outputs)
+    const float* pre1;                           // (B, 4D)
+    const float* att1;                           // (B, R, A) features_att(relu(att_embed(X)))
+    const float* att1_c;                         // (B, T, A)
+    const float* mask;                           // (B, T)
+    const float* capP;                           // (B, T, 2D) [context_gate.W[:, 2D:] H | sc_affine.W H]
+    const float* memQ;                           // (B, T, D)  gate_cmem.W Mem
+    const float* Mem;                            // (B, T, D)
+    const float* pv;                             // (B, R, 4D) X x2h[:, 2D:]^T
+    // exchange buffers (flag-in-data words, zero-filled before the launch)
+    void *x_h1, *x_a2, *x_gt, *x_vs, *x_cn, *x_h2, *x_fc;
+    void* x_cs;                                  // wide variant (decode_persistent_wide.hip): caption scores (B, TMAX)
+    long long* it; int* unfinished; int* alive;
+    long long* seq; float* seq_logp;
+    unsigned* status; unsigned* fault; unsigned spin_limit; int test_stall;
+    int B, D, T, R, A, V, max_len, rpw;
+    long long start_idx, end_idx;
+    // teacher-forced mode (set_editnet_xe_forward, editnet.py:505-546): words from caps, scores of the first bt rows written
+    // out, no pick and no sixth exchange
+    const long long* caps; long long caps_stride;
+    float* predictions; long long ld_pred_b;     // (B, maxT, V)
+    int dlen[PDW_MAXB];                          // decode lengths, descending
+    int stamp_wg;
+    unsigned long long* stamps;
+};
+
+// the wide variant's launch (decode_persistent_wide.hip); P is complete except for the exchange pointers it lays out itself
+int editnet_persistent_wide_launch(PDecEditArgs& P, void* xbuf, PersistentGuard& guard, hipStream_t s, bool* unsupported);
+size_t editnet_persistent_wide_xbytes(int B, int D, int A);
+bool editnet_persistent_wide_ok(int B, int D, int A, int T, int R, int V);
+
 // host side of the stamps: buffer for a launch (or NULL) and the report after it
 inline int pd_stamps_begin(unsigned long long** out, int* wg, hipStream_t s) {
     static const int on = env_int("SET_PDEC_STAMPS", 0);

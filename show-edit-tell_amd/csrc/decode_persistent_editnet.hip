@@ -24,48 +24,6 @@
 
 namespace set {
 
-constexpr int PDEC_RREG = 36;      // image regions whose hoisted x2h products a thread keeps in registers
-
-struct PDecEditArgs {
-    // weights (nn.Linear layout, used in place)
-    const float* al_wih; long long ld_ih;        // attention_lstm.weight_ih (4D, 3D + F): columns [2D, 3D) = h2
-    const float* al_whh;
-    const float* cl_h2h_w;
-    const float* cl_x2h_w; long long ld_x2h;     // copy_lstm.x2h (4D, 2D + F): [0, D) h1, [D, 2D) attend_cap
-    const float *cl_x2h_b, *cl_h2h_b;
-    const float *ca_gate_w, *ca_gate_b;          // (D, 3D): columns [D, 2D) = h1
-    const float *ca_tc_w, *ca_tc_b;              // (D, 2D): columns [D, 2D) = h1
-    const float* ca_sc_b;
-    const float *ca_dec_w, *ca_dec_b, *ca_full_w, *ca_full_b;
-    const float *va_dec_w, *va_dec_b, *va_full_w, *va_full_b;
-    const float *cl_cnew_w, *cl_cnew_b, *cl_cmem_b;
-    const float *fc_w, *fc_b;
-    const float* tok_table; long long ld_tab;    // (V, 10D): [0, 4D) gates, [4D, 5D) tc_affine, [5D, 6D) context_gate
-    // per sequence (prologue outputs)
-    const float* pre1;                           // (B, 4D)
-    const float* att1;                           // (B, R, A) features_att(relu(att_embed(X)))
-    const float* att1_c;                         // (B, T, A)
-    const float* mask;                           // (B, T)
-    const float* capP;                           // (B, T, 2D) [context_gate.W[:, 2D:] H | sc_affine.W H]
-    const float* memQ;                           // (B, T, D)  gate_cmem.W Mem
-    const float* Mem;                            // (B, T, D)
-    const float* pv;                             // (B, R, 4D) X x2h[:, 2D:]^T
-    // exchange buffers (flag-in-data words, zero-filled before the launch)
-    void *x_h1, *x_a2, *x_gt, *x_vs, *x_cn, *x_h2, *x_fc;
-    long long* it; int* unfinished; int* alive;
-    long long* seq; float* seq_logp;
-    unsigned* status; unsigned* fault; unsigned spin_limit; int test_stall;
-    int B, D, T, R, A, V, max_len, rpw;
-    long long start_idx, end_idx;
-    // teacher-forced mode (set_editnet_xe_forward, editnet.py:505-546): words from caps, scores of the first bt rows written
-    // out, no pick and no sixth exchange
-    const long long* caps; long long caps_stride;
-    float* predictions; long long ld_pred_b;     // (B, maxT, V)
-    int dlen[PDEC_MAXB];                         // decode lengths, descending
-    int stamp_wg;
-    unsigned long long* stamps;
-};
-
 template <bool RES>
 __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_k(const PDecEditArgs P) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -567,14 +525,22 @@ static int pedit_lds_floats(int B, int D, int A) {
 
 // [status line | h1 | attend_cap | c_new | h2 | projections | visual scores | fc triples] as 8-byte flag-in-data words
 size_t editnet_persistent_xbytes(int B, int D, int A) {
-    if (B > PDEC_MAXB) return 0;
-    return 128 + (size_t)B * D * 8 * 4 + (size_t)B * 2 * A * 8 + (size_t)B * 64 * 8 + (size_t)B * (D / 4) * 32;
+    if (B > PDW_MAXB) return 0;
+    const size_t wide = editnet_persistent_wide_xbytes(B, D, A);
+    if (B > PDEC_MAXB) return wide;
+    const size_t narrow = 128 + (size_t)B * D * 8 * 4 + (size_t)B * 2 * A * 8 + (size_t)B * 64 * 8 + (size_t)B * (D / 4) * 32;
+    return narrow > wide ? narrow : wide;
 }
+
+// rows from which the wide variant (decode_persistent_wide.hip) takes over (SET_DEC_WIDE_MINB; read per call)
+static int wide_minb() { return env_int("SET_DEC_WIDE_MINB", 5); }
 
 bool editnet_persistent_ok(const SetEditNetDims* d, int max_len) {
     const int on = env_int("SET_DEC_PERSISTENT", 1);                 // (read per call: tests and A/B runs flip it inside one process)
-    const int maxb = env_int("SET_DEC_PERSISTENT_MAXB", PDEC_MAXB);
-    if (!on || d->B > maxb || d->B > PDEC_MAXB || max_len < 1 || d->adaptive) return false;
+    const int maxb = env_int("SET_DEC_PERSISTENT_MAXB", PDW_MAXB);
+    if (!on || d->B > maxb || max_len < 1 || d->adaptive) return false;
+    if (d->B >= wide_minb() || d->B > PDEC_MAXB)                     // 5 .. 16 rows: the wide variant
+        return editnet_persistent_wide_ok(d->B, d->D, d->A, d->T, d->R, d->V) && !persistent_disabled();
     // one mixed tile serves 4 + 4 + 4 rows: 2A attention-projection rows over D / 4 workgroups; 8 score columns per lane
     if (d->D != 64 * PDEC_KB || d->A != 512 || 2 * d->A != d->D || d->T > PDEC_TMAX || d->R > PDEC_RREG || d->R > 64 || (d->R & 1)) return false;
     const int G = d->D / 4;
@@ -594,6 +560,7 @@ int editnet_persistent_greedy(const SetEditNetWeights* w, const SetEditNetDims* 
                               const PDecTeacher* teach) {
     if (!editnet_persistent_ok(d, max_len)) return SET_ERR_UNSUPPORTED;
     const int B = d->B, D = d->D, A = d->A, F = d->F, G = D / 4;
+    const bool wide = B >= wide_minb() || B > PDEC_MAXB;
     PDecEditArgs P{};
     P.al_wih = w->al_wih; P.ld_ih = 3LL * D + F; P.al_whh = w->al_whh; P.cl_h2h_w = w->cl_h2h_w;
     P.cl_x2h_w = w->cl_x2h_w; P.ld_x2h = 2LL * D + F; P.cl_x2h_b = w->cl_x2h_b; P.cl_h2h_b = w->cl_h2h_b;
@@ -628,6 +595,11 @@ int editnet_persistent_greedy(const SetEditNetWeights* w, const SetEditNetDims* 
     const int dev = guard.dev;
     P.spin_limit = guard.spin_limit();
     P.test_stall = guard.test_stall(); P.fault = guard.fault;
+    if (wide) {
+        bool unsupported = true;
+        const int rc = editnet_persistent_wide_launch(P, xbuf, guard, s, &unsupported);
+        return rc != SET_OK ? rc : (unsupported ? SET_ERR_UNSUPPORTED : SET_OK);
+    }
     static bool configured[2][64] = {};
     int lds_max = pedit_lds_floats(PDEC_MAXB, D, A) * (int)sizeof(float);
     if (lds_max > 156 * 1024) lds_max = 156 * 1024;             // (editnet_persistent_ok refuses batches that need more)

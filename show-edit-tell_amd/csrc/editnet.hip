@@ -120,7 +120,7 @@ static EditNetWs carve(const SetEditNetDims* d, void* base) {
     w.enc_order = c.take<int>(B + T);
     w.enc_bar = c.take<char>(persistent_encoder_bar_bytes());
     {
-        const size_t pb = B <= (size_t)PDEC_MAXB ? B : 0;            // only small batches take the persistent decode
+        const size_t pb = B <= (size_t)PDW_MAXB ? B : 0;             // only small batches take the persistent decode
         w.pd_pv = c.take<float>(pb * R * 4 * D);
         w.pd_x = c.take<char>(editnet_persistent_xbytes((int)B, (int)D, (int)A));
     }

@@ -35,7 +35,11 @@ typedef const f32x4 __attribute__((address_space(1)))* gptr4;
 // each) are then both bank-conflict-free, and a 128x64x32 stage pair is 48 KB -> three workgroups per CU.
 constexpr int LDS_STRIDE = 32;
 
+#ifdef SET_EXPERIMENTAL_GEMMS
 static int gemm_split_mode() { static int v = env_int("SET_GEMM_SPLIT", 0); return v; }
+#else
+static constexpr int gemm_split_mode() { return 0; }     // (the bf16x3 kernel is not in the shipped library)
+#endif
 
 struct GemmTask {
     const float* A[GEMM_MAX_SEG];
@@ -526,670 +530,14 @@ __global__ void __launch_bounds__(256) gemm_nt_f32_asm(const int ntasks, const i
 #undef ASM_HALF_ROUND
 
 // ---------------------------------------------------------------------------------------------
-// Round 4: the 64-row class with the WEIGHT operand taken off LDS (`gemm_nt_f32_wreg`, SET_GEMM_WREG).
-//
-// gemm_nt_f32<64,64,2,2> moves 3 LDS "operand words" per MFMA (each wave reads one A and one W value per lane and MFMA
-// from LDS, and the workgroup writes 16 KB per 64 MFMAs into it) and is bound by what the chip sustains for that mix of
-// MFMA + LDS + L2 traffic (clock 2.0 GHz under this load against 2.4 for bare MFMAs).  Here
-//   * the four waves are 2 (column halves of the 64x64 tile) x 2 (K groups): a wave owns a 64 x 32 piece of the output —
-//     TWO 32x32 accumulators that share every weight fragment — over every other k-tile of the workgroup's K slice;
-//   * the weight fragments never see LDS: lane (j = l & 31, h = l >> 5) loads W[n0 + j][8 kk + 4 h .. +3] of its wave's 32
-//     columns straight from global memory as 16-byte pieces — already the B operand of four v_mfma_f32_32x32x2_f32 (K inside
-//     an 8-block permuted exactly as the LDS fragment reads of the activations permute it) — two k-tiles ahead, each piece
-//     re-requested as soon as its MFMAs have issued;
-//   * only the 64 x 32 activation tile of each K group goes through LDS (shared by the group's two waves; same XOR-swizzled
-//     image, same conflict-free ds_write_b128 / ds_read_b128 as above), two register stages + two LDS buffers;
-//   * per MFMA: 1 LDS operand word read (was 2), 0.5 written (was 1), one barrier per 32 MFMAs of a wave (was 16);
-//   * after the loop the two K groups exchange one 32x32 accumulator each through LDS (group 0 keeps rows 0-31, group 1
-//     rows 32-63; sum order group 0 + group 1, fixed), so all four waves store, through the same epilogue.
-// Same task descriptors, K segments, split-K slabs, bias / activation epilogue as gemm_nt_f32.
+// Variants that were built, measured and LOST (EXPERIMENTS.md 3.1b, 4.1): the weights-to-registers kernel, the LDS-DMA
+// kernel and the bf16x3 split-precision kernel live in experimental/gemm_variants.inc and are compiled only with
+// -DSET_EXPERIMENTAL_GEMMS (tools/ubench builds; SET_HIPCC_FLAGS=-DSET_EXPERIMENTAL_GEMMS python -m show_edit_tell_amd.build --force).
+// The shipped library does not contain them; their environment switches are ignored there.
 // ---------------------------------------------------------------------------------------------
-#ifdef SET_WREG_A2
-#define WR_WAVES_PER_SIMD 2
-#else
-#define WR_WAVES_PER_SIMD 3
+#ifdef SET_EXPERIMENTAL_GEMMS
+#include "experimental/gemm_variants.inc"
 #endif
-__global__ void __launch_bounds__(256, WR_WAVES_PER_SIMD) gemm_nt_f32_wreg(const int ntasks, const int wb1, const int wb2, const int wb3,
-                                                        const int wb4, const int wb5, const int* const gate_alive,
-        const int* const gate_nrows, const GemmLaunch L) {
-    constexpr int BM = 64, BN = 64;
-    constexpr int GROUP_FLOATS = BM * LDS_STRIDE;                  // one K group's activation tile (8 KB)
-    __shared__ __attribute__((aligned(16))) float lds[2][2 * GROUP_FLOATS];
-
-    const int tid = threadIdx.x;
-    // the wave index decides control flow here (K group, tile counts): make it a scalar for the compiler, or every
-    // `j < nt` becomes an exec-mask branch and the segment selects turn into per-lane loads of the kernel arguments
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave & 1, wk = wave >> 1;                       // column half, K group
-    int ti = 0;
-    {
-        const int bid = (int)blockIdx.x;
-        if (1 < ntasks && bid >= wb1) ti = 1;
-        if (2 < ntasks && bid >= wb2) ti = 2;
-        if (3 < ntasks && bid >= wb3) ti = 3;
-        if (4 < ntasks && bid >= wb4) ti = 4;
-        if (5 < ntasks && bid >= wb5) ti = 5;
-    }
-    const GemmTask& T = L.t[ti];
-    const int local = (int)blockIdx.x - T.wg_begin;
-    const int tm = local / T.tm_stride;
-    const int rem = local - tm * T.tm_stride;
-    if (rem >= T.tiles_n * T.ksplit) return;          // padding slot
-    const int ks = rem % T.ksplit;
-    const int tn = rem / T.ksplit;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int kt0 = (int)(((long long)ks * T.ktiles) / T.ksplit);
-    const int kt1 = (int)(((long long)(ks + 1) * T.ktiles) / T.ksplit);
-    if (gate_alive && *gate_alive == 0) return;                    // (the compacted row list is not supported here: gemm_group)
-    const int epi_m = T.M;
-    auto epi_row = [](int row) { return row; };
-    // this K group's k-tiles: kt0 + wk, kt0 + wk + 2, ...  (local index j <-> global k-tile kt0 + wk + 2 j)
-    const int nt_wg = kt1 - kt0;
-    const int nt = (nt_wg - wk + 1) >> 1;                          // tiles of this group
-    const int nt_max = (nt_wg + 1) >> 1;                           // tiles of group 0 = barrier rounds of the workgroup
-
-    // ---- activation staging: thread g (0..127 of the group) -> rows g/8 + 16 i, 16-byte column g%8
-    const int tg = tid & 127;
-    const int srow = tg >> 3, scol = (tg & 7) * 4;
-    const int sswz = ((tg & 7) ^ ((srow >> 1) & 7)) * 4;           // rows srow + 16 i share (r >> 1) & 7
-    int arow[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { const int r = m0 + srow + 16 * i; arow[i] = r < T.M ? r : T.M - 1; }
-    // ---- weight fragments: lane -> row n0 + 32 wn + (lane & 31), floats 4 (lane >> 5) + 8 kk of a k-tile
-    const int frow = lane & 31, fh = lane >> 5;
-    int wrow = n0 + 32 * wn + frow;
-    wrow = wrow < T.N ? wrow : T.N - 1;
-
-    // Operand addresses are derived per k-tile from the (wave-uniform) global k-tile index with branch-free selects over the
-    // <= 3 K segments: a dozen SALU + a few 64-bit VALU adds per 32 MFMAs, no running pointers, no seek branches (the seek
-    // code of gemm_nt_f32, instantiated for two streams x two rounds, cost 540 spilled SGPRs here).
-    const long long arow_l[4] = {arow[0], arow[1], arow[2], arow[3]};
-    const int nseg_ = T.nseg, ke0_ = T.kt_end[0], ke1_ = T.kt_end[1];
-    const float *A0_ = T.A[0], *A1_ = T.A[1], *A2_ = T.A[2], *W0_ = T.W[0], *W1_ = T.W[1], *W2_ = T.W[2];
-    const long long la0_ = T.lda[0], la1_ = T.lda[1], la2_ = T.lda[2], lw0_ = T.ldw[0], lw1_ = T.ldw[1], lw2_ = T.ldw[2];
-#define WR_SEG(G)                                                                                       \
-        const int g_ = (G);                                                                             \
-        const bool s1_ = nseg_ > 1 && g_ >= ke0_, s2_ = nseg_ > 2 && g_ >= ke1_;                        \
-        const int kb_ = s2_ ? ke1_ : (s1_ ? ke0_ : 0);                                                  \
-        const long long ko_ = (long long)(g_ - kb_) * GEMM_BK;
-    // Loads are UNCONDITIONAL (a request past the group's last tile repeats that tile: a cache hit whose result is never
-    // used): with a branch around a load the compiler's s_waitcnt placement must assume the path with fewer requests
-    // outstanding and ends up draining the whole queue (vmcnt(0)) in the middle of every round.
-    const int jlast = nt > 0 ? nt - 1 : 0;
-    const int glast = kt1 - 1;
-#define WR_TILE(J) ({ int j_ = (J) < jlast ? (J) : jlast; int g_ = kt0 + wk + 2 * j_; g_ < glast ? g_ : glast; })
-#define WR_STAGE_A(J, RA)                                                                               \
-    {                                                                                                   \
-        WR_SEG(WR_TILE(J))                                                                              \
-        const float* Ab_ = (s2_ ? A2_ : (s1_ ? A1_ : A0_)) + ko_ + scol;                                \
-        const long long lda_ = s2_ ? la2_ : (s1_ ? la1_ : la0_);                                        \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) RA[i] = *(gptr4)(Ab_ + arow_l[i] * lda_);         \
-    }
-#define WR_LSTORE(BUF, RA)                                                                              \
-    {                                                                                                   \
-        float* sA_ = lds[(BUF)] + wk * GROUP_FLOATS;                                                    \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
-            *reinterpret_cast<f32x4*>(sA_ + (srow + 16 * i) * LDS_STRIDE + sswz) = RA[i];               \
-    }
-    // weight stream: one row pointer per tile (WR_W_BEGIN), its four 16-byte pieces are requested one by one
-    const float* pw = nullptr;
-#define WR_W_BEGIN(J)                                                                                   \
-    {                                                                                                   \
-        WR_SEG(WR_TILE(J))                                                                              \
-        const float* Wb_ = (s2_ ? W2_ : (s1_ ? W1_ : W0_)) + ko_ + 4 * fh;                              \
-        const long long ldw_ = s2_ ? lw2_ : (s1_ ? lw1_ : lw0_);                                        \
-        pw = Wb_ + (long long)wrow * ldw_;                                                              \
-    }
-#define WR_W_PIECE(KK, WR) WR[KK] = *(gptr4)(pw + 8 * (KK));
-
-    f32x16 acc2[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc2[i][e] = 0.f;
-    int fo[4];                                                     // swizzled float offset of k-chunk 2 kk + (lane >> 5)
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) fo[kk] = (((kk * 2 + fh) ^ ((frow >> 1) & 7)) * 4);
-
-    f32x4 we[4], wo[4];                   // weight fragments of the even / odd local tiles
-#define WR_FRAG(KK, FA)                                                                                  \
-    {                                                                                                   \
-        FA[0] = *reinterpret_cast<const f32x4*>(sA + fo[KK]);                                           \
-        FA[1] = *reinterpret_cast<const f32x4*>(sA + 32 * LDS_STRIDE + fo[KK]);                         \
-    }
-#define WR_MFMA(FA, W4)                                                                                 \
-    {                                                                                                   \
-        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0].x, (W4).x, acc2[0], 0, 0, 0);              \
-        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1].x, (W4).x, acc2[1], 0, 0, 0);              \
-        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0].y, (W4).y, acc2[0], 0, 0, 0);              \
-        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1].y, (W4).y, acc2[1], 0, 0, 0);              \
-        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0].z, (W4).z, acc2[0], 0, 0, 0);              \
-        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1].z, (W4).z, acc2[1], 0, 0, 0);              \
-        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[0].w, (W4).w, acc2[0], 0, 0, 0);              \
-        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[1].w, (W4).w, acc2[1], 0, 0, 0);              \
-    }
-    // one round: MFMAs of local tile J (activations from lds[BUF], weights from WR); meanwhile the register stage RA (tile
-    // J + 1) goes to lds[BUF ^ 1] and is re-requested with tile J + 3, and every weight piece is re-requested with tile
-    // J + 2's as soon as its MFMAs have issued.  Straight-line code: both K groups run the same `nfull` rounds; the odd
-    // k-tile of a slice, if any, is group 0's and is contracted after the loop (WR_TAIL).
-    // The hand-written order must survive the compiler: MFMAs are pure values to LLVM and get sunk past the weight
-    // re-requests (which then go through temporaries and come back as v_mov copies behind s_waitcnt vmcnt(0)); an IR-level
-    // sched_barrier does not stop that.  An empty volatile asm that "rewrites" both accumulators and clobbers memory does:
-    // every MFMA before it must have issued, every load / LDS access after it stays after it.
-#define WR_SB() asm volatile("" : "+a"(acc2[0]), "+a"(acc2[1]) : : "memory")
-#define WR_ROUND(J, BUF, RA, WR)                                                                        \
-    {                                                                                                   \
-        const float* sA = lds[BUF] + wk * GROUP_FLOATS + frow * LDS_STRIDE;                             \
-        f32x4 fa0[2], fa1[2];                                                                           \
-        WR_FRAG(0, fa0);                                                                                \
-        WR_FRAG(1, fa1);                                                                                \
-        WR_SB();                                                                                        \
-        WR_MFMA(fa0, WR[0]);                                                                            \
-        WR_SB();                                                                                        \
-        WR_W_BEGIN((J) + 2);                                                                            \
-        WR_W_PIECE(0, WR);                                                                              \
-        WR_LSTORE((BUF) ^ 1, RA);                                                                       \
-        WR_STAGE_A((J) + WR_ADIST, RA);                                                                 \
-        WR_FRAG(2, fa0);                                                                                \
-        WR_SB();                                                                                        \
-        WR_MFMA(fa1, WR[1]);                                                                            \
-        WR_SB();                                                                                        \
-        WR_W_PIECE(1, WR);                                                                              \
-        WR_FRAG(3, fa1);                                                                                \
-        WR_SB();                                                                                        \
-        WR_MFMA(fa0, WR[2]);                                                                            \
-        WR_SB();                                                                                        \
-        WR_W_PIECE(2, WR);                                                                              \
-        WR_SB();                                                                                        \
-        WR_MFMA(fa1, WR[3]);                                                                            \
-        WR_SB();                                                                                        \
-        WR_W_PIECE(3, WR);                                                                              \
-        __syncthreads();                                                                                \
-    }
-#define WR_TAIL(BUF, WR)                                                                                \
-    {                                                                                                   \
-        const float* sA = lds[BUF] + frow * LDS_STRIDE;                                                 \
-        f32x4 fa0[2], fa1[2];                                                                           \
-        WR_FRAG(0, fa0);                                                                                \
-        WR_FRAG(1, fa1);                                                                                \
-        WR_MFMA(fa0, WR[0]);                                                                            \
-        WR_FRAG(2, fa0);                                                                                \
-        WR_MFMA(fa1, WR[1]);                                                                            \
-        WR_FRAG(3, fa1);                                                                                \
-        WR_MFMA(fa0, WR[2]);                                                                            \
-        WR_MFMA(fa1, WR[3]);                                                                            \
-    }
-#ifdef SET_WREG_A2
-    // two activation register stages (tile j + 1 landed, tile j + 2 in flight at the top of round j): 16 more registers,
-    // two waves per SIMD
-#define WR_ADIST 3
-    f32x4 ra0[4], ra1[4];
-    {
-        WR_STAGE_A(0, ra0);                  // tile 0
-        WR_W_BEGIN(0);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) WR_W_PIECE(kk, we);
-        WR_STAGE_A(1, ra1);                  // tile 1
-        WR_W_BEGIN(1);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) WR_W_PIECE(kk, wo);
-        WR_LSTORE(0, ra0);
-        WR_STAGE_A(2, ra0);                  // tile 2
-    }
-    __syncthreads();
-#define WR_RA_EVEN ra1
-#define WR_RA_ODD ra0
-#else
-    // one activation register stage: tile j + 1 is requested in round j - 1 (right after the stage went to LDS) and stored
-    // in round j — the activations are a few MB that every workgroup of the launch re-reads, i.e. L2 hits
-#define WR_ADIST 2
-    f32x4 ra0[4];
-    {
-        // requests in the order a round issues them (weight piece 0, the activation tile, pieces 1-3): the queue the first
-        // round finds is then the queue every round finds, and the compiler's vmcnt values at the loop head stay exact
-        WR_W_BEGIN(0);
-        WR_W_PIECE(0, we);
-        WR_STAGE_A(0, ra0);                  // tile 0
-        WR_W_PIECE(1, we);
-        WR_W_PIECE(2, we);
-        WR_W_PIECE(3, we);
-        WR_W_BEGIN(1);
-        WR_W_PIECE(0, wo);
-        WR_LSTORE(0, ra0);
-        WR_STAGE_A(1, ra0);                  // tile 1
-        WR_W_PIECE(1, wo);
-        WR_W_PIECE(2, wo);
-        WR_W_PIECE(3, wo);
-    }
-    __syncthreads();
-#define WR_RA_EVEN ra0
-#define WR_RA_ODD ra0
-#endif
-    // invariant at the top of an even round j: lds[0] = tile j, the register stage(s) hold tile j + 1 (and j + 2), we = W(j),
-    // wo = W(j + 1)
-    const int nfull = nt_wg >> 1;
-    const bool odd_tail = (nt_wg & 1) && wk == 0;        // the slice's odd k-tile is group 0's
-    int j = 0;
-    for (; j + 2 <= nfull; j += 2) {
-        WR_ROUND(j, 0, WR_RA_EVEN, we);
-        WR_ROUND(j + 1, 1, WR_RA_ODD, wo);
-    }
-    if (j < nfull) {                                     // odd number of full rounds: one more on buffer 0
-        WR_ROUND(j, 0, WR_RA_EVEN, we);
-        if (odd_tail) WR_TAIL(1, wo);
-    } else if (odd_tail) {
-        WR_TAIL(0, we);
-    }
-    __syncthreads();                                     // (all fragment reads of the stages are done: the epilogue reuses them)
-#undef WR_ROUND
-#undef WR_ADIST
-#undef WR_RA_EVEN
-#undef WR_RA_ODD
-#undef WR_SB
-#undef WR_TAIL
-#undef WR_MFMA
-#undef WR_FRAG
-#undef WR_W_PIECE
-#undef WR_W_BEGIN
-#undef WR_LSTORE
-#undef WR_STAGE_A
-#undef WR_TILE
-#undef WR_SEG
-    // ---- the two K groups exchange one 32x32 accumulator each (lane-major in lds[1]: conflict-free): group 0 keeps the
-    // tile's rows 0-31, group 1 rows 32-63; every sum is (group 0's partial) + (group 1's partial)
-    {
-        // (static register indices only: `acc2[wk]` with a run-time wk turns into thousands of v_cndmask; the result lands in
-        // acc2[0] for both groups so that no third accumulator is live)
-        float* sX = &lds[1][0] + wave * 1024 + lane;
-        const float* sY = &lds[1][0] + (wave ^ 2) * 1024 + lane;
-        if (wk == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sX[r * 64] = acc2[1][r];
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sX[r * 64] = acc2[0][r];
-        }
-        __syncthreads();
-        if (wk == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[0][r] = acc2[0][r] + sY[r * 64];
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[0][r] = sY[r * 64] + acc2[1][r];
-        }
-    }
-    f32x16 (&acc)[1][1] = *reinterpret_cast<f32x16 (*)[1][1]>(&acc2[0]);
-    constexpr int TM = 1, TN = 1, KG = 1;
-    const int kg = 0, wm = wk;
-    // (the shared epilogue transposes through lds[0], which nobody reads any more: the last round's barrier is behind us)
-#include "gemm_f32_epilogue.inc"
-}
-
-// ---------------------------------------------------------------------------------------------
-// The same grouped GEMM with the operand tiles staged by LDS-DMA (`global_load_lds_dwordx4`): no VGPR round trip and no
-// ds_write pass.  A wave-instruction lands 64 x 16 B = 1 KB = eight 128-byte rows of the stage CONTIGUOUSLY (the LDS
-// destination is wave-uniform base + lane * 16), so the XOR swizzle of the 16-byte chunks is applied on the SOURCE side:
-// lane l of the piece that fills rows r0..r0+7 writes chunk position c' = l & 7 of row r = r0 + (l >> 3) and therefore
-// fetches logical chunk c = c' ^ ((r >> 1) & 7) of that row — still one full 128-byte line per 8 lanes.  The MFMA fragment
-// reads are those of gemm_nt_f32 (same image).  Three stages: while tile kt is contracted, tile kt+1 has landed or is
-// landing and tile kt+2 is being requested; one raw s_barrier per k-tile, counted vmcnt so that a DMA stays in flight
-// across the barrier (__syncthreads() would drain it: an LDS-DMA is a pending LDS write on the VM counter).
-// ---------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void* lds_vptr;
-typedef const __attribute__((address_space(1))) void* glb_vptr;
-
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ void __launch_bounds__(256) gemm_nt_f32_dma(const int ntasks, const int wb1, const int wb2, const int wb3,
-                                                       const int wb4, const int wb5, const int* const gate_alive,
-        const int* const gate_nrows, const GemmLaunch L) {
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
-    constexpr int KG = 1;
-    constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
-    constexpr int ROWS = BM + BN;                        // rows of one stage: A tile rows, then W tile rows
-    constexpr int PIECES = ROWS / 32;                    // 8-row DMA pieces per wave per k-tile
-    static_assert(ROWS % 32 == 0 && TM >= 1 && TN >= 1, "tile");
-    constexpr int NSTAGE = 3;
-    __shared__ __attribute__((aligned(16))) float lds[NSTAGE][ROWS * LDS_STRIDE];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6, kg = 0;
-    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
-    int ti = 0;
-    {
-        const int bid = (int)blockIdx.x;
-        if (1 < ntasks && bid >= wb1) ti = 1;
-        if (2 < ntasks && bid >= wb2) ti = 2;
-        if (3 < ntasks && bid >= wb3) ti = 3;
-        if (4 < ntasks && bid >= wb4) ti = 4;
-        if (5 < ntasks && bid >= wb5) ti = 5;
-    }
-    const GemmTask& T = L.t[ti];
-    const int local = (int)blockIdx.x - T.wg_begin;
-    const int tm = local / T.tm_stride;
-    const int rem = local - tm * T.tm_stride;
-    if (rem >= T.tiles_n * T.ksplit) return;          // padding slot
-    if (gate_alive && *gate_alive == 0) return;                    // (the compacted row list is not supported here: gemm_group)
-    const int ks = rem % T.ksplit;
-    const int tn = rem / T.ksplit;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int kt0 = (int)(((long long)ks * T.ktiles) / T.ksplit);
-    const int kt1 = (int)(((long long)(ks + 1) * T.ktiles) / T.ksplit);
-    const int epi_m = T.M;
-    auto epi_row = [](int row) { return row; };
-
-    // ---- DMA assignment: piece i of this wave fills stage rows [8 * (wave * PIECES + i), +8); lane -> (row, chunk position)
-    int prow[PIECES];            // global row (clamped) of this lane's stage row, in A (stage row < BM) or W
-    int pcol[PIECES];            // float offset of the logical chunk this lane fetches
-    bool pisw[PIECES];
-#pragma unroll
-    for (int i = 0; i < PIECES; ++i) {
-        const int sr = 8 * (wave * PIECES + i) + (lane >> 3);        // stage row
-        pisw[i] = sr >= BM;
-        int r = pisw[i] ? n0 + (sr - BM) : m0 + sr;
-        const int lim = pisw[i] ? T.N : T.M;
-        prow[i] = r < lim ? r : lim - 1;
-        pcol[i] = ((lane & 7) ^ ((sr >> 1) & 7)) * 4;
-    }
-    const float* pp[PIECES];     // running per-lane source pointers inside the current K segment
-    int seg_end = 0;
-#define DMA_SEEK(KT)                                                                                    \
-    {                                                                                                   \
-        const int kt_ = (KT);                                                                           \
-        int s_ = 0, kbase_ = 0;                                                                         \
-        _Pragma("unroll") for (int i = 0; i < GEMM_MAX_SEG - 1; ++i)                                    \
-            if (i + 1 < T.nseg && kt_ >= T.kt_end[i]) { s_ = i + 1; kbase_ = T.kt_end[i]; }             \
-        const float* Ab_ = T.A[0];                                                                      \
-        const float* Wb_ = T.W[0];                                                                      \
-        long long lda_ = T.lda[0], ldw_ = T.ldw[0];                                                     \
-        seg_end = T.kt_end[0];                                                                          \
-        _Pragma("unroll") for (int i = 1; i < GEMM_MAX_SEG; ++i)                                        \
-            if (s_ == i) { Ab_ = T.A[i]; Wb_ = T.W[i]; lda_ = T.lda[i]; ldw_ = T.ldw[i]; seg_end = T.kt_end[i]; } \
-        const long long koff_ = (long long)(kt_ - kbase_) * GEMM_BK;                                    \
-        _Pragma("unroll") for (int i = 0; i < PIECES; ++i)                                              \
-            pp[i] = (pisw[i] ? Wb_ + prow[i] * ldw_ : Ab_ + prow[i] * lda_) + koff_ + pcol[i];          \
-    }
-    // request tile KT into stage SLOT (no-op past the end of the slice)
-#define DMA_ISSUE(KT, SLOT)                                                                             \
-    if ((KT) < kt1) {                                                                                   \
-        if ((KT) == seg_end) DMA_SEEK(KT);                                                              \
-        _Pragma("unroll") for (int i = 0; i < PIECES; ++i) {                                            \
-            __builtin_amdgcn_global_load_lds((glb_vptr)pp[i],                                           \
-                (lds_vptr)(&lds[SLOT][(8 * (wave * PIECES + i)) * LDS_STRIDE]), 16, 0, 0);              \
-            pp[i] += GEMM_BK;                                                                           \
-        }                                                                                               \
-    }
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int frow = lane & 31;
-    int fo[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) fo[kk] = (((kk * 2 + (lane >> 5)) ^ ((frow >> 1) & 7)) * 4);
-
-    if (kt0 < kt1) {
-        DMA_SEEK(kt0);
-        DMA_ISSUE(kt0, 0);
-        DMA_ISSUE(kt0 + 1, 1);
-    }
-    int slot = 0;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        // tile kt has landed once this wave's older pieces are done (the PIECES of tile kt+1 may still fly) and every wave
-        // has said so at the barrier; the barrier also tells that everybody is done READING stage (kt-1) % 3 = (kt+2) % 3
-        if (kt + 1 < kt1) { if constexpr (PIECES == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                            else if constexpr (PIECES == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const int nslot = slot == 0 ? 2 : slot - 1;             // (slot + 2) % 3
-        DMA_ISSUE(kt + 2, nslot);
-        const float* sA = &lds[slot][0] + (wm * TM * 32 + frow) * LDS_STRIDE;
-        const float* sW = &lds[slot][0] + BM * LDS_STRIDE + (wn * TN * 32 + frow) * LDS_STRIDE;
-        f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-#define DMA_FRAG(KK, FA, FB)                                                                            \
-        {                                                                                               \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
-                FA[i] = *reinterpret_cast<const f32x4*>(sA + i * 32 * LDS_STRIDE + fo[KK]);             \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                              \
-                FB[j] = *reinterpret_cast<const f32x4*>(sW + j * 32 * LDS_STRIDE + fo[KK]);             \
-        }
-#define DMA_MFMA(FA, FB)                                                                                \
-        {                                                                                               \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                              \
-                _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                        \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].x, FB[j].x, acc[i][j], 0, 0, 0); \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].y, FB[j].y, acc[i][j], 0, 0, 0); \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].z, FB[j].z, acc[i][j], 0, 0, 0); \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].w, FB[j].w, acc[i][j], 0, 0, 0); \
-                }                                                                                       \
-        }
-        DMA_FRAG(0, fa0, fb0);
-        DMA_FRAG(1, fa1, fb1);
-        DMA_MFMA(fa0, fb0);
-        DMA_FRAG(2, fa0, fb0);
-        DMA_MFMA(fa1, fb1);
-        DMA_FRAG(3, fa1, fb1);
-        DMA_MFMA(fa0, fb0);
-        DMA_MFMA(fa1, fb1);
-        slot = slot == 2 ? 0 : slot + 1;
-    }
-#undef DMA_FRAG
-#undef DMA_MFMA
-#undef DMA_ISSUE
-#undef DMA_SEEK
-    __syncthreads();                                     // all fragment reads done: the stages are free for the epilogue
-#include "gemm_f32_epilogue.inc"
-}
-
-// ---------------------------------------------------------------------------------------------
-// EXPERIMENTAL, opt-in (SET_GEMM_SPLIT=1; never the default, never the headline number): the same grouped
-// GEMM on the bf16 matrix pipe with every fp32 operand split EXACTLY into three bf16 values
-//      x = hi + mid + lo        (8 + 8 + 8 significand bits, by truncation and exact fp32 subtraction)
-// and six of the nine partial products accumulated in fp32 (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; the
-// dropped ones are <= 2^-24 relative, i.e. at the level of one fp32 rounding).  v_mfma_f32_32x32x16_bf16 has 16x
-// the rate of v_mfma_f32_32x32x2_f32, so six of them cost 2.67x less matrix-pipe time than the fp32 chain.
-// Splitting happens on the fly when a k-tile is staged into LDS (weights stay fp32 in HBM, nothing is
-// repacked); LDS holds three bf16 planes per operand, 64-B rows, 16-B chunks XOR-swizzled by (row>>2)&3 so
-// that the ds_write_b64 of the staging and the ds_read_b128 of the fragments are bank-conflict-free.
-// Same task descriptors, K segments, split-K slabs and epilogue as gemm_nt_f32<128,64>.
-// ---------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-__global__ void __launch_bounds__(256) gemm_nt_split_bf16(const GemmLaunch L) {
-    constexpr int BM = 128, BN = 64, TM = 2, LA = 4, LW = 2;
-    constexpr int ROWB = 64;                              // bytes per LDS row (32 bf16)
-    constexpr int PLANE_A = BM * ROWB, PLANE_W = BN * ROWB;
-    constexpr int BUF = 3 * (PLANE_A + PLANE_W);          // 36 KB per stage
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
-
-    int ti = 0;
-#pragma unroll
-    for (int i = 1; i < GEMM_MAX_TASKS; ++i)
-        if (i < L.ntasks && (int)blockIdx.x >= L.t[i].wg_begin) ti = i;
-    const GemmTask& T = L.t[ti];
-    // workgroup -> (row tile tm, column tile tn, k-slice ks).  Row tiles of the same (tn, ks) read the same
-    // weight block; their block ids differ by tm_stride, a multiple of 8, so they land on the SAME XCD (blocks
-    // go round-robin over the 8 XCDs) and the second reader finds the block in that XCD's L2.
-    const int local = (int)blockIdx.x - T.wg_begin;
-    const int tm = local / T.tm_stride;
-    const int rem = local - tm * T.tm_stride;
-    if (rem >= T.tiles_n * T.ksplit) return;          // padding slot
-    const int ks = rem % T.ksplit;
-    const int tn = rem / T.ksplit;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int kt0 = (int)(((long long)ks * T.ktiles) / T.ksplit);
-    const int kt1 = (int)(((long long)(ks + 1) * T.ktiles) / T.ksplit);
-
-    const int srow = tid >> 3, kc = tid & 7, scol = kc * 4;
-    // byte offset of this thread's 8-byte store inside a plane row
-    const int soff = srow * ROWB + (((kc >> 1) ^ ((srow >> 2) & 3)) << 4) + ((kc & 1) << 3);
-    int arow[LA], wrow[LW];
-#pragma unroll
-    for (int i = 0; i < LA; ++i) { int r = m0 + srow + 32 * i; arow[i] = r < T.M ? r : T.M - 1; }
-#pragma unroll
-    for (int i = 0; i < LW; ++i) { int r = n0 + srow + 32 * i; wrow[i] = r < T.N ? r : T.N - 1; }
-
-    f32x4 ra0[LA], rw0[LW], ra1[LA], rw1[LW];
-    const float* pa[LA];
-    const float* pw[LW];
-    int seg_end = 0;
-#define SPL_SEEK(KT)                                                                                    \
-    {                                                                                                   \
-        const int kt_ = (KT);                                                                           \
-        int s_ = 0, kbase_ = 0;                                                                         \
-        _Pragma("unroll") for (int i = 0; i < GEMM_MAX_SEG - 1; ++i)                                    \
-            if (i + 1 < T.nseg && kt_ >= T.kt_end[i]) { s_ = i + 1; kbase_ = T.kt_end[i]; }             \
-        const float* Ab_ = T.A[0];                                                                      \
-        const float* Wb_ = T.W[0];                                                                      \
-        long long lda_ = T.lda[0], ldw_ = T.ldw[0];                                                     \
-        seg_end = T.kt_end[0];                                                                          \
-        _Pragma("unroll") for (int i = 1; i < GEMM_MAX_SEG; ++i)                                        \
-            if (s_ == i) { Ab_ = T.A[i]; Wb_ = T.W[i]; lda_ = T.lda[i]; ldw_ = T.ldw[i]; seg_end = T.kt_end[i]; } \
-        const long long koff_ = (long long)(kt_ - kbase_) * GEMM_BK + scol;                             \
-        _Pragma("unroll") for (int i = 0; i < LA; ++i) pa[i] = Ab_ + arow[i] * lda_ + koff_;            \
-        _Pragma("unroll") for (int i = 0; i < LW; ++i) pw[i] = Wb_ + wrow[i] * ldw_ + koff_;            \
-    }
-#define SPL_GLOAD(RA, RW)                                                                           \
-    {                                                                                                   \
-        _Pragma("unroll") for (int i = 0; i < LA; ++i) { RA[i] = *(gptr4)(pa[i]); pa[i] += GEMM_BK; } \
-        _Pragma("unroll") for (int i = 0; i < LW; ++i) { RW[i] = *(gptr4)(pw[i]); pw[i] += GEMM_BK; } \
-    }
-#define SPL_STAGE(KT, RA, RW)                                                                       \
-    if ((KT) < kt1) {                                                                                   \
-        if ((KT) == seg_end) SPL_SEEK(KT);                                                              \
-        SPL_GLOAD(RA, RW);                                                                          \
-    }
-    // registers (fp32) -> three bf16 planes in LDS
-#define SPL_LSTORE(B, RA, RW)                                                                       \
-    {                                                                                                   \
-        char* sA_ = smem + (B) * BUF + soff;                                                            \
-        char* sW_ = smem + (B) * BUF + 3 * PLANE_A + soff;                                              \
-        _Pragma("unroll") for (int i = 0; i < LA; ++i) {                                                \
-            u32x2 h_, m_, l_;                                                                           \
-            split3(RA[i], h_, m_, l_);                                                                  \
-            *reinterpret_cast<u32x2*>(sA_ + i * 32 * ROWB) = h_;                                        \
-            *reinterpret_cast<u32x2*>(sA_ + i * 32 * ROWB + PLANE_A) = m_;                              \
-            *reinterpret_cast<u32x2*>(sA_ + i * 32 * ROWB + 2 * PLANE_A) = l_;                          \
-        }                                                                                               \
-        _Pragma("unroll") for (int i = 0; i < LW; ++i) {                                                \
-            u32x2 h_, m_, l_;                                                                           \
-            split3(RW[i], h_, m_, l_);                                                                  \
-            *reinterpret_cast<u32x2*>(sW_ + i * 32 * ROWB) = h_;                                        \
-            *reinterpret_cast<u32x2*>(sW_ + i * 32 * ROWB + PLANE_W) = m_;                              \
-            *reinterpret_cast<u32x2*>(sW_ + i * 32 * ROWB + 2 * PLANE_W) = l_;                          \
-        }                                                                                               \
-    }
-
-    f32x16 acc[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-
-    const int frow = lane & 31;
-    const int fsw = (frow >> 2) & 3;
-    // byte offsets of this lane's fragment rows (A: 2 sub-tiles, W: 1) and of its chunk in k16-step 0 / 1
-    const int fa0 = (wm * 64 + frow) * ROWB, fw0 = (wn * 32 + frow) * ROWB;
-    const int fc[2] = {(((lane >> 5)) ^ fsw) << 4, ((2 + (lane >> 5)) ^ fsw) << 4};
-#define SPL_FRAG(S, FA, FW)                                                                             \
-    {                                                                                                   \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
-            _Pragma("unroll") for (int p = 0; p < 3; ++p)                                               \
-                FA[i][p] = *reinterpret_cast<const u32x4*>(sA + p * PLANE_A + fa0 + i * 32 * ROWB + fc[S]); \
-        _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                   \
-            FW[p] = *reinterpret_cast<const u32x4*>(sW + p * PLANE_W + fw0 + fc[S]);                    \
-    }
-#define SPL_MM(I, PA, PW) acc[I] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                             \
-        __builtin_bit_cast(bf16x8, fa_[I][PA]), __builtin_bit_cast(bf16x8, fw_[PW]), acc[I], 0, 0, 0)
-    // six products per sub-tile, smallest first; the two sub-tiles alternate so consecutive MFMAs are independent
-#define SPL_MFMA(FA, FW)                                                                                \
-    {                                                                                                   \
-        auto& fa_ = FA; auto& fw_ = FW;                                                                 \
-        SPL_MM(0, 0, 2); SPL_MM(1, 0, 2);                                                               \
-        SPL_MM(0, 2, 0); SPL_MM(1, 2, 0);                                                               \
-        SPL_MM(0, 1, 1); SPL_MM(1, 1, 1);                                                               \
-        SPL_MM(0, 0, 1); SPL_MM(1, 0, 1);                                                               \
-        SPL_MM(0, 1, 0); SPL_MM(1, 1, 0);                                                               \
-        SPL_MM(0, 0, 0); SPL_MM(1, 0, 0);                                                               \
-    }
-    // One k-tile.  The split of tile kt+1 (VALU) and its LDS stores are issued IN BETWEEN the 24 MFMAs of tile kt
-    // (sched_group_barrier pins the interleave: the matrix pipe runs 32 cycles per MFMA, enough for ~7 VALU
-    // issues), so the conversion work hides under the matrix pipe instead of alternating with it.  The store
-    // is unconditional: on the last tile it writes stale registers into the buffer nobody reads again.
-#define SPL_ITER(KT, B, RA, RW)                                                                     \
-    {                                                                                                   \
-        const char* sA = smem + (B) * BUF;                                                              \
-        const char* sW = smem + (B) * BUF + 3 * PLANE_A;                                                \
-        u32x4 fA0[TM][3], fW0[3], fA1[TM][3], fW1[3];                                                   \
-        SPL_FRAG(0, fA0, fW0);                                                                          \
-        SPL_FRAG(1, fA1, fW1);                                                                          \
-        SPL_LSTORE((B) ^ 1, RA, RW);                                                                \
-        SPL_MFMA(fA0, fW0);                                                                             \
-        SPL_MFMA(fA1, fW1);                                                                             \
-        _Pragma("unroll") for (int q_ = 0; q_ < 24; ++q_) {                                             \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                          \
-            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);                                          \
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                          \
-        }                                                                                               \
-        SPL_STAGE((KT) + 3, RA, RW);                                                                \
-        __syncthreads();                                                                                \
-    }
-    if (kt0 < kt1) {
-        SPL_SEEK(kt0);
-        SPL_GLOAD(ra0, rw0);
-        SPL_STAGE(kt0 + 1, ra1, rw1);
-        SPL_LSTORE(0, ra0, rw0);
-        SPL_STAGE(kt0 + 2, ra0, rw0);
-        __syncthreads();
-    }
-    for (int kt = kt0; kt < kt1; kt += 2) {
-        SPL_ITER(kt, 0, ra1, rw1);
-        if (kt + 1 < kt1) SPL_ITER(kt + 1, 1, ra0, rw0);
-    }
-#undef SPL_ITER
-#undef SPL_MFMA
-#undef SPL_MM
-#undef SPL_FRAG
-#undef SPL_LSTORE
-#undef SPL_STAGE
-#undef SPL_GLOAD
-#undef SPL_SEEK
-
-    float* Cs = T.C + (long long)ks * T.slab_stride;
-    const bool fused = (T.ksplit == 1);
-    const int crow0 = m0 + wm * 64 + 4 * (lane >> 5);
-    const int col = n0 + wn * 32 + (lane & 31);
-    if (col < T.N) {
-        const float bv = (fused && T.bias) ? T.bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = crow0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                if (row < T.M) {
-                    float v = acc[i][r];
-                    if (fused) v = apply_act(v + bv, T.act);
-                    Cs[(long long)row * T.ldc + col] = v;
-                }
-            }
-        }
-    }
-}
-
-
-
 
 // ---------------------------------------------------------------------------------------------
 // <= 16 rows (the decode batch of BASELINE.json configs[0], beam search, the tail of a ragged teacher-forced batch): the
@@ -1298,13 +646,23 @@ int gemm_tile_m(int M) {
     static const int bm16_upto = env_int("SET_GEMM_BM16_UPTO", 16);
     return M <= bm16_upto ? 16 : (M <= bm32_upto ? 32 : (M <= bm64_upto ? 64 : 128));
 }
+#ifdef SET_EXPERIMENTAL_GEMMS
 static int gemm_dma() { static int v = env_int("SET_GEMM_DMA", 0); return v; }
+static int gemm_kgroups() { static int v = env_int("SET_GEMM_KGROUPS", 1); return v; }
+static int gemm_bn128() { static int v = env_int("SET_GEMM_BN128", 0); return v; }
+#else
+static constexpr int gemm_dma() { return 0; }
+static constexpr int gemm_kgroups() { return 1; }
+static constexpr int gemm_bn128() { return 0; }
+#endif
 int g_gemm_asm_force = -1;         // tools/ubench: switch kernels inside one process (-1: the environment decides)
 static int gemm_asm() { static int v = env_int("SET_GEMM_ASM", 1); return g_gemm_asm_force >= 0 ? g_gemm_asm_force : v; }
 int g_gemm_wreg_force = -1;        // tools/ubench: switch kernels inside one process (-1: the environment decides)
+#ifdef SET_EXPERIMENTAL_GEMMS
 static int gemm_wreg() { static int v = env_int("SET_GEMM_WREG", 0); return g_gemm_wreg_force >= 0 ? g_gemm_wreg_force : v; }
-static int gemm_kgroups() { static int v = env_int("SET_GEMM_KGROUPS", 1); return v; }
-static int gemm_bn128() { static int v = env_int("SET_GEMM_BN128", 0); return v; }
+#else
+static constexpr int gemm_wreg() { return 0; }
+#endif
 static int tile_m_of(const GemmProb& p) { return (p.bm_hint == 64 || p.bm_hint == 128) ? p.bm_hint : gemm_tile_m(p.M); }
 // Row-tile class of one launch.  Up to 512 rows: from M (above).  Beyond: 128x64 tiles unless 64x64 tiles leave the CUs a
 // more even load — a launch takes about ceil(workgroups / 256 CUs) rounds of one tile's k-loop, and a 64-row tile's k-loop
@@ -1315,7 +673,11 @@ static int tile_m_of(const GemmProb& p) { return (p.bm_hint == 64 || p.bm_hint =
 // halves of a weight block (same workgroup count as two 64x64 tiles, each weight byte fetched once instead of relying on
 // the second row tile's L2 hit; the activation rows are re-read by twice as many workgroups, from L2)
 static bool use_bn32(const GemmProb* probs, int n) {
+#ifdef SET_EXPERIMENTAL_GEMMS
     static const int on = env_int("SET_GEMM_BN32", 0);
+#else
+    constexpr int on = 0;
+#endif
     if (!on || n <= 0 || probs[0].bm_hint || gemm_split_mode()) return false;
     for (int i = 0; i < n; ++i)
         if (probs[i].M <= 64 || probs[i].M > 128 || gemm_tile_m(probs[i].M) != 64) return false;
@@ -1479,6 +841,7 @@ int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag
     dim3 grid(wg), block(256);
     static const char* split_tag = getenv("SET_GEMM_SPLIT_TAG");     // debug: restrict the split kernel to one call site
     const bool split_here = gemm_split_mode() && (!split_tag || !*split_tag || strstr(tag ? tag : "untagged", split_tag));
+#ifdef SET_EXPERIMENTAL_GEMMS
     if (bm == 128 && bn == 64 && split_here) {
         constexpr int kLds = 2 * 3 * (128 + 64) * 64;
         static bool attr_set = false;
@@ -1488,7 +851,10 @@ int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag
             attr_set = true;
         }
         hipLaunchKernelGGL(gemm_nt_split_bf16, grid, block, kLds, stream, L);
-    } else {
+    } else
+#endif
+    {
+        (void)split_here;
         const int nt = L.ntasks, w1 = L.t[1].wg_begin, w2 = L.t[2].wg_begin, w3 = L.t[3].wg_begin, w4 = L.t[4].wg_begin,
                   w5 = L.t[5].wg_begin;
         const int* ga = L.gate.alive_prev;
@@ -1496,22 +862,26 @@ int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag
         const int gate_mode = ga ? 1 : 0;
         if (bm == 16)
             hipLaunchKernelGGL(gemv_nt_f32, grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
+#ifdef SET_EXPERIMENTAL_GEMMS
         else if (bm == 128 && bn == 32)
             hipLaunchKernelGGL((gemm_nt_f32<128, 32, 4, 1>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
         else if (bm == 128 && bn == 128)
             hipLaunchKernelGGL((gemm_nt_f32<128, 128, 2, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
         else if (bm == 128 && gemm_dma())
             hipLaunchKernelGGL((gemm_nt_f32_dma<128, 64, 2, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
+#endif
         else if (bm == 128 && gate_mode)
             hipLaunchKernelGGL((gemm_nt_f32<128, 64, 2, 2, 1, 1>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
         else if (bm == 128)
             hipLaunchKernelGGL((gemm_nt_f32<128, 64, 2, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
+#ifdef SET_EXPERIMENTAL_GEMMS
         else if (bm == 64 && gemm_wreg())
             hipLaunchKernelGGL(gemm_nt_f32_wreg, grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
         else if (bm == 64 && gemm_kgroups() == 2)
             hipLaunchKernelGGL((gemm_nt_f32<64, 64, 2, 2, 2>), grid, dim3(512), 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
         else if (bm == 64 && gemm_dma())
             hipLaunchKernelGGL((gemm_nt_f32_dma<64, 64, 2, 2>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
+#endif
         else if (bm == 64 && bn == 64 && gemm_asm() && slices_in_one_segment(L))
             if (gate_mode) hipLaunchKernelGGL((gemm_nt_f32_asm<1>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);
             else hipLaunchKernelGGL((gemm_nt_f32_asm<0>), grid, block, 0, stream, nt, w1, w2, w3, w4, w5, ga, gn, L);

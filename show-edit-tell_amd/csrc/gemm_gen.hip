@@ -232,6 +232,9 @@ __global__ void __launch_bounds__(256) gemm_gen_f32(const GenLaunch L) {
         __syncthreads();
     }
     // invariant at the top of an even step: lds[0] = tile kt, ra1/rb1 = tile kt+1, ra0/rb0 = tile kt+2
+    // (measured and not kept, round 5: four k-tiles per trip so that only one LDS store in four drains both register stages
+    // — the compiler's wait-count pass forgets the order of the requests in flight at the loop header — made the 128x64
+    // TN products 19 % SLOWER, 677 -> 804 us for the x2h weight gradient)
     for (int kt = kt0; kt < kt1; kt += 2) {
         GEN_ITER(kt, 0, ra1, rb1);
         if (kt + 1 < kt1) GEN_ITER(kt + 1, 1, ra0, rb0);

@@ -153,7 +153,8 @@ int persistent_encoder(const float* w_hh, const float* xg, long long ld_xg_row, 
 
 struct PDecTeacher { const int64_t* caps; long long caps_stride; float* predictions; const int* host_decode_lengths; };   // teacher-forced mode
 // decode_persistent.hip: the greedy loop of a small batch as one launch with grid barriers
-constexpr int PDEC_MAXB = 8;
+constexpr int PDEC_MAXB = 8;          // rows of the <= 8-row persistent decode kernels
+constexpr int PDW_MAXB = 16;          // rows of the wide EditNet variant (decode_persistent_wide.hip): one full 16-row MFMA tile
 size_t dcnet_persistent_xbytes(int B, int D, int A);
 bool dcnet_persistent_ok(const SetDcnetDims* d, int max_len);
 int dcnet_persistent_greedy(const SetDcnetWeights* w, const SetDcnetDims* d, const float* pre1, const float* att1_c,

@@ -168,7 +168,7 @@ def oracle_greedy_reference(model, sd, wm, prev, plen, X=None, max_len=18):
     return seq, logp, margins, top2
 
 
-def check_two_paths_rows(seq_a, logp_a, seq_b, logp_b, margins, tol=1e-5, margin_min=MARGIN_MIN):
+def check_two_paths_rows(seq_a, logp_a, seq_b, logp_b, margins, tol=2e-5, margin_min=MARGIN_MIN):
     """Two implementations of the same decode (e.g. the persistent launch and the per-step loop): on every row that never
     passes a near-tie of the reference trajectory (`margins` (S,B)) ids are bit-identical and log-probs within `tol`; a
     near-tie row must agree up to its first near-tie step.  Returns the number of near-tie rows."""
@@ -176,11 +176,12 @@ def check_two_paths_rows(seq_a, logp_a, seq_b, logp_b, margins, tol=1e-5, margin
     ok = ~amb
     assert np.array_equal(seq_a[ok], seq_b[ok]), "ids differ on rows without a near-tie"
     if ok.any():
-        assert np.abs(logp_a[ok] - logp_b[ok]).max() < tol
+        e = float(np.abs(logp_a[ok] - logp_b[ok]).max())
+        assert e < tol, "log-probs of the two paths differ by %.3e (tol %.1e; each is within 1e-4 of the oracle)" % (e, tol)
     for b in np.nonzero(amb)[0]:
         t_star = int(np.argmax(margins[:, b] < margin_min))
         n = min(t_star, seq_a.shape[1])
         assert np.array_equal(seq_a[b, :n], seq_b[b, :n]), "near-tie row %d differs before its near-tie step %d" % (b, t_star)
         if n:
-            assert np.abs(logp_a[b, :n] - logp_b[b, :n]).max() < tol
+            assert float(np.abs(logp_a[b, :n] - logp_b[b, :n]).max()) < tol
     return int(amb.sum())

@@ -205,11 +205,13 @@ def test_editnet_persistent_decode_matches_golden_and_per_step(name):
     assert float((logp - ref[1]).abs().max()) < 1e-5
 
 
-def test_editnet_persistent_xe_forward_matches_golden_and_per_step():
-    """The teacher-forced forward of EditNet under no_grad at B <= 8 (editnet.py:505-546) on the persistent launch: golden,
-    per-step loop (scores within 2e-5, the same zero pattern behind each caption's length)."""
-    d, xe, rl = editnet_modules("editnet_full_b4")
-    c, g = d["case"], parity.load("editnet_full_b4")
+@pytest.mark.parametrize("name", ["editnet_full_b4", "editnet_full_v9490"])
+def test_editnet_persistent_xe_forward_matches_golden_and_per_step(name):
+    """The teacher-forced forward of EditNet under no_grad at B <= 16 (editnet.py:505-546) on the persistent launch: golden,
+    per-step loop (scores within 2e-5, the same zero pattern behind each caption's length).  B = 4: the <= 4-row kernel;
+    the B = 5 / V = 9490 fixture: the wide variant in teacher-forced mode."""
+    d, xe, rl = editnet_modules(name)
+    c, g = d["case"], parity.load(name)
     args = (to_dev(d["X"]), to_dev(d["caps"]), to_dev(d["clen"]), to_dev(d["prev"]), to_dev(d["plen"]), False, 0.0)
     with torch.no_grad():
         xe(*args)
@@ -225,11 +227,12 @@ def test_editnet_persistent_xe_forward_matches_golden_and_per_step():
     assert float((pred - ref[0]).abs().max()) < 2e-5 * max(1.0, float(ref[0].abs().max()))
 
 
-@pytest.mark.parametrize("B", [1, 2, 3, 5, 6, 7, 8])
+@pytest.mark.parametrize("B", [1, 2, 3, 5, 6, 7, 8, 9, 12, 13, 16])
 def test_editnet_persistent_decode_other_batch_sizes(B):
-    """1 .. 8 rows, random features and ragged previous captions, all T = 19 timesteps: the persistent launch against the NUMPY
+    """1 .. 16 rows, random features and ragged previous captions, all T = 19 timesteps: the persistent launch against the NUMPY
     ORACLE and the per-step loop, row by row with the oracle's margins (see the DCNet twin above), and run-to-run
-    determinism."""
+    determinism.  From 5 rows on the launch is the wide variant (csrc/decode_persistent_wide.hip: one activation buffer,
+    attention scores spread over the grid, a full 16-row MFMA tile at B = 16)."""
     d, xe, rl = editnet_modules("editnet_full_b4")
     prev, plen = _random_prev(B, d["prev"].shape[1], 200 + B)
     X = to_dev(np.abs(np.random.RandomState(300 + B).randn(B, d["X"].shape[1], d["X"].shape[2])).astype(np.float32))
