@@ -190,6 +190,24 @@ int set_editnet_greedy_begun(const SetEditNetWeights* w, const SetEditNetDims* d
                              int64_t end_idx, int max_len, int64_t* seq, float* seq_logp, void* ws,
                              size_t ws_bytes, void* stream);
 
+/* Beam search of ONE image, the reference's own evaluate() shape (editnet.py:601-713: batch = 1 image, beam k = 3), as
+ * prologue + ONE persistent launch (csrc/decode_persistent_wide.hip, beam mode): the d->B <= 4 rows of the workspace are the
+ * k hypotheses — X (k, R, F), prev (k, T), prevlen (k) hold the image's inputs k times — and every timestep ends with the
+ * reference's pick (editnet.py:654-699: log-softmax, + running scores, flat top-k over k V, parent / word split, completed
+ * hypotheses leave, k shrinks) instead of the arg-max; recurrent state follows the parent map inside the launch.  The
+ * search stops when every hypothesis has ended or after max_picks picks (the reference's 50-step limit: max_picks = 51).
+ * Outputs (device): hist_parent / hist_word (max_picks, 4) = parent slot and appended word of every slot after every pick —
+ * the host follows them back to read a sequence; best_score / best_word [1] and result [4] = {pick index of the best
+ * completed hypothesis (-1: none), its parent slot, hypotheses still alive, picks made}.  A time-out poisons best_score with
+ * NaN and result[2..3] = -1 (SET_ERR_FAULT at the next call).  SET_ERR_UNSUPPORTED (nothing was touched: take
+ * set_editnet_step + set_beam_pick_f32): no token table, k > 4, adaptive features, dimensions the persistent launch does
+ * not cover.  Parity: tests/test_hip_beam.py against the reference's beam goldens. */
+int set_editnet_beam_persistent(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X,
+                                const float* image_mean, const int64_t* prev, const int64_t* prevlen,
+                                int64_t start_idx, int64_t end_idx, int max_picks, int32_t* hist_parent,
+                                int64_t* hist_word, float* best_score, int64_t* best_word, int32_t* result,
+                                void* ws, size_t ws_bytes, void* stream);
+
 /* The same loop with multinomial sampling (editnet_rl.py:521-528, sample_rl=True, eval mode, no gradients):
  * it ~ Categorical(softmax(logits)) drawn on the device with Philox4x32-10 (counter = (row, timestep, offset),
  * key = seed): reproducible for a given (seed, offset), independent streams for different offsets.
@@ -483,6 +501,16 @@ int set_select_bwd_acc_f32(const float* dsel, const float* Mem, const float* alp
  * cols, all leading dimensions: multiples of 4; pointers 16-byte aligned. */
 int set_dropout_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int cols, float p, uint64_t seed,
                     uint64_t offset, void* stream);
+/* set_dropout_f32 of ONE operand for `steps` timesteps in one launch: y + t * y_step = dropout(x) drawn at offset + t
+ * (t = 0 .. steps - 1), bit for bit what `steps` calls write.  The per-timestep region dropout of the train-mode forward
+ * (editnet.py:441: `att_embed`'s nn.Dropout sees the same relu(W X) with a fresh mask every timestep) is the caller. */
+int set_dropout_steps_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t y_step, int rows, int cols, int steps,
+                          float p, uint64_t seed, uint64_t offset, void* stream);
+/* its backward over all timesteps: dx (+)= sum_t dy[t] * (y[t] != 0 ? scale : 0), t ascending — what `steps` accumulating
+ * calls of set_dropout_bwd_f32 leave in dx, bit for bit */
+int set_dropout_bwd_steps_f32(const float* dy, int64_t lddy, int64_t dy_step, const float* y, int64_t ldy, int64_t y_step,
+                              float* dx, int64_t ldx, int rows, int cols, int steps, float scale, int accumulate,
+                              void* stream);
 /* EmbeddingC.forward in train mode (editnet.py:299-302) in one launch: set_embed_relu_f32 followed by set_dropout_f32
  * in place (the same counters, hence the same mask for a (seed, offset) pair) */
 int set_embed_relu_dropout_f32(const float* table, const int64_t* ids, int64_t ids_stride, float* out, int64_t ldo,

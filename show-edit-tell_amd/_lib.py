@@ -166,6 +166,8 @@ PROTOTYPES = {
                                 _P, _Z, _P]),
     "set_decode_row_limits": (_I, [_P]),
     "set_editnet_greedy_begun": (_I, [C.POINTER(EditNetWeights), C.POINTER(EditNetDims), _P, _L, _L, _I, _P, _P, _P, _Z, _P]),
+    "set_editnet_beam_persistent": (_I, [C.POINTER(EditNetWeights), C.POINTER(EditNetDims), _P, _P, _P, _P, _L, _L, _I, _P, _P, _P, _P, _P,
+                                         _P, _Z, _P]),
     "set_editnet_sample": (_I, [C.POINTER(EditNetWeights), C.POINTER(EditNetDims), _P, _P, _P, _P, _L, _L, _I, _U, _U, _P,
                                 _P, _P, _Z, _P]),
     "set_editnet_xe_forward": (_I, [C.POINTER(EditNetWeights), C.POINTER(EditNetDims), _P, _P, _P, _L,
@@ -236,6 +238,8 @@ PROTOTYPES = {
     "set_dropout_f32": (_I, [_P, _L, _P, _L, _I, _I, C.c_float, _U, _U, _P]),
     "set_embed_relu_dropout_f32": (_I, [_P, _P, _L, _P, _L, _I, _I, _I, C.c_float, _U, _U, _P]),
     "set_dropout_bwd_f32": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, C.c_float, _I, _P]),
+    "set_dropout_steps_f32": (_I, [_P, _L, _P, _L, _L, _I, _I, _I, C.c_float, _U, _U, _P]),
+    "set_dropout_bwd_steps_f32": (_I, [_P, _L, _L, _P, _L, _L, _P, _L, _I, _I, _I, C.c_float, _I, _P]),
     "set_dropout_bwd_philox_f32": (_I, [_P, _L, _P, _L, _I, _I, C.c_float, _U, _U, _I, _P]),
     "set_rowsum_mask_f32": (_I, [_P, _L, _I, _I, _P, _P]),
     "set_pack_f32": (_I, [_P, _L, _I, _I, C.POINTER(_P), C.POINTER(_L), C.POINTER(_I), _I, _P]),

@@ -136,10 +136,17 @@ struct PDecEditArgs {
     int dlen[PDW_MAXB];                          // decode lengths, descending
     int stamp_wg;
     unsigned long long* stamps;
+    // beam mode of the wide variant (set_editnet_beam_persistent): the rows are the k hypotheses of ONE image
+    void* x_fcb;                                 // (B, G, 12) per-slice (max, sum exp, 4 x (score, word)) words
+    int* bm_hist_par;                            // (max_len, 4) parent slot of every slot after every pick
+    long long* bm_hist_word;                     // (max_len, 4) word appended to every slot at every pick
+    float* bm_best_score;                        // [1] best completed hypothesis (-inf: none)
+    long long* bm_best_word;                     // [1] its last word (<end>)
+    int* bm_result;                              // [4] pick index and parent slot of the best completed hypothesis, k_left, picks made
 };
 
 // the wide variant's launch (decode_persistent_wide.hip); P is complete except for the exchange pointers it lays out itself
-int editnet_persistent_wide_launch(PDecEditArgs& P, void* xbuf, PersistentGuard& guard, hipStream_t s, bool* unsupported);
+int editnet_persistent_wide_launch(PDecEditArgs& P, void* xbuf, PersistentGuard& guard, hipStream_t s, bool* unsupported, bool beam = false);
 size_t editnet_persistent_wide_xbytes(int B, int D, int A);
 bool editnet_persistent_wide_ok(int B, int D, int A, int T, int R, int V);
 

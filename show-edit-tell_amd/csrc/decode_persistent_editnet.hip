@@ -557,10 +557,13 @@ int editnet_persistent_greedy(const SetEditNetWeights* w, const SetEditNetDims* 
                               const float* att1_c, const float* mask, const float* capP, const float* memQ, const float* Mem,
                               const float* pv, void* xbuf, long long* it, int* unfinished, int* alive, long long start_idx,
                               long long end_idx, int max_len, long long* seq, float* seq_logp, hipStream_t s,
-                              const PDecTeacher* teach) {
-    if (!editnet_persistent_ok(d, max_len)) return SET_ERR_UNSUPPORTED;
+                              const PDecTeacher* teach, const PDecBeam* beam) {
+    if (beam) {         // beam mode lives in the wide variant, whatever the row count
+        if (!env_int("SET_DEC_PERSISTENT", 1) || max_len < 1 || d->adaptive || persistent_disabled() ||
+            !editnet_persistent_wide_ok(d->B, d->D, d->A, d->T, d->R, d->V)) return SET_ERR_UNSUPPORTED;
+    } else if (!editnet_persistent_ok(d, max_len)) return SET_ERR_UNSUPPORTED;
     const int B = d->B, D = d->D, A = d->A, F = d->F, G = D / 4;
-    const bool wide = B >= wide_minb() || B > PDEC_MAXB;
+    const bool wide = beam || B >= wide_minb() || B > PDEC_MAXB;
     PDecEditArgs P{};
     P.al_wih = w->al_wih; P.ld_ih = 3LL * D + F; P.al_whh = w->al_whh; P.cl_h2h_w = w->cl_h2h_w;
     P.cl_x2h_w = w->cl_x2h_w; P.ld_x2h = 2LL * D + F; P.cl_x2h_b = w->cl_x2h_b; P.cl_h2h_b = w->cl_h2h_b;
@@ -595,9 +598,13 @@ int editnet_persistent_greedy(const SetEditNetWeights* w, const SetEditNetDims* 
     const int dev = guard.dev;
     P.spin_limit = guard.spin_limit();
     P.test_stall = guard.test_stall(); P.fault = guard.fault;
+    if (beam) {
+        P.bm_hist_par = beam->hist_par; P.bm_hist_word = (long long*)beam->hist_word; P.bm_best_score = beam->best_score;
+        P.bm_best_word = (long long*)beam->best_word; P.bm_result = beam->result;
+    }
     if (wide) {
         bool unsupported = true;
-        const int rc = editnet_persistent_wide_launch(P, xbuf, guard, s, &unsupported);
+        const int rc = editnet_persistent_wide_launch(P, xbuf, guard, s, &unsupported, beam != nullptr);
         return rc != SET_OK ? rc : (unsupported ? SET_ERR_UNSUPPORTED : SET_OK);
     }
     static bool configured[2][64] = {};

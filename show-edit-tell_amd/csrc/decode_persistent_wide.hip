@@ -40,6 +40,8 @@ namespace set {
 namespace {
 
 constexpr int PW_U = 16;           // 16-byte requests a lane keeps in flight while it fills LDS from an exchange buffer
+constexpr int PW_BEAM_K = 4;       // beam mode: hypotheses (= rows) at most
+constexpr int PW_BEAM_W = 12;      // ... words a workgroup publishes per row: max, sum exp, 4 x (value, index), 2 pads
 constexpr int PW_RS = PDEC_RREG + 1;   // row strides of the hoisted-product tables in LDS: odd, so that the (thread, index) gathers
 constexpr int PW_TS = PDEC_TMAX + 1;   // of 256 threads spread over all banks
 
@@ -89,6 +91,9 @@ __device__ __forceinline__ void pw_wargmax(float& best, int& bi) {
 
 }  // namespace
 
+// BEAM: the rows are the k <= PW_BEAM_K hypotheses of ONE image and the loop is the reference's beam search (editnet.py:643-713)
+// instead of the greedy loop — see "beam mode" below.
+template <bool BEAM>
 __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_wide_k(const PDecEditArgs P) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ long long sTok[PDW_MAXB];
@@ -110,6 +115,16 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_wide_k(con
     float* sPz = sPv + B * 16 * PW_RS;                   // (B, 8, TMAX) hoisted caption-context products of the owned columns
     float* sCon = sPz + B * 8 * PW_TS;               // [cap_decoder_att.b | cap_full_att.w | decoder_att.b | full_att.w] (4, A)
     const float* sF = sX;
+    // beam mode only: every workgroup's per-slice candidates, the previous timestep's h2h products (added through the parent
+    // map), the cell states on their way through the parent map, the per-row candidate lists of the pick
+    float* sFB = sCon + 4 * A;                           // (B, G, PW_BEAM_W)
+    float* sRedP = sFB + (BEAM ? B * G * PW_BEAM_W : 0); // [4 waves][16][16]
+    float* sCst = sRedP + (BEAM ? 4 * 256 : 0);          // (2, B, 4) c1 | c2 of the owned units
+    float* sCand = sCst + (BEAM ? 2 * PW_BEAM_K * 4 : 0);// (B, K, 2) (score, flat index) of every row's best K candidates
+    __shared__ int sPar[PW_BEAM_K];                      // parent slot of every slot (identity before the first pick)
+    __shared__ float sScore[PW_BEAM_K];                  // running scores of the slots (-inf = dead)
+    __shared__ int sKleft;
+    __shared__ float sBest;                              // best completed hypothesis so far
     const LLWatch watch{P.status, P.fault, P.spin_limit};
 
 #define PW_SYNC() __syncthreads()
@@ -194,13 +209,21 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_wide_k(con
     const __amdgpu_buffer_rsrc_t cnrs = __builtin_amdgcn_make_buffer_rsrc(P.x_cn, 0, B * D * 8, 0x00027000);
     const __amdgpu_buffer_rsrc_t h2rs = __builtin_amdgcn_make_buffer_rsrc(P.x_h2, 0, B * D * 8, 0x00027000);
     const __amdgpu_buffer_rsrc_t fcrs = __builtin_amdgcn_make_buffer_rsrc(P.x_fc, 0, B * G * 32, 0x00027000);
+    const __amdgpu_buffer_rsrc_t fbrs = __builtin_amdgcn_make_buffer_rsrc(BEAM ? P.x_fcb : P.x_fc, 0, BEAM ? B * G * PW_BEAM_W * 8 : 32, 0x00027000);
 
     // ---- initial state (init_hidden_state, editnet.py:494-495): zeros; every row is fed <start>
     if (tid < B) { sTok[tid] = P.start_idx; sUnf[tid] = 1; }
+    if (BEAM && tid < PW_BEAM_K) { sPar[tid] = tid; sScore[tid] = tid == 0 ? 0.f : -INFINITY; }   // step 1: all rows are identical, only row 0 counts
+    if (BEAM) for (int i = tid; i < 4 * 256; i += PDEC_THREADS) sRedP[i] = 0.f;                   // h2h h2 of the zero initial state
+    if (BEAM && tid == 0) {
+        sKleft = B; sBest = -INFINITY;
+        if (wg == 0) { P.bm_best_score[0] = -INFINITY; P.bm_best_word[0] = 0; P.bm_result[0] = -1; P.bm_result[1] = -1; P.bm_result[2] = B; P.bm_result[3] = 0; }
+    }
     __syncthreads();
 
     // weight tiles rotate through three register buffers (one workgroup per CU: 512 registers per lane):
-    //   X1: wb<-T3 wa<-T4 wc<-T1 | after the projections' poll: wb<-T5 wa<-T6 wc<-F0 | S4: wb<-F1 | S5: wa<-F2 | S6: wc<-T0' wb<-T2'
+    //   X1: wb<-T3 wa<-T4 wc<-T1 | after the projections' poll: wb<-T5 | after the scores' poll: wa<-T6 wc<-F0 | S4: wb<-F1 |
+    //   S5: wa<-F2 | S6: wc<-T0' wb<-T2'
     f32x4 wa[PDEC_KB], wb[PDEC_KB], wc[PDEC_KB];
     unsigned tag = 0;
     {
@@ -231,13 +254,18 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_wide_k(con
 #pragma unroll
             for (int e = 0; e < 4; ++e) sRed[(kq * 3 + 0) * 256 + (4 * g + e) * 16 + r] = acc1[e];
         }
+        if (BEAM && pair) { sCst[pb * 4 + pu] = c1; sCst[PW_BEAM_K * 4 + pb * 4 + pu] = c2; }
         PW_SYNC();
+        // beam mode: slot pb continues hypothesis sPar[pb] of the previous timestep — its cell states and the gate products
+        // that were contracted before the pick (S2 / S1' of the previous timestep) are read through the parent map
+        const int par = BEAM ? sPar[pair ? pb : 0] : pb;
+        if (BEAM && pair) { c1 = sCst[par * 4 + pu]; c2 = sCst[PW_BEAM_K * 4 + par * 4 + pu]; }
         ++tag;                                                   // X1: h1
         if (pair && !(P.test_stall && wg == 0)) {
             float gq[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int o = pb * 16 + q * 4 + pu;
+                const int o = par * 16 + q * 4 + pu;
                 gq[q] = ((((sRed[o] + sRed[3 * 256 + o]) + sRed[6 * 256 + o]) + sRed[9 * 256 + o]) + pre[q]) + tg[q];
             }
             const float ai = pd_sigm(gq[0]), af = pd_sigm(gq[1]), ag = tanhf(gq[2]), ao = pd_sigm(gq[3]);
@@ -298,9 +326,7 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_wide_k(con
             pv0 = (f32x4){__uint_as_float(q[4].x), __uint_as_float(q[4].z), __uint_as_float(q[5].x), __uint_as_float(q[5].z)};
             pv1 = (f32x4){__uint_as_float(q[6].x), __uint_as_float(q[6].z), __uint_as_float(q[7].x), __uint_as_float(q[7].z)};
         }
-        pd_load(wb, pT5);
-        pd_load_if(wa, pT6, v6);
-        pd_load_if(wc, pF[0], vF[0]);
+        pd_load(wb, pT5);                                        // S4's tile: one tile ahead of the (small) score exchange
         PD_STAMP(4);
         float cs_val = 0.f, vs_val = 0.f;
         if (cs_on) {
@@ -324,6 +350,8 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_wide_k(con
         PD_STAMP(5);
         PW_STAGE(csrs, sAlc, B, T, PDEC_TMAX);                   // (T and R are even: editnet_persistent_wide_ok)
         PW_STAGE(vsrs, sAlv, B, R, 64);
+        pd_load_if(wa, pT6, v6);                                 // S5's (short) tile and fc's first one stream under the softmaxes
+        pd_load_if(wc, pF[0], vF[0]);                            // and the attend_cap exchange
         PW_SYNC();
         PD_STAMP(6);
         // ================= S3b: both softmaxes of every row, SelectC's arg-max (editnet.py:375-376, :409-416, :446)
@@ -390,7 +418,11 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_wide_k(con
             const int o = cb * 16 + crr;
             float s = 0.f;
             for (int rr = 0; rr < R; ++rr) s += sAlv[cb * 64 + rr] * sPv[tid * PW_RS + rr];
-            const float g2 = ((sRed[2 * 256 + o] + sRed[5 * 256 + o]) + sRed[8 * 256 + o]) + sRed[11 * 256 + o];
+            float g2 = ((sRed[2 * 256 + o] + sRed[5 * 256 + o]) + sRed[8 * 256 + o]) + sRed[11 * 256 + o];
+            if (BEAM) {                                          // + copy_lstm.h2h h2 of the PARENT hypothesis (S1' of the previous timestep)
+                const int op = sPar[cb] * 16 + crr;
+                g2 += ((sRedP[op] + sRedP[256 + op]) + sRedP[512 + op]) + sRedP[768 + op];
+            }
             sG[o] = (g2 + s) + b2;
         }
         PW_SYNC();
@@ -466,6 +498,184 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_wide_k(con
                 }
             }
             PW_SYNC();                                           // sRed is rewritten by the next timestep's S1
+            continue;
+        }
+        if constexpr (BEAM) {
+            // ================= beam mode (editnet.py:654-699; the bookkeeping of csrc/beam.hip beam_pick_k for ONE image):
+            // X6 carries, per row and vocabulary slice, (max, sum exp) and the slice's B best (score, word) pairs — a global
+            // top-B over B x V candidates takes at most B from one slice
+            ++tag;
+            if (kq < B) {
+                const int b = kq;
+                const int j = lane >> 4, rr = lane & 15, row = row0 + lane;
+                const bool ok = lane < 16 * PDEC_FC_TILES && lane < P.rpw && row < V;
+                float x = -INFINITY;
+                if (ok) {
+                    const int o = j * 256 + b * 16 + rr;
+                    x = (((sRed[o] + sRed[3 * 256 + o]) + sRed[6 * 256 + o]) + sRed[9 * 256 + o]) + fcb_lane;
+                }
+                float cvv[PW_BEAM_K];
+                int cii[PW_BEAM_K];
+                float xx = x;
+#pragma unroll
+                for (int q = 0; q < PW_BEAM_K; ++q) {
+                    float bv = -INFINITY;
+                    int bix = 0x7fffffff;
+                    if (q < B) {
+                        if (xx > -INFINITY) { bv = xx; bix = row; }
+                        pw_wargmax(bv, bix);
+                        if (ok && row == bix) xx = -INFINITY;
+                    }
+                    cvv[q] = bv; cii[q] = bix;
+                }
+                const float mx = cvv[0];
+                float se = (ok && mx > -INFINITY) ? expf(x - mx) : 0.f;
+                se = pw_wsum(se);
+                if (lane < PW_BEAM_W) {
+                    float v = 0.f;
+                    if (lane == 0) v = mx;
+                    else if (lane == 1) v = se;
+                    else if (lane < 2 + 2 * PW_BEAM_K) {
+                        const int q = (lane - 2) >> 1;
+                        float cv_ = cvv[0]; int ci_ = cii[0];
+#pragma unroll
+                        for (int u = 1; u < PW_BEAM_K; ++u) if (q == u) { cv_ = cvv[u]; ci_ = cii[u]; }
+                        v = (lane & 1) ? __int_as_float(ci_) : cv_;
+                    }
+                    ll_put(fbrs, (b * G + wg) * PW_BEAM_W + lane, v, tag);
+                }
+            }
+            // S1' (see the greedy path); copy_lstm.h2h h2 goes to LDS: the next timestep adds it through the parent map
+            if (more) {
+                acc1 = acc1n;
+                pd_mma(acc1, wc, aX);
+                f32x4 accp = zero4;
+                pd_mma(accp, wb, aX);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sRedP[kq * 256 + (4 * g + e) * 16 + r] = accp[e];
+                acc2 = zero4;
+            }
+            PW_SYNC();
+            PW_STAGE(fbrs, sFB, B * G, PW_BEAM_W, PW_BEAM_W);
+            PW_SYNC();
+            // ---- every workgroup runs the same pick.  Wave j: log-sum-exp of row j and its B best candidates
+            if (kq < B) {
+                const int j = kq;
+                const float scj = sScore[j];
+                float ov[PW_BEAM_K];
+                int oi[PW_BEAM_K];
+#pragma unroll
+                for (int q = 0; q < PW_BEAM_K; ++q) { ov[q] = -INFINITY; oi[q] = 0x7fffffff; }
+                if (scj > -INFINITY) {                           // (uniform in the wave; dead slots take no part)
+                    float cv[16];
+                    int ci[16];
+                    float pm[4], ps[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float* e = sFB + ((j * G + lane + 64 * i) * PW_BEAM_W);
+                        pm[i] = e[0]; ps[i] = e[1];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { cv[4 * i + q] = e[2 + 2 * q]; ci[4 * i + q] = __float_as_int(e[3 + 2 * q]); }
+                    }
+                    const float m = pw_wmax(fmaxf(fmaxf(pm[0], pm[1]), fmaxf(pm[2], pm[3])));
+                    float ssum = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ssum += (pm[i] == -INFINITY) ? 0.f : ps[i] * expf(pm[i] - m);
+                    ssum = pw_wsum(ssum);
+                    const float lse = m + logf(ssum);
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        const bool have = ci[c] != 0x7fffffff;
+                        cv[c] = have ? scj + (cv[c] - lse) : -INFINITY;       // score + log-prob, as beam_pick_k forms it
+                        ci[c] = have ? j * V + ci[c] : 0x7fffffff;
+                    }
+#pragma unroll
+                    for (int q = 0; q < PW_BEAM_K; ++q) {
+                        if (q < B) {
+                            float bv = -INFINITY;
+                            int bix = 0x7fffffff;
+#pragma unroll
+                            for (int c = 0; c < 16; ++c)
+                                if (cv[c] > bv || (cv[c] == bv && ci[c] < bix)) { bv = cv[c]; bix = ci[c]; }
+                            if (!(bv > -INFINITY)) bix = 0x7fffffff;
+                            pw_wargmax(bv, bix);
+#pragma unroll
+                            for (int c = 0; c < 16; ++c) if (ci[c] == bix) cv[c] = -INFINITY;
+                            ov[q] = bv; oi[q] = bix;
+                        }
+                    }
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int q = 0; q < PW_BEAM_K; ++q) { sCand[(j * PW_BEAM_K + q) * 2] = ov[q]; sCand[(j * PW_BEAM_K + q) * 2 + 1] = __int_as_float(oi[q]); }
+                }
+            }
+            PW_SYNC();
+            if (tid == 0) {
+                // the B best of the B x B candidates (ties: lowest flat index), then beam_pick_k's bookkeeping
+                const int k = B, kl = sKleft;
+                float pv_[PW_BEAM_K];
+                int pi_[PW_BEAM_K];
+                unsigned taken = 0u;
+                for (int rr_ = 0; rr_ < k; ++rr_) {
+                    float bv = -INFINITY;
+                    int bix = 0x7fffffff, bc = -1;
+                    for (int c = 0; c < k * PW_BEAM_K; ++c) {
+                        if ((taken >> c) & 1u) continue;
+                        if ((c % PW_BEAM_K) >= k) continue;
+                        const float v = sCand[c * 2];
+                        const int ix = __float_as_int(sCand[c * 2 + 1]);
+                        if (ix == 0x7fffffff) continue;
+                        if (v > bv || (v == bv && ix < bix) || bc < 0) { bv = v; bix = ix; bc = c; }
+                    }
+                    if (bc >= 0) taken |= 1u << bc;
+                    pv_[rr_] = bc >= 0 ? bv : -INFINITY;
+                    pi_[rr_] = bc >= 0 ? bix : 0x7fffffff;
+                }
+                int n_end = 0, c_arg = -1, slot = 0;
+                float c_best = -INFINITY;
+                bool live[PW_BEAM_K];
+                for (int rr_ = 0; rr_ < k; ++rr_) {
+                    const int flat = pi_[rr_];
+                    const bool okp = flat != 0x7fffffff && rr_ < kl;          // only the first k_left picks count
+                    const long long word = okp ? flat % V : 0;
+                    const bool is_end = okp && word == P.end_idx;
+                    live[rr_] = okp && !is_end;
+                    if (is_end) {
+                        ++n_end;
+                        if (pv_[rr_] > c_best) { c_best = pv_[rr_]; c_arg = rr_; }   // first maximum
+                    }
+                }
+                if (c_arg >= 0 && c_best > sBest) {
+                    sBest = c_best;
+                    if (wg == 0) {
+                        P.bm_best_score[0] = c_best;
+                        P.bm_best_word[0] = pi_[c_arg] % V;
+                        P.bm_result[0] = t;                              // pick index of the best completed hypothesis
+                        P.bm_result[1] = pi_[c_arg] / V;                 // its parent slot (numbering before this pick)
+                    }
+                }
+                sKleft = kl - n_end;
+                for (int pass = 0; pass < 2; ++pass)
+                    for (int rr_ = 0; rr_ < k; ++rr_) {
+                        if ((pass == 0) != live[rr_]) continue;
+                        const int flat = pi_[rr_];
+                        const int parent = flat != 0x7fffffff ? flat / V : 0;
+                        const long long word = flat != 0x7fffffff ? flat % V : 0;
+                        sScore[slot] = live[rr_] ? pv_[rr_] : -INFINITY;
+                        sTok[slot] = live[rr_] ? word : 0;
+                        sPar[slot] = parent;
+                        if (wg == 0) {
+                            P.bm_hist_par[t * PW_BEAM_K + slot] = parent;
+                            P.bm_hist_word[t * PW_BEAM_K + slot] = word;
+                        }
+                        ++slot;
+                    }
+                if (wg == 0) { P.bm_result[2] = sKleft; P.bm_result[3] = t + 1; }
+            }
+            PW_SYNC();
+            PD_STAMP(16);
+            if (sKleft == 0) break;                              // every hypothesis has ended (editnet.py:700-701)
             continue;
         }
         ++tag;                                                   // X6: triples
@@ -564,20 +774,24 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) editnet_persistent_wide_k(con
                 const int row = row0_ + i % P.rpw, bt_ = i / P.rpw;
                 if (row < V) P.predictions[(long long)(bt_ / P.max_len) * P.ld_pred_b + (long long)(bt_ % P.max_len) * V + row] = qnan;
             }
+        } else if (BEAM) {
+            if (wg == 0 && tid == 0) { P.bm_best_score[0] = qnan; P.bm_result[2] = -1; P.bm_result[3] = -1; }   // never a search result
         } else if (wg == 0) {
             for (int i = tid; i < B * P.max_len; i += PDEC_THREADS) { P.seq_logp[i] = qnan; P.seq[i] = 0; }
         }
     }
 }
 
-static int pwide_lds_floats(int B, int D, int A) {
-    return B * (D + 4) + 4 * 3 * 256 + PDW_MAXB * (PDEC_TMAX + 64 + 16 + 8 + 8) + B * 16 * PW_RS + B * 8 * PW_TS + 4 * A;
+static int pwide_lds_floats(int B, int D, int A, bool beam = false) {
+    const int base = B * (D + 4) + 4 * 3 * 256 + PDW_MAXB * (PDEC_TMAX + 64 + 16 + 8 + 8) + B * 16 * PW_RS + B * 8 * PW_TS + 4 * A;
+    return base + (beam ? B * (D / 4) * PW_BEAM_W + 4 * 256 + 2 * PW_BEAM_K * 4 + PW_BEAM_K * PW_BEAM_K * 2 : 0);
 }
 
 // [status line | h1 | attend_cap | c_new | h2 | projections | caption scores | visual scores | fc triples] as flag-in-data words
 size_t editnet_persistent_wide_xbytes(int B, int D, int A) {
     if (B > PDW_MAXB) return 0;
-    return 128 + (size_t)B * D * 8 * 4 + (size_t)B * 2 * A * 8 + (size_t)B * PDEC_TMAX * 8 + (size_t)B * 64 * 8 + (size_t)B * (D / 4) * 32;
+    return 128 + (size_t)B * D * 8 * 4 + (size_t)B * 2 * A * 8 + (size_t)B * PDEC_TMAX * 8 + (size_t)B * 64 * 8 + (size_t)B * (D / 4) * 32 +
+           (B <= PW_BEAM_K ? (size_t)B * (D / 4) * PW_BEAM_W * 8 : 0);       // + the beam mode's candidate words
 }
 
 bool editnet_persistent_wide_ok(int B, int D, int A, int T, int R, int V) {
@@ -592,13 +806,14 @@ bool editnet_persistent_wide_ok(int B, int D, int A, int T, int R, int V) {
     return true;
 }
 
-static int g_pwide_capacity[64] = {};
-static int g_pwide_capacity_lds[64] = {};
+static int g_pwide_capacity[2][64] = {};
+static int g_pwide_capacity_lds[2][64] = {};
 
-int editnet_persistent_wide_launch(PDecEditArgs& P, void* xbuf, PersistentGuard& guard, hipStream_t s, bool* unsupported) {
+int editnet_persistent_wide_launch(PDecEditArgs& P, void* xbuf, PersistentGuard& guard, hipStream_t s, bool* unsupported, bool beam) {
     *unsupported = true;
     const int B = P.B, D = P.D, A = P.A, G = D / 4;
     if (!editnet_persistent_wide_ok(B, D, A, P.T, P.R, P.V)) return SET_OK;
+    if (beam && (B > PW_BEAM_K || P.caps || (long long)B * P.V >= 0x7fffffffLL)) return SET_OK;
     {
         char* x = (char*)xbuf;
         P.status = (unsigned*)x; x += 128;
@@ -609,16 +824,18 @@ int editnet_persistent_wide_launch(PDecEditArgs& P, void* xbuf, PersistentGuard&
         P.x_a2 = x; x += (size_t)B * 2 * A * 8;
         P.x_cs = x; x += (size_t)B * PDEC_TMAX * 8;
         P.x_vs = x; x += (size_t)B * 64 * 8;
-        P.x_fc = x;
+        P.x_fc = x; x += (size_t)B * G * 32;
+        P.x_fcb = x;
     }
-    const void* kern = reinterpret_cast<const void*>(&editnet_persistent_wide_k);
-    const int lds = pwide_lds_floats(B, D, A) * (int)sizeof(float);
-    static bool configured[64] = {};
-    int lds_max = pwide_lds_floats(PDW_MAXB, D, A) * (int)sizeof(float);
+    const void* kern = beam ? reinterpret_cast<const void*>(&editnet_persistent_wide_k<true>)
+                            : reinterpret_cast<const void*>(&editnet_persistent_wide_k<false>);
+    const int lds = pwide_lds_floats(B, D, A, beam) * (int)sizeof(float);
+    static bool configured[2][64] = {};
+    int lds_max = pwide_lds_floats(beam ? PW_BEAM_K : PDW_MAXB, D, A, beam) * (int)sizeof(float);
     if (lds_max > 156 * 1024) lds_max = 156 * 1024;
-    if (guard.set_lds(kern, lds_max, configured) != SET_OK) return SET_OK;
-    int& cap = g_pwide_capacity[guard.dev];
-    int& cap_lds = g_pwide_capacity_lds[guard.dev];
+    if (lds > lds_max || guard.set_lds(kern, lds_max, configured[beam ? 1 : 0]) != SET_OK) return SET_OK;
+    int& cap = g_pwide_capacity[beam ? 1 : 0][guard.dev];
+    int& cap_lds = g_pwide_capacity_lds[beam ? 1 : 0][guard.dev];
     if (cap == 0 || lds > cap_lds) {
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, PDEC_THREADS, (size_t)lds) != hipSuccess ||
@@ -635,11 +852,12 @@ int editnet_persistent_wide_launch(PDecEditArgs& P, void* xbuf, PersistentGuard&
     if (G > cap) return SET_OK;
     *unsupported = false;
     const double wbytes = 4.0 * ((double)P.V * D + 5.0 * 4 * D * D + 3.0 * D * D + 2.0 * A * D);
-    ProfScope ps("persistent_decode", s, 2.0 * B * wbytes / 4.0 * P.max_len, wbytes * P.max_len);
+    ProfScope ps(beam ? "persistent_beam" : "persistent_decode", s, 2.0 * B * wbytes / 4.0 * P.max_len, wbytes * P.max_len);
     SET_TRY(guard.serialise(s));
     SET_HIP_TRY(hipMemsetAsync(xbuf, 0, editnet_persistent_wide_xbytes(B, D, A), s));    // no word of an earlier decode may carry a tag of this one
     SET_TRY(pd_stamps_begin(&P.stamps, &P.stamp_wg, s));
-    hipLaunchKernelGGL(editnet_persistent_wide_k, dim3(G), dim3(PDEC_THREADS), lds, s, P);
+    if (beam) hipLaunchKernelGGL(editnet_persistent_wide_k<true>, dim3(G), dim3(PDEC_THREADS), lds, s, P);
+    else hipLaunchKernelGGL(editnet_persistent_wide_k<false>, dim3(G), dim3(PDEC_THREADS), lds, s, P);
     SET_LAUNCH_CHECK();
     SET_TRY(guard.launched(s));
     SET_TRY(pd_stamps_report(P.stamps, P.stamp_wg, 16, P.max_len, s));

@@ -604,6 +604,27 @@ int set_editnet_greedy_begun(const SetEditNetWeights* w, const SetEditNetDims* d
                    stream, true);
 }
 
+int set_editnet_beam_persistent(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X, const float* image_mean,
+                                const int64_t* prev, const int64_t* prevlen, int64_t start_idx, int64_t end_idx, int max_picks,
+                                int32_t* hist_parent, int64_t* hist_word, float* best_score, int64_t* best_word,
+                                int32_t* result, void* ws, size_t ws_bytes, void* stream) {
+    if (!w || !d || !X || !prev || !prevlen || !hist_parent || !hist_word || !best_score || !best_word || !result || max_picks < 1)
+        return SET_ERR_ARG;
+    if (start_idx < 0 || start_idx >= d->V) return SET_ERR_ARG;
+    // (nothing is touched before the checks that can answer SET_ERR_UNSUPPORTED)
+    if (!(w->tok_table && (d->D % 64 == 0) && env_int("SET_NO_FUSED", 0) == 0)) return SET_ERR_UNSUPPORTED;
+    if (d->B > 4 || d->adaptive || !env_int("SET_DEC_PERSISTENT", 1) || persistent_disabled() ||
+        !editnet_persistent_wide_ok(d->B, d->D, d->A, d->T, d->R, d->V) || !editnet_persistent_ok(d, 1))
+        return SET_ERR_UNSUPPORTED;
+    EditNetWs W;
+    SET_TRY(prep(d, ws, ws_bytes, &W));
+    hipStream_t st = (hipStream_t)stream;
+    SET_TRY(begin_impl(w, d, X, image_mean, prev, prevlen, W, st));      // (includes Pv = X x2h[:, 2D:]^T: editnet_persistent_ok)
+    const PDecBeam beam{hist_parent, hist_word, best_score, best_word, result};
+    return editnet_persistent_greedy(w, d, W.pre1, W.att1, W.att1_c, W.mask, W.cap_proj, W.mem_proj, W.Mem, W.pd_pv, W.pd_x, W.it,
+                                     W.unfinished, W.alive, start_idx, end_idx, max_picks, nullptr, nullptr, st, nullptr, &beam);
+}
+
 int set_editnet_sample(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X, const float* image_mean,
                        const int64_t* prev, const int64_t* prevlen, int64_t start_idx, int64_t end_idx, int max_len,
                        uint64_t seed, uint64_t offset, int64_t* seq, float* seq_logp, void* ws, size_t ws_bytes,

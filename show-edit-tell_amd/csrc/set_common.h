@@ -152,6 +152,7 @@ int persistent_encoder(const float* w_hh, const float* xg, long long ld_xg_row, 
                        int B, int D, int T, hipStream_t s);
 
 struct PDecTeacher { const int64_t* caps; long long caps_stride; float* predictions; const int* host_decode_lengths; };   // teacher-forced mode
+struct PDecBeam { int* hist_par; int64_t* hist_word; float* best_score; int64_t* best_word; int* result; };                // beam mode (one image, rows = hypotheses)
 // decode_persistent.hip: the greedy loop of a small batch as one launch with grid barriers
 constexpr int PDEC_MAXB = 8;          // rows of the <= 8-row persistent decode kernels
 constexpr int PDW_MAXB = 16;          // rows of the wide EditNet variant (decode_persistent_wide.hip): one full 16-row MFMA tile
@@ -164,11 +165,13 @@ int dcnet_persistent_greedy(const SetDcnetWeights* w, const SetDcnetDims* d, con
 
 size_t editnet_persistent_xbytes(int B, int D, int A);
 bool editnet_persistent_ok(const SetEditNetDims* d, int max_len);
+bool editnet_persistent_wide_ok(int B, int D, int A, int T, int R, int V);    // decode_persistent_wide.hip
+bool persistent_disabled();                                                   // encoder_persistent.hip: a persistent launch timed out earlier
 int editnet_persistent_greedy(const SetEditNetWeights* w, const SetEditNetDims* d, const float* pre1, const float* att1,
                               const float* att1_c, const float* mask, const float* capP, const float* memQ, const float* Mem,
                               const float* pv, void* xbuf, long long* it, int* unfinished, int* alive, long long start_idx,
                               long long end_idx, int max_len, long long* seq, float* seq_logp, hipStream_t s,
-                              const PDecTeacher* teach = nullptr);
+                              const PDecTeacher* teach = nullptr, const PDecBeam* beam = nullptr);
 
 // a per-row gathered addend: value(m, n) = tab[ids[m*id_stride]*ld + col0 + n]   (tab == NULL: none)
 struct RowGather {

@@ -61,6 +61,47 @@ __global__ void __launch_bounds__(256) dropout_bwd_philox_k(const float* dy, lon
     *reinterpret_cast<f32x4*>(o) = v;
 }
 
+// The same dropout of ONE operand for `steps` timesteps in one launch: y[t] = dropout(x) with the counters of timestep t
+// (offset + t: rng.offset(site, t) keeps t in the low bits), bit for bit what `steps` launches of dropout_k write.  The
+// region embedding of the train-mode forward (editnet.py:441, fresh mask per timestep) is the caller: 19 launches of
+// 10 us become one that is bound by its 358 MB of stores.
+__global__ void __launch_bounds__(256) dropout_steps_k(const float* x, long long ldx, float* y, long long ldy, long long y_step,
+                                                       int rows, int cols4, int steps, float p, float scale,
+                                                       unsigned long long seed, unsigned long long offset) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)rows * cols4) return;
+    const int r = (int)(i / cols4), c = (int)(i - (long long)r * cols4);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + 4 * c);
+    for (int t = 0; t < steps; ++t) {
+        const unsigned long long off = offset + (unsigned long long)t;
+        uint32_t k[4] = {(uint32_t)r, (uint32_t)c, (uint32_t)off, (uint32_t)(off >> 32)};
+        philox4x32_10(k, (uint32_t)seed, (uint32_t)(seed >> 32));
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = ((float)(k[e] >> 8) * (1.0f / 16777216.0f) >= p) ? v[e] * scale : 0.f;
+        *reinterpret_cast<f32x4*>(y + (long long)t * y_step + r * ldy + 4 * c) = o;
+    }
+}
+
+// dx (+)= sum_t dy[t] * (y[t] != 0 ? scale : 0), t ascending: what `steps` accumulating launches of dropout_bwd_k leave in
+// dx, bit for bit, with dx read and written once
+__global__ void __launch_bounds__(256) dropout_bwd_steps_k(const float* dy, long long lddy, long long dy_step, const float* y,
+                                                           long long ldy, long long y_step, float* dx, long long ldx, int rows,
+                                                           int cols4, int steps, float scale, int accumulate) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)rows * cols4) return;
+    const int r = (int)(i / cols4), c = (int)(i - (long long)r * cols4);
+    float* o = dx + r * ldx + 4 * c;
+    f32x4 v = accumulate ? *reinterpret_cast<const f32x4*>(o) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < steps; ++t) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dy + (long long)t * dy_step + r * lddy + 4 * c);
+        const f32x4 yy = *reinterpret_cast<const f32x4*>(y + (long long)t * y_step + r * ldy + 4 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += yy[e] != 0.f ? g[e] * scale : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(o) = v;
+}
+
 // EmbeddingC.forward in train mode (editnet.py:299-302): relu(table[ids]) followed by the dropout of dropout_k (same
 // counters: the result equals set_embed_relu_f32 + set_dropout_f32 in place), one launch
 __global__ void __launch_bounds__(256) embed_relu_dropout_k(const float* table, const int64_t* ids, long long ids_stride,
@@ -141,6 +182,33 @@ int set_dropout_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int rows
     hipLaunchKernelGGL(dropout_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)ldx, y,
                        (long long)ldy, rows, cols >> 2, p, 1.0f / (1.0f - p), (unsigned long long)seed,
                        (unsigned long long)offset);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+int set_dropout_steps_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t y_step, int rows, int cols, int steps,
+                          float p, uint64_t seed, uint64_t offset, void* stream) {
+    if (!x || !y || rows <= 0 || cols <= 0 || steps <= 0 || !(p >= 0.f) || !(p < 1.f)) return SET_ERR_ARG;
+    if ((cols & 3) || (ldx & 3) || (ldy & 3) || (y_step & 3) || !aligned16(x) || !aligned16(y)) return SET_ERR_UNSUPPORTED;
+    const long long n = (long long)rows * (cols >> 2);
+    hipLaunchKernelGGL(dropout_steps_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)ldx, y,
+                       (long long)ldy, (long long)y_step, rows, cols >> 2, steps, p, 1.0f / (1.0f - p), (unsigned long long)seed,
+                       (unsigned long long)offset);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+int set_dropout_bwd_steps_f32(const float* dy, int64_t lddy, int64_t dy_step, const float* y, int64_t ldy, int64_t y_step,
+                              float* dx, int64_t ldx, int rows, int cols, int steps, float scale, int accumulate,
+                              void* stream) {
+    if (!dy || !y || !dx || rows <= 0 || cols <= 0 || steps <= 0) return SET_ERR_ARG;
+    if ((cols & 3) || (lddy & 3) || (ldy & 3) || (ldx & 3) || (dy_step & 3) || (y_step & 3) || !aligned16(dy) || !aligned16(y) ||
+        !aligned16(dx))
+        return SET_ERR_UNSUPPORTED;
+    const long long n = (long long)rows * (cols >> 2);
+    hipLaunchKernelGGL(dropout_bwd_steps_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy,
+                       (long long)lddy, (long long)dy_step, y, (long long)ldy, (long long)y_step, dx, (long long)ldx, rows,
+                       cols >> 2, steps, scale, accumulate);
     SET_LAUNCH_CHECK();
     return SET_OK;
 }

@@ -209,7 +209,66 @@ def beam_search_ensemble_batched(decoder, dae, image_features, previous_caption,
 # eval_full.py:96-109) -> (token list incl. <start>/<end>, score of the chosen hypothesis; NaN if the
 # 50-step limit was hit).  NI = 1 case of the batched on-device search above.
 # ------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def _beam_search_editnet_persistent(decoder, image_features, previous_caption, prev_caplen, word_map, beam_size, max_steps=50):
+    """ONE image, k <= 4: prologue + one persistent launch for the whole search (include/set_hip.h
+    set_editnet_beam_persistent; the rows of the launch are the k hypotheses).  Returns None when the library answers
+    SET_ERR_UNSUPPORTED (no token table yet, k > 4, dimensions outside the persistent launch): the caller takes the
+    per-step search."""
+    import ctypes as C
+    from . import _lib
+    from ._lib import check, ptr, stream_of
+    k = int(beam_size)
+    if k < 1 or k > 4 or image_features.shape[0] != 1 or getattr(decoder, "_adaptive", 0):
+        return None
+    decoder.eval()
+    lib = _lib.load()
+    dev = image_features.device
+    X = image_features.float().expand(k, -1, -1).contiguous()
+    prev = previous_caption.long().expand(k, -1).contiguous()
+    plen = prev_caplen.reshape(-1).long().expand(k).contiguous()
+    picks = max_steps + 1
+    dims = decoder._dims(k, prev.shape[1], X.shape[1], picks)
+    w = decoder._weights(dims)
+    if not w.tok_table:
+        return None
+    ws = decoder._workspace(dims)
+    hist_par = torch.empty(picks, 4, dtype=torch.int32, device=dev)
+    hist_word = torch.empty(picks, 4, dtype=torch.long, device=dev)
+    best_score = torch.empty(1, dtype=torch.float32, device=dev)
+    best_word = torch.empty(1, dtype=torch.long, device=dev)
+    result = torch.empty(4, dtype=torch.int32, device=dev)
+    rc = lib.set_editnet_beam_persistent(C.byref(w), C.byref(dims), ptr(X), None, ptr(prev), ptr(plen), int(word_map['<start>']),
+                                         int(word_map['<end>']), picks, ptr(hist_par), ptr(hist_word), ptr(best_score),
+                                         ptr(best_word), ptr(result), ptr(ws), ws.numel(), stream_of(dev))
+    if rc == 2:                                                    # SET_ERR_UNSUPPORTED: nothing was touched
+        return None
+    check(rc, "set_editnet_beam_persistent")
+    best_t, best_parent, k_left, made = (int(v) for v in result.cpu())      # the search's only host synchronisation
+    if made < 0:
+        raise _lib.SetError("set_editnet_beam_persistent: the persistent launch timed out (result poisoned)")
+    hp, hw = hist_par[:made].cpu().numpy(), hist_word[:made].cpu().numpy()
+
+    def trace(t_last, slot):
+        out = []
+        for t in range(t_last, -1, -1):
+            out.append(int(hw[t, slot]))
+            slot = int(hp[t, slot])
+        return out[::-1]
+
+    start = int(word_map['<start>'])
+    if k_left > 0:                                                 # ran into the step limit (editnet.py:702-704,711)
+        return ([start] + trace(made - 1, 0))[:18], float("nan")
+    return [start] + trace(best_t - 1, best_parent) + [int(best_word.item())], float(best_score.item())
+
+
 def beam_search_editnet(decoder, image_features, previous_caption, prev_caplen, word_map, beam_size=3):
+    """The reference's own calling convention, ONE image per call (editnet.py:601-613).  k <= 4 with the token table
+    active: one persistent launch (csrc/decode_persistent_wide.hip, beam mode); otherwise the NI = 1 case of the batched
+    search."""
+    one = _beam_search_editnet_persistent(decoder, image_features, previous_caption, prev_caplen, word_map, beam_size)
+    if one is not None:
+        return one
     seqs, scores = beam_search_editnet_batched(decoder, image_features, previous_caption, prev_caplen, word_map,
                                                beam_size, return_scores=True)
     return seqs[0], scores[0]

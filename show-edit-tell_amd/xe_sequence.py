@@ -252,9 +252,12 @@ class _XESequence(torch.autograd.Function):
         # rows keep the per-step products over the live rows only.
         att1_hoisted = train and sum(bts) >= _ATT1_HOIST_LIVE * T * B
         if train:
-            for t in range(T):
-                rows_t = B if att1_hoisted else bts[t]
-                ops.dropout(Yin.view(B * R, D), L["FE"][t].view(B * R, D), rows_t * R, D, cfg.p_region, cfg.seed, scale_off(2, t))
+            if att1_hoisted:               # every row of every timestep: ONE launch (set_dropout_steps_f32 == T launches, bit for bit)
+                check(lib.set_dropout_steps_f32(Yin.data_ptr(), D, L["FE"].data_ptr(), D, B * R * D, B * R, D, T, cfg.p_region,
+                                                cfg.seed, scale_off(2, 0), st), "set_dropout_steps_f32")
+            else:
+                for t in range(T):
+                    ops.dropout(Yin.view(B * R, D), L["FE"][t].view(B * R, D), bts[t] * R, D, cfg.p_region, cfg.seed, scale_off(2, t))
             if att1_hoisted:
                 ops.linear(L["FE"].view(T * B * R, D), P["va_fa_w"], P["va_fa_b"], L["ATT1"].view(T * B * R, Adim), T * B * R)
 
@@ -548,8 +551,12 @@ class _XESequence(torch.autograd.Function):
         # instead of a read-modify-write of all of dH in every timestep
         if dfe_after:                      # rows of finished sequences are zero in DATT1, hence in DFE
             DFE = A.gemm(DATT1.view(T * B * R, Adim), False, P["va_fa_w"], True, T * B * R, D, Adim).view(T, B * R, D)
-            for t in range(T):
-                ops.dropout_bwd(DFE[t], L["FE"][t].view(B * R, D), dYin.view(B * R, D), bts[t] * R, D, sc_reg, True)
+            if min(bts) == B:              # all rows live at every timestep: the T accumulating launches as one (same sums, same order)
+                check(lib.set_dropout_bwd_steps_f32(DFE.data_ptr(), D, B * R * D, L["FE"].data_ptr(), D, B * R * D, dYin.data_ptr(), D,
+                                                    B * R, D, T, sc_reg, 1, st), "set_dropout_bwd_steps_f32")
+            else:
+                for t in range(T):
+                    ops.dropout_bwd(DFE[t], L["FE"][t].view(B * R, D), dYin.view(B * R, D), bts[t] * R, D, sc_reg, True)
             del DFE
         if _DEMB_HOIST:
             # d emb[t] = [dz | dt](t) . [gate_w[:, :D]; tc_w[:, :D]] + dgates1(t) . W_ih[:, :D] is consumed by nothing inside the

@@ -136,6 +136,42 @@ def test_dropout_kernels():
     assert lib.set_dropout_f32(x.data_ptr(), cols, y.data_ptr(), cols, rows, cols, 1.0, 1, 0, st) == 1      # SET_ERR_ARG
 
 
+def test_dropout_steps_kernels_equal_per_step_launches():
+    """set_dropout_steps_f32 / set_dropout_bwd_steps_f32 (all timesteps of the region dropout in one launch) are bit for bit
+    the per-timestep launches they replace: same counters (offset + t), same accumulation order over t."""
+    from show_edit_tell_amd import _lib, rng
+    lib, dev = _lib.load(), _dev()
+    st = _lib.stream_of(dev)
+    rows, cols, T, p, seed = 36 * 7, 256, 5, 0.5, 991
+    x = torch.relu(torch.randn(rows, cols, device=dev))
+    off0 = rng.offset(rng.SITE_REGION, 0)
+    ys = torch.empty(T, rows, cols, device=dev)
+    _lib.check(lib.set_dropout_steps_f32(x.data_ptr(), cols, ys.data_ptr(), cols, rows * cols, rows, cols, T, p, seed, off0, st),
+               "set_dropout_steps_f32")
+    ref = torch.empty_like(ys)
+    for t in range(T):
+        _lib.check(lib.set_dropout_f32(x.data_ptr(), cols, ref[t].data_ptr(), cols, rows, cols, p, seed,
+                                       rng.offset(rng.SITE_REGION, t), st), "set_dropout_f32")
+    assert torch.equal(ys, ref)
+    assert not torch.equal(ys[0], ys[1])
+    dy = torch.randn(T, rows, cols, device=dev)
+    dx = torch.randn(rows, cols, device=dev)
+    dx_ref = dx.clone()
+    _lib.check(lib.set_dropout_bwd_steps_f32(dy.data_ptr(), cols, rows * cols, ys.data_ptr(), cols, rows * cols, dx.data_ptr(), cols,
+                                             rows, cols, T, 2.0, 1, st), "set_dropout_bwd_steps_f32")
+    for t in range(T):
+        _lib.check(lib.set_dropout_bwd_f32(dy[t].data_ptr(), cols, ys[t].data_ptr(), cols, dx_ref.data_ptr(), cols, rows, cols,
+                                           2.0, 1, st), "set_dropout_bwd_f32")
+    assert torch.equal(dx, dx_ref)
+    _lib.check(lib.set_dropout_bwd_steps_f32(dy.data_ptr(), cols, rows * cols, ys.data_ptr(), cols, rows * cols, dx.data_ptr(), cols,
+                                             rows, cols, T, 2.0, 0, st), "set_dropout_bwd_steps_f32")
+    dx_ref.zero_()
+    for t in range(T):
+        _lib.check(lib.set_dropout_bwd_f32(dy[t].data_ptr(), cols, ys[t].data_ptr(), cols, dx_ref.data_ptr(), cols, rows, cols,
+                                           2.0, 1, st), "set_dropout_bwd_f32")
+    assert torch.equal(dx, dx_ref)
+
+
 def test_pack_rows():
     from show_edit_tell_amd import _lib
     lib, dev = _lib.load(), _dev()

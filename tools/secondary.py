@@ -200,8 +200,31 @@ def beam(dev, images=128, k=3):
     prev, plen = (torch.from_numpy(x).to(dev) for x in synth.prev_captions(31, images, T, V, 5))
     t_e, seqs = _timed(lambda: evaluate.beam_search_editnet_batched(dec, X, prev, plen, wm, k), 3, 2)   # 2 warm-ups: the token tables are built on the second call
     t_x, _ = _timed(lambda: evaluate.beam_search_ensemble_batched(dec, dae, X, prev, plen, wm, k), 3, 2)
+    # the reference's own evaluate() shape: ONE image per call (editnet.py:601-613).  Persistent launch in beam mode vs the
+    # per-step search (SET_DEC_PERSISTENT=0), 16 images each after two warm-up calls (token table, workspaces)
+    import os
+
+    def per_image():
+        for i in range(2):
+            evaluate.beam_search_editnet(dec, X[i:i + 1], prev[i:i + 1], plen[i:i + 1], wm, k)
+        t, out = _timed(lambda: [evaluate.beam_search_editnet(dec, X[i:i + 1], prev[i:i + 1], plen[i:i + 1], wm, k) for i in range(16)], 2, 1)
+        return t / 16, out
+    t_one, out_one = per_image()
+    old = os.environ.get("SET_DEC_PERSISTENT")
+    os.environ["SET_DEC_PERSISTENT"] = "0"
+    try:
+        t_one_steps, out_steps = per_image()
+    finally:
+        if old is None:
+            del os.environ["SET_DEC_PERSISTENT"]
+        else:
+            os.environ["SET_DEC_PERSISTENT"] = old
+    same = sum(int(a[0] == b[0]) for a, b in zip(out_one, out_steps))
     return {"workload": "beam search k=%d over %d images at once (editnet.py:595-718, eval_full.py:88-218)" % (k, images),
             "editnet_ms": round(1e3 * t_e, 2), "ensemble_ms": round(1e3 * t_x, 2),
+            "editnet_one_image_per_call_ms": round(1e3 * t_one, 3), "editnet_one_image_per_call_per_step_kernels_ms": round(1e3 * t_one_steps, 3),
+            "one_image_per_call_same_tokens": "%d of 16" % same,
+            "one_image_per_call_mean_len": round(float(np.mean([len(o[0]) for o in out_one])), 2),
             "images_per_sec_editnet": round(images / t_e, 1), "mean_caption_len": round(float(np.mean([len(s) for s in seqs])), 2)}
 
 
