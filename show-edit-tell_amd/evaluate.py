@@ -233,21 +233,26 @@ def _beam_search_editnet_persistent(decoder, image_features, previous_caption, p
     if not w.tok_table:
         return None
     ws = decoder._workspace(dims)
-    hist_par = torch.empty(picks, 4, dtype=torch.int32, device=dev)
-    hist_word = torch.empty(picks, 4, dtype=torch.long, device=dev)
-    best_score = torch.empty(1, dtype=torch.float32, device=dev)
-    best_word = torch.empty(1, dtype=torch.long, device=dev)
-    result = torch.empty(4, dtype=torch.int32, device=dev)
+    # every output of the launch in ONE device buffer: [hist_word (picks, 4) i64 | best_word i64 | hist_parent (picks, 4) i32 |
+    # result (4) i32 | best_score f32], read back with a single copy (the search's only host synchronisation)
+    n_hw, n_hp = picks * 4 * 8, picks * 4 * 4
+    buf = torch.empty(n_hw + 8 + n_hp + 16 + 8, dtype=torch.uint8, device=dev)
+    o_bw, o_hp, o_res, o_bs = n_hw, n_hw + 8, n_hw + 8 + n_hp, n_hw + 8 + n_hp + 16
+    base = buf.data_ptr()
     rc = lib.set_editnet_beam_persistent(C.byref(w), C.byref(dims), ptr(X), None, ptr(prev), ptr(plen), int(word_map['<start>']),
-                                         int(word_map['<end>']), picks, ptr(hist_par), ptr(hist_word), ptr(best_score),
-                                         ptr(best_word), ptr(result), ptr(ws), ws.numel(), stream_of(dev))
+                                         int(word_map['<end>']), picks, base + o_hp, base, base + o_bs, base + o_bw, base + o_res,
+                                         ptr(ws), ws.numel(), stream_of(dev))
     if rc == 2:                                                    # SET_ERR_UNSUPPORTED: nothing was touched
         return None
     check(rc, "set_editnet_beam_persistent")
-    best_t, best_parent, k_left, made = (int(v) for v in result.cpu())      # the search's only host synchronisation
+    host = buf.cpu().numpy()
+    hw = host[:n_hw].view("int64").reshape(picks, 4)
+    hp = host[o_hp:o_hp + n_hp].view("int32").reshape(picks, 4)
+    best_t, best_parent, k_left, made = (int(v) for v in host[o_res:o_res + 16].view("int32"))
+    best_word_h = int(host[o_bw:o_bw + 8].view("int64")[0])
+    best_score_h = float(host[o_bs:o_bs + 4].view("float32")[0])
     if made < 0:
         raise _lib.SetError("set_editnet_beam_persistent: the persistent launch timed out (result poisoned)")
-    hp, hw = hist_par[:made].cpu().numpy(), hist_word[:made].cpu().numpy()
 
     def trace(t_last, slot):
         out = []
@@ -259,7 +264,7 @@ def _beam_search_editnet_persistent(decoder, image_features, previous_caption, p
     start = int(word_map['<start>'])
     if k_left > 0:                                                 # ran into the step limit (editnet.py:702-704,711)
         return ([start] + trace(made - 1, 0))[:18], float("nan")
-    return [start] + trace(best_t - 1, best_parent) + [int(best_word.item())], float(best_score.item())
+    return [start] + trace(best_t - 1, best_parent) + [best_word_h], best_score_h
 
 
 def beam_search_editnet(decoder, image_features, previous_caption, prev_caplen, word_map, beam_size=3):

@@ -204,16 +204,22 @@ def beam(dev, images=128, k=3):
     # per-step search (SET_DEC_PERSISTENT=0), 16 images each after two warm-up calls (token table, workspaces)
     import os
 
-    def per_image():
+    def per_image(model=None):
+        model = dec if model is None else model
         for i in range(2):
-            evaluate.beam_search_editnet(dec, X[i:i + 1], prev[i:i + 1], plen[i:i + 1], wm, k)
-        t, out = _timed(lambda: [evaluate.beam_search_editnet(dec, X[i:i + 1], prev[i:i + 1], plen[i:i + 1], wm, k) for i in range(16)], 2, 1)
+            evaluate.beam_search_editnet(model, X[i:i + 1], prev[i:i + 1], plen[i:i + 1], wm, k)
+        t, out = _timed(lambda: [evaluate.beam_search_editnet(model, X[i:i + 1], prev[i:i + 1], plen[i:i + 1], wm, k) for i in range(16)], 2, 1)
         return t / 16, out
     t_one, out_one = per_image()
+    # the same with captions that END (a larger <end> bias: searches finish after ~10 picks instead of running into the
+    # reference's 50-step limit, which every search of the model above does)
+    dec_short = _editnet(editnet.DecoderC, dev, wm, end_boost=5.5).eval()
+    t_short, out_short = per_image(dec_short)
     old = os.environ.get("SET_DEC_PERSISTENT")
     os.environ["SET_DEC_PERSISTENT"] = "0"
     try:
         t_one_steps, out_steps = per_image()
+        t_short_steps, _ = per_image(dec_short)
     finally:
         if old is None:
             del os.environ["SET_DEC_PERSISTENT"]
@@ -225,6 +231,11 @@ def beam(dev, images=128, k=3):
             "editnet_one_image_per_call_ms": round(1e3 * t_one, 3), "editnet_one_image_per_call_per_step_kernels_ms": round(1e3 * t_one_steps, 3),
             "one_image_per_call_same_tokens": "%d of 16" % same,
             "one_image_per_call_mean_len": round(float(np.mean([len(o[0]) for o in out_one])), 2),
+            "one_image_per_call_searches_at_step_limit": "%d of 16" % sum(int(np.isnan(o[1])) for o in out_one),
+            "editnet_one_image_per_call_ending_captions_ms": round(1e3 * t_short, 3),
+            "editnet_one_image_per_call_ending_captions_per_step_kernels_ms": round(1e3 * t_short_steps, 3),
+            "ending_captions_mean_len": round(float(np.mean([len(o[0]) for o in out_short])), 2),
+            "ending_captions_searches_at_step_limit": "%d of 16" % sum(int(np.isnan(o[1])) for o in out_short),
             "images_per_sec_editnet": round(images / t_e, 1), "mean_caption_len": round(float(np.mean([len(s) for s in seqs])), 2)}
 
 
