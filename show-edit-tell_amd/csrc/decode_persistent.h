@@ -1,4 +1,4 @@
-// Shared pieces of the persistent small-batch decode kernels (decode_persistent.hip: DCNet, decode_persistent_editnet.hip:
+// Shared pieces of the persistent small-batch decode kernels (decode_persistent.hip: DCNet, decode_persistent_wide.hip:
 // EditNet): constants, the MFMA GEMV tile helpers and the diagnostic time stamps.
 #pragma once
 #include <cstdio>
@@ -11,8 +11,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef const f32x4 __attribute__((address_space(1)))* gptr4;
 
-// (PDEC_MAXB = 16 batch rows, set_common.h: one 16-row MFMA tile)
-constexpr int PDEC_TREG = 20;      // ... of which a wave keeps the hoisted attention rows of ONE batch row in registers (B <= 4)
+// (set_common.h: PDEC_MAXB = 8 rows in the DCNet kernel, PDW_MAXB = 16 — one full 16-row MFMA tile — in the EditNet kernel)
+constexpr int PDEC_TREG = 20;      // DCNet, B <= 4: previous-caption positions whose hoisted attention rows a wave keeps in registers
 constexpr int PDEC_TMAX = 32;      // previous-caption positions held in registers by the Pc gather
 constexpr int PDEC_KB = 16;        // 16-wide k-blocks per wave and gate tile: D = 1024 -> K quarter 256
 constexpr int PDEC_THREADS = 256;
@@ -67,6 +67,51 @@ __device__ __forceinline__ float pd_wmax(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
 }
+
+// ---- wave reductions on DPP: quad swaps, half-row mirror, row mirror leave every lane of a 16-lane row with the row's
+// result; the four rows are then combined in a fixed order from four v_readlane
+template <int CTRL>
+__device__ __forceinline__ float pw_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int pw_dppi(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ float pw_lane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+__device__ __forceinline__ float pw_wsum(float v) {
+    v += pw_dpp<0xB1>(v);            // quad_perm [1,0,3,2]
+    v += pw_dpp<0x4E>(v);            // quad_perm [2,3,0,1]
+    v += pw_dpp<0x141>(v);           // row_half_mirror
+    v += pw_dpp<0x140>(v);           // row_mirror
+    return ((pw_lane(v, 0) + pw_lane(v, 16)) + pw_lane(v, 32)) + pw_lane(v, 48);
+}
+__device__ __forceinline__ float pw_wmax(float v) {
+    v = fmaxf(v, pw_dpp<0xB1>(v));
+    v = fmaxf(v, pw_dpp<0x4E>(v));
+    v = fmaxf(v, pw_dpp<0x141>(v));
+    v = fmaxf(v, pw_dpp<0x140>(v));
+    return fmaxf(fmaxf(pw_lane(v, 0), pw_lane(v, 16)), fmaxf(pw_lane(v, 32), pw_lane(v, 48)));
+}
+// (largest value, smallest index among equals): torch.max's first-index rule; a NaN never wins a comparison
+__device__ __forceinline__ void pw_wargmax(float& best, int& bi) {
+#define PW_STEP(CTRL)                                                                  \
+    {                                                                                  \
+        const float ob = pw_dpp<CTRL>(best);                                           \
+        const int oi = pw_dppi<CTRL>(bi);                                              \
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }              \
+    }
+    PW_STEP(0xB1) PW_STEP(0x4E) PW_STEP(0x141) PW_STEP(0x140)
+#undef PW_STEP
+    float b = pw_lane(best, 0);
+    int i = __builtin_amdgcn_readlane(bi, 0);
+#pragma unroll
+    for (int l = 16; l < 64; l += 16) {
+        const float ob = pw_lane(best, l);
+        const int oi = __builtin_amdgcn_readlane(bi, l);
+        if (ob > b || (ob == b && oi < i)) { b = ob; i = oi; }
+    }
+    best = b; bi = i;
+}
+
 
 template <int KB>
 __device__ __forceinline__ void pd_load(f32x4 (&w)[KB], const float* p) {

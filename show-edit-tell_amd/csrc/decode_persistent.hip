@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
     f32x4 wa[PDEC_KB], wb[PDEC_KB];
     // loop-invariant operands of the attention phase: the hoisted context products of this thread's gate row ...
     if (gcol)
-        for (int tt = 0; tt < PDEC_TMAX; ++tt) sPc[tid * PDEC_TMAX + tt] = tt < T ? P.pc[((long long)cb * T + tt) * 4 * D + ccol] : 0.f;
+        for (int tt = 0; tt < PDEC_TMAX; ++tt) sPc[tid * (PDEC_TMAX + 1) + tt] = tt < T ? P.pc[((long long)cb * T + tt) * 4 * D + ccol] : 0.f;
     __syncthreads();
     // ... and (RES) this wave's row of cap_features_att
     f32x4 a1r[RES ? PDEC_TREG : 1][2];
@@ -264,15 +264,15 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
                     // masked position (or past T): its score is -1e10 whatever it is.  Not in the resident variant: a branch here makes
                     // the compiler wait for fc's tile (requested above to stream under this arithmetic) before the first score
                     if (!RES && !((live >> tt) & 1ull)) continue;
-                    const float sc = pd_wsum(pd_score8(v[u][0] + a2[0], v[u][1] + a2[1], wf[0], wf[1]));
+                    const float sc = pw_wsum(pd_score8(v[u][0] + a2[0], v[u][1] + a2[1], wf[0], wf[1]));
                     if (lane == tt) mine = sc;
                 }
             }
             // masked softmax over the T <= 32 scores inside the wave (one score per lane)
             const float sc = lane < T ? ((mk == 0.f) ? -1e10f : (mine + bf)) : -INFINITY;
-            const float m = pd_wmax(sc);
+            const float m = pw_wmax(sc);
             const float ex = lane < T ? expf(sc - m) : 0.f;
-            const float sum = pd_wsum(ex);
+            const float sum = pw_wsum(ex);
             if (lane < T) sAl[b * PDEC_TMAX + lane] = ex / sum;
         };
         if constexpr (RES) { if (kq < B) attend(kq); }
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
         PD_STAMP(7);
         if (gcol) {
             float s = 0.f;
-            for (int tt = 0; tt < T; ++tt) s += sAl[cb * PDEC_TMAX + tt] * sPc[tid * PDEC_TMAX + tt];
+            for (int tt = 0; tt < T; ++tt) s += sAl[cb * PDEC_TMAX + tt] * sPc[tid * (PDEC_TMAX + 1) + tt];
             sG[cb * 16 + crr] = (g2 + s) + b2;
         }
         __syncthreads();
@@ -347,16 +347,11 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
                 float best = -INFINITY;
                 int bi = 0x7fffffff;
                 if (x > best) { best = x; bi = row; }
-    #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float ob = __shfl_xor(best, o);
-                    const int oi = __shfl_xor(bi, o);
-                    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-                }
+                    pw_wargmax(best, bi);
                 // (a NaN score never wins a comparison: it reaches the sum instead and the row's log-prob is NaN)
                 float se = ok ? expf(x - best) : 0.f;
                 if (best == -INFINITY) se = ok ? x : 0.f;            // no finite score here: 0 for an empty range, NaN for NaN scores
-                se = pd_wsum(se);
+                se = pw_wsum(se);
                 if (lane < 4) ll_put(fcrs, (b * G + wg) * 4 + lane, lane == 0 ? best : (lane == 1 ? __int_as_float(bi) : (lane == 2 ? se : 0.f)), tag);
             };
             if constexpr (RES) { if (kq < B) row_work(kq); }
@@ -394,15 +389,10 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
     #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (pm[i] > best || (pm[i] == best && pi[i] < bi)) { best = pm[i]; bi = pi[i]; }
-    #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float ob = __shfl_xor(best, o);
-                    const int oi = __shfl_xor(bi, o);
-                    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-                }
+                    pw_wargmax(best, bi);
     #pragma unroll
                 for (int i = 0; i < 4; ++i) tot += (pm[i] == -INFINITY) ? ps[i] : ps[i] * expf(pm[i] - best);
-                tot = pd_wsum(tot);
+                tot = pw_wsum(tot);
                 if (lane == 0) {
                     float logp = (best - best) - logf(tot);           // log_softmax at the arg-max, as greedy_pick_k writes it
                     if (bi == 0x7fffffff) { bi = 0; logp = __builtin_nanf(""); }   // all-NaN row: word 0 and a NaN log-prob
@@ -453,7 +443,7 @@ __global__ void __launch_bounds__(PDEC_THREADS, 1) dcnet_persistent_k(const PDec
 static int g_pdec_capacity[64][2] = {};
 static int g_pdec_capacity_lds[64][2] = {};
 static int pdec_lds_floats(int B, int D, int A) {
-    return 2 * B * (D + 4) + 4 * 3 * 256 + PDEC_MAXB * PDEC_TMAX + PDEC_MAXB * 16 + B * A + B * (D / 4) * 4 + 2 * A + B * 16 * PDEC_TMAX;
+    return 2 * B * (D + 4) + 4 * 3 * 256 + PDEC_MAXB * PDEC_TMAX + PDEC_MAXB * 16 + B * A + B * (D / 4) * 4 + 2 * A + B * 16 * (PDEC_TMAX + 1);
 }
 
 

@@ -1,5 +1,5 @@
-// Persistent greedy decode of EditNet for 5 .. 16 rows (editnet_rl.py:485-549): ONE launch of D / 4 workgroups for the whole
-// free-running loop, the construction of decode_persistent_editnet.hip (a workgroup OWNS four hidden units, streams their
+// Persistent greedy decode of EditNet for 1 .. 16 rows (editnet_rl.py:485-549): ONE launch of D / 4 workgroups for the whole
+// free-running loop, the construction of decode_persistent.hip (DCNet) (a workgroup OWNS four hidden units, streams their
 // weight rows as B operands of v_mfma_f32_16x16x4_f32 — the tile has 16 batch rows, all of them used here — and finishes every
 // pointwise stage itself; what other workgroups need travels as flag-in-data words, grid_barrier.h) re-cut for the things
 // that grow with the batch:
@@ -44,50 +44,6 @@ constexpr int PW_BEAM_K = 4;       // beam mode: hypotheses (= rows) at most
 constexpr int PW_BEAM_W = 12;      // ... words a workgroup publishes per row: max, sum exp, 4 x (value, index), 2 pads
 constexpr int PW_RS = PDEC_RREG + 1;   // row strides of the hoisted-product tables in LDS: odd, so that the (thread, index) gathers
 constexpr int PW_TS = PDEC_TMAX + 1;   // of 256 threads spread over all banks
-
-// ---- wave reductions on DPP: quad swaps, half-row mirror, row mirror leave every lane of a 16-lane row with the row's
-// result; the four rows are then combined in a fixed order from four v_readlane
-template <int CTRL>
-__device__ __forceinline__ float pw_dpp(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
-template <int CTRL>
-__device__ __forceinline__ int pw_dppi(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
-__device__ __forceinline__ float pw_lane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
-__device__ __forceinline__ float pw_wsum(float v) {
-    v += pw_dpp<0xB1>(v);            // quad_perm [1,0,3,2]
-    v += pw_dpp<0x4E>(v);            // quad_perm [2,3,0,1]
-    v += pw_dpp<0x141>(v);           // row_half_mirror
-    v += pw_dpp<0x140>(v);           // row_mirror
-    return ((pw_lane(v, 0) + pw_lane(v, 16)) + pw_lane(v, 32)) + pw_lane(v, 48);
-}
-__device__ __forceinline__ float pw_wmax(float v) {
-    v = fmaxf(v, pw_dpp<0xB1>(v));
-    v = fmaxf(v, pw_dpp<0x4E>(v));
-    v = fmaxf(v, pw_dpp<0x141>(v));
-    v = fmaxf(v, pw_dpp<0x140>(v));
-    return fmaxf(fmaxf(pw_lane(v, 0), pw_lane(v, 16)), fmaxf(pw_lane(v, 32), pw_lane(v, 48)));
-}
-// (largest value, smallest index among equals): torch.max's first-index rule; a NaN never wins a comparison
-__device__ __forceinline__ void pw_wargmax(float& best, int& bi) {
-#define PW_STEP(CTRL)                                                                  \
-    {                                                                                  \
-        const float ob = pw_dpp<CTRL>(best);                                           \
-        const int oi = pw_dppi<CTRL>(bi);                                              \
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }              \
-    }
-    PW_STEP(0xB1) PW_STEP(0x4E) PW_STEP(0x141) PW_STEP(0x140)
-#undef PW_STEP
-    float b = pw_lane(best, 0);
-    int i = __builtin_amdgcn_readlane(bi, 0);
-#pragma unroll
-    for (int l = 16; l < 64; l += 16) {
-        const float ob = pw_lane(best, l);
-        const int oi = __builtin_amdgcn_readlane(bi, l);
-        if (ob > b || (ob == b && oi < i)) { b = ob; i = oi; }
-    }
-    best = b; bi = i;
-}
 
 }  // namespace
 
