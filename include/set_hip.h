@@ -595,6 +595,97 @@ int set_gemm_group_f32(const SetGemmDesc* descs, int n, int a_kminor, int b_kmin
                        void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Split-K partials handed to their consumer instead of being reduced by a launch of their own (round 5; the XE / SCST
+ * backward of xe_sequence.py: 130 reduction launches of ~5 us per training step disappear).  A SetSlabSrc describes one
+ * addend of a (rows, N) gradient: value(m, j) = sum_{s < nslab} p[s * slab_stride + m * ld + j] for m < rows, 0 for the rows
+ * beyond (a sequence that had left the batch when the product ran).  Sums run in slab order, then in list order:
+ * deterministic.
+ * set_gemm_group_slabs_f32 = set_gemm_group_f32 without its reduction: problem i's partials stay in `ws` and out[i]
+ * describes them (nslab >= 2); a problem the plan does not split is written to descs[i].C as usual (accumulate honoured)
+ * and out[i].nslab = 0.  The caller keeps `ws` untouched until every consumer has run.
+ * The *_src entry points are the backward kernels of the decode step with such lists as (part of) their gradient input:
+ * gradient = base (may be NULL) + the listed addends.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct SetSlabSrc {
+    const float* p;
+    int64_t slab_stride;     /* floats between two partials */
+    int64_t ld;              /* floats between two rows */
+    int32_t nslab;           /* 0: this entry contributes nothing */
+    int32_t rows;            /* rows the partials hold */
+} SetSlabSrc;
+#define SET_MAX_SRC 4
+int set_gemm_group_slabs_f32(const SetGemmDesc* descs, int n, int a_kminor, int b_kminor, void* ws, size_t ws_bytes,
+                             SetSlabSrc* out, void* stream);
+/* set_lstm_cell_bwd_f32 with dh = the listed addends (n_dh <= SET_MAX_SRC; 0: dh = 0) */
+int set_lstm_cell_bwd_src_f32(const SetSlabSrc* dh_src, int n_dh, const float* dc, const float* gates, const float* c_prev,
+                              const float* c_new, float* dgates, float* dc_prev, int M, int D, void* stream);
+/* set_copy_gate_bwd_ld_f32 with dh = the listed addends + the backward of the output dropout (editnet.py:545) of dh_drop
+ * (M, D; may be NULL): dh_drop * keep / (1 - p) with the keep mask regenerated from (seed, offset) as
+ * set_dropout_bwd_philox_f32 does; p = 0: dh_drop is added as it is (eval mode). */
+int set_copy_gate_bwd_src_f32(const SetSlabSrc* dh_src, int n_dh, const float* dh_drop, int64_t ld_drop, float p, uint64_t seed,
+                              uint64_t offset, const float* dadp, const float* ogate, int64_t ld_ogate, const float* adp,
+                              const float* cg, const float* cmem, const float* c_new, float* du, float* dcm_direct,
+                              float* dcn_direct, float* do_pre, int M, int D, void* stream);
+/* set_lstm_gates_bwd_f32 / set_select_bwd_acc_f32 / set_context_gate_bwd_ld_f32 / set_attention_bwd_acc_f32 with their
+ * gradient input = base (NULL allowed where noted) + the listed addends.  set_attention_bwd_src_f32 also stores the gradient
+ * it summed to dctx_out (M, Dv) when that is not NULL (the caption context's gradient is needed again after the loop). */
+int set_lstm_gates_bwd_src_f32(const float* dcn_base, const SetSlabSrc* src, int n_src, const float* do_pre, const float* gates,
+                               const float* c_prev, float* dgates, float* dc_prev, int M, int D, void* stream);
+int set_select_bwd_src_f32(const float* dsel_base, const SetSlabSrc* src, int n_src, const float* Mem, const float* alpha,
+                           float* dM, float* dalpha, int M, int T, int D, int acc_dM, void* stream);
+int set_context_gate_bwd_src_f32(const float* dout_base /* may be NULL */, const SetSlabSrc* src, int n_src, const float* zt,
+                                 const float* s, const float* t, float* dz, float* ds, float* dt, int64_t ld_out, int M, int D,
+                                 void* stream);
+int set_attention_bwd_src_f32(const float* dctx_base /* may be NULL */, const SetSlabSrc* src, int n_src, float* dctx_out,
+                              const float* dalpha_ext, const float* alpha, const float* values, const float* att1,
+                              const float* att2, const float* w_full, float* datt1, float* datt2, float* dwfull_part,
+                              float* de, int M, int L, int Dv, int A, int use_tanh, int acc_datt1, int64_t ld_datt2,
+                              void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The timestep loops of the XE / SCST training node as ONE call each (csrc/train_loop.hip): the loop bodies of
+ * editnet.py:505-546 (train mode, teacher-forced, fixed-36 features) and of autograd's BPTT over them, i.e. exactly the
+ * sequence of entry points above that show-edit-tell_amd/xe_sequence.py issues per timestep, with the per-sequence logs
+ * addressed as base + t * (rows of one timestep).  Issued from Python the ~45 launches per timestep cost more host time than
+ * their kernels take (16.3 ms of enqueue for a 16.0-ms step at B = 128).  All pointers are device pointers except `bts`
+ * (host: rows still in the batch at every timestep, editnet.py:506) and `w`.  Logs are (T, B, .) row-major, the state logs
+ * H1 / C1 / H2 / C2 (T + 1, B, D) with slot t = the state BEFORE timestep t.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct SetXELoopArgs {
+    int T, B, R, F, Tc, D, A, V, train;
+    float p_embed, p_out;
+    uint64_t seed, off_embed, off_out;           /* Philox: timestep t of a site draws at off_* + t */
+    const int* bts;
+    const SetEditNetWeights* w;
+    const float *E, *al_wih, *al_whh;
+    const int64_t* tok; int64_t tok_step, tok_stride;      /* word of (t, b) = tok[t * tok_step + b * tok_stride] */
+    const float *X, *H, *Mem, *mask, *att1_c, *pre1, *att1; int64_t att1_step;
+    float *EMB, *H1, *C1, *H2, *C2, *G1, *G2, *WHC, *ZT, *S, *TT, *ALPHAC, *ALPHAV, *ATT2C, *ATT2V, *SEL, *CNEW, *CG, *X2, *H2D;
+    float *gated, *cx, *aimg;                    /* (B, D), (B, D), (B, F) scratch */
+    void* ws_l; size_t ws_l_bytes;               /* set_lstm_cell_workspace_bytes */
+    void* ws_c; size_t ws_c_bytes;               /* set_editnet_attentions_workspace_bytes */
+    void* ws_k; size_t ws_k_bytes;               /* set_copy_lstm_workspace_bytes */
+} SetXELoopArgs;
+int set_editnet_xe_train_loop_f32(const SetXELoopArgs* a, void* stream);
+
+typedef struct SetXEBwdLoopArgs {
+    int T, B, R, F, Tc, D, A, acc_datt1;
+    float p_out;                                 /* 0: eval mode (no output dropout) */
+    uint64_t seed, off_out;
+    const int* bts;
+    const float *cl_cnew_w, *cl_cmem_w, *cl_x2h_w, *cl_h2h_w, *w_ctx, *w_h1, *dec_cat, *al_wih, *al_whh, *va_full, *ca_full;
+    const float *G1, *G2, *C1, *C2, *CG, *SEL, *CNEW, *ZT, *S, *TT, *ALPHAC, *ALPHAV, *ATT2C, *ATT2V, *X, *H, *Mem, *att1_c, *att1;
+    int64_t att1_step;
+    const float* dH2D;                           /* (T, B, D) gradient of fc's input */
+    float *DU, *DGW, *DSZT, *DATT2, *DWFC, *DWFV, *DEC, *DEV, *DCTX, *DG1, *datt1; int64_t datt1_step;
+    float *datt1c, *dMem;
+    float *DC1[2], *DC2[2], *dcm, *dcn, *dop, *dalc;
+    void* slab_ws[5]; size_t slab_ws_bytes;      /* one scratch region per product position of a timestep */
+    float* tmp[11];                              /* (B, N) landing buffers of products the plan does not split */
+} SetXEBwdLoopArgs;
+int set_editnet_xe_train_bwd_loop_f32(const SetXEBwdLoopArgs* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Host-side CIDEr-D for the self-critical reward (HOST pointers, no stream: per-sample n-gram work that shards with
  * the batch; the reference calls an external Python scorer at editnet_rl.py:636).  Sentences are int64 token ids.
  * create: the document-frequency table of preprocess_rl.py:7-55 as n_entries n-grams (entry i = lens[i] <= 4 ids at

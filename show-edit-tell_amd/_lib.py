@@ -139,6 +139,47 @@ class GemmDesc(C.Structure):
                 ("accumulate", C.c_int)]
 
 
+class SlabSrc(C.Structure):
+    """include/set_hip.h SetSlabSrc: one addend of a gradient that is still split-K partials"""
+    _fields_ = [("p", C.c_void_p), ("slab_stride", C.c_int64), ("ld", C.c_int64), ("nslab", C.c_int32), ("rows", C.c_int32)]
+
+
+def _fields(spec):
+    """'int a, b; float c; ptr d, e' style field list -> ctypes _fields_"""
+    kinds = {"int": C.c_int, "float": C.c_float, "u64": C.c_uint64, "i64": C.c_int64, "ptr": C.c_void_p, "size": C.c_size_t}
+    out = []
+    for part in spec.split(";"):
+        part = part.strip()
+        if not part:
+            continue
+        kind, names = part.split(None, 1)
+        for nme in names.split(","):
+            nme = nme.strip()
+            if "[" in nme:
+                base, cnt = nme[:-1].split("[")
+                out.append((base, kinds[kind] * int(cnt)))
+            else:
+                out.append((nme, kinds[kind]))
+    return out
+
+
+class XELoopArgs(C.Structure):
+    """include/set_hip.h SetXELoopArgs"""
+    _fields_ = _fields("int T, B, R, F, Tc, D, A, V, train; float p_embed, p_out; u64 seed, off_embed, off_out; ptr bts; ptr w; "
+                       "ptr E, al_wih, al_whh; ptr tok; i64 tok_step, tok_stride; ptr X, H, Mem, mask, att1_c, pre1, att1; "
+                       "i64 att1_step; ptr EMB, H1, C1, H2, C2, G1, G2, WHC, ZT, S, TT, ALPHAC, ALPHAV, ATT2C, ATT2V, SEL, CNEW, CG, "
+                       "X2, H2D; ptr gated, cx, aimg; ptr ws_l; size ws_l_bytes; ptr ws_c; size ws_c_bytes; ptr ws_k; size ws_k_bytes")
+
+
+class XEBwdLoopArgs(C.Structure):
+    """include/set_hip.h SetXEBwdLoopArgs"""
+    _fields_ = _fields("int T, B, R, F, Tc, D, A, acc_datt1; float p_out; u64 seed, off_out; ptr bts; "
+                       "ptr cl_cnew_w, cl_cmem_w, cl_x2h_w, cl_h2h_w, w_ctx, w_h1, dec_cat, al_wih, al_whh, va_full, ca_full; "
+                       "ptr G1, G2, C1, C2, CG, SEL, CNEW, ZT, S, TT, ALPHAC, ALPHAV, ATT2C, ATT2V, X, H, Mem, att1_c, att1; "
+                       "i64 att1_step; ptr dH2D; ptr DU, DGW, DSZT, DATT2, DWFC, DWFV, DEC, DEV, DCTX, DG1, datt1; i64 datt1_step; "
+                       "ptr datt1c, dMem; ptr DC1[2], DC2[2]; ptr dcm, dcn, dop, dalc; ptr slab_ws[5]; size slab_ws_bytes; ptr tmp[11]")
+
+
 _P = C.c_void_p
 _I = C.c_int
 _L = C.c_int64
@@ -249,6 +290,17 @@ PROTOTYPES = {
     "set_beam_pick_f32": (_I, [_P, _P, _L, _I, _I, _I, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "set_beam_gather_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "set_gemm_group_f32": (_I, [C.POINTER(GemmDesc), _I, _I, _I, _P, _Z, _P]),
+    "set_gemm_group_slabs_f32": (_I, [C.POINTER(GemmDesc), _I, _I, _I, _P, _Z, C.POINTER(SlabSrc), _P]),
+    "set_editnet_xe_train_loop_f32": (_I, [C.POINTER(XELoopArgs), _P]),
+    "set_editnet_xe_train_bwd_loop_f32": (_I, [C.POINTER(XEBwdLoopArgs), _P]),
+    "set_lstm_cell_bwd_src_f32": (_I, [C.POINTER(SlabSrc), _I, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "set_copy_gate_bwd_src_f32": (_I, [C.POINTER(SlabSrc), _I, _P, _L, C.c_float, _U, _U, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P,
+                                       _I, _I, _P]),
+    "set_lstm_gates_bwd_src_f32": (_I, [_P, C.POINTER(SlabSrc), _I, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "set_select_bwd_src_f32": (_I, [_P, C.POINTER(SlabSrc), _I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "set_context_gate_bwd_src_f32": (_I, [_P, C.POINTER(SlabSrc), _I, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    "set_attention_bwd_src_f32": (_I, [_P, C.POINTER(SlabSrc), _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I,
+                                       _L, _P]),
     "set_gemm_f32": (_I, [_P, _L, _I, _P, _L, _I, _P, _L, _I, _I, _I, _I, _P, _Z, _P]),
     "set_ciderd_create": (_P, [_P, _P, _P, _L, C.c_double, _I, C.c_double]),
     "set_ciderd_destroy": (None, [_P]),

@@ -6,6 +6,7 @@
 // Conventions: `gates` holds POST-activation (i, f, g, o) as saved by the train-mode forward;
 // every kernel handles one float4 of hidden units per thread; all outputs are fully overwritten.
 #include "set_common.h"
+#include "philox.h"
 
 namespace set {
 
@@ -25,9 +26,10 @@ __device__ __forceinline__ float wsum(float v) {
 //   d pre-activations: di = dct g i(1-i), df = dct c f(1-f), dg = dct i (1-g^2), do = dh' tanh(c') o(1-o)
 //   dc_prev = dct f
 // ---------------------------------------------------------------------------------------------
+template <bool SRC>
 __global__ void __launch_bounds__(256) lstm_cell_bwd_k(const float* dh, const float* dc_in, const float* gates,
                                                        const float* c_prev, const float* c_new, float* dgates,
-                                                       float* dc_prev, int M, int D) {
+                                                       float* dc_prev, int M, int D, const SrcList S) {
     const int per_row = D >> 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)M * per_row) return;
@@ -37,7 +39,8 @@ __global__ void __launch_bounds__(256) lstm_cell_bwd_k(const float* dh, const fl
     const f32x4 gi = ldb4(gr), gf = ldb4(gr + D), gg = ldb4(gr + 2 * D), go = ldb4(gr + 3 * D);
     const f32x4 cp = ldb4(c_prev + m * D + j), cn = ldb4(c_new + m * D + j);
     f32x4 dhv = {0.f, 0.f, 0.f, 0.f}, dcv = {0.f, 0.f, 0.f, 0.f};
-    if (dh) dhv = ldb4(dh + m * D + j);
+    if constexpr (SRC) dhv = S.load4(dh, m * D + j, m, j);   // dh (may be NULL) + the addends still in split-K partials
+    else if (dh) dhv = ldb4(dh + m * D + j);
     if (dc_in) dcv = ldb4(dc_in + m * D + j);
     f32x4 di, df, dg, dou, dcp;
 #pragma unroll
@@ -63,17 +66,31 @@ __global__ void __launch_bounds__(256) lstm_cell_bwd_k(const float* dh, const fl
 //     du = dadp_t (cm - cn) cg (1-cg) ; dcm_direct = dadp_t cg ; dcn_direct = dadp_t (1-cg)
 // stage 2 (after dcn = dcn_direct + du W_n on the host side) is lstm_gates_bwd_k.
 // ---------------------------------------------------------------------------------------------
+template <bool SRC>
 __global__ void __launch_bounds__(256) copy_gate_bwd_k(const float* dh, const float* dadp_in, const float* ogate,
                                                        const float* adp, const float* cg, const float* cmem,
                                                        const float* c_new, float* du, float* dcm_direct,
-                                                       float* dcn_direct, float* do_pre, int M, int D, long long ld_og) {
+                                                       float* dcn_direct, float* do_pre, int M, int D, long long ld_og,
+                                                       const SrcList S, const float* dh_drop, long long ld_drop, float p_drop,
+                                                       float sc_drop, unsigned long long seed, unsigned long long offset) {
     const int per_row = D >> 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)M * per_row) return;
     const long long o = idx * 4;
     const long long m = idx / per_row;
     f32x4 dhv = {0.f, 0.f, 0.f, 0.f}, dav = {0.f, 0.f, 0.f, 0.f};
-    if (dh) dhv = ldb4(dh + o);
+    const int j = (int)(o - m * D);
+    if constexpr (SRC) dhv = S.load4(dh, o, m, j);
+    else if (dh) dhv = ldb4(dh + o);
+    if (SRC && dh_drop) {                                           // + the output dropout's backward (dropout_bwd_philox_k, fused)
+        const f32x4 g = ldb4(dh_drop + m * ld_drop + j);
+        if (p_drop > 0.f) {
+            uint32_t k[4] = {(uint32_t)m, (uint32_t)(j >> 2), (uint32_t)offset, (uint32_t)(offset >> 32)};
+            philox4x32_10(k, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dhv[e] += ((float)(k[e] >> 8) * (1.0f / 16777216.0f) >= p_drop) ? g[e] * sc_drop : 0.f;
+        } else dhv += g;
+    }
     if (dadp_in) dav = ldb4(dadp_in + o);
     const f32x4 og = ldb4(ogate + m * ld_og + (o - m * D)), ad = ldb4(adp + o), g = ldb4(cg + o), cm = ldb4(cmem + o), cn = ldb4(c_new + o);
     f32x4 duv, dcm, dcn, dop;
@@ -90,9 +107,10 @@ __global__ void __launch_bounds__(256) copy_gate_bwd_k(const float* dh, const fl
 }
 
 // LSTM gate backward given the gradient of the new cell state and the o-gate pre-activation gradient
+template <bool SRC>
 __global__ void __launch_bounds__(256) lstm_gates_bwd_k(const float* dcn, const float* do_pre, const float* gates,
                                                         const float* c_prev, float* dgates, float* dc_prev, int M,
-                                                        int D) {
+                                                        int D, const SrcList S) {
     const int per_row = D >> 2;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)M * per_row) return;
@@ -100,7 +118,7 @@ __global__ void __launch_bounds__(256) lstm_gates_bwd_k(const float* dcn, const 
     const int j = (int)(idx - m * per_row) << 2;
     const float* gr = gates + m * 4 * D + j;
     const f32x4 gi = ldb4(gr), gf = ldb4(gr + D), gg = ldb4(gr + 2 * D);
-    const f32x4 cp = ldb4(c_prev + m * D + j), dct = ldb4(dcn + m * D + j), dop = ldb4(do_pre + m * D + j);
+    const f32x4 cp = ldb4(c_prev + m * D + j), dct = SRC ? S.load4(dcn, m * D + j, m, j) : ldb4(dcn + m * D + j), dop = ldb4(do_pre + m * D + j);
     f32x4 di, df, dg, dcp;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -118,15 +136,16 @@ __global__ void __launch_bounds__(256) lstm_gates_bwd_k(const float* dcn, const 
 // context gating backward (editnet.py:378-380): out = zt s + (1-zt) t, zt = sig(z), s = tanh(.), t = tanh(.)
 //   dz_pre = dout (s - t) zt (1-zt) ; ds_pre = dout zt (1-s^2) ; dt_pre = dout (1-zt)(1-t^2)
 // ---------------------------------------------------------------------------------------------
+template <bool SRC>
 __global__ void __launch_bounds__(256) context_gate_bwd_k(const float* dout, const float* zt, const float* s,
                                                           const float* t, float* dz, float* ds, float* dt, long long n4,
-                                                          int D4, long long ld_out) {
+                                                          int D4, long long ld_out, const SrcList S) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n4) return;
     const long long o = idx * 4;
     const long long m = idx / D4;
     const long long oo = m * ld_out + (o - m * 4 * D4);       // the three outputs share a row stride (>= D)
-    const f32x4 d = ldb4(dout + o), z = ldb4(zt + o), sv = ldb4(s + o), tv = ldb4(t + o);
+    const f32x4 d = SRC ? S.load4(dout, o, m, (int)(o - m * 4 * D4)) : ldb4(dout + o), z = ldb4(zt + o), sv = ldb4(s + o), tv = ldb4(t + o);
     f32x4 a, b, c;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -259,24 +278,42 @@ __global__ void __launch_bounds__(256) attention_bwd_k(const float* dctx, const 
 // results as attention_bwd_k up to the order of those two sums.
 constexpr int ATTW_RB = 3;       // value rows of a wave in flight
 constexpr int ATTW_SB = 10;      // projection rows of a thread in flight
-template <bool TANH>
+template <bool TANH, bool SRC>
 __global__ void __launch_bounds__(512) attention_bwd_wide_k(const float* dctx, const float* dalpha_ext, const float* alpha,
                                                            const float* Vals, const float* att1, const float* att2,
                                                            const float* w_full, float* datt1, float* datt2,
                                                            float* dwfull_part, float* de_out, int L, int Dv, int A,
-                                                           int acc_datt1, long long ld_datt2) {
+                                                           int acc_datt1, long long ld_datt2, const SrcList S, float* dctx_out) {
     __shared__ float s_da[ATTB_MAX];
     __shared__ float s_de[ATTB_MAX];
     __shared__ float s_dot;
     __shared__ __attribute__((aligned(16))) float s_acc[4 * 128 * 4 * 2];     // [slice][column group][acc2 | accw] float4
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* dc = dctx + (long long)b * Dv;
     constexpr int NQ = 8;                                   // Dv <= 2048
     f32x4 dcr[NQ];
+    if constexpr (SRC) {
+        // the gradient row is still split-K partials: summed ONCE by the block (one float4 per thread, every partial requested
+        // before the first add), parked in LDS — s_acc is free until the projection pass — and handed to the eight waves
+        f32x4* s_dc = reinterpret_cast<f32x4*>(s_acc);
+        if (tid * 4 < Dv) {
+            const f32x4 v = S.load4(dctx, (long long)b * Dv + tid * 4, b, tid * 4);
+            s_dc[tid] = v;
+            if (dctx_out) stb4(dctx_out + (long long)b * Dv + tid * 4, v);
+        }
+        __syncthreads();
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int d = lane * 4 + 256 * q;
-        dcr[q] = d < Dv ? ldb4(dc + d) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < NQ; ++q) {
+            const int d = lane * 4 + 256 * q;
+            dcr[q] = d < Dv ? s_dc[lane + 64 * q] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();                                    // (s_acc is reused below)
+    } else {
+        const float* dc = dctx + (long long)b * Dv;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int d = lane * 4 + 256 * q;
+            dcr[q] = d < Dv ? ldb4(dc + d) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
     }
     for (int l0 = wave; l0 < L; l0 += 8 * ATTW_RB) {
         f32x4 xr[ATTW_RB][NQ];
@@ -371,8 +408,9 @@ __global__ void __launch_bounds__(512) attention_bwd_wide_k(const float* dctx, c
 // SelectC backward (editnet.py:409-420): sel = w M[j*], w = a + (1 - a_detached)
 //   dM[b, j*] = w dsel ; dalpha[b, j*] = <dsel, M[b, j*]> ; zero elsewhere
 // ---------------------------------------------------------------------------------------------
+template <bool SRC>
 __global__ void __launch_bounds__(256) select_bwd_k(const float* dsel, const float* Mem, const float* alpha, float* dM,
-                                                    float* dalpha, int T, int D, int acc_dm) {
+                                                    float* dalpha, int T, int D, int acc_dm, const SrcList S) {
     __shared__ int s_arg;
     __shared__ float s_val, s_red[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -391,18 +429,28 @@ __global__ void __launch_bounds__(256) select_bwd_k(const float* dsel, const flo
     const int js = s_arg;
     const float w = s_val * 1.f + (1.f - s_val);
     float dot = 0.f;
-    for (int t = 0; t < T; ++t)
+    if (acc_dm) {
+        // accumulate: only the selected row of dM changes — no walk over the T rows
         for (int d = tid * 4; d < D; d += 1024) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (t == js) {
-                const f32x4 g = ldb4(dsel + (long long)b * D + d), m = ldb4(Mem + ((long long)b * T + t) * D + d);
-                v = g * w;
-                dot += g[0] * m[0] + g[1] * m[1] + g[2] * m[2] + g[3] * m[3];
-            }
-            float* o = dM + ((long long)b * T + t) * D + d;
-            if (!acc_dm) stb4(o, v);
-            else if (t == js) stb4(o, ldb4(o) + v);         // accumulate: only the selected row changes
+            const f32x4 g = SRC ? S.load4(dsel, (long long)b * D + d, b, d) : ldb4(dsel + (long long)b * D + d);
+            const f32x4 m = ldb4(Mem + ((long long)b * T + js) * D + d);
+            dot += g[0] * m[0] + g[1] * m[1] + g[2] * m[2] + g[3] * m[3];
+            float* o = dM + ((long long)b * T + js) * D + d;
+            stb4(o, ldb4(o) + g * w);
         }
+    } else {
+        for (int t = 0; t < T; ++t)
+            for (int d = tid * 4; d < D; d += 1024) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (t == js) {
+                    const f32x4 g = SRC ? S.load4(dsel, (long long)b * D + d, b, d) : ldb4(dsel + (long long)b * D + d);
+                    const f32x4 m = ldb4(Mem + ((long long)b * T + t) * D + d);
+                    v = g * w;
+                    dot += g[0] * m[0] + g[1] * m[1] + g[2] * m[2] + g[3] * m[3];
+                }
+                stb4(dM + ((long long)b * T + t) * D + d, v);
+            }
+    }
     dot = wsum(dot);
     if (lane == 0) s_red[wave] = dot;
     __syncthreads();
@@ -512,11 +560,121 @@ __global__ void __launch_bounds__(256) enc_cell_bwd_k(const float* dh_out, const
     stb4(dh_pass + b * D + j, zero);
 }
 
+// validate a caller's addend list and copy it into the by-value kernel argument
+int make_src_list(const SetSlabSrc* src, int n, SrcList* out) {
+    out->n = 0;
+    if (n < 0 || n > SET_MAX_SRC || (n > 0 && !src)) return SET_ERR_ARG;
+    for (int i = 0; i < n; ++i) {
+        const SetSlabSrc& e = src[i];
+        if (e.nslab < 0 || e.rows < 0) return SET_ERR_ARG;
+        if (e.nslab > 0 && (!e.p || !aligned16(e.p) || (e.ld & 3) || (e.slab_stride & 3))) return SET_ERR_UNSUPPORTED;
+        out->s[i] = e;
+    }
+    out->n = n;
+    return SET_OK;
+}
+
 }  // namespace set
 
 using namespace set;
 
 extern "C" {
+
+int set_gemm_group_slabs_f32(const SetGemmDesc* descs, int n, int a_kminor, int b_kminor, void* ws, size_t ws_bytes,
+                             SetSlabSrc* out, void* stream) {
+    if (!out) return SET_ERR_ARG;
+    return gemm_gen_group(descs, n, a_kminor, b_kminor, ws, ws_bytes, (hipStream_t)stream, out);
+}
+
+int set_lstm_cell_bwd_src_f32(const SetSlabSrc* dh_src, int n_dh, const float* dc, const float* gates, const float* c_prev,
+                              const float* c_new, float* dgates, float* dc_prev, int M, int D, void* stream) {
+    if (!gates || !c_prev || !c_new || !dgates || !dc_prev || M <= 0 || D <= 0) return SET_ERR_ARG;
+    if (D & 3) return SET_ERR_UNSUPPORTED;
+    SrcList S;
+    SET_TRY(make_src_list(dh_src, n_dh, &S));
+    const long long n = (long long)M * (D >> 2);
+    ProfScope ps("lstm_cell_bwd", (hipStream_t)stream, 0.0, 4.0 * M * D * 13.0);
+    hipLaunchKernelGGL(lstm_cell_bwd_k<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr,
+                       dc, gates, c_prev, c_new, dgates, dc_prev, M, D, S);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+int set_copy_gate_bwd_src_f32(const SetSlabSrc* dh_src, int n_dh, const float* dh_drop, int64_t ld_drop, float p, uint64_t seed,
+                              uint64_t offset, const float* dadp, const float* ogate, int64_t ld_ogate, const float* adp,
+                              const float* cg, const float* cmem, const float* c_new, float* du, float* dcm_direct,
+                              float* dcn_direct, float* do_pre, int M, int D, void* stream) {
+    if (!ogate || !adp || !cg || !cmem || !c_new || !du || !dcm_direct || !dcn_direct || !do_pre || M <= 0 || D <= 0)
+        return SET_ERR_ARG;
+    if (!(p >= 0.f) || !(p < 1.f)) return SET_ERR_ARG;
+    if ((D & 3) || (ld_ogate & 3) || ld_ogate < D || (dh_drop && ((ld_drop & 3) || ld_drop < D || !aligned16(dh_drop))))
+        return SET_ERR_UNSUPPORTED;
+    SrcList S;
+    SET_TRY(make_src_list(dh_src, n_dh, &S));
+    const long long n = (long long)M * (D >> 2);
+    hipLaunchKernelGGL(copy_gate_bwd_k<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr,
+                       dadp, ogate, adp, cg, cmem, c_new, du, dcm_direct, dcn_direct, do_pre, M, D, (long long)ld_ogate, S, dh_drop,
+                       (long long)ld_drop, p, 1.0f / (1.0f - p), (unsigned long long)seed, (unsigned long long)offset);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+int set_lstm_gates_bwd_src_f32(const float* dcn_base, const SetSlabSrc* src, int n_src, const float* do_pre, const float* gates,
+                               const float* c_prev, float* dgates, float* dc_prev, int M, int D, void* stream) {
+    if (!do_pre || !gates || !c_prev || !dgates || !dc_prev || M <= 0 || D <= 0) return SET_ERR_ARG;
+    if (D & 3) return SET_ERR_UNSUPPORTED;
+    SrcList S;
+    SET_TRY(make_src_list(src, n_src, &S));
+    const long long n = (long long)M * (D >> 2);
+    hipLaunchKernelGGL(lstm_gates_bwd_k<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dcn_base, do_pre,
+                       gates, c_prev, dgates, dc_prev, M, D, S);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+int set_select_bwd_src_f32(const float* dsel_base, const SetSlabSrc* src, int n_src, const float* Mem, const float* alpha,
+                           float* dM, float* dalpha, int M, int T, int D, int acc_dM, void* stream) {
+    if (!Mem || !alpha || !dM || !dalpha || M <= 0 || T <= 0 || D <= 0) return SET_ERR_ARG;
+    if (D & 3) return SET_ERR_UNSUPPORTED;
+    SrcList S;
+    SET_TRY(make_src_list(src, n_src, &S));
+    hipLaunchKernelGGL(select_bwd_k<true>, dim3(M), dim3(256), 0, (hipStream_t)stream, dsel_base, Mem, alpha, dM, dalpha, T, D, acc_dM, S);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+int set_context_gate_bwd_src_f32(const float* dout_base, const SetSlabSrc* src, int n_src, const float* zt, const float* s,
+                                 const float* t, float* dz, float* ds, float* dt, int64_t ld_out, int M, int D, void* stream) {
+    if (!zt || !s || !t || !dz || !ds || !dt || M <= 0 || D <= 0) return SET_ERR_ARG;
+    if ((D & 3) || (ld_out & 3) || ld_out < D) return SET_ERR_UNSUPPORTED;
+    SrcList S;
+    SET_TRY(make_src_list(src, n_src, &S));
+    const long long n = (long long)M * (D >> 2);
+    hipLaunchKernelGGL(context_gate_bwd_k<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dout_base, zt, s,
+                       t, dz, ds, dt, n, D >> 2, (long long)ld_out, S);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+int set_attention_bwd_src_f32(const float* dctx_base, const SetSlabSrc* src, int n_src, float* dctx_out, const float* dalpha_ext,
+                              const float* alpha, const float* values, const float* att1, const float* att2,
+                              const float* w_full, float* datt1, float* datt2, float* dwfull_part, float* de, int M, int L,
+                              int Dv, int A, int use_tanh, int acc_datt1, int64_t ld_datt2, void* stream) {
+    if (!alpha || !values || !att1 || !att2 || !w_full || !datt1 || !datt2 || !dwfull_part || M <= 0) return SET_ERR_ARG;
+    if (ld_datt2 <= 0) ld_datt2 = A;
+    if (L > ATTB_MAX || (A & 3) || (Dv & 3) || A > 1024 || Dv > 2048 || (ld_datt2 & 3) || ld_datt2 < A) return SET_ERR_UNSUPPORTED;
+    SrcList S;
+    SET_TRY(make_src_list(src, n_src, &S));
+    hipStream_t st = (hipStream_t)stream;
+    if (use_tanh)
+        hipLaunchKernelGGL((attention_bwd_wide_k<true, true>), dim3(M), dim3(512), 0, st, dctx_base, dalpha_ext, alpha, values, att1, att2,
+                           w_full, datt1, datt2, dwfull_part, de, L, Dv, A, acc_datt1, (long long)ld_datt2, S, dctx_out);
+    else
+        hipLaunchKernelGGL((attention_bwd_wide_k<false, true>), dim3(M), dim3(512), 0, st, dctx_base, dalpha_ext, alpha, values, att1, att2,
+                           w_full, datt1, datt2, dwfull_part, de, L, Dv, A, acc_datt1, (long long)ld_datt2, S, dctx_out);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
 
 int set_lstm_cell_bwd_f32(const float* dh, const float* dc, const float* gates, const float* c_prev, const float* c_new,
                           float* dgates, float* dc_prev, int M, int D, void* stream) {
@@ -524,8 +682,8 @@ int set_lstm_cell_bwd_f32(const float* dh, const float* dc, const float* gates, 
     if (D & 3) return SET_ERR_UNSUPPORTED;
     const long long n = (long long)M * (D >> 2);
     ProfScope ps("lstm_cell_bwd", (hipStream_t)stream, 0.0, 4.0 * M * D * 13.0);
-    hipLaunchKernelGGL(lstm_cell_bwd_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dh, dc, gates,
-                       c_prev, c_new, dgates, dc_prev, M, D);
+    hipLaunchKernelGGL(lstm_cell_bwd_k<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dh, dc, gates,
+                       c_prev, c_new, dgates, dc_prev, M, D, SrcList());
     SET_LAUNCH_CHECK();
     return SET_OK;
 }
@@ -537,8 +695,9 @@ int set_copy_gate_bwd_ld_f32(const float* dh, const float* dadp, const float* og
         return SET_ERR_ARG;
     if ((D & 3) || (ld_ogate & 3) || ld_ogate < D) return SET_ERR_UNSUPPORTED;
     const long long n = (long long)M * (D >> 2);
-    hipLaunchKernelGGL(copy_gate_bwd_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dh, dadp, ogate,
-                       adp, cg, cmem, c_new, du, dcm_direct, dcn_direct, do_pre, M, D, (long long)ld_ogate);
+    hipLaunchKernelGGL(copy_gate_bwd_k<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dh, dadp, ogate,
+                       adp, cg, cmem, c_new, du, dcm_direct, dcn_direct, do_pre, M, D, (long long)ld_ogate, SrcList(),
+                       (const float*)nullptr, 0LL, 0.f, 1.f, 0ULL, 0ULL);
     SET_LAUNCH_CHECK();
     return SET_OK;
 }
@@ -554,8 +713,8 @@ int set_lstm_gates_bwd_f32(const float* dcn, const float* do_pre, const float* g
     if (!dcn || !do_pre || !gates || !c_prev || !dgates || !dc_prev || M <= 0 || D <= 0) return SET_ERR_ARG;
     if (D & 3) return SET_ERR_UNSUPPORTED;
     const long long n = (long long)M * (D >> 2);
-    hipLaunchKernelGGL(lstm_gates_bwd_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dcn, do_pre,
-                       gates, c_prev, dgates, dc_prev, M, D);
+    hipLaunchKernelGGL(lstm_gates_bwd_k<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dcn, do_pre,
+                       gates, c_prev, dgates, dc_prev, M, D, SrcList());
     SET_LAUNCH_CHECK();
     return SET_OK;
 }
@@ -565,8 +724,8 @@ int set_context_gate_bwd_ld_f32(const float* dout, const float* zt, const float*
     if (!dout || !zt || !s || !t || !dz || !ds || !dt || M <= 0 || D <= 0) return SET_ERR_ARG;
     if ((D & 3) || (ld_out & 3) || ld_out < D) return SET_ERR_UNSUPPORTED;
     const long long n = (long long)M * (D >> 2);
-    hipLaunchKernelGGL(context_gate_bwd_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dout, zt, s,
-                       t, dz, ds, dt, n, D >> 2, (long long)ld_out);
+    hipLaunchKernelGGL(context_gate_bwd_k<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dout, zt, s,
+                       t, dz, ds, dt, n, D >> 2, (long long)ld_out, SrcList());
     SET_LAUNCH_CHECK();
     return SET_OK;
 }
@@ -624,11 +783,11 @@ int set_attention_bwd_acc_f32(const float* dctx, const float* dalpha_ext, const 
     static const int wide = env_int("SET_ATT_BWD_WIDE", 1);
     if (wide && !dvalues) {                                  // 512 threads per row, several rows of every operand in flight
         if (use_tanh)
-            hipLaunchKernelGGL(attention_bwd_wide_k<true>, dim3(M), dim3(512), 0, st, dctx, dalpha_ext, alpha, values, att1, att2,
-                               w_full, datt1, datt2, dwfull_part, de, L, Dv, A, acc_datt1, (long long)ld_datt2);
+            hipLaunchKernelGGL((attention_bwd_wide_k<true, false>), dim3(M), dim3(512), 0, st, dctx, dalpha_ext, alpha, values, att1, att2,
+                               w_full, datt1, datt2, dwfull_part, de, L, Dv, A, acc_datt1, (long long)ld_datt2, SrcList(), (float*)nullptr);
         else
-            hipLaunchKernelGGL(attention_bwd_wide_k<false>, dim3(M), dim3(512), 0, st, dctx, dalpha_ext, alpha, values, att1, att2,
-                               w_full, datt1, datt2, dwfull_part, de, L, Dv, A, acc_datt1, (long long)ld_datt2);
+            hipLaunchKernelGGL((attention_bwd_wide_k<false, false>), dim3(M), dim3(512), 0, st, dctx, dalpha_ext, alpha, values, att1, att2,
+                               w_full, datt1, datt2, dwfull_part, de, L, Dv, A, acc_datt1, (long long)ld_datt2, SrcList(), (float*)nullptr);
         SET_LAUNCH_CHECK();
         return SET_OK;
     }
@@ -654,7 +813,7 @@ int set_select_bwd_acc_f32(const float* dsel, const float* Mem, const float* alp
                            int T, int D, int acc_dM, void* stream) {
     if (!dsel || !Mem || !alpha || !dM || !dalpha || M <= 0 || T <= 0 || D <= 0) return SET_ERR_ARG;
     if (D & 3) return SET_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(select_bwd_k, dim3(M), dim3(256), 0, (hipStream_t)stream, dsel, Mem, alpha, dM, dalpha, T, D, acc_dM);
+    hipLaunchKernelGGL(select_bwd_k<false>, dim3(M), dim3(256), 0, (hipStream_t)stream, dsel, Mem, alpha, dM, dalpha, T, D, acc_dM, SrcList());
     SET_LAUNCH_CHECK();
     return SET_OK;
 }

@@ -434,7 +434,8 @@ static void launch_gen(const GenLaunch& L, int a_kmaj, int b_kmaj, unsigned wgs,
 // n independent problems of the same operand layout in ONE launch (+ one reduction launch when any is split):
 // the Linear backward of a module computes several dX = dY.W products per timestep that are each too small to
 // fill the chip.  All problems must fall into the same row-tile class.
-int gemm_gen_group(const SetGemmDesc* d, int n, int a_kminor, int b_kminor, void* ws, size_t ws_bytes, hipStream_t s) {
+int gemm_gen_group(const SetGemmDesc* d, int n, int a_kminor, int b_kminor, void* ws, size_t ws_bytes, hipStream_t s,
+                   SetSlabSrc* slabs_out) {
     if (n <= 0) return SET_OK;
     if (n > GEN_MAX_TASKS || !d) return SET_ERR_ARG;
     static const int bm64_upto = env_int("SET_GEMM_GEN_BM64_UPTO", 512);    // same finding as the forward kernel
@@ -569,7 +570,9 @@ int gemm_gen_group(const SetGemmDesc* d, int n, int a_kminor, int b_kminor, void
         else {
             T.C = (float*)((char*)ws + ws_off); T.ldc = T.N; T.slab_stride = (long long)(slab / sizeof(float));
             ws_off += (size_t)ksplit * slab;
-            if (counters && (counters_used + tiles[i]) * sizeof(unsigned) <= GEN_COUNTER_BYTES &&
+            if (slabs_out) {
+                // (the consumer reduces: set_gemm_group_slabs_f32)
+            } else if (counters && (counters_used + tiles[i]) * sizeof(unsigned) <= GEN_COUNTER_BYTES &&
                 (size_t)ksplit * slab < ((size_t)1 << 31)) {
                 T.counters = counters + counters_used;
                 counters_used += tiles[i];
@@ -578,6 +581,11 @@ int gemm_gen_group(const SetGemmDesc* d, int n, int a_kminor, int b_kminor, void
                 red_blocks += (int)(((long long)T.M * (T.N >> 2) + 255) / 256);
                 red_bytes += 4.0 * T.M * T.N * (ksplit + 1.0);
             }
+        }
+        if (slabs_out) {
+            SetSlabSrc& o = slabs_out[i];
+            o.p = ksplit > 1 ? T.C : nullptr; o.slab_stride = T.slab_stride; o.ld = T.ldc; o.nslab = ksplit > 1 ? ksplit : 0;
+            o.rows = T.M;
         }
         static const int vec_epi = env_int("SET_GEMM_VEC_EPILOGUE", 1);
         T.vec_store = vec_epi && !(T.N & 3) && !(T.ldc & 3) && !(T.slab_stride & 3) && aligned16(T.C);

@@ -83,7 +83,8 @@ int gemm_group(const GemmProb* probs, int n, hipStream_t stream, const char* tag
 // gemm_gen.hip: C (+)= a . b^T with either operand stored k-major or k-minor (training backward)
 int gemm_gen(const float* A, long long lda, int a_kminor, const float* B, long long ldb, int b_kminor, float* C,
              long long ldc, int M, int N, int K, int accumulate, void* ws, size_t ws_bytes, hipStream_t s);
-int gemm_gen_group(const SetGemmDesc* d, int n, int a_kminor, int b_kminor, void* ws, size_t ws_bytes, hipStream_t s);
+int gemm_gen_group(const SetGemmDesc* d, int n, int a_kminor, int b_kminor, void* ws, size_t ws_bytes, hipStream_t s,
+                   SetSlabSrc* slabs_out = nullptr);   // slabs_out: split problems keep their partials (no reduction launch)
 int gemm_tile_m(int M);   // BM the launcher will pick for M rows
 
 // ---------------------------------------------------------------------------------------------
@@ -109,6 +110,54 @@ struct RowGateScope {
     ~RowGateScope() { g_row_gate = prev; }
 };
 extern thread_local const int* g_row_limit;   // set_decode_row_limits(): per-row cap on the caption length of the greedy loops (or NULL)
+
+// ---------------------------------------------------------------------------------------------
+// Addends of a gradient that are still split-K partials (include/set_hip.h SetSlabSrc): the consumer sums them while it
+// loads, so the products that feed it need no reduction launch.  Per entry the partials are added in slab order, the
+// entries in list order.
+// ---------------------------------------------------------------------------------------------
+struct SrcList {
+    SetSlabSrc s[SET_MAX_SRC];
+    int n = 0;
+#if defined(__HIPCC__)
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    // base value (or 0) + every addend at (row m, columns j .. j + 3).  Four partials of every entry are requested before any
+    // is added (a loop of "load, add" with a run-time trip count waits for every load in turn: the consumers took 2 - 8 us
+    // longer than the reduction launch they replace); the sums keep slab order within an entry and list order between entries
+    __device__ __forceinline__ v4 load4(const float* base, long long base_off, long long m, int j) const {
+        v4 v = base ? *reinterpret_cast<const v4*>(base + base_off) : (v4){0.f, 0.f, 0.f, 0.f};
+        if (n <= 0) return v;
+        const v4 z = {0.f, 0.f, 0.f, 0.f};
+        v4 acc[SET_MAX_SRC];
+        const float* q[SET_MAX_SRC];
+        int cnt[SET_MAX_SRC], maxn = 0;
+#pragma unroll
+        for (int i = 0; i < SET_MAX_SRC; ++i) {
+            const bool on = i < n && s[i].nslab > 0 && m < s[i].rows;
+            cnt[i] = on ? s[i].nslab : 0;
+            q[i] = on ? s[i].p + m * s[i].ld + j : nullptr;
+            acc[i] = z;
+            maxn = cnt[i] > maxn ? cnt[i] : maxn;
+        }
+        for (int k0 = 0; k0 < maxn; k0 += 4) {
+            v4 x[SET_MAX_SRC][4];
+#pragma unroll
+            for (int i = 0; i < SET_MAX_SRC; ++i)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    x[i][u] = (k0 + u < cnt[i]) ? *reinterpret_cast<const v4*>(q[i] + (long long)(k0 + u) * s[i].slab_stride) : z;
+#pragma unroll
+            for (int i = 0; i < SET_MAX_SRC; ++i)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[i] += x[i][u];
+        }
+#pragma unroll
+        for (int i = 0; i < SET_MAX_SRC; ++i) v += acc[i];
+        return v;
+    }
+#endif
+};
+int make_src_list(const SetSlabSrc* src, int n, SrcList* out);     // backward.hip: validates (alignment, counts) and copies
 
 // ---------------------------------------------------------------------------------------------
 // slab views consumed by the pointwise kernels: value(m,n) = sum_s p[s*stride + m*ld + n]

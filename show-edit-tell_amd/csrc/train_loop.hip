@@ -1,0 +1,161 @@
+// The timestep loops of the XE / SCST training node (show-edit-tell_amd/xe_sequence.py) as ONE C call each.
+//
+// The node's forward and backward are ~45 kernel launches per timestep; issued from Python (a ctypes call, a handful of
+// tensor views and data_ptr() reads per launch) the HOST needs 16.3 ms to enqueue a B = 128 training step whose kernels
+// take 16.0 ms — the step was bound by the interpreter, and everything taken off the GPU side was invisible
+// (EXPERIMENTS.md 5.5).  Here the same entry points are called in the same order from C: the host's share drops to the
+// launches themselves.  Nothing new is computed in this file — every call below is an entry point of include/set_hip.h that
+// the Python loop called with the same arguments (the reference's loop body: editnet.py:505-546 forward, autograd's
+// BPTT over it backward); the per-sequence logs are addressed as base + t * step.
+#include "set_common.h"
+
+using namespace set;
+
+extern "C" {
+
+int set_editnet_xe_train_loop_f32(const SetXELoopArgs* a, void* stream) {
+    if (!a || !a->w || !a->bts || a->T <= 0 || a->B <= 0) return SET_ERR_ARG;
+    const int T = a->T, B = a->B, R = a->R, F = a->F, Tc = a->Tc, D = a->D, A = a->A;
+    const long long K1 = 3LL * D + F, K2 = 2LL * D + F, BD = (long long)B * D;
+    for (int t = 0; t < T; ++t) {
+        const int bt = a->bts[t];
+        if (bt <= 0) break;
+        float* emb = a->EMB + BD * t;
+        const int64_t* tok = a->tok + a->tok_step * t;
+        // EmbeddingC (editnet.py:513): relu(E[tok]) (+ dropout in train mode)
+        if (a->train && a->p_embed > 0.f)
+            SET_TRY(set_embed_relu_dropout_f32(a->E, tok, a->tok_stride, emb, D, bt, D, a->V, a->p_embed, a->seed,
+                                               a->off_embed + (uint64_t)t, stream));
+        else
+            SET_TRY(set_embed_relu_f32(a->E, tok, a->tok_stride, emb, D, bt, D, a->V, stream));
+        // attention_lstm (editnet.py:523-524) on the emb / h2 column blocks; the invariant columns are in pre1
+        float* h1 = a->H1 + BD * (t + 1);
+        SET_TRY(set_lstm_cell_pre_train_f32(emb, D, a->al_wih, K1, D, a->H2 + BD * t, D, a->al_wih + 2 * D, K1, D, a->H1 + BD * t,
+                                            a->al_whh, a->pre1, 4LL * D, a->C1 + BD * t, h1, a->C1 + BD * (t + 1),
+                                            a->G1 + 4 * BD * t, bt, D, a->ws_l, a->ws_l_bytes, stream));
+        // both attentions + SelectC (editnet.py:534-540)
+        float* sel = a->SEL + BD * t;
+        SET_TRY(set_editnet_attentions_train_f32(a->w, a->H, a->att1_c, a->mask, a->Mem, a->X, a->att1 + a->att1_step * t, nullptr,
+                                                 h1, emb, a->gated, a->ALPHAC + (long long)B * Tc * t, a->cx, a->ZT + BD * t,
+                                                 a->S + BD * t, a->TT + BD * t, sel, a->aimg, a->ALPHAV + (long long)B * R * t,
+                                                 a->ATT2C + (long long)B * A * t, a->ATT2V + (long long)B * A * t, bt, Tc, R, F, D, A,
+                                                 a->ws_c, a->ws_c_bytes, stream));
+        {   // the concatenated operands the time-batched weight gradients read: [word | h1 | ctx], [h1 | gated | attend_img]
+            const float* src3[3] = {emb, h1, a->cx};
+            const int64_t ld3[3] = {D, D, D};
+            const int c3[3] = {D, D, D};
+            SET_TRY(set_pack_f32(a->WHC + 3 * BD * t, 3LL * D, bt, 3, src3, ld3, c3, 0, stream));
+            const float* srcx[3] = {h1, a->gated, a->aimg};
+            const int64_t ldx[3] = {D, D, F};
+            const int cx_[3] = {D, D, F};
+            SET_TRY(set_pack_f32(a->X2 + (long long)B * K2 * t, K2, bt, 3, srcx, ldx, cx_, 0, stream));
+        }
+        // CopyLSTMCellC (editnet.py:541-543)
+        SET_TRY(set_copy_lstm_train_f32(a->w, a->X2 + (long long)B * K2 * t, K2, (int)K2, a->H2 + BD * t, a->C2 + BD * t, sel,
+                                        a->H2 + BD * (t + 1), a->C2 + BD * (t + 1), a->G2 + 4 * BD * t, a->CNEW + BD * t,
+                                        a->CG + BD * t, bt, D, a->ws_k, a->ws_k_bytes, stream));
+        if (a->train && a->p_out > 0.f)          // nn.Dropout before fc (editnet.py:545)
+            SET_TRY(set_dropout_f32(a->H2 + BD * (t + 1), D, a->H2D + BD * t, D, bt, D, a->p_out, a->seed, a->off_out + (uint64_t)t,
+                                    stream));
+    }
+    return SET_OK;
+}
+
+// one grouped dX launch whose split problems keep their partials (set_gemm_group_slabs_f32); an unsplit problem lands in
+// its own (B, N) buffer and is described as one "partial"
+static int bwd_products(const float* dy, long long lddy, int M, int K, int n, const float* const* w, const long long* ldw,
+                        const int* N, float* const* tmp, void* ws, size_t ws_bytes, SetSlabSrc* out, void* stream) {
+    SetGemmDesc d[4];
+    for (int i = 0; i < n; ++i) d[i] = SetGemmDesc{dy, lddy, w[i], ldw[i], tmp[i], N[i], M, N[i], K, 0};
+    SET_TRY(set_gemm_group_slabs_f32(d, n, 0, 1, ws, ws_bytes, out, stream));
+    for (int i = 0; i < n; ++i)
+        if (out[i].nslab == 0) out[i] = SetSlabSrc{tmp[i], 0, N[i], 1, M};
+    return SET_OK;
+}
+
+int set_editnet_xe_train_bwd_loop_f32(const SetXEBwdLoopArgs* a, void* stream) {
+    if (!a || !a->bts || a->T <= 0 || a->B <= 0) return SET_ERR_ARG;
+    const int T = a->T, B = a->B, R = a->R, F = a->F, Tc = a->Tc, D = a->D, A = a->A;
+    const long long BD = (long long)B * D, K1 = 3LL * D + F, K2 = 2LL * D + F;
+    SetSlabSrc nxt_dh2[2], nxt_dh1{};
+    int n_dh2 = 0, have_dh1 = 0;
+    for (int t = T - 1; t >= 0; --t) {
+        const int bt = a->bts[t];
+        if (bt <= 0) continue;
+        float* du = a->DU + BD * t;
+        float* dgw = a->DGW + 4 * BD * t;
+        float* dc2_in = a->DC2[t & 1];
+        float* dc2_out = a->DC2[(t & 1) ^ 1];
+        // ---- CopyLSTMCellC backward (editnet.py:265-285); dh2 = recurrent addends + the output dropout's backward (fused)
+        SET_TRY(set_copy_gate_bwd_src_f32(n_dh2 ? nxt_dh2 : nullptr, n_dh2, a->dH2D + BD * t, D, a->p_out, a->seed,
+                                          a->off_out + (uint64_t)t, dc2_in, a->G2 + 4 * BD * t + 3 * D, 4LL * D, a->C2 + BD * (t + 1),
+                                          a->CG + BD * t, a->SEL + BD * t, a->CNEW + BD * t, du, a->dcm, a->dcn, a->dop, bt, D, stream));
+        SetSlabSrc g3[2], g5[4], g9[2], g11[1], g13[2];
+        {
+            const float* w[2] = {a->cl_cnew_w, a->cl_cmem_w};
+            const long long ldw[2] = {D, D};
+            const int N[2] = {D, D};
+            SET_TRY(bwd_products(du, D, bt, D, 2, w, ldw, N, a->tmp + 0, a->slab_ws[0], a->slab_ws_bytes, g3, stream));
+        }
+        SET_TRY(set_lstm_gates_bwd_src_f32(a->dcn, &g3[0], 1, a->dop, a->G2 + 4 * BD * t, a->C2 + BD * t, dgw, dc2_out, bt, D, stream));
+        {
+            const float* w[4] = {a->cl_x2h_w, a->cl_x2h_w + D, a->cl_x2h_w + 2 * D, a->cl_h2h_w};
+            const long long ldw[4] = {K2, K2, K2, D};
+            const int N[4] = {D, D, F, D};
+            SET_TRY(bwd_products(dgw, 4LL * D, bt, 4 * D, 4, w, ldw, N, a->tmp + 2, a->slab_ws[1], a->slab_ws_bytes, g5, stream));
+        }
+        // ---- SelectC backward
+        SET_TRY(set_select_bwd_src_f32(a->dcm, &g3[1], 1, a->Mem, a->ALPHAC + (long long)B * Tc * t, a->dMem, a->dalc, bt, Tc, D, 1,
+                                       stream));
+        // ---- VisualAttentionC backward
+        SET_TRY(set_attention_bwd_src_f32(nullptr, &g5[2], 1, nullptr, nullptr, a->ALPHAV + (long long)B * R * t, a->X,
+                                          a->att1 + a->att1_step * t, a->ATT2V + (long long)B * A * t, a->va_full,
+                                          a->datt1 + a->datt1_step * t, a->DATT2 + 2LL * B * A * t, a->DWFV + (long long)B * A * t,
+                                          a->DEV + (long long)B * R * t, bt, R, F, A, 0, a->acc_datt1, 2LL * A, stream));
+        // ---- CaptionAttentionC backward
+        float* dszt = a->DSZT + 3 * BD * t;
+        SET_TRY(set_context_gate_bwd_src_f32(nullptr, &g5[1], 1, a->ZT + BD * t, a->S + BD * t, a->TT + BD * t, dszt + D, dszt,
+                                             dszt + 2 * D, 3LL * D, bt, D, stream));
+        {
+            const float* w[2] = {a->w_ctx, a->w_h1};
+            const long long ldw[2] = {D, D};
+            const int N[2] = {D, D};
+            // [ds | dz] x w_ctx -> d ctx ; [dz | dt] x w_h1 -> dh1: two column ranges of dszt, one grouped launch
+            SetGemmDesc d[2] = {SetGemmDesc{dszt, 3LL * D, w[0], ldw[0], a->tmp[6], D, bt, D, 2 * D, 0},
+                                SetGemmDesc{dszt + D, 3LL * D, w[1], ldw[1], a->tmp[7], D, bt, D, 2 * D, 0}};
+            SET_TRY(set_gemm_group_slabs_f32(d, 2, 0, 1, a->slab_ws[2], a->slab_ws_bytes, g9, stream));
+            for (int i = 0; i < 2; ++i)
+                if (g9[i].nslab == 0) g9[i] = SetSlabSrc{a->tmp[6 + i], 0, N[i], 1, bt};
+        }
+        SET_TRY(set_attention_bwd_src_f32(nullptr, &g9[0], 1, a->DCTX + BD * t, a->dalc, a->ALPHAC + (long long)B * Tc * t, a->H,
+                                          a->att1_c, a->ATT2C + (long long)B * A * t, a->ca_full, a->datt1c,
+                                          a->DATT2 + 2LL * B * A * t + A, a->DWFC + (long long)B * A * t, a->DEC + (long long)B * Tc * t,
+                                          bt, Tc, D, A, 1, 1, 2LL * A, stream));
+        {
+            const float* w[1] = {a->dec_cat};
+            const long long ldw[1] = {D};
+            const int N[1] = {D};
+            SET_TRY(bwd_products(a->DATT2 + 2LL * B * A * t, 2LL * A, bt, 2 * A, 1, w, ldw, N, a->tmp + 8, a->slab_ws[3],
+                                 a->slab_ws_bytes, g11, stream));
+        }
+        // ---- attention LSTM backward: dh1 = the W_hh term of the next timestep + this timestep's three addends
+        SetSlabSrc dh1[4];
+        int n1 = 0;
+        if (have_dh1) dh1[n1++] = nxt_dh1;
+        dh1[n1++] = g5[0]; dh1[n1++] = g9[1]; dh1[n1++] = g11[0];
+        SET_TRY(set_lstm_cell_bwd_src_f32(dh1, n1, a->DC1[t & 1], a->G1 + 4 * BD * t, a->C1 + BD * t, a->C1 + BD * (t + 1),
+                                          a->DG1 + 4 * BD * t, a->DC1[(t & 1) ^ 1], bt, D, stream));
+        {
+            const float* w[2] = {a->al_wih + 2 * D, a->al_whh};
+            const long long ldw[2] = {K1, D};
+            const int N[2] = {D, D};
+            SET_TRY(bwd_products(a->DG1 + 4 * BD * t, 4LL * D, bt, 4 * D, 2, w, ldw, N, a->tmp + 9, a->slab_ws[4], a->slab_ws_bytes,
+                                 g13, stream));
+        }
+        nxt_dh2[0] = g5[3]; nxt_dh2[1] = g13[0]; n_dh2 = 2;
+        nxt_dh1 = g13[1]; have_dh1 = 1;
+    }
+    return SET_OK;
+}
+
+}  // extern "C"

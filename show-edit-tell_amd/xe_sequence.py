@@ -123,6 +123,25 @@ class _Ops:
 
 
 _DEMB_HOIST = os.environ.get("SET_DEMB_HOIST", "1") != "0"     # time-batched d emb products of the backward (round 4)
+# round 5: the per-timestep dX products of the backward hand their split-K partials to the kernels that consume them
+# (include/set_hip.h SetSlabSrc / *_src entry points) instead of reducing them with a launch each: 6 launches less per
+# timestep (5 reductions + the output dropout's backward).  SET_SLAB_DIRECT=0: the round-4 chain.
+_SLAB_DIRECT = os.environ.get("SET_SLAB_DIRECT", "1") != "0"
+# round 5: the two timestep loops as ONE C call each (csrc/train_loop.hip: the same entry points in the same order) — issued
+# from Python their ~45 launches per timestep cost the host more than the kernels take.  SET_XE_C_LOOPS=0: the Python loops.
+_C_LOOPS = os.environ.get("SET_XE_C_LOOPS", "1") != "0"
+_slab_ws = {}
+
+
+def _slab_scratch(dev, slot, nbytes=32 << 20):
+    """partials of one product position of the backward chain: its own region, alive until the consumers have run"""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, slot)
+    ws = _slab_ws.get(key)
+    if ws is None:
+        if len(_slab_ws) >= 40:
+            _slab_ws.clear()
+        ws = _slab_ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    return ws
 _ATT1_HOIST_LIVE = 0.75     # all-timestep region projection when at least this fraction of the (t, b) rows is live
 # Overlapped weight gradients (round 3): the time-batched dW contractions (0.4 TFLOP, the chip's full width) only become
 # possible when the back-propagation through time has produced the gradient logs — but the BPTT loop itself is a chain of
@@ -261,7 +280,28 @@ class _XESequence(torch.autograd.Function):
             if att1_hoisted:
                 ops.linear(L["FE"].view(T * B * R, D), P["va_fa_w"], P["va_fa_b"], L["ATT1"].view(T * B * R, Adim), T * B * R)
 
-        for t in range(T):
+        c_loop = (_C_LOOPS and ro is None and not ss and not adaptive and (att1_hoisted or not train) and dev.type == "cuda")
+        if c_loop:
+            a = _lib.XELoopArgs()
+            a.T, a.B, a.R, a.F, a.Tc, a.D, a.A, a.V, a.train = T, B, R, F, Tc, D, Adim, E.shape[0], int(bool(train))
+            a.p_embed, a.p_out = float(cfg.p_embed if train else 0.0), float(cfg.p_out if train else 0.0)
+            a.seed, a.off_embed, a.off_out = int(cfg.seed), scale_off(1, 0), scale_off(3, 0)
+            bts_c = (C.c_int * T)(*bts)
+            a.bts = C.cast(bts_c, C.c_void_p)
+            a.w = C.addressof(w)
+            a.E, a.al_wih, a.al_whh = E.data_ptr(), wih.data_ptr(), P["al_whh"].data_ptr()
+            a.tok, a.tok_step, a.tok_stride = caps.data_ptr(), 1, cap_stride
+            a.X, a.H, a.Mem, a.mask, a.att1_c, a.pre1 = (x.data_ptr() for x in (X, H, Mem, mask, att1_c, pre1))
+            a.att1, a.att1_step = (L["ATT1"].data_ptr(), B * R * Adim) if train else (Yin.data_ptr(), 0)
+            for k in ("EMB", "H1", "C1", "H2", "C2", "G1", "G2", "WHC", "ZT", "S", "TT", "ALPHAC", "ALPHAV", "ATT2C", "ATT2V", "SEL",
+                      "CNEW", "CG", "X2"):
+                setattr(a, k, L[k].data_ptr())
+            a.H2D = L["H2D"].data_ptr() if (train and cfg.p_out > 0) else None
+            a.gated, a.cx, a.aimg = gated.data_ptr(), cx.data_ptr(), aimg.data_ptr()
+            a.ws_l, a.ws_l_bytes, a.ws_c, a.ws_c_bytes = ws_l.data_ptr(), ws_l.numel(), ws_c.data_ptr(), ws_c.numel()
+            a.ws_k, a.ws_k_bytes = ws_k.data_ptr(), ws_k.numel()
+            check(lib.set_editnet_xe_train_loop_f32(C.byref(a), st), "set_editnet_xe_train_loop_f32")
+        for t in (range(T) if not c_loop else ()):
             bt = bts[t]
             emb = L["EMB"][t]
             if ss and t >= 1:              # editnet.py:508-520 on the device: draw from softmax(scores of step t-1)
@@ -475,7 +515,133 @@ class _XESequence(torch.autograd.Function):
                     A.gemm(dy, True, x, True, prm.shape[0], Kb, dy.shape[0], out=out, accumulate=not overwrite)
             return side
 
-        for t in range(T - 1, -1, -1):
+        slab_direct = _SLAB_DIRECT and _DEMB_HOIST and dlast is None and dev.type == "cuda"
+        c_loop = slab_direct and _C_LOOPS and (dfe_after or not train) and not mid
+        if c_loop:
+            a = _lib.XEBwdLoopArgs()
+            a.T, a.B, a.R, a.F, a.Tc, a.D, a.A, a.acc_datt1 = T, B, R, F, Tc, D, Adim, 0 if train else 1
+            a.p_out = float(cfg.p_out if (train and cfg.p_out > 0) else 0.0)
+            a.seed, a.off_out = int(cfg.seed), rng.offset(rng.SITE_OUT, 0)
+            bts_c = (C.c_int * T)(*bts)
+            a.bts = C.cast(bts_c, C.c_void_p)
+            a.cl_cnew_w, a.cl_cmem_w, a.cl_x2h_w, a.cl_h2h_w = (P[k].data_ptr() for k in ("cl_cnew_w", "cl_cmem_w", "cl_x2h_w", "cl_h2h_w"))
+            a.w_ctx, a.w_h1, a.dec_cat = w_ctx.data_ptr(), w_h1.data_ptr(), dec_cat.data_ptr()
+            a.al_wih, a.al_whh, a.va_full, a.ca_full = wih.data_ptr(), P["al_whh"].data_ptr(), va_full.data_ptr(), ca_full.data_ptr()
+            for k in ("G1", "G2", "C1", "C2", "CG", "SEL", "CNEW", "ZT", "S", "TT", "ALPHAC", "ALPHAV", "ATT2C", "ATT2V"):
+                setattr(a, k, L[k].data_ptr())
+            a.X, a.H, a.Mem, a.att1_c = X.data_ptr(), H.data_ptr(), Mem.data_ptr(), att1_c.data_ptr()
+            a.att1, a.att1_step = (L["ATT1"].data_ptr(), B * R * Adim) if train else (Yin.data_ptr(), 0)
+            a.dH2D = dH2D.data_ptr()
+            a.DU, a.DGW, a.DSZT, a.DATT2, a.DWFC, a.DWFV = (x.data_ptr() for x in (DU, DGW, DSZT, DATT2, DWFC, DWFV))
+            a.DEC, a.DEV, a.DCTX, a.DG1 = DEC.data_ptr(), DEV.data_ptr(), DCTX.data_ptr(), DG1.data_ptr()
+            a.datt1, a.datt1_step = (DATT1.data_ptr(), B * R * Adim) if train else (dYin.data_ptr(), 0)
+            a.datt1c, a.dMem = datt1c.data_ptr(), dMem.data_ptr()
+            a.DC1[0], a.DC1[1], a.DC2[0], a.DC2[1] = DC1[0].data_ptr(), DC1[1].data_ptr(), DC2[0].data_ptr(), DC2[1].data_ptr()
+            a.dcm, a.dcn, a.dop, a.dalc = dcm.data_ptr(), dcn.data_ptr(), dop.data_ptr(), dalc.data_ptr()
+            keep = [_slab_scratch(dev, i) for i in range(5)]
+            for i, w_ in enumerate(keep):
+                a.slab_ws[i] = w_.data_ptr()
+            a.slab_ws_bytes = keep[0].numel()
+            tmp_n = (D, D, D, D, F, D, D, D, D, D, D)
+            tmps = [_e(B, n_, dev=dev) for n_ in tmp_n]
+            for i, t_ in enumerate(tmps):
+                a.tmp[i] = t_.data_ptr()
+            check(lib.set_editnet_xe_train_bwd_loop_f32(C.byref(a), st), "set_editnet_xe_train_bwd_loop_f32")
+        if slab_direct and not c_loop:
+            SS = _lib.SlabSrc
+            tmp = {}                       # (slot, task) -> (B, N) buffer a product lands in when the plan does not split it
+
+            def gslabs(slot, items):
+                """[(dy, w_view, N)] -> one SlabSrc per problem: its split-K partials in this slot's scratch, or (unsplit) the
+                product itself; ONE launch, no reduction launch"""
+                n = len(items)
+                descs = (_lib.GemmDesc * n)()
+                outs = (SS * n)()
+                for i, (dy, wv) in enumerate(items):
+                    M, N, K = dy.shape[0], wv.shape[1], dy.shape[1]
+                    o = tmp.get((slot, i))
+                    if o is None:
+                        o = tmp[(slot, i)] = _e(B, N, dev=dev)
+                    a, lda = A._mat(dy)
+                    b_, ldb = A._mat(wv)
+                    descs[i] = _lib.GemmDesc(a.data_ptr(), lda, b_.data_ptr(), ldb, o.data_ptr(), N, M, N, K, 0)
+                ws = _slab_scratch(dev, slot)
+                check(lib.set_gemm_group_slabs_f32(descs, n, 0, 1, ws.data_ptr(), ws.numel(), outs, st), "set_gemm_group_slabs_f32")
+                res = []
+                for i, (dy, wv) in enumerate(items):
+                    e = outs[i]
+                    if e.nslab == 0:       # written whole: one "partial"
+                        e = SS(tmp[(slot, i)].data_ptr(), 0, wv.shape[1], 1, dy.shape[0])
+                    else:
+                        e = SS(e.p, e.slab_stride, e.ld, e.nslab, e.rows)
+                    res.append(e)
+                return res
+
+            def srcs(lst):
+                lst = [e for e in lst if e is not None]
+                return ((SS * len(lst))(*lst) if lst else None), len(lst)
+
+            p_out = cfg.p_out if (train and cfg.p_out > 0) else 0.0
+            nxt_dh2, nxt_dh1 = [], None    # addends of dh2 / the W_hh term of dh1 produced by the timestep after this one
+            for t in range(T - 1, -1, -1):
+                bt = bts[t]
+                r = lambda x: _rows(x, bt)
+                du, dgw = DU[t], DGW[t]
+                dc2_in, dc2_out = DC2[t & 1], DC2[(t & 1) ^ 1]
+                # ---- CopyLSTMCellC backward: dh2 = recurrent addends + the output dropout's backward of d fc-input (fused)
+                a_, n_ = srcs(nxt_dh2)
+                check(lib.set_copy_gate_bwd_src_f32(a_, n_, dH2D[t].data_ptr(), D, p_out, cfg.seed, rng.offset(rng.SITE_OUT, t),
+                                                    dc2_in.data_ptr(), L["G2"][t][:, 3 * D:].data_ptr(), 4 * D,
+                                                    L["C2"][t + 1].data_ptr(), L["CG"][t].data_ptr(), L["SEL"][t].data_ptr(),
+                                                    L["CNEW"][t].data_ptr(), du.data_ptr(), dcm.data_ptr(), dcn.data_ptr(),
+                                                    dop.data_ptr(), bt, D, st), "set_copy_gate_bwd_src_f32")
+                g3 = gslabs(0, [(r(du), P["cl_cnew_w"]), (r(du), P["cl_cmem_w"])])
+                a_, n_ = srcs([g3[0]])
+                check(lib.set_lstm_gates_bwd_src_f32(dcn.data_ptr(), a_, n_, dop.data_ptr(), L["G2"][t].data_ptr(),
+                                                     L["C2"][t].data_ptr(), dgw.data_ptr(), dc2_out.data_ptr(), bt, D, st),
+                      "set_lstm_gates_bwd_src_f32")
+                g5 = gslabs(1, [(r(dgw), x2h_w[:, :D]), (r(dgw), x2h_w[:, D:2 * D]), (r(dgw), x2h_w[:, 2 * D:]), (r(dgw), P["cl_h2h_w"])])
+                # ---- SelectC backward: dMem += ..., dalpha_c
+                a_, n_ = srcs([g3[1]])
+                check(lib.set_select_bwd_src_f32(dcm.data_ptr(), a_, n_, Mem.data_ptr(), L["ALPHAC"][t].data_ptr(), dMem.data_ptr(),
+                                                 dalc.data_ptr(), bt, Tc, D, 1, st), "set_select_bwd_src_f32")
+                # ---- VisualAttentionC backward
+                att1 = L["ATT1"][t] if train else Yin
+                datt1 = DATT1[t] if train else dYin
+                a_, n_ = srcs([g5[2]])
+                check(lib.set_attention_bwd_src_f32(None, a_, n_, None, None, L["ALPHAV"][t].data_ptr(), X.data_ptr(), att1.data_ptr(),
+                                                    L["ATT2V"][t].data_ptr(), va_full.data_ptr(), datt1.data_ptr(),
+                                                    DATT2[t].data_ptr(), DWFV[t].data_ptr(), DEV[t].data_ptr(), bt, R, F, Adim, 0,
+                                                    0 if train else 1, 2 * Adim, st), "set_attention_bwd_src_f32")
+                if train and not dfe_after:
+                    A.gemm(datt1.view(B * R, Adim)[:bt * R], False, P["va_fa_w"], True, bt * R, D, Adim, out=dfe[:bt * R])
+                    ops.dropout_bwd(dfe, L["FE"][t].view(B * R, D), dYin.view(B * R, D), bt * R, D, sc_reg, True)
+                # ---- CaptionAttentionC backward
+                dszt = DSZT[t]
+                a_, n_ = srcs([g5[1]])
+                check(lib.set_context_gate_bwd_src_f32(None, a_, n_, L["ZT"][t].data_ptr(), L["S"][t].data_ptr(), L["TT"][t].data_ptr(),
+                                                       dszt[:, D:].data_ptr(), dszt.data_ptr(), dszt[:, 2 * D:].data_ptr(), 3 * D, bt,
+                                                       D, st), "set_context_gate_bwd_src_f32")
+                g9 = gslabs(2, [(r(dszt)[:, :2 * D], w_ctx), (r(dszt)[:, D:], w_h1)])
+                a_, n_ = srcs([g9[0]])
+                check(lib.set_attention_bwd_src_f32(None, a_, n_, DCTX[t].data_ptr(), dalc.data_ptr(), L["ALPHAC"][t].data_ptr(),
+                                                    H.data_ptr(), att1_c.data_ptr(), L["ATT2C"][t].data_ptr(), ca_full.data_ptr(),
+                                                    datt1c.data_ptr(), DATT2[t][:, Adim:].data_ptr(), DWFC[t].data_ptr(),
+                                                    DEC[t].data_ptr(), bt, Tc, D, Adim, 1, 1, 2 * Adim, st),
+                      "set_attention_bwd_src_f32")
+                g11 = gslabs(3, [(r(DATT2[t]), dec_cat)])
+                # ---- attention LSTM backward: dh1 = W_hh term of the next timestep + the three addends of this one
+                dc1_in, dc1_out = DC1[t & 1], DC1[(t & 1) ^ 1]
+                a_, n_ = srcs([nxt_dh1, g5[0], g9[1], g11[0]])
+                check(lib.set_lstm_cell_bwd_src_f32(a_, n_, dc1_in.data_ptr(), L["G1"][t].data_ptr(), L["C1"][t].data_ptr(),
+                                                    L["C1"][t + 1].data_ptr(), DG1[t].data_ptr(), dc1_out.data_ptr(), bt, D, st),
+                      "set_lstm_cell_bwd_src_f32")
+                dg1 = r(DG1[t])
+                g13 = gslabs(4, [(dg1, wih[:, 2 * D:3 * D]), (dg1, P["al_whh"])])
+                nxt_dh2, nxt_dh1 = [g5[3], g13[0]], g13[1]
+                if mid and t == mid and all(A._is_leaf_param(params[i]) for i in range(len(params)) if need[i]):
+                    early = launch_early()
+        for t in (range(T - 1, -1, -1) if not slab_direct else ()):
             bt = bts[t]
             r = lambda x: _rows(x, bt)
             h1 = L["H1"][t + 1]
