@@ -351,50 +351,16 @@ __global__ void __launch_bounds__(256) gemm_gen_f32(const GenLaunch L) {
         }
         return;
     }
-    if (T.vec_store) {
-        // 16-byte stores through a per-wave LDS transpose of each 32x32 sub-tile (same epilogue as gemm_nt_f32)
-        float* sT = &lds[0][0] + wave * 1024;
-        const int trow = lane >> 3, tcol = (lane & 7) * 4;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * TN * 32 + j * 32 + tcol;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                if (i + j) __syncthreads();
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sT[((r & 3) + 8 * (r >> 2) + 4 * kh) * 32 + frow] = acc[i][j][r];
-                __syncthreads();
-                const int rbase = m0 + wm * TM * 32 + i * 32 + trow;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 v4 = *reinterpret_cast<const f32x4*>(sT + q * 256 + lane * 4);
-                    const int row = rbase + 8 * q;
-                    if (row < T.M && col < T.N) {
-                        f32x4* p = reinterpret_cast<f32x4*>(Cs + (long long)row * T.ldc + col);
-                        *p = acc_c ? *p + v4 : v4;
-                    }
-                }
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = ccol0 + j * 32;
-        if (col >= T.N) continue;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = crow0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                if (row < T.M) {
-                    float* p = Cs + (long long)row * T.ldc + col;
-                    *p = acc_c ? *p + acc[i][j][r] : acc[i][j][r];
-                }
-            }
-        }
-    }
+#include "gemm_gen_epilogue.inc"
 }
+
+// The hand-written k-loop of the 128x64 class (round 5, `gemm_gen_asm<A_KMAJ>`): built, BIT-IDENTICAL to gemm_gen_f32, and not
+// faster (x2h weight gradient 122.7 vs 122.2 TFLOP/s: once the predicated loads were gone — HWB above — the compiler-scheduled
+// loop runs at the clock-limited rate inside a round of tiles; what is left is tile quantisation).  It lives in
+// experimental/gemm_gen_asm_kernel.inc, compiled only with -DSET_EXPERIMENTAL_GEMMS (SET_GEMM_GEN_ASM=1 selects it there).
+#ifdef SET_EXPERIMENTAL_GEMMS
+#include "experimental/gemm_gen_asm_kernel.inc"
+#endif
 
 // out[m, n] (+)= sum over slabs, slab 0 first; one launch serves every split task of a group
 __global__ void __launch_bounds__(256) slab_reduce_k(const GenLaunch L) {
@@ -599,7 +565,21 @@ int gemm_gen_group(const SetGemmDesc* d, int n, int a_kminor, int b_kminor, void
         const char* name = a_kminor ? (b_kminor ? "gemm_gen_f32<tn>" : "gemm_gen_f32<tt>")
                                     : (b_kminor ? "gemm_gen_f32<nn>" : "gemm_gen_f32<nt>");
         ProfScope ps(name, s, flops, bytes);
-        if (counters_used > 0) {
+        // the hand-written k-loop: 128x64 tiles, B k-minor (dX, dW), operands addressable by a 31-bit offset, and with a
+        // k-major A a contraction length that fills its last k-tile (SET_GEMM_GEN_ASM=0: the compiler-scheduled kernel)
+        bool use_asm = false;
+#ifdef SET_EXPERIMENTAL_GEMMS
+        static const int asm_on = env_int("SET_GEMM_GEN_ASM", 0);
+        use_asm = asm_on && hwb && bm == 128 && b_kminor && counters_used == 0;
+        if (use_asm && !a_kminor)
+            for (int i = 0; i < n; ++i) if (L.t[i].K & 31) use_asm = false;
+        if (use_asm) {
+            if (a_kminor) hipLaunchKernelGGL(gemm_gen_asm<false>, dim3((unsigned)wg), dim3(256), 0, s, L);
+            else hipLaunchKernelGGL(gemm_gen_asm<true>, dim3((unsigned)wg), dim3(256), 0, s, L);
+        }
+#endif
+        if (use_asm) {
+        } else if (counters_used > 0) {
             if (bm == 128) launch_gen<128, 64, true, false>(L, !a_kminor, !b_kminor, (unsigned)wg, s);
             else launch_gen<64, 64, true, false>(L, !a_kminor, !b_kminor, (unsigned)wg, s);
         } else if (hwb) {
