@@ -33,7 +33,43 @@ import numpy as np
 import torch
 
 
-class AdaptiveFeatureReader:
+class _PinnedRing:
+    """The ring of pinned host slots both readers produce into.  Allocated ONCE (pinning 37 MB buffers is slow), shared by
+    every iteration of the reader.  A slot is `lent` from the moment a batch in it is handed out until release(): a new
+    iteration starts with the slots that are not lent (a batch of an earlier iteration whose H2D copy is still in flight
+    keeps its slot until it is released — late releases just add the slot to the current free list, never a second token for a
+    slot that is already free).  Plain `for batch in reader:` loops release the previous batch's slot when the next one is
+    asked for; a DevicePrefetcher (which keeps several batches in flight and releases each after its copy) switches that off
+    through `manual_release`."""
+    manual_release = False
+
+    def _ring_init(self):
+        self._slots, self._free, self._lent, self._ring_lock = None, None, set(), threading.Lock()
+
+    def _ring_ensure(self, make_slot):
+        if self._slots is None:
+            self._slots = [make_slot() for _ in range(self.depth)]
+        with self._ring_lock:
+            self._free = queue.Queue()
+            for i in range(self.depth):
+                if i not in self._lent:
+                    self._free.put(i)
+
+    def _lend(self, slot):
+        with self._ring_lock:
+            self._lent.add(slot)
+
+    def release(self, slot):
+        """hand a pinned slot back (DevicePrefetcher: once its H2D copy has completed); releasing twice is harmless"""
+        if slot is None or self._free is None:
+            return
+        with self._ring_lock:
+            if slot in self._lent:
+                self._lent.discard(slot)
+                self._free.put(slot)
+
+
+class AdaptiveFeatureReader(_PinnedRing):
     """Iterable of `(images (B,R,F) fp32, images_mean (B,F) fp32, *extras)` host batches in pinned memory.
 
     att_dir / fc_dir : directories holding `<image_id>.npz` (array 'feat', (n,F), n <= R) and `<image_id>.npy` (F,)
@@ -49,8 +85,7 @@ class AdaptiveFeatureReader:
         self.R, self.F = max_regions, feat_dim
         self.workers, self.depth = max(1, workers), max(2, depth)
         self.pin = torch.cuda.is_available() if pin is None else pin
-        self._slots = None
-        self._free = None
+        self._ring_init()
 
     def __len__(self):
         return len(self.id_batches)
@@ -59,10 +94,7 @@ class AdaptiveFeatureReader:
         bmax = max(len(b) for b in self.id_batches)
         mk = lambda *shape: (torch.empty(*shape, dtype=torch.float32).pin_memory() if self.pin
                              else torch.empty(*shape, dtype=torch.float32))
-        self._slots = [(mk(bmax, self.R, self.F), mk(bmax, self.F)) for _ in range(self.depth)]
-        self._free = queue.Queue()
-        for i in range(self.depth):
-            self._free.put(i)
+        self._ring_ensure(lambda: (mk(bmax, self.R, self.F), mk(bmax, self.F)))
 
     def _load_one(self, img_np, mean_np, row, image_id):
         with np.load(os.path.join(self.att_dir, "%d.npz" % image_id)) as z:
@@ -73,11 +105,6 @@ class AdaptiveFeatureReader:
         img_np[row, :n] = feat                       # converts to fp32 on the way (float64 files included)
         img_np[row, n:] = 0.0                        # zero padding = the reference's np.zeros((B,100,2048))
         mean_np[row] = np.load(os.path.join(self.fc_dir, "%d.npy" % image_id))
-
-    def release(self, slot):
-        """hand a pinned slot back (called by DevicePrefetcher once its H2D copy has completed)"""
-        if slot is not None and self._free is not None:
-            self._free.put(slot)
 
     def __iter__(self):
         self._alloc()
@@ -106,6 +133,7 @@ class AdaptiveFeatureReader:
 
         th = threading.Thread(target=producer, daemon=True)
         th.start()
+        prev = None
         try:
             while True:
                 item = ready.get()
@@ -117,12 +145,18 @@ class AdaptiveFeatureReader:
                 img, mean = self._slots[slot]
                 batch = HostBatch((img[:n], mean[:n]) + tuple(self.extras[bi] if self.extras is not None else ()))
                 batch.slot, batch.owner = slot, self
+                if not self.manual_release and prev is not None:
+                    self.release(prev)                   # plain iteration: the previous batch's slot goes back
+                self._lend(slot)
+                prev = slot
                 yield batch
         finally:
             stop.set()
+            if not self.manual_release and prev is not None:
+                self.release(prev)
 
 
-class FixedFeatureReader:
+class FixedFeatureReader(_PinnedRing):
     """Iterable of `(images (B,R,F) fp32, *extras)` host batches in pinned memory for the fixed-region feature files of the
     reference's datasets (`COCOTrainDataset.__getitem__`, editnet.py:46-74: `objdet = self.objdet[i // cpi]`; the row
     `objdet[1]` of `val_features` if `objdet[0] == "v"` else of `train_features`).
@@ -149,8 +183,15 @@ class FixedFeatureReader:
         self.R, self.F = int(any_store.shape[1]), int(any_store.shape[2])
         self.workers, self.depth = max(1, workers), max(2, depth)
         self.pin = torch.cuda.is_available() if pin is None else pin
-        self._slots = None
-        self._free = None
+        self._ring_init()
+        # the splits and rows every batch names are checked here, not in a worker thread half way through an epoch
+        for b in self.ref_batches:
+            for sp, row in b:
+                key = "v" if sp == "v" else "t"
+                if key not in self.stores:
+                    raise KeyError('a sample names the "%s" split but stores has no "%s" entry' % (sp, key))
+                if not 0 <= row < int(self.stores[key].shape[0]):
+                    raise IndexError("row %d of split %r is outside its store (%d rows)" % (row, sp, int(self.stores[key].shape[0])))
 
     def _open(self, src):
         if isinstance(src, (str, os.PathLike)):
@@ -182,18 +223,11 @@ class FixedFeatureReader:
     def __len__(self):
         return len(self.ref_batches)
 
-    def release(self, slot):
-        if slot is not None and self._free is not None:
-            self._free.put(slot)
-
     def _alloc(self):
         bmax = max(len(b) for b in self.ref_batches)
         mk = lambda *shape: (torch.empty(*shape, dtype=torch.float32).pin_memory() if self.pin
                              else torch.empty(*shape, dtype=torch.float32))
-        self._slots = [mk(bmax, self.R, self.F) for _ in range(self.depth)]
-        self._free = queue.Queue()
-        for i in range(self.depth):
-            self._free.put(i)
+        self._ring_ensure(lambda: mk(bmax, self.R, self.F))
 
     def _load_one(self, img_np, i, ref):
         split, row = ref
@@ -226,6 +260,7 @@ class FixedFeatureReader:
 
         th = threading.Thread(target=producer, daemon=True)
         th.start()
+        prev = None
         try:
             while True:
                 item = ready.get()
@@ -236,9 +271,15 @@ class FixedFeatureReader:
                 bi, slot, n = item
                 batch = HostBatch((self._slots[slot][:n],) + tuple(self.extras[bi] if self.extras is not None else ()))
                 batch.slot, batch.owner = slot, self
+                if not self.manual_release and prev is not None:
+                    self.release(prev)                   # plain iteration: the previous batch's slot goes back
+                self._lend(slot)
+                prev = slot
                 yield batch
         finally:
             stop.set()
+            if not self.manual_release and prev is not None:
+                self.release(prev)
 
 
 class HostBatch(tuple):
@@ -278,6 +319,8 @@ class DevicePrefetcher:
         ring = getattr(iterable, "depth", None)
         if isinstance(ring, int) and ring >= 1:
             self.depth = max(1, min(self.depth, ring - 1))
+        if isinstance(iterable, _PinnedRing):
+            iterable.manual_release = True       # several batches in flight here: each slot is returned after ITS copy
         self.queue = []
         self.record_timing = record_timing
         self.timeline = []

@@ -89,13 +89,23 @@ class FlatGradBuckets:
         for f in self.flat:
             f.zero_()
         self.touched = set()
-        if not getattr(self, "_hooked", False):
-            # gradients produced by plain autograd accumulation (not announced through deferred_param_grads) are seen here
-            for p in self.params:
-                p.register_post_accumulate_grad_hook(lambda t, _self=self: _self.touched.add(id(t)))
-            self._hooked = True
+        if not getattr(self, "_hooks", None):
+            # gradients produced by plain autograd accumulation (not announced through deferred_param_grads) are seen here.
+            # The handles are kept: close() removes the hooks when the buckets are rebuilt (they would otherwise pile up on
+            # the same parameters and keep the old buckets alive)
+            self._hooks = [p.register_post_accumulate_grad_hook(lambda t, _self=self: _self.touched.add(id(t)))
+                           for p in self.params]
         for p in self.params:
             p.grad = self.view[id(p)]
+
+    def close(self):
+        """detach from the parameters: hooks removed, `.grad` views of these buckets dropped"""
+        for h in getattr(self, "_hooks", None) or ():
+            h.remove()
+        self._hooks = None
+        for p in self.params:
+            if p.grad is not None and p.grad.data_ptr() == self.view[id(p)].data_ptr():
+                p.grad = None
 
     def touch(self, grad):
         """the backward announces a parameter whose gradient it wrote (BucketedAllReduce.add)"""
@@ -122,6 +132,8 @@ def flat_grad_buckets(module, params, bucket_bytes=None, first=()):
     fb = module.__dict__.get("_grad_buckets")
     sig = tuple((id(p), p.numel(), p.device) for p in params)
     if fb is None or fb.sig != sig or fb.bucket_bytes != (bucket_bytes or BUCKET_BYTES):
+        if fb is not None:
+            fb.close()
         fb = FlatGradBuckets(params, bucket_bytes or BUCKET_BYTES, first)
         fb.bucket_bytes = bucket_bytes or BUCKET_BYTES
         module.__dict__["_grad_buckets"] = fb

@@ -60,3 +60,44 @@ def test_dp_gradient_allreduce_matches_big_batch(world):
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert len(ret) == world
     assert max(ret.values()) < 1e-6, dict(ret)
+
+
+def test_flat_grad_buckets_touched_set_equals_single_rank_grads_and_hooks_are_removed():
+    """FlatGradBuckets (the persistent flat gradient buffers of the data-parallel step): the set of parameters it reports as
+    touched by a backward == the set of parameters that get a gradient in the plain single-rank step (the others keep
+    `.grad = None` after release_untouched, as Adam expects), and rebuilding the buckets removes the accumulate hooks of
+    the old ones instead of piling new ones on top."""
+    from show_edit_tell_amd.train import FlatGradBuckets, flat_grad_buckets
+    torch.manual_seed(1)
+    used = torch.nn.Linear(6, 4)
+    unused = torch.nn.Linear(3, 3)                       # takes no part in the graph
+    mod = torch.nn.ModuleDict({"a": used, "b": unused})
+    params = list(mod.parameters())
+    x = torch.randn(5, 6)
+    # single-rank reference: which parameters get a gradient
+    for p in params:
+        p.grad = None
+    used(x).sum().backward()
+    ref = {id(p) for p in params if p.grad is not None}
+    ref_grads = {id(p): p.grad.clone() for p in params if p.grad is not None}
+    fb = flat_grad_buckets(mod, params, bucket_bytes=64)
+    fb.attach()
+    assert all(p.grad is not None and p.grad.data_ptr() == fb.view[id(p)].data_ptr() for p in params)
+    used(x).sum().backward()
+    assert fb.touched == ref
+    assert fb.release_untouched() == len(params) - len(ref)
+    assert {id(p) for p in params if p.grad is not None} == ref
+    for p in params:
+        if id(p) in ref:
+            assert torch.equal(p.grad, ref_grads[id(p)])
+    hooks = lambda p: len(getattr(p, "_post_accumulate_grad_hooks", None) or {})
+    assert all(hooks(p) == 1 for p in params)
+    # another bucket size -> the buckets are rebuilt: old hooks gone, one hook per parameter again after attach()
+    fb2 = flat_grad_buckets(mod, params, bucket_bytes=4096)
+    assert fb2 is not fb and all(hooks(p) == 0 for p in params)
+    fb2.attach()
+    assert all(hooks(p) == 1 for p in params)
+    used(x).sum().backward()
+    assert fb2.touched == ref
+    fb2.close()
+    assert all(hooks(p) == 0 and p.grad is None for p in params)

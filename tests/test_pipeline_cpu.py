@@ -159,3 +159,44 @@ def test_fixed_reader_needs_h5py_for_hdf5(tmp_path):
     open(p, "wb").write(b"x")
     with pytest.raises(RuntimeError, match="convert"):
         pipeline.FixedFeatureReader({"t": p}, [[("t", 0)]], pin=False)
+
+
+def test_fixed_reader_ring_is_allocated_once_and_survives_stale_and_missing_releases(tmp_path):
+    """the pinned ring is allocated once and reused by every epoch; a plain `for` loop (nobody calls release)
+    runs through more batches than the ring has slots; a batch of an earlier iteration that is released late never gives the
+    ring a second token for a slot; samples that name a split without a store are refused at construction."""
+    import pytest
+    ds = _fixed_dataset(tmp_path)
+    cpi = ds["cpi"]
+    n = len(ds["captions"])
+    batches = [list(range(i, min(i + 4, n))) for i in range(0, n, 4)]
+    refs = [[tuple(ds["objdet"][i // cpi][:2]) for i in b] for b in batches]
+    assert len(batches) > 3
+    reader = pipeline.FixedFeatureReader({"t": ds["tp"], "v": ds["vp"]}, refs, workers=2, depth=3, pin=False)
+    seen = [b[0].clone() for b in reader]                       # plain iteration, no release() anywhere: must not stall
+    assert len(seen) == len(batches)
+    slots = [t.data_ptr() for t in reader._slots]
+    again = [b[0].clone() for b in reader]
+    assert [t.data_ptr() for t in reader._slots] == slots, "the ring is allocated once"
+    assert all(torch.equal(a, b) for a, b in zip(seen, again))
+    # manual release (what DevicePrefetcher does): break early holding one batch, start a new epoch, release late
+    reader.manual_release = True
+    it = iter(reader)
+    held = next(it)
+    it.close()
+    it2 = iter(reader)
+    first = next(it2)
+    assert held.slot in reader._lent and first.slot != held.slot
+    reader.release(held.slot)
+    reader.release(held.slot)                                   # twice: harmless
+    reader.release(first.slot)
+    rest = []
+    for b in it2:
+        rest.append(b[0].clone())
+        reader.release(b.slot)
+    assert len(rest) == len(batches) - 1
+    assert reader._free.qsize() + len(reader._lent) == reader.depth
+    with pytest.raises(KeyError):
+        pipeline.FixedFeatureReader({"t": ds["tp"]}, [[("v", 0)]], pin=False)
+    with pytest.raises(IndexError):
+        pipeline.FixedFeatureReader({"t": ds["tp"]}, [[("t", 10 ** 6)]], pin=False)
