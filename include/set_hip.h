@@ -527,6 +527,18 @@ int set_dropout_bwd_philox_f32(const float* dy, int64_t lddy, float* dx, int64_t
 size_t set_colsum_workspace_bytes(int cols);
 int set_colsum_f32(const float* x, int64_t ld, int rows, int cols, float* out, int accumulate, void* ws,
                    size_t ws_bytes, void* stream);
+/* Several column sums as ONE pair of launches (the ~16 bias gradients of a training step; reference: autograd's per-bias
+ * sum over (t, b) of every nn.Linear / nn.LSTMCell bias, editnet.py:223-560): out (+)= colsum(x), and out2 (+)= the same sums
+ * when non-NULL (two biases fed by the same gradient: LSTMCell's bias_ih / bias_hh).  Deterministic (no atomics);
+ * n <= SET_COLSUM_MAX; cols, ld multiples of 4; ws of set_colsum_group_workspace_bytes(d, n). */
+#define SET_COLSUM_MAX 24
+typedef struct SetColsumDesc {
+    const float* x; int64_t ld; int rows; int cols;
+    float* out; int accumulate;
+    float* out2; int accumulate2;
+} SetColsumDesc;
+size_t set_colsum_group_workspace_bytes(const SetColsumDesc* d, int n);
+int set_colsum_group_f32(const SetColsumDesc* d, int n, void* ws, size_t ws_bytes, void* stream);
 /* mask[r] = (sum_c x[r, c] != 0) as 0/1 floats: the data-derived region mask of the adaptive model
  * (adaptive_features/editnet_adaptive.py:449-453) on the per-step, dropped-out region embedding. */
 int set_rowsum_mask_f32(const float* x, int64_t ld, int rows, int cols, float* mask, void* stream);

@@ -144,6 +144,12 @@ class SlabSrc(C.Structure):
     _fields_ = [("p", C.c_void_p), ("slab_stride", C.c_int64), ("ld", C.c_int64), ("nslab", C.c_int32), ("rows", C.c_int32)]
 
 
+class ColsumDesc(C.Structure):
+    """include/set_hip.h SetColsumDesc: one column sum of a grouped launch (set_colsum_group_f32)"""
+    _fields_ = [("x", C.c_void_p), ("ld", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32), ("out", C.c_void_p),
+                ("accumulate", C.c_int32), ("out2", C.c_void_p), ("accumulate2", C.c_int32)]
+
+
 def _fields(spec):
     """'int a, b; float c; ptr d, e' style field list -> ctypes _fields_"""
     kinds = {"int": C.c_int, "float": C.c_float, "u64": C.c_uint64, "i64": C.c_int64, "ptr": C.c_void_p, "size": C.c_size_t}
@@ -276,6 +282,8 @@ PROTOTYPES = {
     "set_clip_adam_f32": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_float, _I, _P, _P, _Z, _P]),
     "set_colsum_workspace_bytes": (_Z, [_I]),
     "set_colsum_f32": (_I, [_P, _L, _I, _I, _P, _I, _P, _Z, _P]),
+    "set_colsum_group_workspace_bytes": (_Z, [_P, _I]),
+    "set_colsum_group_f32": (_I, [_P, _I, _P, _Z, _P]),
     "set_dropout_f32": (_I, [_P, _L, _P, _L, _I, _I, C.c_float, _U, _U, _P]),
     "set_embed_relu_dropout_f32": (_I, [_P, _P, _L, _P, _L, _I, _I, _I, C.c_float, _U, _U, _P]),
     "set_dropout_bwd_f32": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, C.c_float, _I, _P]),

@@ -262,25 +262,26 @@ def deferred_param_grads(on_ready=None):
                 cat_cache[key] = torch.cat(ts, 0)
             return cat_cache[key]
 
-        colsums = {}       # two biases fed by the SAME output gradients (nn.LSTMCell's bias_ih / bias_hh, the x2h / h2h pair of
-                           # the copy cell, gate_cnew / gate_cmem) share one column sum
+        # bias gradients first, all of them as one grouped column-sum launch; two biases fed by the SAME output gradients
+        # (nn.LSTMCell's bias_ih / bias_hh, the x2h / h2h pair of the copy cell, gate_cnew / gate_cmem) share one problem
+        problems = {}
         for param, (dys, xs) in pending.values():
-            dy = cat(dys)
             if xs is None:
-                key = tuple(id(t) for t in dys)
-                g = colsums.get(key)
-                if g is None:
-                    g = colsums[key] = _colsum(dy)
-                if param.grad is None:
-                    param.grad = g.reshape(param.shape).clone()
-                else:
-                    param.grad.add_(g.reshape(param.shape))
+                problems.setdefault(tuple(id(t) for t in dys), (dys, []))[1].append(param)
+        if problems:
+            _colsum_group([(cat(dys), plist) for dys, plist in problems.values()])
+            if on_ready is not None:
+                for _, plist in problems.values():
+                    for q in plist:
+                        on_ready(q)
+        for param, (dys, xs) in pending.values():
+            if xs is None:
+                continue
+            dy, x = cat(dys), cat(xs)
+            if param.grad is None:
+                param.grad = _wgrad_mm(dy, x)
             else:
-                x = cat(xs)
-                if param.grad is None:
-                    param.grad = _wgrad_mm(dy, x)
-                else:
-                    _wgrad_mm(dy, x, out=param.grad)
+                _wgrad_mm(dy, x, out=param.grad)
             if on_ready is not None:
                 on_ready(param)
     finally:
@@ -389,6 +390,54 @@ def _colsum(dy, out=None):
     check(lib.set_colsum_f32(ptr(dy), ld, rows, cols, ptr(out), int(acc), ptr(ws), ws.numel(), stream_of(dy.device)),
           "set_colsum_f32")
     return out
+
+
+_colsum_ws = {}
+
+
+def _colsum_group(problems):
+    """problems = [(dy, [param, ...])]: every listed parameter's .grad (+)= the column sums of dy, all problems in ONE pair of
+    launches (set_colsum_group_f32) — a training step has ~16 bias gradients, each of which was two launches plus an add.
+    Problems the grouped kernel cannot take (non-fp32, ragged columns, unaligned .grad views) go through _colsum."""
+    lib = _lib.load()
+    descs, keep, rest = [], [], []
+    for dy, plist in problems:
+        ok = dy.is_cuda and dy.dtype == torch.float32 and dy.dim() == 2 and dy.shape[1] % 4 == 0 and dy.shape[0] >= 64
+        if ok:
+            for q in plist:
+                g = q.grad
+                if g is not None and (not g.is_contiguous() or g.data_ptr() % 16 or g.dtype != torch.float32 or g.numel() != dy.shape[1]):
+                    ok = False
+        if not ok or len(descs) + (len(plist) + 1) // 2 > 24:
+            rest.append((dy, plist))
+            continue
+        dy, ld = _mat(dy)
+        keep.append(dy)
+        outs = []
+        for q in plist:
+            acc = q.grad is not None
+            if not acc:
+                q.grad = torch.empty(q.shape, dtype=torch.float32, device=dy.device)
+            outs.append((q.grad, acc))
+        for i in range(0, len(outs), 2):
+            o2 = outs[i + 1] if i + 1 < len(outs) else (None, False)
+            descs.append((dy.data_ptr(), ld, dy.shape[0], dy.shape[1], outs[i][0].data_ptr(), int(outs[i][1]),
+                          o2[0].data_ptr() if o2[0] is not None else None, int(o2[1])))
+    if descs:
+        arr = (_lib.ColsumDesc * len(descs))(*[_lib.ColsumDesc(*d) for d in descs])
+        dev = keep[0].device
+        need = lib.set_colsum_group_workspace_bytes(arr, len(descs))
+        ws = _colsum_ws.get(dev)
+        if ws is None or ws.numel() * 4 < need:
+            ws = _colsum_ws[dev] = torch.empty((need + 3) // 4 + 1024, dtype=torch.float32, device=dev)
+        check(lib.set_colsum_group_f32(arr, len(descs), ptr(ws), ws.numel() * 4, stream_of(dev)), "set_colsum_group_f32")
+    for dy, plist in rest:
+        g = _colsum(dy)
+        for q in plist:
+            if q.grad is None:
+                q.grad = g.reshape(q.shape).clone()
+            else:
+                q.grad.add_(g.reshape(q.shape))
 
 
 def _bgrad(param, dy, eager=False):

@@ -108,11 +108,11 @@ __global__ void __launch_bounds__(256) copy_gate_bwd_k(const float* dh, const fl
 
 // LSTM gate backward given the gradient of the new cell state and the o-gate pre-activation gradient
 template <bool SRC>
-__global__ void __launch_bounds__(256) lstm_gates_bwd_k(const float* dcn, const float* do_pre, const float* gates,
-                                                        const float* c_prev, float* dgates, float* dc_prev, int M,
-                                                        int D, const SrcList S) {
+__device__ __forceinline__ void lstm_gates_bwd_body(const int blk, const float* dcn, const float* do_pre, const float* gates,
+                                                    const float* c_prev, float* dgates, float* dc_prev, int M, int D,
+                                                    const SrcList& S) {
     const int per_row = D >> 2;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long idx = (long long)blk * blockDim.x + threadIdx.x;
     if (idx >= (long long)M * per_row) return;
     const long long m = idx / per_row;
     const int j = (int)(idx - m * per_row) << 2;
@@ -131,16 +131,22 @@ __global__ void __launch_bounds__(256) lstm_gates_bwd_k(const float* dcn, const 
     stb4(dr, di); stb4(dr + D, df); stb4(dr + 2 * D, dg); stb4(dr + 3 * D, dop);
     stb4(dc_prev + m * D + j, dcp);
 }
+template <bool SRC>
+__global__ void __launch_bounds__(256) lstm_gates_bwd_k(const float* dcn, const float* do_pre, const float* gates,
+                                                        const float* c_prev, float* dgates, float* dc_prev, int M,
+                                                        int D, const SrcList S) {
+    lstm_gates_bwd_body<SRC>(blockIdx.x, dcn, do_pre, gates, c_prev, dgates, dc_prev, M, D, S);
+}
 
 // ---------------------------------------------------------------------------------------------
 // context gating backward (editnet.py:378-380): out = zt s + (1-zt) t, zt = sig(z), s = tanh(.), t = tanh(.)
 //   dz_pre = dout (s - t) zt (1-zt) ; ds_pre = dout zt (1-s^2) ; dt_pre = dout (1-zt)(1-t^2)
 // ---------------------------------------------------------------------------------------------
 template <bool SRC>
-__global__ void __launch_bounds__(256) context_gate_bwd_k(const float* dout, const float* zt, const float* s,
-                                                          const float* t, float* dz, float* ds, float* dt, long long n4,
-                                                          int D4, long long ld_out, const SrcList S) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void context_gate_bwd_body(const int blk, const float* dout, const float* zt, const float* s,
+                                                      const float* t, float* dz, float* ds, float* dt, long long n4, int D4,
+                                                      long long ld_out, const SrcList& S) {
+    const long long idx = (long long)blk * blockDim.x + threadIdx.x;
     if (idx >= n4) return;
     const long long o = idx * 4;
     const long long m = idx / D4;
@@ -154,6 +160,12 @@ __global__ void __launch_bounds__(256) context_gate_bwd_k(const float* dout, con
         c[e] = d[e] * (1.f - z[e]) * (1.f - tv[e] * tv[e]);
     }
     stb4(dz + oo, a); stb4(ds + oo, b); stb4(dt + oo, c);
+}
+template <bool SRC>
+__global__ void __launch_bounds__(256) context_gate_bwd_k(const float* dout, const float* zt, const float* s,
+                                                          const float* t, float* dz, float* ds, float* dt, long long n4,
+                                                          int D4, long long ld_out, const SrcList S) {
+    context_gate_bwd_body<SRC>(blockIdx.x, dout, zt, s, t, dz, ds, dt, n4, D4, ld_out, S);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -278,17 +290,23 @@ __global__ void __launch_bounds__(256) attention_bwd_k(const float* dctx, const 
 // results as attention_bwd_k up to the order of those two sums.
 constexpr int ATTW_RB = 3;       // value rows of a wave in flight
 constexpr int ATTW_SB = 10;      // projection rows of a thread in flight
+struct AttBwdArgs {
+    const float* dctx; const float* dalpha_ext; const float* alpha; const float* Vals; const float* att1; const float* att2;
+    const float* w_full; float* datt1; float* datt2; float* dwfull_part; float* de_out; int L, Dv, A, acc_datt1;
+    long long ld_datt2; float* dctx_out;
+};
 template <bool TANH, bool SRC>
-__global__ void __launch_bounds__(512) attention_bwd_wide_k(const float* dctx, const float* dalpha_ext, const float* alpha,
-                                                           const float* Vals, const float* att1, const float* att2,
-                                                           const float* w_full, float* datt1, float* datt2,
-                                                           float* dwfull_part, float* de_out, int L, int Dv, int A,
-                                                           int acc_datt1, long long ld_datt2, const SrcList S, float* dctx_out) {
+__device__ __forceinline__ void attention_bwd_wide_body(const int b, const AttBwdArgs& P, const SrcList& S) {
     __shared__ float s_da[ATTB_MAX];
     __shared__ float s_de[ATTB_MAX];
     __shared__ float s_dot;
     __shared__ __attribute__((aligned(16))) float s_acc[4 * 128 * 4 * 2];     // [slice][column group][acc2 | accw] float4
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *dctx = P.dctx, *dalpha_ext = P.dalpha_ext, *alpha = P.alpha, *Vals = P.Vals, *att1 = P.att1, *att2 = P.att2,
+                *w_full = P.w_full;
+    float *datt1 = P.datt1, *datt2 = P.datt2, *dwfull_part = P.dwfull_part, *de_out = P.de_out, *dctx_out = P.dctx_out;
+    const int L = P.L, Dv = P.Dv, A = P.A, acc_datt1 = P.acc_datt1;
+    const long long ld_datt2 = P.ld_datt2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NQ = 8;                                   // Dv <= 2048
     f32x4 dcr[NQ];
     if constexpr (SRC) {
@@ -403,17 +421,31 @@ __global__ void __launch_bounds__(512) attention_bwd_wide_k(const float* dctx, c
         }
     }
 }
+template <bool TANH, bool SRC>
+__global__ void __launch_bounds__(512) attention_bwd_wide_k(const AttBwdArgs P, const SrcList S) {
+    attention_bwd_wide_body<TANH, SRC>(blockIdx.x, P, S);
+}
+// visual attention backward + context gating backward of one timestep in one launch (both wait for the same grouped dX
+// product and feed the next one): blocks [0, M) = attention rows, the rest = context-gate elements, 512 threads each
+struct CtxGateArgs { const float* dout; const float* zt; const float* s; const float* t; float* dz; float* ds; float* dt;
+                     long long n4; int D4; long long ld_out; };
+template <bool SRC>
+__global__ void __launch_bounds__(512) attention_ctxgate_bwd_k(const AttBwdArgs P, const SrcList S, const CtxGateArgs C,
+                                                               const SrcList SC, int M) {
+    if ((int)blockIdx.x < M) attention_bwd_wide_body<false, SRC>(blockIdx.x, P, S);
+    else context_gate_bwd_body<SRC>(blockIdx.x - M, C.dout, C.zt, C.s, C.t, C.dz, C.ds, C.dt, C.n4, C.D4, C.ld_out, SC);
+}
 
 // ---------------------------------------------------------------------------------------------
 // SelectC backward (editnet.py:409-420): sel = w M[j*], w = a + (1 - a_detached)
 //   dM[b, j*] = w dsel ; dalpha[b, j*] = <dsel, M[b, j*]> ; zero elsewhere
 // ---------------------------------------------------------------------------------------------
 template <bool SRC>
-__global__ void __launch_bounds__(256) select_bwd_k(const float* dsel, const float* Mem, const float* alpha, float* dM,
-                                                    float* dalpha, int T, int D, int acc_dm, const SrcList S) {
+__device__ __forceinline__ void select_bwd_body(const int b, const float* dsel, const float* Mem, const float* alpha, float* dM,
+                                                float* dalpha, int T, int D, int acc_dm, const SrcList& S) {
     __shared__ int s_arg;
     __shared__ float s_val, s_red[4];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 64) {
         float best = -INFINITY; int bi = 0x7fffffff;
         for (int t = tid; t < T; t += 64) { const float a = alpha[(long long)b * T + t]; if (a > best) { best = a; bi = t; } }
@@ -456,6 +488,22 @@ __global__ void __launch_bounds__(256) select_bwd_k(const float* dsel, const flo
     __syncthreads();
     for (int t = tid; t < T; t += 256)
         dalpha[(long long)b * T + t] = (t == js) ? ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) : 0.f;
+}
+template <bool SRC>
+__global__ void __launch_bounds__(256) select_bwd_k(const float* dsel, const float* Mem, const float* alpha, float* dM,
+                                                    float* dalpha, int T, int D, int acc_dm, const SrcList S) {
+    select_bwd_body<SRC>(blockIdx.x, dsel, Mem, alpha, dM, dalpha, T, D, acc_dm, S);
+}
+// LSTM gate backward + SelectC backward of one timestep in one launch (both wait for the same grouped dX product):
+// blocks [0, nG) = gate elements, the next M = selection rows
+template <bool SRC>
+__global__ void __launch_bounds__(256) lstm_gates_select_bwd_k(const float* dcn, const float* do_pre, const float* gates,
+                                                               const float* c_prev, float* dgates, float* dc_prev, int M, int D,
+                                                               const SrcList S, int nG, const float* dsel, const float* Mem,
+                                                               const float* alpha, float* dM, float* dalpha, int T, int acc_dm,
+                                                               const SrcList SS) {
+    if ((int)blockIdx.x < nG) lstm_gates_bwd_body<SRC>(blockIdx.x, dcn, do_pre, gates, c_prev, dgates, dc_prev, M, D, S);
+    else select_bwd_body<SRC>(blockIdx.x - nG, dsel, Mem, alpha, dM, dalpha, T, D, acc_dm, SS);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -574,6 +622,48 @@ int make_src_list(const SetSlabSrc* src, int n, SrcList* out) {
     return SET_OK;
 }
 
+
+// ---- merged launches of the training timestep loop (train_loop.hip): two kernels that wait for the same grouped product and
+// whose outputs feed the same next product run as ONE launch (the step is bound by its ~12 dependent launches, not by bytes)
+int lstm_gates_select_bwd_src(const float* dcn_base, const SetSlabSrc* src, const float* do_pre, const float* gates,
+                              const float* c_prev, float* dgates, float* dc_prev, const float* dsel_base, const SetSlabSrc* ssrc,
+                              const float* Mem, const float* alpha, float* dM, float* dalpha, int M, int T, int D, int acc_dM,
+                              hipStream_t st) {
+    if (!do_pre || !gates || !c_prev || !dgates || !dc_prev || !Mem || !alpha || !dM || !dalpha || M <= 0 || T <= 0 || D <= 0)
+        return SET_ERR_ARG;
+    if (D & 3) return SET_ERR_UNSUPPORTED;
+    SrcList S, SS;
+    SET_TRY(make_src_list(src, 1, &S));
+    SET_TRY(make_src_list(ssrc, 1, &SS));
+    const int nG = (int)(((long long)M * (D >> 2) + 255) / 256);
+    hipLaunchKernelGGL(lstm_gates_select_bwd_k<true>, dim3(nG + M), dim3(256), 0, st, dcn_base, do_pre, gates, c_prev, dgates, dc_prev,
+                       M, D, S, nG, dsel_base, Mem, alpha, dM, dalpha, T, acc_dM, SS);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+int attention_ctxgate_bwd_src(const SetSlabSrc* src, const float* alpha, const float* values, const float* att1, const float* att2,
+                              const float* w_full, float* datt1, float* datt2, float* dwfull_part, float* de, int M, int L, int Dv,
+                              int A, int acc_datt1, long long ld_datt2, const SetSlabSrc* csrc, const float* zt, const float* s,
+                              const float* t, float* dz, float* ds, float* dt, long long ld_out, int D, hipStream_t st) {
+    if (!alpha || !values || !att1 || !att2 || !w_full || !datt1 || !datt2 || !dwfull_part || !zt || !s || !t || !dz || !ds || !dt ||
+        M <= 0 || D <= 0)
+        return SET_ERR_ARG;
+    if (L > ATTB_MAX || (A & 3) || (Dv & 3) || A > 1024 || Dv > 2048 || (ld_datt2 & 3) || ld_datt2 < A || (D & 3) || (ld_out & 3) ||
+        ld_out < D)
+        return SET_ERR_UNSUPPORTED;
+    SrcList S, SC;
+    SET_TRY(make_src_list(src, 1, &S));
+    SET_TRY(make_src_list(csrc, 1, &SC));
+    const long long n4 = (long long)M * (D >> 2);
+    const AttBwdArgs P{nullptr, nullptr, alpha, values, att1, att2, w_full, datt1, datt2, dwfull_part, de, L, Dv, A, acc_datt1, ld_datt2,
+                       nullptr};
+    const CtxGateArgs Cg{nullptr, zt, s, t, dz, ds, dt, n4, D >> 2, ld_out};
+    hipLaunchKernelGGL(attention_ctxgate_bwd_k<true>, dim3(M + (unsigned)((n4 + 511) / 512)), dim3(512), 0, st, P, S, Cg, SC, M);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
 }  // namespace set
 
 using namespace set;
@@ -667,11 +757,9 @@ int set_attention_bwd_src_f32(const float* dctx_base, const SetSlabSrc* src, int
     SET_TRY(make_src_list(src, n_src, &S));
     hipStream_t st = (hipStream_t)stream;
     if (use_tanh)
-        hipLaunchKernelGGL((attention_bwd_wide_k<true, true>), dim3(M), dim3(512), 0, st, dctx_base, dalpha_ext, alpha, values, att1, att2,
-                           w_full, datt1, datt2, dwfull_part, de, L, Dv, A, acc_datt1, (long long)ld_datt2, S, dctx_out);
+        hipLaunchKernelGGL((attention_bwd_wide_k<true, true>), dim3(M), dim3(512), 0, st, AttBwdArgs{dctx_base, dalpha_ext, alpha, values, att1, att2, w_full, datt1, datt2, dwfull_part, de, L, Dv, A, acc_datt1, (long long)ld_datt2, dctx_out}, S);
     else
-        hipLaunchKernelGGL((attention_bwd_wide_k<false, true>), dim3(M), dim3(512), 0, st, dctx_base, dalpha_ext, alpha, values, att1, att2,
-                           w_full, datt1, datt2, dwfull_part, de, L, Dv, A, acc_datt1, (long long)ld_datt2, S, dctx_out);
+        hipLaunchKernelGGL((attention_bwd_wide_k<false, true>), dim3(M), dim3(512), 0, st, AttBwdArgs{dctx_base, dalpha_ext, alpha, values, att1, att2, w_full, datt1, datt2, dwfull_part, de, L, Dv, A, acc_datt1, (long long)ld_datt2, dctx_out}, S);
     SET_LAUNCH_CHECK();
     return SET_OK;
 }
@@ -782,12 +870,10 @@ int set_attention_bwd_acc_f32(const float* dctx, const float* dalpha_ext, const 
     hipStream_t st = (hipStream_t)stream;
     static const int wide = env_int("SET_ATT_BWD_WIDE", 1);
     if (wide && !dvalues) {                                  // 512 threads per row, several rows of every operand in flight
-        if (use_tanh)
-            hipLaunchKernelGGL((attention_bwd_wide_k<true, false>), dim3(M), dim3(512), 0, st, dctx, dalpha_ext, alpha, values, att1, att2,
-                               w_full, datt1, datt2, dwfull_part, de, L, Dv, A, acc_datt1, (long long)ld_datt2, SrcList(), (float*)nullptr);
-        else
-            hipLaunchKernelGGL((attention_bwd_wide_k<false, false>), dim3(M), dim3(512), 0, st, dctx, dalpha_ext, alpha, values, att1, att2,
-                               w_full, datt1, datt2, dwfull_part, de, L, Dv, A, acc_datt1, (long long)ld_datt2, SrcList(), (float*)nullptr);
+        const AttBwdArgs P{dctx, dalpha_ext, alpha, values, att1, att2, w_full, datt1, datt2, dwfull_part, de, L, Dv, A, acc_datt1,
+                           (long long)ld_datt2, nullptr};
+        if (use_tanh) hipLaunchKernelGGL((attention_bwd_wide_k<true, false>), dim3(M), dim3(512), 0, st, P, SrcList());
+        else hipLaunchKernelGGL((attention_bwd_wide_k<false, false>), dim3(M), dim3(512), 0, st, P, SrcList());
         SET_LAUNCH_CHECK();
         return SET_OK;
     }

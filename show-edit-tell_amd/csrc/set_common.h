@@ -158,6 +158,16 @@ struct SrcList {
 #endif
 };
 int make_src_list(const SetSlabSrc* src, int n, SrcList* out);     // backward.hip: validates (alignment, counts) and copies
+// merged launches of the training timestep loop (backward.hip; called by train_loop.hip): LSTM gate backward + SelectC
+// backward, visual attention backward + context gating backward — same results as the separate entry points
+int lstm_gates_select_bwd_src(const float* dcn_base, const SetSlabSrc* src, const float* do_pre, const float* gates,
+                              const float* c_prev, float* dgates, float* dc_prev, const float* dsel_base, const SetSlabSrc* ssrc,
+                              const float* Mem, const float* alpha, float* dM, float* dalpha, int M, int T, int D, int acc_dM,
+                              hipStream_t st);
+int attention_ctxgate_bwd_src(const SetSlabSrc* src, const float* alpha, const float* values, const float* att1, const float* att2,
+                              const float* w_full, float* datt1, float* datt2, float* dwfull_part, float* de, int M, int L, int Dv,
+                              int A, int acc_datt1, long long ld_datt2, const SetSlabSrc* csrc, const float* zt, const float* s,
+                              const float* t, float* dz, float* ds, float* dt, long long ld_out, int D, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // slab views consumed by the pointwise kernels: value(m,n) = sum_s p[s*stride + m*ld + n]

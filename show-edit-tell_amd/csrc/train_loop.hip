@@ -97,25 +97,40 @@ int set_editnet_xe_train_bwd_loop_f32(const SetXEBwdLoopArgs* a, void* stream) {
             const int N[2] = {D, D};
             SET_TRY(bwd_products(du, D, bt, D, 2, w, ldw, N, a->tmp + 0, a->slab_ws[0], a->slab_ws_bytes, g3, stream));
         }
-        SET_TRY(set_lstm_gates_bwd_src_f32(a->dcn, &g3[0], 1, a->dop, a->G2 + 4 * BD * t, a->C2 + BD * t, dgw, dc2_out, bt, D, stream));
+        // LSTM gate backward + SelectC backward: one launch (both wait for g3)
+        static const int merged = env_int("SET_XE_BWD_MERGED", 1);
+        if (merged) {
+            SET_TRY(lstm_gates_select_bwd_src(a->dcn, &g3[0], a->dop, a->G2 + 4 * BD * t, a->C2 + BD * t, dgw, dc2_out, a->dcm, &g3[1],
+                                              a->Mem, a->ALPHAC + (long long)B * Tc * t, a->dMem, a->dalc, bt, Tc, D, 1,
+                                              (hipStream_t)stream));
+        } else {
+            SET_TRY(set_lstm_gates_bwd_src_f32(a->dcn, &g3[0], 1, a->dop, a->G2 + 4 * BD * t, a->C2 + BD * t, dgw, dc2_out, bt, D,
+                                               stream));
+            SET_TRY(set_select_bwd_src_f32(a->dcm, &g3[1], 1, a->Mem, a->ALPHAC + (long long)B * Tc * t, a->dMem, a->dalc, bt, Tc, D, 1,
+                                           stream));
+        }
         {
             const float* w[4] = {a->cl_x2h_w, a->cl_x2h_w + D, a->cl_x2h_w + 2 * D, a->cl_h2h_w};
             const long long ldw[4] = {K2, K2, K2, D};
             const int N[4] = {D, D, F, D};
             SET_TRY(bwd_products(dgw, 4LL * D, bt, 4 * D, 4, w, ldw, N, a->tmp + 2, a->slab_ws[1], a->slab_ws_bytes, g5, stream));
         }
-        // ---- SelectC backward
-        SET_TRY(set_select_bwd_src_f32(a->dcm, &g3[1], 1, a->Mem, a->ALPHAC + (long long)B * Tc * t, a->dMem, a->dalc, bt, Tc, D, 1,
-                                       stream));
-        // ---- VisualAttentionC backward
-        SET_TRY(set_attention_bwd_src_f32(nullptr, &g5[2], 1, nullptr, nullptr, a->ALPHAV + (long long)B * R * t, a->X,
-                                          a->att1 + a->att1_step * t, a->ATT2V + (long long)B * A * t, a->va_full,
-                                          a->datt1 + a->datt1_step * t, a->DATT2 + 2LL * B * A * t, a->DWFV + (long long)B * A * t,
-                                          a->DEV + (long long)B * R * t, bt, R, F, A, 0, a->acc_datt1, 2LL * A, stream));
-        // ---- CaptionAttentionC backward
+        // ---- VisualAttentionC backward + the context gating backward of CaptionAttentionC: one launch (both wait for g5)
         float* dszt = a->DSZT + 3 * BD * t;
-        SET_TRY(set_context_gate_bwd_src_f32(nullptr, &g5[1], 1, a->ZT + BD * t, a->S + BD * t, a->TT + BD * t, dszt + D, dszt,
-                                             dszt + 2 * D, 3LL * D, bt, D, stream));
+        if (merged) {
+            SET_TRY(attention_ctxgate_bwd_src(&g5[2], a->ALPHAV + (long long)B * R * t, a->X, a->att1 + a->att1_step * t,
+                                              a->ATT2V + (long long)B * A * t, a->va_full, a->datt1 + a->datt1_step * t,
+                                              a->DATT2 + 2LL * B * A * t, a->DWFV + (long long)B * A * t, a->DEV + (long long)B * R * t, bt,
+                                              R, F, A, a->acc_datt1, 2LL * A, &g5[1], a->ZT + BD * t, a->S + BD * t, a->TT + BD * t,
+                                              dszt + D, dszt, dszt + 2 * D, 3LL * D, D, (hipStream_t)stream));
+        } else {
+            SET_TRY(set_attention_bwd_src_f32(nullptr, &g5[2], 1, nullptr, nullptr, a->ALPHAV + (long long)B * R * t, a->X,
+                                              a->att1 + a->att1_step * t, a->ATT2V + (long long)B * A * t, a->va_full,
+                                              a->datt1 + a->datt1_step * t, a->DATT2 + 2LL * B * A * t, a->DWFV + (long long)B * A * t,
+                                              a->DEV + (long long)B * R * t, bt, R, F, A, 0, a->acc_datt1, 2LL * A, stream));
+            SET_TRY(set_context_gate_bwd_src_f32(nullptr, &g5[1], 1, a->ZT + BD * t, a->S + BD * t, a->TT + BD * t, dszt + D, dszt,
+                                                 dszt + 2 * D, 3LL * D, bt, D, stream));
+        }
         {
             const float* w[2] = {a->w_ctx, a->w_h1};
             const long long ldw[2] = {D, D};

@@ -168,6 +168,89 @@ __global__ void __launch_bounds__(256) colsum_final_k(const float* part, int col
     *reinterpret_cast<f32x4*>(out + 4 * c) = acc;
 }
 
+
+// Grouped form: the ~16 bias gradients of one training step (every one a column sum over the same (t, b) rows) as TWO
+// launches instead of 32.  Problem j owns the blocks [blk0[j], blk0[j+1]) of pass 1 (column tiles x row chunks; the number of
+// chunks grows with the rows, so the (T B R, A) projection gradient fills the chip instead of 128 workgroups) and the
+// float4 columns [c0[j], c0[j+1]) of pass 2; up to two destinations per problem (two biases fed by the same gradient).
+struct ColsumGroup {
+    const float* x[SET_COLSUM_MAX]; long long ld[SET_COLSUM_MAX]; float* out[SET_COLSUM_MAX]; float* out2[SET_COLSUM_MAX];
+    int rows[SET_COLSUM_MAX], cols4[SET_COLSUM_MAX], chunks[SET_COLSUM_MAX];
+    int blk0[SET_COLSUM_MAX + 1], c0[SET_COLSUM_MAX + 1];
+    long long p0[SET_COLSUM_MAX];           // float4 offset of the problem's partials
+    unsigned acc, acc2;
+    int n;
+};
+__global__ void __launch_bounds__(256) colsum_group_partial_k(const ColsumGroup G, float* part) {
+    __shared__ f32x4 s_red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int j = 0;
+    for (int k = 1; k < G.n; ++k)
+        if ((int)blockIdx.x >= G.blk0[k]) j = k;
+    const int local = blockIdx.x - G.blk0[j], cols4 = G.cols4[j], rows = G.rows[j], tiles = (cols4 + 63) >> 6;
+    const int chunk = local / tiles, c = (local - chunk * tiles) * 64 + lane;
+    const int per = (rows + G.chunks[j] - 1) / G.chunks[j];
+    const int r0 = chunk * per, r1 = r0 + per < rows ? r0 + per : rows;
+    const float* x = G.x[j];
+    const long long ld = G.ld[j];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (c < cols4) {
+        int r = r0 + wave;
+        for (; r + 12 < r1; r += 16) {          // four rows of this wave in flight, added in row order
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + r * ld + 4 * c);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(x + (r + 4) * ld + 4 * c);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(x + (r + 8) * ld + 4 * c);
+            const f32x4 v3 = *reinterpret_cast<const f32x4*>(x + (r + 12) * ld + 4 * c);
+            acc += v0; acc += v1; acc += v2; acc += v3;
+        }
+        for (; r < r1; r += 4) acc += *reinterpret_cast<const f32x4*>(x + r * ld + 4 * c);
+    }
+    s_red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && c < cols4)
+        *reinterpret_cast<f32x4*>(part + (G.p0[j] + (long long)chunk * cols4 + c) * 4) =
+            (s_red[0][lane] + s_red[1][lane]) + (s_red[2][lane] + s_red[3][lane]);
+}
+// pass 2: a workgroup = 64 float4 columns x 4 slices of the chunks (slice s adds chunks s, s + 4, ... in order; the four
+// slice sums are added in slice order) — the partials of a column are 64-256 rows, one thread walking them alone is latency
+__global__ void __launch_bounds__(256) colsum_group_final_k(const ColsumGroup G, const float* part) {
+    __shared__ f32x4 s_red[4][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int g = blockIdx.x * 64 + lane;
+    const bool on = g < G.c0[G.n];
+    int j = 0;
+    for (int k = 1; k < G.n; ++k)
+        if (g >= G.c0[k]) j = k;
+    const int c = g - G.c0[j], cols4 = G.cols4[j], nk = G.chunks[j];
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    if (on) {
+        const float* p = part + (G.p0[j] + c) * 4;
+        int k = slice;
+        for (; k + 12 < nk; k += 16) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (long long)k * cols4 * 4);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (long long)(k + 4) * cols4 * 4);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (long long)(k + 8) * cols4 * 4);
+            const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (long long)(k + 12) * cols4 * 4);
+            sum += v0; sum += v1; sum += v2; sum += v3;
+        }
+        for (; k < nk; k += 4) sum += *reinterpret_cast<const f32x4*>(p + (long long)k * cols4 * 4);
+    }
+    s_red[slice][lane] = sum;
+    __syncthreads();
+    if (slice != 0 || !on) return;
+    sum = (s_red[0][lane] + s_red[1][lane]) + (s_red[2][lane] + s_red[3][lane]);
+    float* o = G.out[j] + 4 * c;
+    *reinterpret_cast<f32x4*>(o) = ((G.acc >> j) & 1u) ? *reinterpret_cast<const f32x4*>(o) + sum : sum;
+    if (G.out2[j]) {
+        float* o2 = G.out2[j] + 4 * c;
+        *reinterpret_cast<f32x4*>(o2) = ((G.acc2 >> j) & 1u) ? *reinterpret_cast<const f32x4*>(o2) + sum : sum;
+    }
+}
+static inline int colsum_group_chunks(int rows) {
+    const int c = (rows + 255) / 256;
+    return c < COLSUM_CHUNKS ? COLSUM_CHUNKS : c > 256 ? 256 : c;
+}
+
 }  // namespace set
 
 using namespace set;
@@ -292,6 +375,43 @@ int set_colsum_f32(const float* x, int64_t ld, int rows, int cols, float* out, i
     hipLaunchKernelGGL(colsum_partial_k, dim3(cdiv(cols4, 64), COLSUM_CHUNKS), dim3(256), 0, st, x, (long long)ld, rows, cols4,
                        (float*)ws);
     hipLaunchKernelGGL(colsum_final_k, dim3(cdiv(cols4, 256)), dim3(256), 0, st, (const float*)ws, cols4, out, accumulate);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+size_t set_colsum_group_workspace_bytes(const SetColsumDesc* d, int n) {
+    if (!d || n <= 0) return 0;
+    size_t b = 256;
+    for (int j = 0; j < n; ++j)
+        if (d[j].rows > 0 && d[j].cols > 0) b += (size_t)colsum_group_chunks(d[j].rows) * round_up((size_t)d[j].cols, 4) * sizeof(float);
+    return b;
+}
+
+int set_colsum_group_f32(const SetColsumDesc* d, int n, void* ws, size_t ws_bytes, void* stream) {
+    if (!d || n <= 0 || n > SET_COLSUM_MAX) return SET_ERR_ARG;
+    if (!ws || !aligned16(ws) || ws_bytes < set_colsum_group_workspace_bytes(d, n) - 256) return SET_ERR_WORKSPACE;
+    ColsumGroup G{};
+    G.n = n;
+    long long p = 0;
+    int blk = 0, c0 = 0;
+    for (int j = 0; j < n; ++j) {
+        const SetColsumDesc& e = d[j];
+        if (!e.x || !e.out || e.rows <= 0 || e.cols <= 0) return SET_ERR_ARG;
+        if ((e.cols & 3) || (e.ld & 3) || e.ld < e.cols || !aligned16(e.x) || !aligned16(e.out) || (e.out2 && !aligned16(e.out2)))
+            return SET_ERR_UNSUPPORTED;
+        G.x[j] = e.x; G.ld[j] = e.ld; G.out[j] = e.out; G.out2[j] = e.out2; G.rows[j] = e.rows; G.cols4[j] = e.cols >> 2;
+        G.chunks[j] = colsum_group_chunks(e.rows);
+        if (e.accumulate) G.acc |= 1u << j;
+        if (e.accumulate2) G.acc2 |= 1u << j;
+        G.blk0[j] = blk; G.c0[j] = c0; G.p0[j] = p;
+        blk += cdiv(G.cols4[j], 64) * G.chunks[j];
+        c0 += G.cols4[j];
+        p += (long long)G.chunks[j] * G.cols4[j];
+    }
+    G.blk0[n] = blk; G.c0[n] = c0;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_group_partial_k, dim3(blk), dim3(256), 0, st, G, (float*)ws);
+    hipLaunchKernelGGL(colsum_group_final_k, dim3(cdiv(c0, 64)), dim3(256), 0, st, G, (const float*)ws);
     SET_LAUNCH_CHECK();
     return SET_OK;
 }

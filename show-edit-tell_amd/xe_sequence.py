@@ -785,12 +785,10 @@ class _XESequence(torch.autograd.Function):
         datt2 = DATT2.view(TB, 2 * Adim)
         W("ca_dec_w", datt2[:, Adim:], h1_all); Bg("ca_dec_b", datt2[:, Adim:])
         W("va_dec_w", datt2[:, :Adim], h1_all); Bg("va_dec_b", datt2[:, :Adim])
-        if need[pidx["ca_full_w"]]:
-            g[pidx["ca_full_w"]] = A._colsum(DWFC.view(TB, Adim)).view(1, Adim)
+        Bg("ca_full_w", DWFC.view(TB, Adim))
         if need[pidx["ca_full_b"]]:
             g[pidx["ca_full_b"]] = DEC.sum().reshape(1)
-        if need[pidx["va_full_w"]]:
-            g[pidx["va_full_w"]] = A._colsum(DWFV.view(TB, Adim)).view(1, Adim)
+        Bg("va_full_w", DWFV.view(TB, Adim))
         if need[pidx["va_full_b"]]:
             g[pidx["va_full_b"]] = DEV.sum().reshape(1)
         if train:

@@ -288,6 +288,39 @@ def test_colsum_kernel():
     assert torch.allclose(A._colsum(big[:, 64:192]), big[:, 64:192].sum(0), atol=1e-4)
 
 
+def test_grouped_colsum_equals_single_colsums():
+    """set_colsum_group_f32 (every bias gradient of a step as one pair of launches): per problem the sums of the single kernel
+    (to rounding: the partials are combined in a different order), `.grad` created or accumulated, a shared problem
+    writing both of its parameters, and the problems the grouped kernel cannot take (ragged columns, few rows) falling back"""
+    from show_edit_tell_amd import autograd_ops as A
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(9)
+    shapes = [(2432, 4096), (87552, 512), (2432, 1024), (100, 64), (2432, 6), (40, 8)]
+    xs = [torch.randn(r, c, generator=g).to(dev) for r, c in shapes]
+    strided = torch.randn(2432, 3072, generator=g).to(dev)
+    xs.append(strided[:, 1024:2048])                               # a column block of a wider log
+    params = [[torch.nn.Parameter(torch.zeros(x.shape[1], device=dev)) for _ in range(1 + (i % 2))] for i, x in enumerate(xs)]
+    params[2][0].grad = torch.full((1024,), 2.0, device=dev)        # accumulate
+    params[0] = [torch.nn.Parameter(torch.zeros(1, 4096, device=dev))]   # a (1, A) parameter (full_att.weight)
+    A._colsum_group([(x, pl) for x, pl in zip(xs, params)])
+    for i, (x, pl) in enumerate(zip(xs, params)):
+        ref = x.double().sum(0).float()
+        tol = 1e-3 * float(ref.abs().max())
+        for j, q in enumerate(pl):
+            want = ref + (2.0 if (i == 2 and j == 0) else 0.0)
+            assert q.grad.shape == q.shape
+            assert torch.allclose(q.grad.reshape(-1), want, rtol=1e-4, atol=tol), (i, j)
+        if len(pl) == 2:
+            assert torch.equal(pl[0].grad, pl[1].grad)
+    first = [q.grad.clone() for pl in params for q in pl]
+    for pl in params:
+        for q in pl:
+            q.grad = None
+    params[2][0].grad = torch.full((1024,), 2.0, device=dev)
+    A._colsum_group([(x, pl) for x, pl in zip(xs, params)])
+    assert all(torch.equal(a, q.grad) for a, q in zip(first, [q for pl in params for q in pl]))    # deterministic
+
+
 def test_dcnet_rollout_node_equals_per_operator_rollout(monkeypatch):
     """DCNet (dcnet_rl.py:286-346, sample_rl) in eval mode: node and per-operator route draw the same words, same
     log-probs, equal gradients; the teacher-forced node equals the per-operator XE route on a ragged batch"""
