@@ -158,6 +158,16 @@ struct SrcList {
 #endif
 };
 int make_src_list(const SetSlabSrc* src, int n, SrcList* out);     // backward.hip: validates (alignment, counts) and copies
+// all-timestep / merged pointwise launches of the teacher-forced training loop (train_seq.hip; called by train_loop.hip):
+// bit for bit what the per-timestep entry points write
+constexpr int SET_STEPS_MAX = 64;
+int embed_relu_dropout_steps(const float* table, const int64_t* ids, long long ids_step, long long ids_stride, float* out,
+                             long long out_step, long long ldo, const int* bts, int T, int B, int D, int V, float p, uint64_t seed,
+                             uint64_t offset, hipStream_t st);
+int dropout_xsteps(const float* x, long long x_step, long long ldx, float* y, long long y_step, long long ldy, const int* bts, int T,
+                   int B, int cols, float p, uint64_t seed, uint64_t offset, hipStream_t st);
+int pack2(float* dst0, long long ldd0, int nseg0, const float* const* src0, const int64_t* ld0, const int* cols0, float* dst1,
+          long long ldd1, int nseg1, const float* const* src1, const int64_t* ld1, const int* cols1, int rows, hipStream_t st);
 // merged launches of the training timestep loop (backward.hip; called by train_loop.hip): LSTM gate backward + SelectC
 // backward, visual attention backward + context gating backward — same results as the separate entry points
 int lstm_gates_select_bwd_src(const float* dcn_base, const SetSlabSrc* src, const float* do_pre, const float* gates,

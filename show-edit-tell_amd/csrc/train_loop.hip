@@ -17,13 +17,21 @@ int set_editnet_xe_train_loop_f32(const SetXELoopArgs* a, void* stream) {
     if (!a || !a->w || !a->bts || a->T <= 0 || a->B <= 0) return SET_ERR_ARG;
     const int T = a->T, B = a->B, R = a->R, F = a->F, Tc = a->Tc, D = a->D, A = a->A;
     const long long K1 = 3LL * D + F, K2 = 2LL * D + F, BD = (long long)B * D;
+    // teacher forcing: every timestep's word is known, the dropped-out h2 is read after the loop — both pointwise sites run
+    // once for all timesteps (SET_XE_STEPS_HOIST=0: inside the loop, as the reference's loop body has them)
+    static const int hoist_env = env_int("SET_XE_STEPS_HOIST", 1);
+    const bool hoist = hoist_env && T <= SET_STEPS_MAX;
+    if (hoist)
+        SET_TRY(embed_relu_dropout_steps(a->E, a->tok, a->tok_step, a->tok_stride, a->EMB, BD, D, a->bts, T, B, D, a->V,
+                                         a->train ? a->p_embed : 0.f, a->seed, a->off_embed, (hipStream_t)stream));
     for (int t = 0; t < T; ++t) {
         const int bt = a->bts[t];
         if (bt <= 0) break;
         float* emb = a->EMB + BD * t;
         const int64_t* tok = a->tok + a->tok_step * t;
         // EmbeddingC (editnet.py:513): relu(E[tok]) (+ dropout in train mode)
-        if (a->train && a->p_embed > 0.f)
+        if (hoist) {
+        } else if (a->train && a->p_embed > 0.f)
             SET_TRY(set_embed_relu_dropout_f32(a->E, tok, a->tok_stride, emb, D, bt, D, a->V, a->p_embed, a->seed,
                                                a->off_embed + (uint64_t)t, stream));
         else
@@ -44,20 +52,22 @@ int set_editnet_xe_train_loop_f32(const SetXELoopArgs* a, void* stream) {
             const float* src3[3] = {emb, h1, a->cx};
             const int64_t ld3[3] = {D, D, D};
             const int c3[3] = {D, D, D};
-            SET_TRY(set_pack_f32(a->WHC + 3 * BD * t, 3LL * D, bt, 3, src3, ld3, c3, 0, stream));
             const float* srcx[3] = {h1, a->gated, a->aimg};
             const int64_t ldx[3] = {D, D, F};
             const int cx_[3] = {D, D, F};
-            SET_TRY(set_pack_f32(a->X2 + (long long)B * K2 * t, K2, bt, 3, srcx, ldx, cx_, 0, stream));
+            SET_TRY(pack2(a->WHC + 3 * BD * t, 3LL * D, 3, src3, ld3, c3, a->X2 + (long long)B * K2 * t, K2, 3, srcx, ldx, cx_, bt,
+                          (hipStream_t)stream));
         }
         // CopyLSTMCellC (editnet.py:541-543)
         SET_TRY(set_copy_lstm_train_f32(a->w, a->X2 + (long long)B * K2 * t, K2, (int)K2, a->H2 + BD * t, a->C2 + BD * t, sel,
                                         a->H2 + BD * (t + 1), a->C2 + BD * (t + 1), a->G2 + 4 * BD * t, a->CNEW + BD * t,
                                         a->CG + BD * t, bt, D, a->ws_k, a->ws_k_bytes, stream));
-        if (a->train && a->p_out > 0.f)          // nn.Dropout before fc (editnet.py:545)
+        if (a->train && a->p_out > 0.f && !hoist)          // nn.Dropout before fc (editnet.py:545)
             SET_TRY(set_dropout_f32(a->H2 + BD * (t + 1), D, a->H2D + BD * t, D, bt, D, a->p_out, a->seed, a->off_out + (uint64_t)t,
                                     stream));
     }
+    if (a->train && a->p_out > 0.f && hoist)
+        SET_TRY(dropout_xsteps(a->H2 + BD, BD, D, a->H2D, BD, D, a->bts, T, B, D, a->p_out, a->seed, a->off_out, (hipStream_t)stream));
     return SET_OK;
 }
 

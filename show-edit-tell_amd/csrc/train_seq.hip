@@ -169,6 +169,69 @@ __global__ void __launch_bounds__(256) colsum_final_k(const float* part, int col
 }
 
 
+// ---- all-timestep forms for the teacher-forced training loop (train_loop.hip): the words of every timestep are known before
+// the loop and the dropped-out h2 is only read after it, so the embedding and the output dropout of T timesteps are ONE
+// launch each (grid.y = t; timestep t covers its first bt[t] rows, with the counters of the per-step launches: same bits),
+// and the two operand logs a timestep packs are one launch
+struct StepRows { int bt[SET_STEPS_MAX]; };
+__global__ void __launch_bounds__(256) embed_relu_dropout_steps_k(const float* table, const int64_t* ids, long long ids_step,
+                                                                  long long ids_stride, float* out, long long out_step,
+                                                                  long long ldo, const StepRows R, int D4, int V, float p, float scale,
+                                                                  unsigned long long seed, unsigned long long offset) {
+    const int t = blockIdx.y;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)R.bt[t] * D4) return;
+    const int r = (int)(i / D4), c = (int)(i - (long long)r * D4);
+    long long id = ids[t * ids_step + r * ids_stride];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(table + id * (4LL * D4) + 4 * c);
+    f32x4 o;
+    if (p > 0.f) {
+        const unsigned long long off = offset + (unsigned long long)t;
+        uint32_t k[4] = {(uint32_t)r, (uint32_t)c, (uint32_t)off, (uint32_t)(off >> 32)};
+        philox4x32_10(k, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = v[e] > 0.f ? v[e] : 0.f;
+            o[e] = ((float)(k[e] >> 8) * (1.0f / 16777216.0f) >= p) ? x * scale : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = v[e] > 0.f ? v[e] : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(out + t * out_step + r * ldo + 4 * c) = o;
+}
+__global__ void __launch_bounds__(256) dropout_xsteps_k(const float* x, long long x_step, long long ldx, float* y, long long y_step,
+                                                        long long ldy, const StepRows R, int cols4, float p, float scale,
+                                                        unsigned long long seed, unsigned long long offset) {
+    const int t = blockIdx.y;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)R.bt[t] * cols4) return;
+    const int r = (int)(i / cols4), c = (int)(i - (long long)r * cols4);
+    const unsigned long long off = offset + (unsigned long long)t;
+    uint32_t k[4] = {(uint32_t)r, (uint32_t)c, (uint32_t)off, (uint32_t)(off >> 32)};
+    philox4x32_10(k, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + t * x_step + r * ldx + 4 * c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = ((float)(k[e] >> 8) * (1.0f / 16777216.0f) >= p) ? v[e] * scale : 0.f;
+    *reinterpret_cast<f32x4*>(y + t * y_step + r * ldy + 4 * c) = o;
+}
+__device__ __forceinline__ void pack_body(const long long i, float* dst, long long ldd, int rows, int cols4, const PackArgs& a) {
+    if (i >= (long long)rows * cols4) return;
+    const int r = (int)(i / cols4), c = (int)(i - (long long)r * cols4);
+    int s = 0, c0 = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (k + 1 < a.nseg && c >= a.c4_end[k]) { s = k + 1; c0 = a.c4_end[k]; }
+    *reinterpret_cast<f32x4*>(dst + r * ldd + 4 * c) = *reinterpret_cast<const f32x4*>(a.src[s] + r * a.ld[s] + 4 * (c - c0));
+}
+__global__ void __launch_bounds__(256) pack2_k(float* dst0, long long ldd0, int cols4_0, PackArgs a0, int nblk0, float* dst1,
+                                               long long ldd1, int cols4_1, PackArgs a1, int rows) {
+    if ((int)blockIdx.x < nblk0) pack_body((long long)blockIdx.x * 256 + threadIdx.x, dst0, ldd0, rows, cols4_0, a0);
+    else pack_body((long long)(blockIdx.x - nblk0) * 256 + threadIdx.x, dst1, ldd1, rows, cols4_1, a1);
+}
+
 // Grouped form: the ~16 bias gradients of one training step (every one a column sum over the same (t, b) rows) as TWO
 // launches instead of 32.  Problem j owns the blocks [blk0[j], blk0[j+1]) of pass 1 (column tiles x row chunks; the number of
 // chunks grows with the rows, so the (T B R, A) projection gradient fills the chip instead of 128 workgroups) and the
@@ -246,6 +309,65 @@ __global__ void __launch_bounds__(256) colsum_group_final_k(const ColsumGroup G,
         *reinterpret_cast<f32x4*>(o2) = ((G.acc2 >> j) & 1u) ? *reinterpret_cast<const f32x4*>(o2) + sum : sum;
     }
 }
+static int pack_args(PackArgs* a, int nseg, const float* const* src, const int64_t* ld, const int* cols, int* c4_out) {
+    int c4 = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (i < nseg) {
+            if (!src[i] || cols[i] <= 0) return SET_ERR_ARG;
+            if ((cols[i] & 3) || (ld[i] & 3) || !aligned16(src[i])) return SET_ERR_UNSUPPORTED;
+            c4 += cols[i] >> 2;
+            a->src[i] = src[i]; a->ld[i] = ld[i];
+        } else { a->src[i] = nullptr; a->ld[i] = 0; }
+        a->c4_end[i] = c4;
+    }
+    a->nseg = nseg;
+    *c4_out = c4;
+    return SET_OK;
+}
+
+int embed_relu_dropout_steps(const float* table, const int64_t* ids, long long ids_step, long long ids_stride, float* out,
+                             long long out_step, long long ldo, const int* bts, int T, int B, int D, int V, float p, uint64_t seed,
+                             uint64_t offset, hipStream_t st) {
+    if (!table || !ids || !out || !bts || T <= 0 || T > SET_STEPS_MAX || B <= 0 || D <= 0 || V <= 0 || !(p >= 0.f) || !(p < 1.f))
+        return SET_ERR_ARG;
+    if ((D & 3) || (ldo & 3) || (out_step & 3) || !aligned16(table) || !aligned16(out)) return SET_ERR_UNSUPPORTED;
+    StepRows R{};
+    for (int t = 0; t < T; ++t) R.bt[t] = bts[t] < 0 ? 0 : (bts[t] > B ? B : bts[t]);
+    const long long n = (long long)B * (D >> 2);
+    hipLaunchKernelGGL(embed_relu_dropout_steps_k, dim3((unsigned)((n + 255) / 256), T), dim3(256), 0, st, table, ids, ids_step,
+                       ids_stride, out, out_step, ldo, R, D >> 2, V, p, 1.0f / (1.0f - p), (unsigned long long)seed,
+                       (unsigned long long)offset);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+int dropout_xsteps(const float* x, long long x_step, long long ldx, float* y, long long y_step, long long ldy, const int* bts, int T,
+                   int B, int cols, float p, uint64_t seed, uint64_t offset, hipStream_t st) {
+    if (!x || !y || !bts || T <= 0 || T > SET_STEPS_MAX || B <= 0 || cols <= 0 || !(p >= 0.f) || !(p < 1.f)) return SET_ERR_ARG;
+    if ((cols & 3) || (ldx & 3) || (ldy & 3) || (x_step & 3) || (y_step & 3) || !aligned16(x) || !aligned16(y)) return SET_ERR_UNSUPPORTED;
+    StepRows R{};
+    for (int t = 0; t < T; ++t) R.bt[t] = bts[t] < 0 ? 0 : (bts[t] > B ? B : bts[t]);
+    const long long n = (long long)B * (cols >> 2);
+    hipLaunchKernelGGL(dropout_xsteps_k, dim3((unsigned)((n + 255) / 256), T), dim3(256), 0, st, x, x_step, ldx, y, y_step, ldy, R,
+                       cols >> 2, p, 1.0f / (1.0f - p), (unsigned long long)seed, (unsigned long long)offset);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+int pack2(float* dst0, long long ldd0, int nseg0, const float* const* src0, const int64_t* ld0, const int* cols0, float* dst1,
+          long long ldd1, int nseg1, const float* const* src1, const int64_t* ld1, const int* cols1, int rows, hipStream_t st) {
+    if (!dst0 || !dst1 || rows <= 0 || nseg0 <= 0 || nseg0 > 4 || nseg1 <= 0 || nseg1 > 4) return SET_ERR_ARG;
+    if ((ldd0 & 3) || (ldd1 & 3) || !aligned16(dst0) || !aligned16(dst1)) return SET_ERR_UNSUPPORTED;
+    PackArgs a0, a1;
+    int c0 = 0, c1 = 0;
+    SET_TRY(pack_args(&a0, nseg0, src0, ld0, cols0, &c0));
+    SET_TRY(pack_args(&a1, nseg1, src1, ld1, cols1, &c1));
+    const int n0 = (int)(((long long)rows * c0 + 255) / 256), n1 = (int)(((long long)rows * c1 + 255) / 256);
+    hipLaunchKernelGGL(pack2_k, dim3(n0 + n1), dim3(256), 0, st, dst0, ldd0, c0, a0, n0, dst1, ldd1, c1, a1, rows);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
 static inline int colsum_group_chunks(int rows) {
     const int c = (rows + 255) / 256;
     return c < COLSUM_CHUNKS ? COLSUM_CHUNKS : c > 256 ? 256 : c;
