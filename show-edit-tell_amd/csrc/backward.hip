@@ -489,6 +489,15 @@ __device__ __forceinline__ void select_bwd_body(const int b, const float* dsel, 
     for (int t = tid; t < T; t += 256)
         dalpha[(long long)b * T + t] = (t == js) ? ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) : 0.f;
 }
+// both attention backwards of one timestep in one launch: blocks [0, M) = visual rows, [M, 2M) = caption rows.  The visual
+// one only needs the copy cell's input gradient, the caption one additionally the context-gate product that follows it — run
+// together after that product, the 128-workgroup visual kernel (half the chip idle for 19 us) leaves the dependent chain
+template <bool SRC>
+__global__ void __launch_bounds__(512) attention_pair_bwd_k(const AttBwdArgs PV, const SrcList SV, const AttBwdArgs PC,
+                                                            const SrcList SCp, int M) {
+    if ((int)blockIdx.x < M) attention_bwd_wide_body<false, SRC>(blockIdx.x, PV, SV);
+    else attention_bwd_wide_body<true, SRC>(blockIdx.x - M, PC, SCp);
+}
 template <bool SRC>
 __global__ void __launch_bounds__(256) select_bwd_k(const float* dsel, const float* Mem, const float* alpha, float* dM,
                                                     float* dalpha, int T, int D, int acc_dm, const SrcList S) {
@@ -638,6 +647,33 @@ int lstm_gates_select_bwd_src(const float* dcn_base, const SetSlabSrc* src, cons
     const int nG = (int)(((long long)M * (D >> 2) + 255) / 256);
     hipLaunchKernelGGL(lstm_gates_select_bwd_k<true>, dim3(nG + M), dim3(256), 0, st, dcn_base, do_pre, gates, c_prev, dgates, dc_prev,
                        M, D, S, nG, dsel_base, Mem, alpha, dM, dalpha, T, acc_dM, SS);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+static int att_bwd_check(const AttBwdArgs& P) {
+    if (!P.alpha || !P.Vals || !P.att1 || !P.att2 || !P.w_full || !P.datt1 || !P.datt2 || !P.dwfull_part) return SET_ERR_ARG;
+    if (P.L > ATTB_MAX || (P.A & 3) || (P.Dv & 3) || P.A > 1024 || P.Dv > 2048 || (P.ld_datt2 & 3) || P.ld_datt2 < P.A)
+        return SET_ERR_UNSUPPORTED;
+    return SET_OK;
+}
+
+int attention_pair_bwd_src(const SetSlabSrc* vsrc, const float* alpha_v, const float* X, const float* att1_v, const float* att2_v,
+                           const float* wfull_v, float* datt1_v, float* datt2_v, float* dwf_v, float* de_v, int R, int F, int acc_v,
+                           const SetSlabSrc* csrc, float* dctx_out, const float* dalpha_ext, const float* alpha_c, const float* H,
+                           const float* att1_c, const float* att2_c, const float* wfull_c, float* datt1_c, float* datt2_c,
+                           float* dwf_c, float* de_c, int Tc, int D, int acc_c, int M, int A, long long ld_datt2, hipStream_t st) {
+    if (M <= 0) return SET_ERR_ARG;
+    const AttBwdArgs PV{nullptr, nullptr, alpha_v, X, att1_v, att2_v, wfull_v, datt1_v, datt2_v, dwf_v, de_v, R, F, A, acc_v, ld_datt2,
+                        nullptr};
+    const AttBwdArgs PC{nullptr, dalpha_ext, alpha_c, H, att1_c, att2_c, wfull_c, datt1_c, datt2_c, dwf_c, de_c, Tc, D, A, acc_c,
+                        ld_datt2, dctx_out};
+    SET_TRY(att_bwd_check(PV));
+    SET_TRY(att_bwd_check(PC));
+    SrcList SV, SCp;
+    SET_TRY(make_src_list(vsrc, 1, &SV));
+    SET_TRY(make_src_list(csrc, 1, &SCp));
+    hipLaunchKernelGGL(attention_pair_bwd_k<true>, dim3(2 * M), dim3(512), 0, st, PV, SV, PC, SCp, M);
     SET_LAUNCH_CHECK();
     return SET_OK;
 }

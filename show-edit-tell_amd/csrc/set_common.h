@@ -174,6 +174,11 @@ int lstm_gates_select_bwd_src(const float* dcn_base, const SetSlabSrc* src, cons
                               const float* c_prev, float* dgates, float* dc_prev, const float* dsel_base, const SetSlabSrc* ssrc,
                               const float* Mem, const float* alpha, float* dM, float* dalpha, int M, int T, int D, int acc_dM,
                               hipStream_t st);
+int attention_pair_bwd_src(const SetSlabSrc* vsrc, const float* alpha_v, const float* X, const float* att1_v, const float* att2_v,
+                           const float* wfull_v, float* datt1_v, float* datt2_v, float* dwf_v, float* de_v, int R, int F, int acc_v,
+                           const SetSlabSrc* csrc, float* dctx_out, const float* dalpha_ext, const float* alpha_c, const float* H,
+                           const float* att1_c, const float* att2_c, const float* wfull_c, float* datt1_c, float* datt2_c,
+                           float* dwf_c, float* de_c, int Tc, int D, int acc_c, int M, int A, long long ld_datt2, hipStream_t st);
 int attention_ctxgate_bwd_src(const SetSlabSrc* src, const float* alpha, const float* values, const float* att1, const float* att2,
                               const float* w_full, float* datt1, float* datt2, float* dwfull_part, float* de, int M, int L, int Dv,
                               int A, int acc_datt1, long long ld_datt2, const SetSlabSrc* csrc, const float* zt, const float* s,

@@ -108,7 +108,7 @@ int set_editnet_xe_train_bwd_loop_f32(const SetXEBwdLoopArgs* a, void* stream) {
             SET_TRY(bwd_products(du, D, bt, D, 2, w, ldw, N, a->tmp + 0, a->slab_ws[0], a->slab_ws_bytes, g3, stream));
         }
         // LSTM gate backward + SelectC backward: one launch (both wait for g3)
-        static const int merged = env_int("SET_XE_BWD_MERGED", 1);
+        static const int merged = env_int("SET_XE_BWD_MERGED", 2);
         if (merged) {
             SET_TRY(lstm_gates_select_bwd_src(a->dcn, &g3[0], a->dop, a->G2 + 4 * BD * t, a->C2 + BD * t, dgw, dc2_out, a->dcm, &g3[1],
                                               a->Mem, a->ALPHAC + (long long)B * Tc * t, a->dMem, a->dalc, bt, Tc, D, 1,
@@ -127,7 +127,12 @@ int set_editnet_xe_train_bwd_loop_f32(const SetXEBwdLoopArgs* a, void* stream) {
         }
         // ---- VisualAttentionC backward + the context gating backward of CaptionAttentionC: one launch (both wait for g5)
         float* dszt = a->DSZT + 3 * BD * t;
-        if (merged) {
+        // merged == 2: the context gate alone here, BOTH attention backwards in one launch after the product it feeds (the
+        // visual one leaves the dependent chain); merged == 1: visual attention + context gate here, caption attention later
+        if (merged == 2) {
+            SET_TRY(set_context_gate_bwd_src_f32(nullptr, &g5[1], 1, a->ZT + BD * t, a->S + BD * t, a->TT + BD * t, dszt + D, dszt,
+                                                 dszt + 2 * D, 3LL * D, bt, D, stream));
+        } else if (merged) {
             SET_TRY(attention_ctxgate_bwd_src(&g5[2], a->ALPHAV + (long long)B * R * t, a->X, a->att1 + a->att1_step * t,
                                               a->ATT2V + (long long)B * A * t, a->va_full, a->datt1 + a->datt1_step * t,
                                               a->DATT2 + 2LL * B * A * t, a->DWFV + (long long)B * A * t, a->DEV + (long long)B * R * t, bt,
@@ -152,6 +157,15 @@ int set_editnet_xe_train_bwd_loop_f32(const SetXEBwdLoopArgs* a, void* stream) {
             for (int i = 0; i < 2; ++i)
                 if (g9[i].nslab == 0) g9[i] = SetSlabSrc{a->tmp[6 + i], 0, N[i], 1, bt};
         }
+        if (merged == 2) {
+            SET_TRY(attention_pair_bwd_src(&g5[2], a->ALPHAV + (long long)B * R * t, a->X, a->att1 + a->att1_step * t,
+                                           a->ATT2V + (long long)B * A * t, a->va_full, a->datt1 + a->datt1_step * t,
+                                           a->DATT2 + 2LL * B * A * t, a->DWFV + (long long)B * A * t, a->DEV + (long long)B * R * t, R, F,
+                                           a->acc_datt1, &g9[0], a->DCTX + BD * t, a->dalc, a->ALPHAC + (long long)B * Tc * t, a->H,
+                                           a->att1_c, a->ATT2C + (long long)B * A * t, a->ca_full, a->datt1c,
+                                           a->DATT2 + 2LL * B * A * t + A, a->DWFC + (long long)B * A * t, a->DEC + (long long)B * Tc * t,
+                                           Tc, D, 1, bt, A, 2LL * A, (hipStream_t)stream));
+        } else
         SET_TRY(set_attention_bwd_src_f32(nullptr, &g9[0], 1, a->DCTX + BD * t, a->dalc, a->ALPHAC + (long long)B * Tc * t, a->H,
                                           a->att1_c, a->ATT2C + (long long)B * A * t, a->ca_full, a->datt1c,
                                           a->DATT2 + 2LL * B * A * t + A, a->DWFC + (long long)B * A * t, a->DEC + (long long)B * Tc * t,
