@@ -673,10 +673,13 @@ typedef struct SetXELoopArgs {
     const int64_t* tok; int64_t tok_step, tok_stride;      /* word of (t, b) = tok[t * tok_step + b * tok_stride] */
     const float *X, *H, *Mem, *mask, *att1_c, *pre1, *att1; int64_t att1_step;
     float *EMB, *H1, *C1, *H2, *C2, *G1, *G2, *WHC, *ZT, *S, *TT, *ALPHAC, *ALPHAV, *ATT2C, *ATT2V, *SEL, *CNEW, *CG, *X2, *H2D;
-    float *gated, *cx, *aimg;                    /* (B, D), (B, D), (B, F) scratch */
+    float *gated, *cx, *aimg;                    /* (B, D), (B, D), (B, F) scratch — or (T, B, .) logs, see step_logs */
     void* ws_l; size_t ws_l_bytes;               /* set_lstm_cell_workspace_bytes */
     void* ws_c; size_t ws_c_bytes;               /* set_editnet_attentions_workspace_bytes */
     void* ws_k; size_t ws_k_bytes;               /* set_copy_lstm_workspace_bytes */
+    int step_logs;                               /* 1: gated / cx / aimg hold every timestep; the copy cell contracts its input
+                                                    as the segments [h1 | gated | attend_img] where they lie and X2 / WHC are
+                                                    packed ONCE after the loop (0: one packing launch per timestep) */
 } SetXELoopArgs;
 int set_editnet_xe_train_loop_f32(const SetXELoopArgs* a, void* stream);
 

@@ -174,7 +174,8 @@ class XELoopArgs(C.Structure):
     _fields_ = _fields("int T, B, R, F, Tc, D, A, V, train; float p_embed, p_out; u64 seed, off_embed, off_out; ptr bts; ptr w; "
                        "ptr E, al_wih, al_whh; ptr tok; i64 tok_step, tok_stride; ptr X, H, Mem, mask, att1_c, pre1, att1; "
                        "i64 att1_step; ptr EMB, H1, C1, H2, C2, G1, G2, WHC, ZT, S, TT, ALPHAC, ALPHAV, ATT2C, ATT2V, SEL, CNEW, CG, "
-                       "X2, H2D; ptr gated, cx, aimg; ptr ws_l; size ws_l_bytes; ptr ws_c; size ws_c_bytes; ptr ws_k; size ws_k_bytes")
+                       "X2, H2D; ptr gated, cx, aimg; ptr ws_l; size ws_l_bytes; ptr ws_c; size ws_c_bytes; ptr ws_k; size ws_k_bytes; "
+                       "int step_logs")
 
 
 class XEBwdLoopArgs(C.Structure):

@@ -319,40 +319,69 @@ int set_select_f32(const float* Mem, const float* alpha_c, float* sel, int M, in
 size_t set_copy_lstm_workspace_bytes(int M, int D, int Kx) {
     (void)Kx;
     if (M <= 0 || D <= 0) return 0;
-    return fbytes(KS * (size_t)M * 4 * D) + 2 * fbytes(KS * (size_t)M * D) + 2 * fbytes((size_t)M * D) + 256;
+    return 2 * fbytes(KS * (size_t)M * 4 * D) + 2 * fbytes(KS * (size_t)M * D) + 2 * fbytes((size_t)M * D) + 256;
 }
 
-static int copy_lstm_impl(const SetEditNetWeights* w, const float* x, int64_t ldx, int Kx, const float* h2,
-                          const float* c2, const float* c_memory, float* h_out, float* c_out, float* gates_out,
-                          float* cnew_out, float* cg_out, int M, int D, void* ws, size_t ws_bytes, void* stream) {
-    if (!w || !x || !h2 || !c2 || !c_memory || !h_out || !c_out || M <= 0 || D <= 0 || Kx <= 0) return SET_ERR_ARG;
+}  // extern "C"
+namespace set {
+// the input rows x = [x_0 | x_1 | ...] given as 1..3 column segments (segment i: K[i] columns, row stride ld[i]) contracted
+// against the matching column blocks of x2h.weight — the training loop feeds [h1 | gated | attend_img] from where the
+// producing kernels left them instead of packing a row first
+int copy_lstm_segs(const SetEditNetWeights* w, int nseg, const float* const* xs, const int64_t* lds, const int* Ks, const float* h2,
+                   const float* c2, const float* c_memory, float* h_out, float* c_out, float* gates_out, float* cnew_out,
+                   float* cg_out, int M, int D, void* ws, size_t ws_bytes, void* stream) {
+    if (!w || !xs || !lds || !Ks || nseg <= 0 || nseg > 3 || !h2 || !c2 || !c_memory || !h_out || !c_out || M <= 0 || D <= 0)
+        return SET_ERR_ARG;
+    int Kx = 0;
+    for (int i = 0; i < nseg; ++i) {
+        if (!xs[i] || Ks[i] <= 0 || lds[i] < Ks[i]) return SET_ERR_ARG;
+        Kx += Ks[i];
+    }
     if (!ws || !aligned16(ws) || ws_bytes < set_copy_lstm_workspace_bytes(M, D, Kx) - 256) return SET_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int tgt = gemm_target_wgs();
     Carver cv(ws);
     float* s_g = cv.take<float>(KS * (size_t)M * 4 * D);
+    float* s_g2 = cv.take<float>(KS * (size_t)M * 4 * D);
     float* s_m = cv.take<float>(KS * (size_t)M * D);
     float* s_n = cv.take<float>(KS * (size_t)M * D);
     float* c_new = cv.take<float>((size_t)M * D);
     float* ogate = cv.take<float>((size_t)M * D);
     if (cnew_out) c_new = cnew_out;
-    GemmProb a[2];
+    // a problem holds GEMM_MAX_SEG = 3 segments: [x | h2] fits one problem when x is one or two segments; three x segments
+    // make h2 W_hh^T its own problem whose partials the pointwise kernel adds (same launch either way)
+    const bool own = nseg + 1 > GEMM_MAX_SEG;
+    GemmProb a[3];
     a[0] = slab_prob(s_g, M, 4 * D, M);
-    a[0].add(x, ldx, w->cl_x2h_w, Kx, Kx);
-    a[0].add(h2, D, w->cl_h2h_w, D, D);
+    for (int i = 0, k0 = 0; i < nseg; k0 += Ks[i], ++i) a[0].add(xs[i], lds[i], w->cl_x2h_w + k0, Kx, Ks[i]);
     a[1] = slab_prob(s_m, M, D, M);
     a[1].add(c_memory, D, w->cl_cmem_w, D, D);
-    plan_ksplit(a, 2, tgt);
-    SET_TRY(gemm_group(a, 2, st));
+    if (own) {
+        a[2] = slab_prob(s_g2, M, 4 * D, M);
+        a[2].add(h2, D, w->cl_h2h_w, D, D);
+    } else {
+        a[0].add(h2, D, w->cl_h2h_w, D, D);
+    }
+    plan_ksplit(a, own ? 3 : 2, tgt);
+    SET_TRY(gemm_group(a, own ? 3 : 2, st));
     const Slabs none{nullptr, 0, 0, 0};
-    SET_TRY(lstm_pointwise(slabs_of(a[0]), none, none, nullptr, 0, w->cl_x2h_b, w->cl_h2h_b, c2, c_new, nullptr, ogate,
-                           M, D, st, RowGather(), gates_out));
+    SET_TRY(lstm_pointwise(slabs_of(a[0]), own ? slabs_of(a[2]) : none, none, nullptr, 0, w->cl_x2h_b, w->cl_h2h_b, c2, c_new,
+                           nullptr, ogate, M, D, st, RowGather(), gates_out));
     GemmProb e = slab_prob(s_n, M, D, M);
     e.add(c_new, D, w->cl_cnew_w, D, D);
     plan_ksplit(&e, 1, tgt);
     SET_TRY(gemm_group(&e, 1, st));
     return copy_gate_pointwise(slabs_of(e), w->cl_cnew_b, slabs_of(a[1]), w->cl_cmem_b, c_new, c_memory, ogate, c_out,
                                h_out, M, D, st, cg_out);
+}
+}  // namespace set
+extern "C" {
+static int copy_lstm_impl(const SetEditNetWeights* w, const float* x, int64_t ldx, int Kx, const float* h2,
+                          const float* c2, const float* c_memory, float* h_out, float* c_out, float* gates_out,
+                          float* cnew_out, float* cg_out, int M, int D, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || Kx <= 0) return SET_ERR_ARG;
+    return copy_lstm_segs(w, 1, &x, &ldx, &Kx, h2, c2, c_memory, h_out, c_out, gates_out, cnew_out, cg_out, M, D, ws, ws_bytes,
+                          stream);
 }
 
 int set_copy_lstm_f32(const SetEditNetWeights* w, const float* x, int64_t ldx, int Kx, const float* h2,

@@ -158,6 +158,9 @@ struct SrcList {
 #endif
 };
 int make_src_list(const SetSlabSrc* src, int n, SrcList* out);     // backward.hip: validates (alignment, counts) and copies
+int copy_lstm_segs(const SetEditNetWeights* w, int nseg, const float* const* xs, const int64_t* lds, const int* Ks, const float* h2,
+                   const float* c2, const float* c_memory, float* h_out, float* c_out, float* gates_out, float* cnew_out,
+                   float* cg_out, int M, int D, void* ws, size_t ws_bytes, void* stream);      // ops.hip
 // all-timestep / merged pointwise launches of the teacher-forced training loop (train_seq.hip; called by train_loop.hip):
 // bit for bit what the per-timestep entry points write
 constexpr int SET_STEPS_MAX = 64;

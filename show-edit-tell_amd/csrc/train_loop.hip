@@ -43,28 +43,47 @@ int set_editnet_xe_train_loop_f32(const SetXELoopArgs* a, void* stream) {
                                             a->G1 + 4 * BD * t, bt, D, a->ws_l, a->ws_l_bytes, stream));
         // both attentions + SelectC (editnet.py:534-540)
         float* sel = a->SEL + BD * t;
+        const bool logs = a->step_logs != 0;
+        float* gated = a->gated + (logs ? BD * t : 0);
+        float* cx = a->cx + (logs ? BD * t : 0);
+        float* aimg = a->aimg + (logs ? (long long)B * F * t : 0);
         SET_TRY(set_editnet_attentions_train_f32(a->w, a->H, a->att1_c, a->mask, a->Mem, a->X, a->att1 + a->att1_step * t, nullptr,
-                                                 h1, emb, a->gated, a->ALPHAC + (long long)B * Tc * t, a->cx, a->ZT + BD * t,
-                                                 a->S + BD * t, a->TT + BD * t, sel, a->aimg, a->ALPHAV + (long long)B * R * t,
+                                                 h1, emb, gated, a->ALPHAC + (long long)B * Tc * t, cx, a->ZT + BD * t,
+                                                 a->S + BD * t, a->TT + BD * t, sel, aimg, a->ALPHAV + (long long)B * R * t,
                                                  a->ATT2C + (long long)B * A * t, a->ATT2V + (long long)B * A * t, bt, Tc, R, F, D, A,
                                                  a->ws_c, a->ws_c_bytes, stream));
-        {   // the concatenated operands the time-batched weight gradients read: [word | h1 | ctx], [h1 | gated | attend_img]
-            const float* src3[3] = {emb, h1, a->cx};
+        // CopyLSTMCellC (editnet.py:541-543) on [h1 | gated | attend_img]
+        const float* srcx[3] = {h1, gated, aimg};
+        const int64_t ldx[3] = {D, D, F};
+        const int cx_[3] = {D, D, F};
+        if (logs) {
+            SET_TRY(copy_lstm_segs(a->w, 3, srcx, ldx, cx_, a->H2 + BD * t, a->C2 + BD * t, sel, a->H2 + BD * (t + 1),
+                                   a->C2 + BD * (t + 1), a->G2 + 4 * BD * t, a->CNEW + BD * t, a->CG + BD * t, bt, D, a->ws_k,
+                                   a->ws_k_bytes, stream));
+        } else {
+            // the concatenated operands the time-batched weight gradients read: [word | h1 | ctx], [h1 | gated | attend_img]
+            const float* src3[3] = {emb, h1, cx};
             const int64_t ld3[3] = {D, D, D};
             const int c3[3] = {D, D, D};
-            const float* srcx[3] = {h1, a->gated, a->aimg};
-            const int64_t ldx[3] = {D, D, F};
-            const int cx_[3] = {D, D, F};
             SET_TRY(pack2(a->WHC + 3 * BD * t, 3LL * D, 3, src3, ld3, c3, a->X2 + (long long)B * K2 * t, K2, 3, srcx, ldx, cx_, bt,
                           (hipStream_t)stream));
+            SET_TRY(set_copy_lstm_train_f32(a->w, a->X2 + (long long)B * K2 * t, K2, (int)K2, a->H2 + BD * t, a->C2 + BD * t, sel,
+                                            a->H2 + BD * (t + 1), a->C2 + BD * (t + 1), a->G2 + 4 * BD * t, a->CNEW + BD * t,
+                                            a->CG + BD * t, bt, D, a->ws_k, a->ws_k_bytes, stream));
         }
-        // CopyLSTMCellC (editnet.py:541-543)
-        SET_TRY(set_copy_lstm_train_f32(a->w, a->X2 + (long long)B * K2 * t, K2, (int)K2, a->H2 + BD * t, a->C2 + BD * t, sel,
-                                        a->H2 + BD * (t + 1), a->C2 + BD * (t + 1), a->G2 + 4 * BD * t, a->CNEW + BD * t,
-                                        a->CG + BD * t, bt, D, a->ws_k, a->ws_k_bytes, stream));
         if (a->train && a->p_out > 0.f && !hoist)          // nn.Dropout before fc (editnet.py:545)
             SET_TRY(set_dropout_f32(a->H2 + BD * (t + 1), D, a->H2D + BD * t, D, bt, D, a->p_out, a->seed, a->off_out + (uint64_t)t,
                                     stream));
+    }
+    if (a->step_logs) {
+        // the operand rows of ALL timesteps for the time-batched weight gradients, off the recurrence's dependent chain
+        const float* src3[3] = {a->EMB, a->H1 + BD, a->cx};
+        const int64_t ld3[3] = {D, D, D};
+        const int c3[3] = {D, D, D};
+        const float* srcx[3] = {a->H1 + BD, a->gated, a->aimg};
+        const int64_t ldx[3] = {D, D, F};
+        const int cx_[3] = {D, D, F};
+        SET_TRY(pack2(a->WHC, 3LL * D, 3, src3, ld3, c3, a->X2, K2, 3, srcx, ldx, cx_, T * B, (hipStream_t)stream));
     }
     if (a->train && a->p_out > 0.f && hoist)
         SET_TRY(dropout_xsteps(a->H2 + BD, BD, D, a->H2D, BD, D, a->bts, T, B, D, a->p_out, a->seed, a->off_out, (hipStream_t)stream));

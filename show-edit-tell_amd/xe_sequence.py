@@ -130,6 +130,10 @@ _SLAB_DIRECT = os.environ.get("SET_SLAB_DIRECT", "1") != "0"
 # round 5: the two timestep loops as ONE C call each (csrc/train_loop.hip: the same entry points in the same order) — issued
 # from Python their ~45 launches per timestep cost the host more than the kernels take.  SET_XE_C_LOOPS=0: the Python loops.
 _C_LOOPS = os.environ.get("SET_XE_C_LOOPS", "1") != "0"
+# per-timestep output logs instead of a packing launch inside the loop (SetXELoopArgs.step_logs): measured 15.51 vs 15.52 ms at
+# B = 128 — the packing launch it removes from the dependent chain comes back as a third problem of the copy cell's grouped
+# product and a (T B)-row pack after the loop.  Correct (tests/test_hip_sequence.py) but not a win: opt-in.
+_STEP_LOGS = os.environ.get("SET_XE_STEP_LOGS", "0") == "1"
 _slab_ws = {}
 
 
@@ -297,7 +301,11 @@ class _XESequence(torch.autograd.Function):
                       "CNEW", "CG", "X2"):
                 setattr(a, k, L[k].data_ptr())
             a.H2D = L["H2D"].data_ptr() if (train and cfg.p_out > 0) else None
-            a.gated, a.cx, a.aimg = gated.data_ptr(), cx.data_ptr(), aimg.data_ptr()
+            if _STEP_LOGS:                 # per-timestep outputs kept: no packing launch inside the loop (see SetXELoopArgs.step_logs)
+                gl, cl, al = _zl(T, B, D, dev=dev), _zl(T, B, D, dev=dev), _zl(T, B, F, dev=dev)
+                a.gated, a.cx, a.aimg, a.step_logs = gl.data_ptr(), cl.data_ptr(), al.data_ptr(), 1
+            else:
+                a.gated, a.cx, a.aimg, a.step_logs = gated.data_ptr(), cx.data_ptr(), aimg.data_ptr(), 0
             a.ws_l, a.ws_l_bytes, a.ws_c, a.ws_c_bytes = ws_l.data_ptr(), ws_l.numel(), ws_c.data_ptr(), ws_c.numel()
             a.ws_k, a.ws_k_bytes = ws_k.data_ptr(), ws_k.numel()
             check(lib.set_editnet_xe_train_loop_f32(C.byref(a), st), "set_editnet_xe_train_loop_f32")

@@ -98,6 +98,34 @@ def test_sequence_node_train_mode_learns(monkeypatch):
     assert not torch.equal(a, b)
 
 
+@pytest.mark.parametrize("min_len", [6, 20])
+def test_training_loop_schedules_agree(min_len, monkeypatch):
+    """train mode (all three dropout sites on), ragged and uniform lengths: the C timestep loops (merged backward launches,
+    all-timestep embedding / output dropout, one packing launch per timestep), the same with per-timestep output logs (no
+    packing launch inside the loop, the copy cell contracting [h1 | gated | attend_img] as segments) and the Python loops
+    draw the same masks and give the same scores and gradients up to fp32 summation order"""
+    from show_edit_tell_amd import xe_sequence as xs
+    m = _build(203, 64, 32, 256).train()
+    inputs = _inputs(8, 36, 256, 20, 203, min_len)
+    runs = {}
+    for name, c_loops, step_logs in (("c", True, False), ("c_logs", True, True), ("py", False, False)):
+        monkeypatch.setattr(xs, "_C_LOOPS", c_loops)
+        monkeypatch.setattr(xs, "_STEP_LOGS", step_logs)
+        torch.manual_seed(11)
+        runs[name] = _loss_and_grads(m, inputs, True, True, monkeypatch)
+    p0, g0 = runs["py"]
+    gmax = max(float(g.abs().max()) for g in g0.values())
+    for name in ("c", "c_logs"):
+        p1, g1 = runs[name]
+        assert float((p0 - p1).abs().max()) <= 2e-5 * max(1.0, float(p0.abs().max())), name
+        assert set(g0) == set(g1)
+        for k in g0:
+            if k.endswith("full_att.bias"):
+                continue
+            err = float((g0[k] - g1[k]).abs().max()) / max(float(g0[k].abs().max()), 1e-6 * gmax)
+            assert err < 1e-3, (name, k, err)
+
+
 def test_dropout_kernels():
     from show_edit_tell_amd import _lib
     lib, dev = _lib.load(), _dev()
