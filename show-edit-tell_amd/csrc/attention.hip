@@ -671,6 +671,9 @@ int step_attention(const float* att1, Slabs att2, const float* v_dec_bias, const
                    const float* c_b_full, const float* mask, const float* H, const float* Mem, float* c_ctx, float* sel,
                    float* c_alpha, int T, int Dh, int A, int M, hipStream_t s, const CapHoist* hoist, float* v_att2_out,
                    float* c_att2_out) {
+#if defined(SET_EXP_SKIP_POINTWISE) || defined(SET_EXP_SKIP_ATT)      // diagnostic build (EXPERIMENTS 5.7): the launch is dropped, results are garbage
+    return SET_OK;
+#endif
     if (R > ATT_MAX_ROWS || T > ATT_MAX_ROWS || A > 512 || (A & 3) || (F & 3) || (Dh & 3)) return SET_ERR_UNSUPPORTED;
     if (M <= 0) return SET_OK;
     const int fsn = vis_fsn(M, F);

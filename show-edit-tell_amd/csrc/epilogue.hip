@@ -270,6 +270,9 @@ __global__ void __launch_bounds__(256) greedy_pick_k(Slabs logits, const float* 
 int greedy_pick(Slabs logits, const float* bias, int V, int t, int max_len, long long end_idx, long long* seq,
                 float* seq_logp, long long* it, int* unfinished, int* alive, const float* table, float* emb_out,
                 int D, int B, hipStream_t s, const LstmTail* tail) {
+#if defined(SET_EXP_SKIP_POINTWISE) || defined(SET_EXP_SKIP_PICK)      // diagnostic build (EXPERIMENTS 5.7): the launch is dropped, results are garbage
+    return SET_OK;
+#endif
     if (B <= 0) return SET_OK;
     if (D & 3) return SET_ERR_UNSUPPORTED;
     if (tail && !tail_ok(*tail)) return SET_ERR_ARG;

@@ -133,12 +133,16 @@ __global__ void __launch_bounds__(256) lstm_pointwise_k(Slabs g0, Slabs g1, Slab
 // — 10 us for 1.5 MB of slab reads.  64-thread workgroups spread the same threads over 4x as many CUs.
 static int pointwise_block(long long n_threads) {
     static const int small = env_int("SET_POINTWISE_SMALL_BLOCKS", 1);
-    return (small && n_threads <= 16384) ? 64 : 256;
+    static const int small_max = env_int("SET_POINTWISE_SMALL_MAX", 16384);
+    return (small && n_threads <= small_max) ? 64 : 256;
 }
 
 int lstm_pointwise(Slabs g0, Slabs g1, Slabs g2, const float* pre, long long ldpre, const float* b0,
                    const float* b1, const float* c_in, float* c_out, float* h_out, float* ogate_out, int M,
                    int D, hipStream_t s, RowGather gt, float* gates_out) {
+#if defined(SET_EXP_SKIP_POINTWISE) || defined(SET_EXP_SKIP_LSTM)      // diagnostic build (EXPERIMENTS 5.7): the launch is dropped, results are garbage
+    return SET_OK;
+#endif
     if (D & 3) return SET_ERR_UNSUPPORTED;
     const long long n = (long long)M * (D >> 2);
     ProfScope ps("lstm_pointwise", s, 0.0, 4.0 * M * D * (4.0 * (g0.n + g1.n + g2.n + (pre ? 1 : 0)) + 3.0));
@@ -226,6 +230,9 @@ __global__ void __launch_bounds__(256) copy_gate_k(Slabs gn, const float* bn, Sl
 int copy_gate_pointwise(Slabs gn, const float* bn, Slabs gm, const float* bm, const float* c_new,
                         const float* sel, const float* ogate, float* c_out, float* h_out, int M, int D,
                         hipStream_t s, float* cg_out) {
+#if defined(SET_EXP_SKIP_POINTWISE) || defined(SET_EXP_SKIP_CG)      // diagnostic build (EXPERIMENTS 5.7): the launch is dropped, results are garbage
+    return SET_OK;
+#endif
     if (D & 3) return SET_ERR_UNSUPPORTED;
     const long long n = (long long)M * (D >> 2);
     ProfScope ps("copy_gate", s, 0.0, 4.0 * M * D * (gn.n + gm.n + 5.0));

@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import numpy as np
 
 import torch
 import torch.nn as nn
@@ -30,6 +31,17 @@ from ._lib import EditNetDims, EditNetWeights, EDITNET_WEIGHT_FIELDS, check, ptr
 import os as _os
 
 _XE_SEQUENCE = _os.environ.get("SET_XE_SEQUENCE", "1") != "0"     # 0: keep the per-operator autograd loop everywhere
+
+
+_arange = {}
+
+
+def _arange_cached(n, dev):
+    """torch.arange(n) on `dev` (the identity sort order handed back to the caller), made once per (n, device)"""
+    key = (n, dev)
+    if key not in _arange:
+        _arange[key] = torch.arange(n, device=dev)
+    return _arange[key]
 
 
 def _f32c(t):
@@ -573,6 +585,12 @@ class DecoderC(nn.Module):
 
 
     # ---- grad-enabled path -------------------------------------------------------------------
+    def with_host_lengths(self, caption_lengths_host):
+        """the NEXT grad-enabled forward takes its sort order / decode lengths from this host copy of `caption_lengths`
+        (one call; see _forward_autograd)"""
+        self.__dict__["_caplens_host"] = caption_lengths_host
+        return self
+
     def _encoder_autograd(self, seq, seq_len, seed=None, site=None):
         return _caption_encoder_autograd(self.caption_encoder, seq, seq_len, seed, site)
 
@@ -585,14 +603,36 @@ class DecoderC(nn.Module):
         batch_size = encoded_captions.size(0)
         # (stable: rows of equal length keep their input order — any order is a valid outcome of the reference's unstable
         # sort, this one makes the row <-> dropout-stream assignment a function of the inputs alone)
-        caption_lengths, sort_ind = caption_lengths.squeeze(1).sort(dim=0, descending=True, stable=True)
-        X = _f32c(image_features[sort_ind])
-        encoded_captions = encoded_captions[sort_ind]
-        prev = encoded_previous_captions[sort_ind]
-        plen = previous_cap_length[sort_ind]
-        h1, c1 = self.init_hidden_state(batch_size)
-        h2, c2 = self.init_hidden_state(batch_size)
-        decode_lengths = (caption_lengths - 1).tolist()
+        # `caption_lengths_host` (set by the training steps from the data loader's host copy of the lengths, editnet.py:560-563):
+        # the sort order and the decode lengths are computed on the host — no device sort, no `.tolist()` round trip in the
+        # middle of the step — and a batch that already is in order (uniform lengths, a sorting loader) is not gathered at all
+        host = self.__dict__.pop("_caplens_host", None)
+        order = None
+        if host is not None:
+            hl = np.asarray(host.cpu() if torch.is_tensor(host) else host, dtype=np.int64).reshape(-1)
+            if hl.shape[0] == batch_size:
+                order = np.argsort(-hl, kind="stable")           # the same permutation as the stable device sort below
+        if order is not None:
+            decode_lengths = (hl[order] - 1).tolist()
+            if bool((order == np.arange(batch_size)).all()):
+                sort_ind = _arange_cached(batch_size, dev)
+                X, prev, plen = _f32c(image_features), encoded_previous_captions, previous_cap_length
+            else:
+                sort_ind = torch.from_numpy(order).to(dev, non_blocking=True)
+                X = _f32c(image_features[sort_ind])
+                encoded_captions = encoded_captions[sort_ind]
+                prev = encoded_previous_captions[sort_ind]
+                plen = previous_cap_length[sort_ind]
+        else:
+            caption_lengths, sort_ind = caption_lengths.squeeze(1).sort(dim=0, descending=True, stable=True)
+            X = _f32c(image_features[sort_ind])
+            encoded_captions = encoded_captions[sort_ind]
+            prev = encoded_previous_captions[sort_ind]
+            plen = previous_cap_length[sort_ind]
+            decode_lengths = (caption_lengths - 1).tolist()
+        if not _XE_SEQUENCE:                                      # (the sequence node starts from its own zero state)
+            h1, c1 = self.init_hidden_state(batch_size)
+            h2, c2 = self.init_hidden_state(batch_size)
         preds_t = []
         # ONE seed per forward call; every dropout / sampling site is its own Philox offset (rng.py)
         seed = self.__dict__["_fwd_seed"] = rng.next_seed()

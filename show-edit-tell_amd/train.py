@@ -313,8 +313,13 @@ def xe_backward(decoder, image_features, caps, caplens, previous_caption, prev_c
     # host never waits on the device between forward and backward
     n_tok = _token_count(caplens, caplens_host)
     n_glob = global_token_count(n_tok, image_features.device, group) if grp_on else n_tok
-    scores, caps_sorted, decode_lengths, _ = decoder(image_features, caps, caplens, previous_caption, prev_caplen, use_ss,
-                                                     ss_prob)
+    if caplens_host is not None and hasattr(decoder, "with_host_lengths"):
+        decoder.with_host_lengths(caplens_host)      # sort order / decode lengths without a device round trip
+    try:
+        scores, caps_sorted, decode_lengths, _ = decoder(image_features, caps, caplens, previous_caption, prev_caplen, use_ss,
+                                                         ss_prob)
+    finally:
+        decoder.__dict__.pop("_caplens_host", None)
     loss_sum, n_chk, _, _ = xe_loss_sum(scores, caps_sorted, decode_lengths)
     assert n_chk == n_tok, (n_chk, n_tok)
     loss = loss_sum / n_glob

@@ -448,9 +448,10 @@ class _XESequence(torch.autograd.Function):
         dMem = torch.zeros_like(Mem)
         datt1c = torch.zeros_like(att1_c)
         dYin = torch.zeros_like(Yin)                           # train: d relu(att_embed(X)); eval: d features_att(.)
-        DH1, DH2 = _z(B, D, dev=dev), _z(B, D, dev=dev)
-        DC1 = [_z(B, D, dev=dev), _z(B, D, dev=dev)]
-        DC2 = [_z(B, D, dev=dev), _z(B, D, dev=dev)]
+        zero6 = _z(6, B, D, dev=dev)                            # (one fill instead of six)
+        DH1, DH2 = zero6[0], zero6[1]
+        DC1 = [zero6[2], zero6[3]]
+        DC2 = [zero6[4], zero6[5]]
         dcm, dcn, dop = (_e(B, D, dev=dev) for _ in range(3))
         dgated, daimg = _e(B, D, dev=dev), _e(B, F, dev=dev)
         demb, dalc = _e(B, D, dev=dev), _e(B, Tc, dev=dev)

@@ -126,6 +126,27 @@ def test_training_loop_schedules_agree(min_len, monkeypatch):
             assert err < 1e-3, (name, k, err)
 
 
+@pytest.mark.parametrize("order", ["shuffled", "sorted"])
+def test_host_caption_lengths_give_the_same_forward(order, monkeypatch):
+    """`DecoderC.with_host_lengths` (the training steps pass the loader's host copy of the lengths): the sort order and the
+    decode lengths come from the host — same permutation as the stable device sort, an already ordered batch is not gathered —
+    and scores, returned captions, lengths and sort indices are those of the plain call, bit for bit"""
+    from show_edit_tell_amd import editnet
+    monkeypatch.setattr(editnet, "_XE_SEQUENCE", True)
+    m = _build(203, 64, 32, 256).eval()
+    X, caps, clen, prev, plen = _inputs(8, 36, 256, 20, 203, 6)
+    if order == "sorted":
+        idx = clen.squeeze(1).sort(descending=True, stable=True)[1]
+        X, caps, clen, prev, plen = X[idx], caps[idx], clen[idx], prev[idx], plen[idx]
+    with torch.enable_grad():
+        a = m(X, caps, clen, prev, plen, False, 0.0)
+        b = m.with_host_lengths(clen.cpu())(X, caps, clen, prev, plen, False, 0.0)
+    assert "_caplens_host" not in m.__dict__                       # consumed by the call
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2] and torch.equal(a[3], b[3])
+    if order == "sorted":
+        assert torch.equal(b[3], torch.arange(8, device=b[3].device))
+
+
 def test_dropout_kernels():
     from show_edit_tell_amd import _lib
     lib, dev = _lib.load(), _dev()

@@ -34,7 +34,8 @@ def main():
     X = torch.from_numpy(synth.features(seed, B, R, F)).to(dev)
     prev, plen = (torch.from_numpy(x).to(dev) for x in synth.prev_captions(seed, B, T, V, 5))
     caps, clen = (torch.from_numpy(x).to(dev) for x in synth.captions(seed, B, V, 20, 20))
-    def step(): return xe_train_step(dec, opt, X, caps, clen, prev, plen, False, 0.0)
+    clen_host = clen.cpu()        # the data loader's host copy of the lengths
+    def step(): return xe_train_step(dec, opt, X, caps, clen, prev, plen, False, 0.0, caplens_host=clen_host)
     for _ in range(a.warmup): step()
     torch.cuda.synchronize()
     if dist: dist.barrier()

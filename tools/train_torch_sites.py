@@ -27,7 +27,8 @@ def main():
     X = torch.from_numpy(synth.features(25, B, R, F)).to(dev)
     prev, plen = (torch.from_numpy(x).to(dev) for x in synth.prev_captions(25, B, T, V, 5))
     caps, clen = (torch.from_numpy(x).to(dev) for x in synth.captions(25, B, V, 20, 20))
-    step = lambda: xe_train_step(dec, opt, X, caps, clen, prev, plen, False, 0.0)
+    clen_host = clen.cpu()
+    step = lambda: xe_train_step(dec, opt, X, caps, clen, prev, plen, False, 0.0, caplens_host=clen_host)
     for _ in range(3):
         step()
     torch.cuda.synchronize()
