@@ -484,7 +484,7 @@ class _Linear(torch.autograd.Function):
         x2, w, y = ctx.saved_tensors
         dy = _c(dy).reshape(-1, dy.shape[-1])
         if ctx.act == _lib.ACT_RELU:
-            dy = dy * (y > 0)
+            dy = _relu_bwd(dy, y.reshape(dy.shape))
         elif ctx.act == _lib.ACT_TANH:
             dy = dy * (1 - y * y)
         elif ctx.act == _lib.ACT_SIGMOID:
@@ -494,6 +494,19 @@ class _Linear(torch.autograd.Function):
         dw = _wgrad(pw, dy, x2) if ctx.needs_input_grad[1] else None
         db = _bgrad(pb, dy) if ctx.needs_input_grad[2] else None
         return dx, dw, db, None
+
+
+def _relu_bwd(dy, y):
+    """dy * (y > 0) for a ReLU output y (>= 0, so y > 0 <=> y != 0): one launch of the library's dropout-backward kernel with
+    scale 1 instead of a compare and a multiply; anything the kernel does not take goes through torch"""
+    if (dy.is_cuda and dy.dtype == torch.float32 and y.dtype == torch.float32 and dy.dim() == 2 and dy.shape == y.shape and
+            dy.shape[1] % 4 == 0 and dy.is_contiguous() and y.is_contiguous() and dy.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0):
+        out = torch.empty_like(dy)
+        rows, cols = dy.shape
+        check(_lib.load().set_dropout_bwd_f32(ptr(dy), cols, ptr(y), cols, ptr(out), cols, rows, cols, 1.0, 0, stream_of(dy.device)),
+              "set_dropout_bwd_f32")
+        return out
+    return dy * (y > 0)
 
 
 def linear(x, weight, bias, act=_lib.ACT_NONE):
@@ -520,7 +533,7 @@ class _EmbedRelu(torch.autograd.Function):
     def backward(ctx, dout):
         ids, out = ctx.saved_tensors
         D = out.shape[-1]
-        g = (dout * (out > 0)).reshape(-1, D)
+        g = _relu_bwd(_c(dout).reshape(-1, D), out.reshape(-1, D))
         dt = torch.zeros(ctx.V, D, dtype=torch.float32, device=out.device)
         dt.index_add_(0, ids.reshape(-1), g)
         return None, dt
