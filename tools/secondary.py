@@ -306,10 +306,64 @@ def batch_sweep(dev, batches=(1, 4, 8, 16, 32, 64, 128)):
             "rows": rows}
 
 
+def concurrent_small_requests(dev, callers=4, rows=4, rounds=30):
+    """A server with several small requests at once: `callers` independent greedy decodes of `rows` rows,
+    each on its own stream.  Persistent launches are serialised process-wide (one 256-workgroup grid owns the chip), the
+    per-step kernels of different streams overlap: requests per second (a) persistent, one launch per request, (b) per-step
+    loop on `callers` streams, (c) the requests coalesced into ONE persistent call of callers x rows rows (<= 16)."""
+    import os
+    from show_edit_tell_amd import editnet_rl, synth
+    wm = synth.word_map(V)
+    dec = _editnet(editnet_rl.DecoderC, dev, wm).eval()
+    reqs = []
+    for i in range(callers):
+        X = torch.from_numpy(synth.features(60 + i, rows, R, F)).to(dev)
+        prev, plen = (torch.from_numpy(x).to(dev) for x in synth.prev_captions(60 + i, rows, T, V, 5))
+        reqs.append((prev, plen, X))
+    streams = [torch.cuda.Stream(dev) for _ in range(callers)]
+    allp, alll, allx = (torch.cat([r[k] for r in reqs], 0) for k in range(3))
+
+    def separate():
+        for st, (prev, plen, X) in zip(streams, reqs):
+            with torch.cuda.stream(st):
+                dec(wm, prev, plen, X, True, False)
+
+    def run(fn):
+        with torch.no_grad():
+            for _ in range(4):
+                fn()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(rounds):
+                fn()
+            torch.cuda.synchronize()
+        return callers * rounds / (time.perf_counter() - t)
+
+    out = {"workload": "%d concurrent EditNet greedy requests of %d rows, each caller on its own stream" % (callers, rows)}
+    with torch.no_grad():
+        dec(wm, *reqs[0], True, False); dec(wm, *reqs[0], True, False)      # token table
+    out["persistent_serialised_requests_per_sec"] = round(run(separate), 1)
+    old = os.environ.get("SET_DEC_PERSISTENT")
+    os.environ["SET_DEC_PERSISTENT"] = "0"                                  # (read per call)
+    try:
+        out["per_step_loop_on_streams_requests_per_sec"] = round(run(separate), 1)
+    finally:
+        if old is None:
+            os.environ.pop("SET_DEC_PERSISTENT", None)
+        else:
+            os.environ["SET_DEC_PERSISTENT"] = old
+    if callers * rows <= 16:
+        out["coalesced_one_persistent_call_requests_per_sec"] = round(run(lambda: dec(wm, allp, alll, allx, True, False)), 1)
+    out["note"] = ("persistent launches of one process run one after the other (grid_barrier.h PersistentGuard); a server that has "
+                   "several small requests at hand coalesces them into one call of up to 16 rows")
+    return out
+
+
 def all_secondary(dev):
     out = {}
     for name, fn in (("scst", scst), ("adaptive", adaptive), ("dcnet", dcnet), ("dcnet_train", dcnet_train), ("beam", beam),
-                     ("realistic_lengths", realistic_lengths), ("batch_sweep", batch_sweep)):
+                     ("realistic_lengths", realistic_lengths), ("batch_sweep", batch_sweep),
+                     ("concurrent_small_requests", concurrent_small_requests)):
         try:
             out[name] = fn(dev)
         except Exception as e:              # a secondary figure must never break the bench line
