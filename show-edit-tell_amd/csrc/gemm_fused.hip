@@ -63,10 +63,13 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // fused_lds_bytes<...>() bytes
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_n = (EPI == EPI_ENCLSTM) ? (P.N + 7) / 8 : (P.N + 31) / 32;
+    // ENCLSTM: accumulator x holds the 4 gates of the 8 units n0 + 8 x .. (NACC = 2: 16 units per workgroup, the activation
+    // tile is staged once for both)
+    constexpr int EU = 8 * NACC;
+    const int tiles_n = (EPI == EPI_ENCLSTM) ? (P.N + EU - 1) / EU : (P.N + 31) / 32;
     const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
     const int m0 = tm * 32;
-    const int n0 = (EPI == EPI_ENCLSTM) ? tn * 8 : tn * 32;
+    const int n0 = (EPI == EPI_ENCLSTM) ? tn * EU : tn * 32;
     constexpr bool ROWLIST = (EPI == EPI_ENCLSTM);          // rows visited through P.perm
     const int Meff = P.M;
 
@@ -92,9 +95,11 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
             const int j = srow + RPP * i;                   // tile column 0..31
             long long wr;
             if (EPI == EPI_ENCLSTM) {
-                int u = n0 + (j & 7);
+                int u = n0 + 8 * a + (j & 7);
                 u = u < P.N ? u : P.N - 1;
                 wr = (long long)(j >> 3) * P.gate_stride + u;
+                pw[a][i] = (gptr4)(P.W[0] + wr * P.ldw[0] + scol);     // (one weight matrix for every accumulator)
+                continue;
             } else {
                 int c = n0 + j;
                 wr = c < P.N ? c : P.N - 1;
@@ -142,12 +147,17 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
     const long long em = (ROWLIST && P.perm) ? (long long)P.perm[erow_ok ? m0 + erow : Meff - 1] : (long long)(m0 + erow);
     if (EPI == EPI_ENCLSTM && P.nactive && m0 >= P.nactive[P.t]) {
         // every row of this tile has finished (rows are visited longest first): carry the state, skip the contraction
-        const int unit = n0 + eu;
-        if (erow_ok && unit < P.N) P.o0[em * P.N + unit] = P.e1[em * P.N + unit];
+#pragma unroll
+        for (int x = 0; x < NACC; ++x) {
+            const int unit = n0 + 8 * x + eu;
+            if (erow_ok && unit < P.N) P.o0[em * P.N + unit] = P.e1[em * P.N + unit];
+        }
         return;
     }
     f32x4 pre0 = {0.f, 0.f, 0.f, 0.f}, pre1 = {0.f, 0.f, 0.f, 0.f}, pre2 = {0.f, 0.f, 0.f, 0.f}, pre3 = {0.f, 0.f, 0.f, 0.f};
-    float eg[4] = {0.f, 0.f, 0.f, 0.f}, ecp = 0.f, ehin = 0.f;
+    float eg[NACC][4], ecp[NACC], ehin[NACC];
+#pragma unroll
+    for (int x = 0; x < NACC; ++x) { eg[x][0] = eg[x][1] = eg[x][2] = eg[x][3] = 0.f; ecp[x] = 0.f; ehin[x] = 0.f; }
     int elen = 0, epos = 0;
     if (EPI == EPI_CTXGATE) {
         if (erow_ok && n0 + ec4 < P.N) {                 // N % 4 == 0 (host check)
@@ -164,24 +174,45 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
             if (EPI == EPI_COPYGATE1) pre3 = *(gptr4)(P.e3 + em * P.N + n0 + ec4);
         }
     } else {
-        const int unit = n0 + eu;
-        if (erow_ok && unit < P.N) {
+        // The chain row -> length -> word -> table row is three dependent round trips: only its head is requested here, the
+        // word after the first k-tile and the table row after the second (ENC_STAGE1 / ENC_STAGE2 below) — requested ahead of
+        // the contraction, a wave waits for each link before it stages its first tile (4 of the step's 11 fixed microseconds)
+        if (erow_ok) {
             elen = (int)P.lens[em];
-            ehin = P.e1[em * P.N + unit];
-            if (P.t < elen) {
-                epos = P.reverse ? (elen - 1 - P.t) : P.t;
-                long long tok = P.seq ? P.seq[em * P.seq_T + epos] : 0;
-                tok = tok < 0 ? 0 : (tok >= P.seq_V ? P.seq_V - 1 : tok);       // same clamp as embed_relu_k
-                const float* xr = P.seq ? P.e0 + tok * P.ld_xg_row
-                                        : P.e0 + em * P.ld_xg_row + (long long)epos * P.ld_xg_t;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    eg[q] = xr[q * P.N + unit];
-                    if (P.b0) eg[q] += P.b0[q * P.N + unit];
-                }
+            for (int x = 0; x < NACC; ++x) {
+                const int unit = n0 + 8 * x + eu;
+                if (unit >= P.N) continue;
+                ehin[x] = P.e1[em * P.N + unit];
+                ecp[x] = (P.gates ? P.c_in : P.o1)[em * P.N + unit];
             }
-            if (P.t < elen || P.gates) ecp = (P.gates ? P.c_in : P.o1)[em * P.N + unit];
         }
+    }
+    long long etok = 0;
+    float eb[NACC][4];
+#define ENC_STAGE1()                                                                                    \
+    if (EPI == EPI_ENCLSTM && erow_ok) {                                                                \
+        if (P.t < elen) epos = P.reverse ? (elen - 1 - P.t) : P.t;                                      \
+        etok = (P.seq && P.t < elen) ? P.seq[em * P.seq_T + epos] : 0;                                  \
+        _Pragma("unroll") for (int x = 0; x < NACC; ++x)                                                \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                             \
+                const int unit = n0 + 8 * x + eu;                                                       \
+                eb[x][q] = (P.b0 && unit < P.N) ? P.b0[q * P.N + unit] : 0.f;                           \
+            }                                                                                           \
+    }
+#define ENC_STAGE2()                                                                                    \
+    if (EPI == EPI_ENCLSTM && erow_ok && P.t < elen) {                                                  \
+        long long tok = etok < 0 ? 0 : (etok >= P.seq_V ? P.seq_V - 1 : etok);    /* same clamp as embed_relu_k */ \
+        const float* xr = P.seq ? P.e0 + tok * P.ld_xg_row : P.e0 + em * P.ld_xg_row + (long long)epos * P.ld_xg_t; \
+        _Pragma("unroll") for (int x = 0; x < NACC; ++x) {                                              \
+            const int unit = n0 + 8 * x + eu;                                                           \
+            if (unit < P.N) {                                                                           \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                         \
+                    eg[x][q] = xr[q * P.N + unit];                                                      \
+                    if (P.b0) eg[x][q] += eb[x][q];                                                     \
+                }                                                                                       \
+            }                                                                                           \
+        }                                                                                               \
     }
 
     FS_LSTORE(0, ra0, rw0);
@@ -214,8 +245,12 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
     }
     for (int kt = 0; kt < nkt; kt += 2) {
         FS_ITER(kt, 0, ra1, rw1);
+        if (kt == 0) { ENC_STAGE1(); if (nkt < 2) { ENC_STAGE2(); } }
         if (kt + 1 < nkt) FS_ITER(kt + 1, 1, ra0, rw0);
+        if (kt == 0 && nkt >= 2) { ENC_STAGE2(); }
     }
+#undef ENC_STAGE1
+#undef ENC_STAGE2
 #undef FS_ITER
 #undef FS_GLOAD
 #undef FS_LSTORE
@@ -239,16 +274,18 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
     };
 
     if (EPI == EPI_ENCLSTM) {
-        // thread -> (row = tid/8, unit = tid%8); tile columns q*8+u hold gate q of unit u
-        const int unit = n0 + eu;
-        if (erow_ok && unit < P.N) {
+        // thread -> (row = tid/8, unit = tid%8 of every accumulator); tile columns q*8+u hold gate q of unit u
+#pragma unroll
+        for (int x = 0; x < NACC; ++x) {
+            const int unit = n0 + 8 * x + eu;
+            if (!erow_ok || unit >= P.N) continue;
             const int D = P.N;
             if (P.t < elen) {
                 float g[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) g[q] = rsum(0, erow, q * 8 + eu) + eg[q];
+                for (int q = 0; q < 4; ++q) g[q] = rsum(x, erow, q * 8 + eu) + eg[x][q];
                 const float ai = sigm(g[0]), af = sigm(g[1]), ag = tanhf(g[2]), ao = sigm(g[3]);
-                const float cn = af * ecp + ai * ag;
+                const float cn = af * ecp[x] + ai * ag;
                 const float hn = ao * tanhf(cn);
                 P.o1[em * D + unit] = cn;
                 P.o0[em * D + unit] = hn;
@@ -259,17 +296,17 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
                     gr[0] = ai; gr[D] = af; gr[2 * D] = ag; gr[3 * D] = ao;
                 }
             } else {
-                P.o0[em * D + unit] = ehin;                  // finished rows carry their state
+                P.o0[em * D + unit] = ehin[x];               // finished rows carry their state
                 if (P.gates) {                               // grad-enabled forward: position t of a finished row
                     const long long o = em * P.ld_out_b + (long long)P.t * P.ld_out_t + P.out_col0 + unit;
-                    P.o1[em * D + unit] = ecp;
+                    P.o1[em * D + unit] = ecp[x];
                     P.o2[o] = 0.f;
                     if (P.o3) P.o3[o] = 0.f;
                     float* gr = P.gates + em * 4 * D + unit;
                     gr[0] = 0.f; gr[D] = 0.f; gr[2 * D] = 0.f; gr[3 * D] = 0.f;
                 }
             }
-            if (P.hprev) P.hprev[em * P.ld_out_b + (long long)P.t * P.ld_out_t + P.out_col0 + unit] = ehin;
+            if (P.hprev) P.hprev[em * P.ld_out_b + (long long)P.t * P.ld_out_t + P.out_col0 + unit] = ehin[x];
         }
         return;
     }
@@ -410,8 +447,17 @@ int fused_encoder_step(const float* h_in, float* h_out, float* c, const float* w
     P.ld_xg_row = ld_xg_row; P.ld_xg_t = ld_xg_t; P.ld_out_b = ld_out_b; P.ld_out_t = ld_out_t;
     P.t = t; P.reverse = reverse; P.out_col0 = out_col0; P.seq = seq; P.seq_T = seq_T; P.seq_V = seq_V > 0 ? seq_V : 1;
     P.perm = perm; P.nactive = nactive;
-    const int grid = cdiv(B, 32) * cdiv(D, 8);
+    // SET_ENC_UNITS16 (experiment, round 5): 16 units per workgroup — two accumulators on one staged activation tile, 98 MB
+    // through L2 per step at B = 128 instead of 134 — is SLOWER (22.9 / 23.7 us with BK 64 / 128 against 20.5): the step is not
+    // bound by L2 bytes but by each workgroup's serial k-loop (1.15 us per 128-wide k-tile) on top of 11 us of fixed cost
+    static const int u16 = env_int("SET_ENC_UNITS16", 0);
+    static const int u16_min = env_int("SET_ENC_UNITS16_MINB", 64);
     ProfScope ps("fused_encoder_step", s, 8.0 * B * D * D, 4.0 * (4.0 * D * D + 8.0 * B * D));
+    if (u16 && B >= u16_min && D % 16 == 0) {
+        const int grid16 = cdiv(B, 32) * cdiv(D, 16);
+        return u16 == 2 ? launch_fused<2, true, 128, EPI_ENCLSTM>(P, grid16, s) : launch_fused<2, true, 64, EPI_ENCLSTM>(P, grid16, s);
+    }
+    const int grid = cdiv(B, 32) * cdiv(D, 8);
     return launch_fused<1, true, 128, EPI_ENCLSTM>(P, grid, s);
 }
 
