@@ -111,8 +111,7 @@ __device__ __forceinline__ void caption_attention_body(const CapAttArgs& P, int 
         wf[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int a = lane * 4 + 256 * q;
         if (q < nq && a < A) {
-            f32x4 v = ld4a(att2_c.p + (long long)b * att2_c.ld + a);
-            for (int i = 1; i < att2_c.n; ++i) v += ld4a(att2_c.p + (long long)i * att2_c.stride + (long long)b * att2_c.ld + a);
+            const f32x4 v = slab_sum4_at(att2_c, (long long)b * att2_c.ld + a);
             a2[q] = v + ld4a(dec_bias + a);
             wf[q] = ld4a(w_full + a);
             if (P.att2_out && wave == 0 && ds == 0) *reinterpret_cast<f32x4*>(P.att2_out + (long long)b * A + a) = a2[q];
@@ -120,6 +119,26 @@ __device__ __forceinline__ void caption_attention_body(const CapAttArgs& P, int 
     }
     const float bf = b_full[0];
     const int d_lo = P.dsn > 1 ? ds * P.dcols : 0, d_hi = P.dsn > 1 ? d_lo + P.dcols : Dh;      // this workgroup's columns
+    // hoisted-projection mode: the gate epilogue's operands and the first four rows of the P stream do not depend on the
+    // scores — requested here, their round trips run under the scoring phase instead of after the softmax
+    constexpr int PB = 4;
+    const int d_first = d_lo + tid * 4;
+    const bool pre_ok = P.P && d_first < d_hi && T >= PB;
+    f32x4 h_pre0 = {0.f, 0.f, 0.f, 0.f}, h_pre1 = h_pre0, h_bg = h_pre0, h_bs = h_pre0, h_bt = h_pre0, h_vz[PB], h_vs[PB];
+    if (pre_ok) {
+        const long long m = b;
+        h_pre0 = slab_sum4_at(P.cg_ab, m * P.cg_ab.ld + d_first);
+        h_pre1 = slab_sum4_at(P.tc, m * P.tc.ld + d_first);
+        if (P.gz.tab) h_pre0 += ld4a(P.gz.row(m) + d_first);
+        if (P.gtc.tab) h_pre1 += ld4a(P.gtc.row(m) + d_first);
+        h_bg = ld4a(P.b_gate + d_first); h_bs = ld4a(P.b_sc + d_first); h_bt = ld4a(P.b_tc + d_first);
+        const float* pp = P.P + (long long)b * T * 2 * Dh + d_first;
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            h_vz[u] = ld4s(pp + (long long)u * 2 * Dh);
+            h_vs[u] = ld4s(pp + (long long)u * 2 * Dh + Dh);
+        }
+    }
     // each wave scores rows wave, wave+4, ...; RB rows are loaded before any is reduced so that their
     // HBM/L2 round trips overlap (the reductions are 6-step cross-lane chains)
     constexpr int RB = 5;
@@ -165,17 +184,24 @@ __device__ __forceinline__ void caption_attention_body(const CapAttArgs& P, int 
         for (int d = d_lo + tid * 4; d < d_hi; d += 1024) {
             // operands that do not depend on the attention weights first: their latency overlaps the P stream
             const long long m = b;
-            f32x4 pre0 = {0.f, 0.f, 0.f, 0.f}, pre1 = {0.f, 0.f, 0.f, 0.f};
-            for (int i = 0; i < P.cg_ab.n; ++i) pre0 += ld4a(P.cg_ab.p + (long long)i * P.cg_ab.stride + m * P.cg_ab.ld + d);
-            for (int i = 0; i < P.tc.n; ++i) pre1 += ld4a(P.tc.p + (long long)i * P.tc.stride + m * P.tc.ld + d);
-            if (P.gz.tab) pre0 += ld4a(P.gz.row(m) + d);
-            if (P.gtc.tab) pre1 += ld4a(P.gtc.row(m) + d);
-            const f32x4 bg = ld4a(P.b_gate + d), bs = ld4a(P.b_sc + d), bt = ld4a(P.b_tc + d);
+            const bool first = pre_ok && d == d_first;
+            f32x4 pre0 = h_pre0, pre1 = h_pre1, bg = h_bg, bs = h_bs, bt = h_bt;
+            if (!first) {
+                pre0 = slab_sum4_at(P.cg_ab, m * P.cg_ab.ld + d); pre1 = slab_sum4_at(P.tc, m * P.tc.ld + d);
+                if (P.gz.tab) pre0 += ld4a(P.gz.row(m) + d);
+                if (P.gtc.tab) pre1 += ld4a(P.gtc.row(m) + d);
+                bg = ld4a(P.b_gate + d); bs = ld4a(P.b_sc + d); bt = ld4a(P.b_tc + d);
+            }
             const f32x4 mrow = Mem ? ld4a(Mem + ((long long)b * T + js) * Dh + d) : pre0;
             const f32x4 qrow = P.Q ? ld4a(P.Q + ((long long)b * T + js) * Dh + d) : pre0;
             const float* pp = P.P + (long long)b * T * 2 * Dh + d;
             f32x4 zc = {0.f, 0.f, 0.f, 0.f}, sv = {0.f, 0.f, 0.f, 0.f};
             int t = 0;
+            if (first) {                                      // the rows requested before the scoring phase
+#pragma unroll
+                for (int u = 0; u < PB; ++u) { zc += h_vz[u] * sc[u]; sv += h_vs[u] * sc[u]; }
+                t = PB;
+            }
             for (; t + 4 <= T; t += 4) {                      // 8 loads in flight; accumulation stays in t order
                 f32x4 vz[4], vs[4];
 #pragma unroll
@@ -286,8 +312,7 @@ __device__ __forceinline__ void visual_attention_body(const VisAttArgs& P, int b
         wf[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int a = lane * 4 + 256 * q;
         if (q < nq && a < A) {
-            f32x4 v = ld4a(att2.p + (long long)b * att2.ld + a);
-            for (int i = 1; i < att2.n; ++i) v += ld4a(att2.p + (long long)i * att2.stride + (long long)b * att2.ld + a);
+            const f32x4 v = slab_sum4_at(att2, (long long)b * att2.ld + a);
             a2[q] = v + ld4a(dec_bias + a);
             wf[q] = ld4a(w_full + a);
             if (P.att2_out && wave == 0 && fs == 0) *reinterpret_cast<f32x4*>(P.att2_out + (long long)b * A + a) = a2[q];
@@ -428,8 +453,7 @@ __device__ __forceinline__ void visual_attention_v2(const VisAttArgs& P, int b, 
         wf[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int a = lane * 4 + 256 * q;
         if (q < nq && a < A) {
-            f32x4 v = ld4a(att2.p + (long long)b * att2.ld + a);
-            for (int i = 1; i < att2.n; ++i) v += ld4a(att2.p + (long long)i * att2.stride + (long long)b * att2.ld + a);
+            const f32x4 v = slab_sum4_at(att2, (long long)b * att2.ld + a);
             a2[q] = v + ld4a(P.dec_bias + a);
             wf[q] = ld4a(P.w_full + a);
             if (P.att2_out && wave == 0) *reinterpret_cast<f32x4*>(P.att2_out + (long long)b * A + a) = a2[q];
@@ -535,8 +559,8 @@ __device__ __forceinline__ void caption_attention_v2(const CapAttArgs& P, int b,
     f32x4 pre0 = {0.f, 0.f, 0.f, 0.f}, pre1 = {0.f, 0.f, 0.f, 0.f}, bg = pre0, bs = pre0, bt = pre0;
     if (hoisted && half == 0 && col_ok) {
         const long long m = b;
-        for (int i = 0; i < P.cg_ab.n; ++i) pre0 += ld4a(P.cg_ab.p + (long long)i * P.cg_ab.stride + m * P.cg_ab.ld + d0);
-        for (int i = 0; i < P.tc.n; ++i) pre1 += ld4a(P.tc.p + (long long)i * P.tc.stride + m * P.tc.ld + d0);
+        pre0 = slab_sum4_at(P.cg_ab, m * P.cg_ab.ld + d0);
+        pre1 = slab_sum4_at(P.tc, m * P.tc.ld + d0);
         if (P.gz.tab) pre0 += ld4a(P.gz.row(m) + d0);
         if (P.gtc.tab) pre1 += ld4a(P.gtc.row(m) + d0);
         bg = ld4a(P.b_gate + d0); bs = ld4a(P.b_sc + d0); bt = ld4a(P.b_tc + d0);
@@ -550,8 +574,7 @@ __device__ __forceinline__ void caption_attention_v2(const CapAttArgs& P, int b,
         wf[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int a = lane * 4 + 256 * q;
         if (q < nq && a < A) {
-            f32x4 v = ld4a(att2_c.p + (long long)b * att2_c.ld + a);
-            for (int i = 1; i < att2_c.n; ++i) v += ld4a(att2_c.p + (long long)i * att2_c.stride + (long long)b * att2_c.ld + a);
+            const f32x4 v = slab_sum4_at(att2_c, (long long)b * att2_c.ld + a);
             a2[q] = v + ld4a(P.dec_bias + a);
             wf[q] = ld4a(P.w_full + a);
             if (P.att2_out && wave == 0) *reinterpret_cast<f32x4*>(P.att2_out + (long long)b * A + a) = a2[q];

@@ -161,8 +161,8 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
     int elen = 0, epos = 0;
     if (EPI == EPI_CTXGATE) {
         if (erow_ok && n0 + ec4 < P.N) {                 // N % 4 == 0 (host check)
-            for (int i = 0; i < P.s0.n; ++i) pre0 += *(gptr4)(P.s0.p + (long long)i * P.s0.stride + em * P.s0.ld + n0 + ec4);
-            for (int i = 0; i < P.s1.n; ++i) pre1 += *(gptr4)(P.s1.p + (long long)i * P.s1.stride + em * P.s1.ld + n0 + ec4);
+            if (P.s0.n > 0) pre0 = slab_sum4_at(P.s0, em * P.s0.ld + n0 + ec4);
+            if (P.s1.n > 0) pre1 = slab_sum4_at(P.s1, em * P.s1.ld + n0 + ec4);
             if (P.g0.tab) pre0 += *(gptr4)(P.g0.row(em) + n0 + ec4);
             if (P.g1.tab) pre1 += *(gptr4)(P.g1.row(em) + n0 + ec4);
         }

@@ -17,17 +17,8 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4
 // sum of the K-slabs of one GEMM output at (m, n..n+3): slabs are added in index order (fixed,
 // deterministic); loads are issued four slabs at a time so they are in flight together
 __device__ __forceinline__ f32x4 slab_sum4(const Slabs& s, long long m, int n) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (s.n <= 0) return acc;
-    const float* p = s.p + m * s.ld + n;
-    int i = 0;
-    for (; i + 4 <= s.n; i += 4) {
-        const f32x4 v0 = ld4(p + (long long)i * s.stride), v1 = ld4(p + (long long)(i + 1) * s.stride);
-        const f32x4 v2 = ld4(p + (long long)(i + 2) * s.stride), v3 = ld4(p + (long long)(i + 3) * s.stride);
-        acc += v0; acc += v1; acc += v2; acc += v3;
-    }
-    for (; i < s.n; ++i) acc += ld4(p + (long long)i * s.stride);
-    return acc;
+    if (s.n <= 0) return (f32x4){0.f, 0.f, 0.f, 0.f};
+    return slab_sum4_at(s, m * s.ld + n);
 }
 
 // the same for Q column blocks of one row at once (the four gates of an LSTM row): Q x 2 loads in flight

@@ -197,6 +197,28 @@ struct Slabs {
     int n;
 };
 inline Slabs slabs_of(const GemmProb& g) { return Slabs{g.C, g.slab_stride, g.ldc, g.ksplit}; }
+// sum over the slabs of the float4 at element offset `off` of every slab, added in slab order (the deterministic order every
+// consumer uses).  Up to four slabs are REQUESTED together whatever the count: a `for (i < n) acc += load` loop with a run-time
+// trip count is n dependent round trips (the add of iteration i waits for its load before iteration i + 1 issues), which put
+// 3-6 serial L2 latencies at the top of kernels that are otherwise one or two round trips long.
+typedef float slab_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ slab_f32x4 slab_sum4_at(const Slabs& s, long long off) {
+    slab_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* p = s.p + off;
+    for (int i = 0; i < s.n; i += 4) {
+        const int r = s.n - i;
+        const slab_f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const slab_f32x4 v0 = *reinterpret_cast<const slab_f32x4*>(p + (long long)i * s.stride);
+        const slab_f32x4 v1 = r > 1 ? *reinterpret_cast<const slab_f32x4*>(p + (long long)(i + 1) * s.stride) : z;
+        const slab_f32x4 v2 = r > 2 ? *reinterpret_cast<const slab_f32x4*>(p + (long long)(i + 2) * s.stride) : z;
+        const slab_f32x4 v3 = r > 3 ? *reinterpret_cast<const slab_f32x4*>(p + (long long)(i + 3) * s.stride) : z;
+        acc += v0;
+        if (r > 1) acc += v1;
+        if (r > 2) acc += v2;
+        if (r > 3) acc += v3;
+    }
+    return acc;
+}
 
 // prof.hip: RAII timing scope around a kernel launch (no-op unless set_profile_enable(1))
 struct ProfScope {
