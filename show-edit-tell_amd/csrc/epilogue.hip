@@ -50,10 +50,17 @@ __device__ __forceinline__ void tail_finish(const LstmTail& L, int b, int j, con
         if (L.g0.n > 0) g[q] += r.s0[q];
         if (L.g0.n > 1) g[q] += r.s1[q];
     }
-    for (int i = 2; i < L.g0.n; ++i) {
+    for (int i = 2; i < L.g0.n; i += 2) {            // the remaining partials two at a time (requested together, added in order)
         const float* p = L.g0.p + (long long)i * L.g0.stride + (long long)b * L.g0.ld + j;
+        const bool two = i + 1 < L.g0.n;
+        f32x4 v0[4], v1[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) g[q] += *reinterpret_cast<const f32x4*>(p + q * L.D);
+        for (int q = 0; q < 4; ++q) {
+            v0[q] = *reinterpret_cast<const f32x4*>(p + q * L.D);
+            if (two) v1[q] = *reinterpret_cast<const f32x4*>(p + L.g0.stride + q * L.D);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { g[q] += v0[q]; if (two) g[q] += v1[q]; }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {

@@ -57,6 +57,48 @@ __device__ __forceinline__ void slab_accum(f32x4 (&acc)[Q], const Slabs& s, long
     }
 }
 
+// Up to three slab sets added one after the other (set 0's partials in index order, then set 1's, then set 2's — the order
+// three slab_accum calls give) as ONE software-pipelined walk over the flattened partial list: four partials are in flight
+// while the previous four are added.  Three separate calls cost a round trip per batch per set (6 for the copy cell's
+// 6 + 3 + 3 partials: most of the kernel's 10.8 us at B = 128).
+template <int Q>
+__device__ __forceinline__ void slab_accum3(f32x4 (&acc)[Q], const Slabs& s0, const Slabs& s1, const Slabs& s2, long long m,
+                                            int col0, int colstep) {
+    const int n0 = s0.n > 0 ? s0.n : 0, n1 = s1.n > 0 ? s1.n : 0, n2 = s2.n > 0 ? s2.n : 0, n = n0 + n1 + n2;
+    if (n == 0) return;
+    auto at = [&](int i) -> const float* {          // (uniform: scalar selects)
+        if (i < n0) return s0.p + (long long)i * s0.stride + m * s0.ld + col0;
+        if (i < n0 + n1) return s1.p + (long long)(i - n0) * s1.stride + m * s1.ld + col0;
+        return s2.p + (long long)(i - n0 - n1) * s2.stride + m * s2.ld + col0;
+    };
+    f32x4 a[4][Q], b[4][Q];
+#define SA3_LOAD(BUF, I0)                                                                               \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                       \
+        if ((I0) + u < n) {                                                                             \
+            const float* p_ = at((I0) + u);                                                             \
+            _Pragma("unroll") for (int q = 0; q < Q; ++q) BUF[u][q] = ld4(p_ + q * colstep);            \
+        }
+#define SA3_ADD(BUF, I0)                                                                                \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                       \
+        if ((I0) + u < n) {                                                                             \
+            _Pragma("unroll") for (int q = 0; q < Q; ++q) acc[q] += BUF[u][q];                          \
+        }
+    int i = 0;
+    SA3_LOAD(a, 0);
+    for (;;) {
+        if (i + 4 < n) { SA3_LOAD(b, i + 4); }
+        SA3_ADD(a, i);
+        i += 4;
+        if (i >= n) break;
+        if (i + 4 < n) { SA3_LOAD(a, i + 4); }
+        SA3_ADD(b, i);
+        i += 4;
+        if (i >= n) break;
+    }
+#undef SA3_LOAD
+#undef SA3_ADD
+}
+
 // ---------------------------------------------------------------------------------------------
 // LSTM cell pointwise (nn.LSTMCell editnet.py:468,532 / LSTMCellC :235-242 / CopyLSTMCellC :274-280)
 //   gates[m, g*D + j] = g0 + g1 + g2 (slab sums) + pre + b0 + b1 ; order i, f, g, o
@@ -89,9 +131,7 @@ __global__ void __launch_bounds__(256) lstm_pointwise_k(Slabs g0, Slabs g1, Slab
     f32x4 g[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) g[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    slab_accum<4>(g, g0, m, j, D);
-    slab_accum<4>(g, g1, m, j, D);
-    slab_accum<4>(g, g2, m, j, D);
+    slab_accum3<4>(g, g0, g1, g2, m, j, D);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         if (pre) g[q] += xpre[q];
