@@ -77,9 +77,16 @@ def scst(dev, batch=64, samples=5, steps=3):
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
     t = float(np.median(times))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):                     # the training loop's protocol: steps issued back to back, one synchronisation at the end
+        step()
+    torch.cuda.synchronize()
+    t_b2b = (time.perf_counter() - t0) / 5
     return {"workload": "SCST step (editnet_rl.py:649-686): B=%d, %d sampled rollouts per image + greedy baseline + CIDEr-D "
                         "reward + backward + clip + Adam" % (batch, samples),
             "ms_per_step": round(1e3 * t, 2), "steps_ms": [round(1e3 * x, 1) for x in times],
+            "ms_per_step_back_to_back": round(1e3 * t_b2b, 2),
             "decode_steps_per_sec": round(19 * (samples + 1) / t, 1), "native_ciderd": bool(scorer._native)}
 
 
