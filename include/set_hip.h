@@ -680,6 +680,8 @@ typedef struct SetXELoopArgs {
     int step_logs;                               /* 1: gated / cx / aimg hold every timestep; the copy cell contracts its input
                                                     as the segments [h1 | gated | attend_img] where they lie and X2 / WHC are
                                                     packed ONCE after the loop (0: one packing launch per timestep) */
+    const float* rmask; int64_t rmask_step;      /* adaptive features (editnet_adaptive.py:449-453): 0/1 region mask (B, R) of
+                                                    timestep t at rmask + t * rmask_step, or NULL (fixed-36 features) */
 } SetXELoopArgs;
 int set_editnet_xe_train_loop_f32(const SetXELoopArgs* a, void* stream);
 
@@ -697,6 +699,8 @@ typedef struct SetXEBwdLoopArgs {
     float *DC1[2], *DC2[2], *dcm, *dcn, *dop, *dalc;
     void* slab_ws[5]; size_t slab_ws_bytes;      /* one scratch region per product position of a timestep */
     float* tmp[11];                              /* (B, N) landing buffers of products the plan does not split */
+    const float* DLAST;                          /* (T, B, D) or NULL: gradient entering h2 of timestep t directly (adaptive
+                                                    features: d decoder_last_hidden at every row's last timestep, zero elsewhere) */
 } SetXEBwdLoopArgs;
 int set_editnet_xe_train_bwd_loop_f32(const SetXEBwdLoopArgs* a, void* stream);
 

@@ -175,7 +175,7 @@ class XELoopArgs(C.Structure):
                        "ptr E, al_wih, al_whh; ptr tok; i64 tok_step, tok_stride; ptr X, H, Mem, mask, att1_c, pre1, att1; "
                        "i64 att1_step; ptr EMB, H1, C1, H2, C2, G1, G2, WHC, ZT, S, TT, ALPHAC, ALPHAV, ATT2C, ATT2V, SEL, CNEW, CG, "
                        "X2, H2D; ptr gated, cx, aimg; ptr ws_l; size ws_l_bytes; ptr ws_c; size ws_c_bytes; ptr ws_k; size ws_k_bytes; "
-                       "int step_logs")
+                       "int step_logs; ptr rmask; i64 rmask_step")
 
 
 class XEBwdLoopArgs(C.Structure):
@@ -184,7 +184,8 @@ class XEBwdLoopArgs(C.Structure):
                        "ptr cl_cnew_w, cl_cmem_w, cl_x2h_w, cl_h2h_w, w_ctx, w_h1, dec_cat, al_wih, al_whh, va_full, ca_full; "
                        "ptr G1, G2, C1, C2, CG, SEL, CNEW, ZT, S, TT, ALPHAC, ALPHAV, ATT2C, ATT2V, X, H, Mem, att1_c, att1; "
                        "i64 att1_step; ptr dH2D; ptr DU, DGW, DSZT, DATT2, DWFC, DWFV, DEC, DEV, DCTX, DG1, datt1; i64 datt1_step; "
-                       "ptr datt1c, dMem; ptr DC1[2], DC2[2]; ptr dcm, dcn, dop, dalc; ptr slab_ws[5]; size slab_ws_bytes; ptr tmp[11]")
+                       "ptr datt1c, dMem; ptr DC1[2], DC2[2]; ptr dcm, dcn, dop, dalc; ptr slab_ws[5]; size slab_ws_bytes; ptr tmp[11]; "
+                       "ptr DLAST")
 
 
 _P = C.c_void_p

@@ -47,8 +47,8 @@ int set_editnet_xe_train_loop_f32(const SetXELoopArgs* a, void* stream) {
         float* gated = a->gated + (logs ? BD * t : 0);
         float* cx = a->cx + (logs ? BD * t : 0);
         float* aimg = a->aimg + (logs ? (long long)B * F * t : 0);
-        SET_TRY(set_editnet_attentions_train_f32(a->w, a->H, a->att1_c, a->mask, a->Mem, a->X, a->att1 + a->att1_step * t, nullptr,
-                                                 h1, emb, gated, a->ALPHAC + (long long)B * Tc * t, cx, a->ZT + BD * t,
+        SET_TRY(set_editnet_attentions_train_f32(a->w, a->H, a->att1_c, a->mask, a->Mem, a->X, a->att1 + a->att1_step * t,
+                                                 a->rmask ? a->rmask + a->rmask_step * t : nullptr, h1, emb, gated, a->ALPHAC + (long long)B * Tc * t, cx, a->ZT + BD * t,
                                                  a->S + BD * t, a->TT + BD * t, sel, aimg, a->ALPHAV + (long long)B * R * t,
                                                  a->ATT2C + (long long)B * A * t, a->ATT2V + (long long)B * A * t, bt, Tc, R, F, D, A,
                                                  a->ws_c, a->ws_c_bytes, stream));
@@ -106,7 +106,7 @@ int set_editnet_xe_train_bwd_loop_f32(const SetXEBwdLoopArgs* a, void* stream) {
     if (!a || !a->bts || a->T <= 0 || a->B <= 0) return SET_ERR_ARG;
     const int T = a->T, B = a->B, R = a->R, F = a->F, Tc = a->Tc, D = a->D, A = a->A;
     const long long BD = (long long)B * D, K1 = 3LL * D + F, K2 = 2LL * D + F;
-    SetSlabSrc nxt_dh2[2], nxt_dh1{};
+    SetSlabSrc nxt_dh2[3], nxt_dh1{};
     int n_dh2 = 0, have_dh1 = 0;
     for (int t = T - 1; t >= 0; --t) {
         const int bt = a->bts[t];
@@ -116,6 +116,7 @@ int set_editnet_xe_train_bwd_loop_f32(const SetXEBwdLoopArgs* a, void* stream) {
         float* dc2_in = a->DC2[t & 1];
         float* dc2_out = a->DC2[(t & 1) ^ 1];
         // ---- CopyLSTMCellC backward (editnet.py:265-285); dh2 = recurrent addends + the output dropout's backward (fused)
+        if (a->DLAST) nxt_dh2[n_dh2++] = SetSlabSrc{a->DLAST + BD * t, 0, D, 1, bt};
         SET_TRY(set_copy_gate_bwd_src_f32(n_dh2 ? nxt_dh2 : nullptr, n_dh2, a->dH2D + BD * t, D, a->p_out, a->seed,
                                           a->off_out + (uint64_t)t, dc2_in, a->G2 + 4 * BD * t + 3 * D, 4LL * D, a->C2 + BD * (t + 1),
                                           a->CG + BD * t, a->SEL + BD * t, a->CNEW + BD * t, du, a->dcm, a->dcn, a->dop, bt, D, stream));

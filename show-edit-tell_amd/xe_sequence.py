@@ -283,8 +283,10 @@ class _XESequence(torch.autograd.Function):
                     ops.dropout(Yin.view(B * R, D), L["FE"][t].view(B * R, D), bts[t] * R, D, cfg.p_region, cfg.seed, scale_off(2, t))
             if att1_hoisted:
                 ops.linear(L["FE"].view(T * B * R, D), P["va_fa_w"], P["va_fa_b"], L["ATT1"].view(T * B * R, Adim), T * B * R)
+                if adaptive:               # the data-derived region mask of every timestep (editnet_adaptive.py:449-453): one launch
+                    check(lib.set_rowsum_mask_f32(L["FE"].data_ptr(), D, T * B * R, D, L["RMASK"].data_ptr(), st), "set_rowsum_mask_f32")
 
-        c_loop = (_C_LOOPS and ro is None and not ss and not adaptive and (att1_hoisted or not train) and dev.type == "cuda")
+        c_loop = (_C_LOOPS and ro is None and not ss and (att1_hoisted or not train) and dev.type == "cuda")
         if c_loop:
             a = _lib.XELoopArgs()
             a.T, a.B, a.R, a.F, a.Tc, a.D, a.A, a.V, a.train = T, B, R, F, Tc, D, Adim, E.shape[0], int(bool(train))
@@ -308,6 +310,8 @@ class _XESequence(torch.autograd.Function):
                 a.gated, a.cx, a.aimg, a.step_logs = gated.data_ptr(), cx.data_ptr(), aimg.data_ptr(), 0
             a.ws_l, a.ws_l_bytes, a.ws_c, a.ws_c_bytes = ws_l.data_ptr(), ws_l.numel(), ws_c.data_ptr(), ws_c.numel()
             a.ws_k, a.ws_k_bytes = ws_k.data_ptr(), ws_k.numel()
+            if adaptive:
+                a.rmask, a.rmask_step = (L["RMASK"].data_ptr(), B * R) if train else (rmask_eval.data_ptr(), 0)
             check(lib.set_editnet_xe_train_loop_f32(C.byref(a), st), "set_editnet_xe_train_loop_f32")
         for t in (range(T) if not c_loop else ()):
             bt = bts[t]
@@ -336,7 +340,7 @@ class _XESequence(torch.autograd.Function):
                 att1 = L["ATT1"][t]
                 if not att1_hoisted:
                     ops.linear(fe.view(B * R, D), P["va_fa_w"], P["va_fa_b"], att1.view(B * R, Adim), bt * R)
-                if adaptive:
+                if adaptive and not att1_hoisted:
                     check(lib.set_rowsum_mask_f32(fe.data_ptr(), D, bt * R, D, L["RMASK"][t].data_ptr(), st), "set_rowsum_mask_f32")
             else:
                 att1 = Yin
@@ -524,7 +528,13 @@ class _XESequence(torch.autograd.Function):
                     A.gemm(dy, True, x, True, prm.shape[0], Kb, dy.shape[0], out=out, accumulate=not overwrite)
             return side
 
-        slab_direct = _SLAB_DIRECT and _DEMB_HOIST and dlast is None and dev.type == "cuda"
+        slab_direct = _SLAB_DIRECT and _DEMB_HOIST and dev.type == "cuda"
+        DLAST = None
+        if dlast is not None and slab_direct:
+            # d(decoder_last_hidden) enters h2 of every row's LAST timestep: a (T, B, D) log that is zero elsewhere, handed to the
+            # copy-gate backward of every timestep as one more addend of dh2
+            DLAST = _z(T, B, D, dev=dev)
+            DLAST[torch.tensor([l - 1 for l in cfg.decode_lengths], dtype=torch.long, device=dev), torch.arange(B, device=dev)] = dlast
         c_loop = slab_direct and _C_LOOPS and (dfe_after or not train) and not mid
         if c_loop:
             a = _lib.XEBwdLoopArgs()
@@ -541,6 +551,7 @@ class _XESequence(torch.autograd.Function):
             a.X, a.H, a.Mem, a.att1_c = X.data_ptr(), H.data_ptr(), Mem.data_ptr(), att1_c.data_ptr()
             a.att1, a.att1_step = (L["ATT1"].data_ptr(), B * R * Adim) if train else (Yin.data_ptr(), 0)
             a.dH2D = dH2D.data_ptr()
+            a.DLAST = DLAST.data_ptr() if DLAST is not None else None
             a.DU, a.DGW, a.DSZT, a.DATT2, a.DWFC, a.DWFV = (x.data_ptr() for x in (DU, DGW, DSZT, DATT2, DWFC, DWFV))
             a.DEC, a.DEV, a.DCTX, a.DG1 = DEC.data_ptr(), DEV.data_ptr(), DCTX.data_ptr(), DG1.data_ptr()
             a.datt1, a.datt1_step = (DATT1.data_ptr(), B * R * Adim) if train else (dYin.data_ptr(), 0)
@@ -598,7 +609,7 @@ class _XESequence(torch.autograd.Function):
                 du, dgw = DU[t], DGW[t]
                 dc2_in, dc2_out = DC2[t & 1], DC2[(t & 1) ^ 1]
                 # ---- CopyLSTMCellC backward: dh2 = recurrent addends + the output dropout's backward of d fc-input (fused)
-                a_, n_ = srcs(nxt_dh2)
+                a_, n_ = srcs(nxt_dh2 + ([SS(DLAST[t].data_ptr(), 0, D, 1, bt)] if DLAST is not None else []))
                 check(lib.set_copy_gate_bwd_src_f32(a_, n_, dH2D[t].data_ptr(), D, p_out, cfg.seed, rng.offset(rng.SITE_OUT, t),
                                                     dc2_in.data_ptr(), L["G2"][t][:, 3 * D:].data_ptr(), 4 * D,
                                                     L["C2"][t + 1].data_ptr(), L["CG"][t].data_ptr(), L["SEL"][t].data_ptr(),

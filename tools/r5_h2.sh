@@ -1,4 +1,15 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_hip_editnet.py tests/test_hip_dcnet.py tests/test_hip_ops.py tests/test_hip_sequence.py tests/test_hip_train.py tests/test_hip_beam.py -x -q -m gpu 2>&1 | tail -3
-AB_STEPS=100 bash tools/ab_env.sh "SET_ENC_UNITS16=0" 2>&1 | cut -c1-300
+timeout 2000 python -m pytest tests/test_hip_adaptive.py tests/test_hip_sequence.py tests/test_hip_train.py -x -q -m gpu 2>&1 | tail -3
+python - <<'PY'
+import torch, json, sys, os
+sys.path.insert(0, ".")
+from tools import secondary
+print(json.dumps(secondary.adaptive(torch.device("cuda:0"))))
+PY
+SET_XE_C_LOOPS=0 SET_SLAB_DIRECT=0 python - <<'PY'
+import torch, json, sys, os
+sys.path.insert(0, ".")
+from tools import secondary
+print("old path", json.dumps(secondary.adaptive(torch.device("cuda:0"))))
+PY
