@@ -1,15 +1,11 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout 2000 python -m pytest tests/test_hip_adaptive.py tests/test_hip_sequence.py tests/test_hip_train.py -x -q -m gpu 2>&1 | tail -3
-python - <<'PY'
-import torch, json, sys, os
+timeout 2000 python -m pytest tests/test_hip_persistent_decode.py tests/test_hip_editnet.py tests/test_hip_beam.py tests/test_hip_boundary.py -x -q -m gpu 2>&1 | tail -3
+for f in 1 0 1 0; do echo "fork=$f"; SET_PROLOGUE_FORK=$f python - <<'PY'
+import torch, json, sys
 sys.path.insert(0, ".")
 from tools import secondary
-print(json.dumps(secondary.adaptive(torch.device("cuda:0"))))
+r = secondary.batch_sweep(torch.device("cuda:0"), batches=(1, 4, 8, 16))
+print([ (x["batch"], x["ms_per_decode"]) for x in r["rows"]])
 PY
-SET_XE_C_LOOPS=0 SET_SLAB_DIRECT=0 python - <<'PY'
-import torch, json, sys, os
-sys.path.insert(0, ".")
-from tools import secondary
-print("old path", json.dumps(secondary.adaptive(torch.device("cuda:0"))))
-PY
+done
