@@ -52,14 +52,22 @@ struct FusedArgs {
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
 
-template <int NACC, bool SHARED_A, int BK, int EPI>
-__global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
+// NW = waves of the workgroup (4, or 8: the same tile with every k-tile split eight ways — the workgroup's serial k-loop is
+// what bounds these launches (1.15 us per 128-wide k-tile at one or two workgroups per CU), twice the waves halve it; the
+// epilogue is run by the first 256 threads)
+// ST = register stages of the global -> LDS pipeline (2, or 4: tiles kt + 1 .. kt + 4 in registers while tile kt is
+// contracted from LDS — a k-tile takes about half a memory latency with two, the loads of a workgroup are what it waits for)
+template <int NACC, bool SHARED_A, int BK, int EPI, int NW = 4, int ST = 2>
+__global__ void __launch_bounds__(64 * NW) gemm_fused_k(const FusedArgs P) {
+    constexpr int NT = 64 * NW;
+    static_assert(ST == 2 || ST == 4, "two or four register stages");
     constexpr int STRIDE = BK + 4;
     constexpr int NA = SHARED_A ? 1 : NACC;
     constexpr int TILE = 32 * STRIDE;                       // floats per staged operand tile
     constexpr int STAGE = (NA + NACC) * TILE;
-    constexpr int LPT = BK / 32;                            // float4 loads per thread per operand tile
-    constexpr int RED = 4 * NACC * 32 * 33;                 // cross-wave reduction scratch
+    constexpr int LPT = 8 * BK / NT;                        // float4 loads per thread per operand tile
+    constexpr int RED = NW * NACC * 32 * 33;                // cross-wave reduction scratch
+    static_assert(LPT >= 1 && BK % (8 * NW) == 0, "tile / wave count mismatch");
     extern __shared__ __attribute__((aligned(16))) float lds[];   // fused_lds_bytes<...>() bytes
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -75,7 +83,7 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
 
     // staging: thread -> row (tid / (BK/4)) .. covers 32 rows x BK floats with LPT float4 per thread
     constexpr int TPR = BK / 4;                             // threads per row
-    constexpr int RPP = 256 / TPR;                          // rows per pass
+    constexpr int RPP = NT / TPR;                           // rows per pass
     const int srow = tid / TPR, scol = (tid % TPR) * 4;
     gptr4 pa[NA][LPT];
     gptr4 pw[NACC][LPT];
@@ -108,6 +116,7 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
         }
 
     f32x4 ra0[NA][LPT], rw0[NACC][LPT], ra1[NA][LPT], rw1[NACC][LPT];   // two register stages
+    f32x4 ra2[ST == 4 ? NA : 1][LPT], rw2[ST == 4 ? NACC : 1][LPT], ra3[ST == 4 ? NA : 1][LPT], rw3[ST == 4 ? NACC : 1][LPT];
 #define FS_GLOAD(RA, RW)                                                                                \
     {                                                                                                   \
         _Pragma("unroll") for (int a = 0; a < NA; ++a)                                                  \
@@ -140,10 +149,14 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
     const int frow = lane & 31, fk = (lane >> 5) * 4;
     FS_GLOAD(ra0, rw0);                                  // tile 0
     if (nkt > 1) FS_GLOAD(ra1, rw1);                     // tile 1
+    if constexpr (ST == 4) {
+        if (nkt > 2) FS_GLOAD(ra2, rw2);                 // tile 2
+        if (nkt > 3) FS_GLOAD(ra3, rw3);                 // tile 3
+    }
 
     // ---- epilogue operands do not depend on the contraction: fetch them now, under the k-loop
-    const int erow = tid >> 3, ec4 = (tid & 7) * 4, eu = tid & 7;
-    const bool erow_ok = m0 + erow < Meff;
+    const int erow = (tid & 255) >> 3, ec4 = (tid & 7) * 4, eu = tid & 7;
+    const bool erow_ok = tid < 256 && m0 + erow < Meff;
     const long long em = (ROWLIST && P.perm) ? (long long)P.perm[erow_ok ? m0 + erow : Meff - 1] : (long long)(m0 + erow);
     if (EPI == EPI_ENCLSTM && P.nactive && m0 >= P.nactive[P.t]) {
         // every row of this tile has finished (rows are visited longest first): carry the state, skip the contraction
@@ -216,14 +229,15 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
     }
 
     FS_LSTORE(0, ra0, rw0);
-    if (nkt > 2) FS_GLOAD(ra0, rw0);                     // tile 2
+    if constexpr (ST == 4) { if (nkt > 4) FS_GLOAD(ra0, rw0); }          // tile 4
+    else { if (nkt > 2) FS_GLOAD(ra0, rw0); }                            // tile 2
     __syncthreads();
     // invariant at an even step kt: lds[0] = tile kt, ra1 = tile kt+1, ra0 = tile kt+2
 #define FS_ITER(KT, BUF, RA, RW)                                                                        \
     {                                                                                                   \
         const float* sb = lds + (BUF) * STAGE;                                                          \
-        _Pragma("unroll") for (int kb = 0; kb < BK / 32; ++kb) {                                        \
-            const int koff = (wave + 4 * kb) * 8 + fk;                                                  \
+        _Pragma("unroll") for (int kb = 0; kb < BK / (8 * NW); ++kb) {                                  \
+            const int koff = (wave + NW * kb) * 8 + fk;                                                 \
             f32x4 a[NA], b[NACC];                                                                       \
             _Pragma("unroll") for (int x = 0; x < NA; ++x)                                              \
                 a[x] = *reinterpret_cast<const f32x4*>(sb + x * TILE + frow * STRIDE + koff);           \
@@ -238,16 +252,28 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
             }                                                                                           \
             if (kb == 0 && (KT) + 1 < nkt) {                                                            \
                 FS_LSTORE((BUF) ^ 1, RA, RW);                                                           \
-                if ((KT) + 3 < nkt) FS_GLOAD(RA, RW);                                                   \
+                if ((KT) + ST + 1 < nkt) FS_GLOAD(RA, RW);                                              \
             }                                                                                           \
         }                                                                                               \
         __syncthreads();                                                                                \
     }
-    for (int kt = 0; kt < nkt; kt += 2) {
-        FS_ITER(kt, 0, ra1, rw1);
-        if (kt == 0) { ENC_STAGE1(); if (nkt < 2) { ENC_STAGE2(); } }
-        if (kt + 1 < nkt) FS_ITER(kt + 1, 1, ra0, rw0);
-        if (kt == 0 && nkt >= 2) { ENC_STAGE2(); }
+    if constexpr (ST == 4) {
+        // invariant at kt % 4 == 0: lds[0] = tile kt, ra1 .. ra3 = tiles kt + 1 .. kt + 3, ra0 = tile kt + 4
+        for (int kt = 0; kt < nkt; kt += 4) {
+            FS_ITER(kt, 0, ra1, rw1);
+            if (kt == 0) { ENC_STAGE1(); if (nkt < 2) { ENC_STAGE2(); } }
+            if (kt + 1 < nkt) FS_ITER(kt + 1, 1, ra2, rw2);
+            if (kt == 0 && nkt >= 2) { ENC_STAGE2(); }
+            if (kt + 2 < nkt) FS_ITER(kt + 2, 0, ra3, rw3);
+            if (kt + 3 < nkt) FS_ITER(kt + 3, 1, ra0, rw0);
+        }
+    } else {
+        for (int kt = 0; kt < nkt; kt += 2) {
+            FS_ITER(kt, 0, ra1, rw1);
+            if (kt == 0) { ENC_STAGE1(); if (nkt < 2) { ENC_STAGE2(); } }
+            if (kt + 1 < nkt) FS_ITER(kt + 1, 1, ra0, rw0);
+            if (kt == 0 && nkt >= 2) { ENC_STAGE2(); }
+        }
     }
 #undef ENC_STAGE1
 #undef ENC_STAGE2
@@ -267,9 +293,8 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
     __syncthreads();
     auto rsum = [&](int x, int row, int col) {
         float v = red[((0 * NACC + x) * 32 + row) * 33 + col];
-        v += red[((1 * NACC + x) * 32 + row) * 33 + col];
-        v += red[((2 * NACC + x) * 32 + row) * 33 + col];
-        v += red[((3 * NACC + x) * 32 + row) * 33 + col];
+#pragma unroll
+        for (int wv = 1; wv < NW; ++wv) v += red[((wv * NACC + x) * 32 + row) * 33 + col];
         return v;
     };
 
@@ -338,23 +363,23 @@ __global__ void __launch_bounds__(256) gemm_fused_k(const FusedArgs P) {
     if (EPI == EPI_COPYGATE || EPI == EPI_COPYGATE1) *reinterpret_cast<f32x4*>(P.o1 + em * P.N + n0 + ec4) = out1;
 }
 
-template <int NACC, bool SHARED_A, int BK>
+template <int NACC, bool SHARED_A, int BK, int NW = 4>
 constexpr int fused_lds_bytes() {
     constexpr int stage = ((SHARED_A ? 1 : NACC) + NACC) * 32 * (BK + 4);
-    constexpr int red = 4 * NACC * 32 * 33;
+    constexpr int red = NW * NACC * 32 * 33;
     return 4 * ((2 * stage > red) ? 2 * stage : red);
 }
 
-template <int NACC, bool SHARED_A, int BK, int EPI>
+template <int NACC, bool SHARED_A, int BK, int EPI, int NW = 4, int ST = 2>
 static int launch_fused(const FusedArgs& P, int grid, hipStream_t s) {
-    constexpr int bytes = fused_lds_bytes<NACC, SHARED_A, BK>();
+    constexpr int bytes = fused_lds_bytes<NACC, SHARED_A, BK, NW>();
     static bool configured = false;          // raise the dynamic-LDS cap once (idempotent)
     if (!configured) {
-        SET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fused_k<NACC, SHARED_A, BK, EPI>),
+        SET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fused_k<NACC, SHARED_A, BK, EPI, NW, ST>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         configured = true;
     }
-    hipLaunchKernelGGL((gemm_fused_k<NACC, SHARED_A, BK, EPI>), dim3(grid), dim3(256), bytes, s, P);
+    hipLaunchKernelGGL((gemm_fused_k<NACC, SHARED_A, BK, EPI, NW, ST>), dim3(grid), dim3(64 * NW), bytes, s, P);
     SET_LAUNCH_CHECK();
     return SET_OK;
 }
@@ -403,6 +428,10 @@ int fused_copy_gate_pre(const float* c_new, const float* sel, const float* cmem_
     const int grid = cdiv(M, 32) * cdiv(D, 32);
     ProfScope ps("fused_copy_gate", s, 2.0 * M * D * D, 4.0 * (1.0 * D * D + 7.0 * M * D));
     static const int bk128 = env_int("SET_COPYGATE_BK128", 1);
+    // SET_FUSED_NW8 (bit 0: copy gate, bit 1: encoder step): 8-wave workgroups — 13.5 -> 12.7 us / 19.2 -> 18.1 us at B = 128.
+    // (Four register stages, ST = 4, on top of that: no gain — 13.0-13.5 / 18.5-18.7 us; the instantiation is not built.)
+    static const int nw8 = env_int("SET_FUSED_NW8", 3);
+    if (nw8 && bk128 && D % 128 == 0 && grid <= 256) return launch_fused<1, true, 128, EPI_COPYGATE1, 8>(P, grid, s);
     if (bk128 && D % 128 == 0) return launch_fused<1, true, 128, EPI_COPYGATE1>(P, grid, s);
     return launch_fused<1, true, 64, EPI_COPYGATE1>(P, grid, s);
 }
@@ -458,6 +487,8 @@ int fused_encoder_step(const float* h_in, float* h_out, float* c, const float* w
         return u16 == 2 ? launch_fused<2, true, 128, EPI_ENCLSTM>(P, grid16, s) : launch_fused<2, true, 64, EPI_ENCLSTM>(P, grid16, s);
     }
     const int grid = cdiv(B, 32) * cdiv(D, 8);
+    static const int nw8 = env_int("SET_FUSED_NW8", 3);
+    if (nw8 & 2) return launch_fused<1, true, 128, EPI_ENCLSTM, 8>(P, grid, s);
     return launch_fused<1, true, 128, EPI_ENCLSTM>(P, grid, s);
 }
 

@@ -1,11 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout 2000 python -m pytest tests/test_hip_persistent_decode.py tests/test_hip_editnet.py tests/test_hip_beam.py tests/test_hip_boundary.py -x -q -m gpu 2>&1 | tail -3
-for f in 1 0 1 0; do echo "fork=$f"; SET_PROLOGUE_FORK=$f python - <<'PY'
-import torch, json, sys
-sys.path.insert(0, ".")
-from tools import secondary
-r = secondary.batch_sweep(torch.device("cuda:0"), batches=(1, 4, 8, 16))
-print([ (x["batch"], x["ms_per_decode"]) for x in r["rows"]])
-PY
-done
+SET_FUSED_NW8=4 timeout 2000 python -m pytest tests/test_hip_editnet.py tests/test_hip_ops.py tests/test_hip_dcnet.py -x -q -m gpu 2>&1 | tail -3
+SET_FUSED_NW8=5 timeout 2000 python -m pytest tests/test_hip_editnet.py -x -q -m gpu 2>&1 | tail -2
+AB_STEPS=100 bash tools/ab_env.sh "SET_FUSED_NW8=3" "SET_FUSED_NW8=4" "SET_FUSED_NW8=5" 2>&1 | cut -c1-300
