@@ -406,7 +406,9 @@ def _colsum_group(problems):
         if ok:
             for q in plist:
                 g = q.grad
-                if g is not None and (not g.is_contiguous() or g.data_ptr() % 16 or g.dtype != torch.float32 or g.numel() != dy.shape[1]):
+                if q.numel() != dy.shape[1] or q.dtype != torch.float32:
+                    ok = False                  # (not a bias of this gradient: let the plain path raise / broadcast as torch would)
+                elif g is not None and (not g.is_contiguous() or g.data_ptr() % 16 or g.dtype != torch.float32 or g.numel() != dy.shape[1]):
                     ok = False
         if not ok or len(descs) + (len(plist) + 1) // 2 > 24:
             rest.append((dy, plist))
