@@ -97,7 +97,7 @@ static bool tail_ok(const LstmTail& L) {
 constexpr int GP_MAXQ = 12;
 
 template <bool REG, bool TAIL>
-__global__ void __launch_bounds__(256) greedy_pick_k(Slabs logits, const float* bias, int V, int t, int max_len,
+__global__ void SET_VGPR_CAP __launch_bounds__(256) greedy_pick_k(Slabs logits, const float* bias, int V, int t, int max_len,
                                                      long long end_idx, long long* seq, float* seq_logp,
                                                      long long* it_buf, int* unfinished, int* alive,
                                                      const float* table, float* emb_out, int D, const LstmTail tail,

@@ -104,7 +104,7 @@ __device__ __forceinline__ void slab_accum3(f32x4 (&acc)[Q], const Slabs& s0, co
 //   gates[m, g*D + j] = g0 + g1 + g2 (slab sums) + pre + b0 + b1 ; order i, f, g, o
 //   c' = sig(f) c + sig(i) tanh(g);  h' = sig(o) tanh(c')     (h_out / ogate_out optional)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) lstm_pointwise_k(Slabs g0, Slabs g1, Slabs g2, const float* pre,
+__global__ void SET_VGPR_CAP __launch_bounds__(256) lstm_pointwise_k(Slabs g0, Slabs g1, Slabs g2, const float* pre,
                                                         long long ldpre, const float* b0, const float* b1,
                                                         const float* c_in, float* c_out, float* h_out,
                                                         float* ogate_out, int M, int D, RowGather gt,

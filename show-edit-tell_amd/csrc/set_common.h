@@ -5,6 +5,14 @@
 #include <stddef.h>
 #include "../../include/set_hip.h"
 
+// experiment (EXPERIMENTS 5.7): -DSET_EXP_VGPR_CAP=w asks for w waves per SIMD (w = 4: at most 128 registers) of the short decode kernels (co-residency with the
+// GEMM's waves when several batches are in flight)
+#ifdef SET_EXP_VGPR_CAP
+#define SET_VGPR_CAP __attribute__((amdgpu_waves_per_eu(SET_EXP_VGPR_CAP, 8)))
+#else
+#define SET_VGPR_CAP
+#endif
+
 namespace set {
 
 // ---------------------------------------------------------------------------------------------

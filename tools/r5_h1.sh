@@ -1,4 +1,3 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-export SET_ENC_UNITS16=0
-AB_STEPS=60 bash tools/ab.sh "-DSET_EXP_ENC_NOK=1" "-DSET_EXP_ENC_NOK=4" "" 2>&1 | cut -c1-150 | head -3
+AB_STEPS=100 bash tools/ab.sh "" "-DSET_EXP_VGPR_CAP=4" "-DSET_EXP_VGPR_CAP=3" 2>&1 | cut -c1-260
