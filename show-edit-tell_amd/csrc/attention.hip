@@ -397,7 +397,7 @@ __global__ void __launch_bounds__(256) visual_attention_k(const VisAttArgs P) {
 // are independent of each other): workgroups [0, Mv*fsn) stream the image regions, the rest score
 // the previous caption.  Saves one kernel boundary + one ~4.5 us launch floor per timestep and lets
 // the MFMA-free caption attention overlap the HBM-bound region streaming.
-__global__ void SET_VGPR_CAP __launch_bounds__(256) step_attention_k(const VisAttArgs V, const CapAttArgs C, int nvis, const RowGate G) {
+__global__ void SET_VGPR_CAP_ATT __launch_bounds__(256) step_attention_k(const VisAttArgs V, const CapAttArgs C, int nvis, const RowGate G) {
     __shared__ float sc[ATT_MAX_ROWS];
     __shared__ int s_arg;
     if (G.loop_left()) return;                               // decode loops: the reference has left its loop (set_common.h)

@@ -12,6 +12,11 @@
 #else
 #define SET_VGPR_CAP
 #endif
+#ifdef SET_EXP_VGPR_CAP_ATT
+#define SET_VGPR_CAP_ATT __attribute__((amdgpu_waves_per_eu(SET_EXP_VGPR_CAP_ATT, 8)))
+#else
+#define SET_VGPR_CAP_ATT SET_VGPR_CAP
+#endif
 
 namespace set {
 
