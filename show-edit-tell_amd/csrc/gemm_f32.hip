@@ -530,7 +530,7 @@ __global__ void __launch_bounds__(256) gemm_nt_f32_asm(const int ntasks, const i
 #undef ASM_HALF_ROUND
 
 // ---------------------------------------------------------------------------------------------
-// Variants that were built, measured and LOST (EXPERIMENTS.md 3.1b, 4.1): the weights-to-registers kernel, the LDS-DMA
+// Variants that were built, measured and LOST (EXPERIMENTS_r1-r3.md 3.1b, 4.1): the weights-to-registers kernel, the LDS-DMA
 // kernel and the bf16x3 split-precision kernel live in experimental/gemm_variants.inc and are compiled only with
 // -DSET_EXPERIMENTAL_GEMMS (tools/ubench builds; SET_HIPCC_FLAGS=-DSET_EXPERIMENTAL_GEMMS python -m show_edit_tell_amd.build --force).
 // The shipped library does not contain them; their environment switches are ignored there.
