@@ -675,14 +675,16 @@ __global__ void __launch_bounds__(512) caption_attention_v2_k(const CapAttArgs C
     caption_attention_v2(C, blockIdx.x, sc, &s_arg, xch);
 }
 
-static int vis_fsn(int M, int F) {
+static int vis_fsn(int M, int F, int R = 36) {
     // enough workgroups to cover the chip: split the feature axis while slices stay >= 1024 columns
     // measured at B=128: one slice per sample (128 + 128 workgroups) beats 2 or 4 slices (each slice recomputes the scores)
     // small batches (round 3): a handful of rows at one workgroup each leaves the kernel at one CU's streaming rate per
     // row (B = 4: 23 us for 1.2 MB); slices down to 128 columns put ~half the chip on it
     static const int min_cols = env_int("SET_ATT_MIN_COLS", 2048);
     static const int small = env_int("SET_ATT_SMALL_SLICES", 1);
-    const int mc = (small && M < 64) ? 128 : min_cols, want = (small && M < 64) ? 128 : 512;
+    // adaptive features (up to 100 regions: 0.8 MB of X per row): two slices per sample — 64 rows are 64 workgroups walking
+    // 18 dependent rounds of region loads each; B = 64, R = 100: 39.8 -> 31.8 us (four slices: 35.0)
+    const int mc = (small && M < 64) ? 128 : ((R > 48 && min_cols > 1024) ? 1024 : min_cols), want = (small && M < 64) ? 128 : 512;
     int fsn = 1;
     while (M * fsn < want && F / (fsn * 2) >= mc && (F % (fsn * 2 * 4)) == 0) fsn *= 2;
     return fsn;
@@ -699,7 +701,7 @@ int step_attention(const float* att1, Slabs att2, const float* v_dec_bias, const
 #endif
     if (R > ATT_MAX_ROWS || T > ATT_MAX_ROWS || A > 512 || (A & 3) || (F & 3) || (Dh & 3)) return SET_ERR_UNSUPPORTED;
     if (M <= 0) return SET_OK;
-    const int fsn = vis_fsn(M, F);
+    const int fsn = vis_fsn(M, F, R);
     static const int prefetch = env_int("SET_ATT_PREFETCH", 1);
     VisAttArgs V{att1, att2, v_dec_bias, v_w_full, v_b_full, X, rmask, v_ctx, v_alpha, R, F, A, F / fsn, fsn, prefetch, v_att2_out};
     CapAttArgs C{};
@@ -738,7 +740,7 @@ int visual_attention(const float* att1, Slabs att2, const float* dec_bias, const
                      int R, int F, int A, hipStream_t s) {
     if (R > ATT_MAX_ROWS || A > 512 || (A & 3) || (F & 3)) return SET_ERR_UNSUPPORTED;
     if (M <= 0) return SET_OK;
-    const int fsn = vis_fsn(M, F);
+    const int fsn = vis_fsn(M, F, R);
     VisAttArgs P{att1, att2, dec_bias, w_full, b_full, X, rmask, ctx, alpha_out, R, F, A, F / fsn, fsn, 1, nullptr};
     ProfScope ps("visual_attention", s, 0.0, 4.0 * M * ((double)R * A + (double)R * F + F + att2.n * A));
     hipLaunchKernelGGL(visual_attention_k, dim3(M * fsn), dim3(256), 0, s, P);
