@@ -370,6 +370,18 @@ def test_grouped_colsum_equals_single_colsums():
     assert all(torch.equal(a, q.grad) for a, q in zip(first, [q for pl in params for q in pl]))    # deterministic
 
 
+def test_grouped_colsum_more_problems_than_one_launch_takes():
+    """more than SET_COLSUM_MAX (24) problems: the surplus goes through the single kernel, every parameter still gets its sums"""
+    from show_edit_tell_amd import autograd_ops as A
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(10)
+    xs = [torch.randn(128, 64, generator=g).to(dev) for _ in range(30)]
+    ps = [[torch.nn.Parameter(torch.zeros(64, device=dev))] for _ in xs]
+    A._colsum_group(list(zip(xs, ps)))
+    for x, pl in zip(xs, ps):
+        assert torch.allclose(pl[0].grad, x.double().sum(0).float(), rtol=1e-4, atol=1e-4)
+
+
 def test_dcnet_rollout_node_equals_per_operator_rollout(monkeypatch):
     """DCNet (dcnet_rl.py:286-346, sample_rl) in eval mode: node and per-operator route draw the same words, same
     log-probs, equal gradients; the teacher-forced node equals the per-operator XE route on a ragged batch"""
