@@ -23,6 +23,11 @@
  *         encoder, small-batch decode loop: their workgroups must all be resident), the sticky host-mapped fault word and
  *         "persistent kernels disabled" flag behind SET_ERR_FAULT, cached answers of occupancy / LDS-limit queries and of
  *         "dynamic-LDS cap raised for kernel X on device d";
+ *       machine-wide, per device: an advisory lock on /tmp/set_hip_persistent_<pci bus id>.lock (SET_PERSISTENT_LOCK_DIR
+ *         moves it, SET_PERSISTENT_IPC_LOCK=0 switches it off) held until exit by the FIRST process that makes a persistent
+ *         launch on the device; every other process sharing that GPU is answered SET_ERR_UNSUPPORTED by the persistent
+ *         entry points (the per-step kernels; asked again at each call) — two half-resident grids of two processes would
+ *         otherwise wait for each other until the time-out;
  *       environment: SET_* switches are read once per process, except SET_DEC_PERSISTENT / SET_DEC_PERSISTENT_MAXB, which
  *         the small-batch decode reads per call (tests flip them inside one process).
  *     None of it carries results between calls: outputs depend on the arguments only.
@@ -199,9 +204,12 @@ int set_editnet_greedy_begun(const SetEditNetWeights* w, const SetEditNetDims* d
  * Outputs (device): hist_parent / hist_word (max_picks, 4) = parent slot and appended word of every slot after every pick —
  * the host follows them back to read a sequence; best_score / best_word [1] and result [4] = {pick index of the best
  * completed hypothesis (-1: none), its parent slot, hypotheses still alive, picks made}.  A time-out poisons best_score with
- * NaN and result[2..3] = -1 (SET_ERR_FAULT at the next call).  SET_ERR_UNSUPPORTED (nothing was touched: take
- * set_editnet_step + set_beam_pick_f32): no token table, k > 4, adaptive features, dimensions the persistent launch does
- * not cover.  Parity: tests/test_hip_beam.py against the reference's beam goldens. */
+ * NaN and result[2..3] = -1 (SET_ERR_FAULT at the next call).  SET_ERR_UNSUPPORTED (take set_editnet_step +
+ * set_beam_pick_f32): no token table, k > 4, adaptive features, dimensions the persistent launch does not cover, another
+ * process owns the device's persistent launches — all answered BEFORE anything is touched; only a device whose LDS limit or
+ * resident-workgroup capacity turns out too small is answered after the prologue has been written into `ws` (outputs
+ * untouched; the answer is the same for every later call with these dims, so a caller remembers it).
+ * Parity: tests/test_hip_beam.py against the reference's beam goldens. */
 int set_editnet_beam_persistent(const SetEditNetWeights* w, const SetEditNetDims* d, const float* X,
                                 const float* image_mean, const int64_t* prev, const int64_t* prevlen,
                                 int64_t start_idx, int64_t end_idx, int max_picks, int32_t* hist_parent,
@@ -344,6 +352,12 @@ int set_visual_attention_masked_f32(const SetEditNetWeights* w, const float* X, 
 /* SelectC.forward hard mode (editnet.py:403-421): sel = M[b,j*] * (a + (1-a)), j* = argmax alpha_c */
 int set_select_f32(const float* Mem, const float* alpha_c, float* sel, int M, int T, int D,
                    void* stream);
+/* SelectC.forward with soft = True (editnet.py:419-420): sel (M,D) = sum_t alpha_c[b,t] * Mem[b,t,:] (terms added in
+ * index order), and its backward: dM[b,t,:] = alpha[b,t] * dsel[b,:], dalpha[b,t] = <dsel[b,:], Mem[b,t,:]>. */
+int set_select_soft_f32(const float* Mem, const float* alpha_c, float* sel, int M, int T, int D,
+                        void* stream);
+int set_select_soft_bwd_f32(const float* dsel, const float* Mem, const float* alpha, float* dM, float* dalpha,
+                            int M, int T, int D, void* stream);
 /* CopyLSTMCellC.forward (editnet.py:265-285); x (M,2D+F) */
 size_t set_copy_lstm_workspace_bytes(int M, int D, int Kx);
 int set_copy_lstm_f32(const SetEditNetWeights* w, const float* x, int64_t ldx, int Kx,

@@ -250,6 +250,8 @@ PROTOTYPES = {
     "set_visual_attention_masked_f32": (_I, [C.POINTER(EditNetWeights), _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P,
                                              _Z, _P]),
     "set_select_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "set_select_soft_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "set_select_soft_bwd_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "set_copy_lstm_workspace_bytes": (_Z, [_I, _I, _I]),
     "set_copy_lstm_f32": (_I, [C.POINTER(EditNetWeights), _P, _L, _I, _P, _P, _P, _P, _P, _I, _I, _P, _Z, _P]),
     "set_lstm_cell_train_f32": (_I, [_P, _L, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _I, _I, _P, _Z, _P]),

@@ -429,9 +429,14 @@ def _colsum_group(problems):
         arr = (_lib.ColsumDesc * len(descs))(*[_lib.ColsumDesc(*d) for d in descs])
         dev = keep[0].device
         need = lib.set_colsum_group_workspace_bytes(arr, len(descs))
-        ws = _colsum_ws.get(dev)
+        # keyed by (device, stream) like _scratch: the two launches of the grouped column sum share the partials buffer, and two
+        # streams flushing deferred bias gradients at the same time must not share it
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        ws = _colsum_ws.get(key)
         if ws is None or ws.numel() * 4 < need:
-            ws = _colsum_ws[dev] = torch.empty((need + 3) // 4 + 1024, dtype=torch.float32, device=dev)
+            if len(_colsum_ws) >= 16:
+                _colsum_ws.clear()
+            ws = _colsum_ws[key] = torch.empty((need + 3) // 4 + 1024, dtype=torch.float32, device=dev)
         check(lib.set_colsum_group_f32(arr, len(descs), ptr(ws), ws.numel() * 4, stream_of(dev)), "set_colsum_group_f32")
     for dy, plist in rest:
         g = _colsum(dy)
@@ -893,6 +898,39 @@ class _Select(torch.autograd.Function):
 
 def select(Mem, alpha):
     return _Select.apply(Mem, alpha)
+
+
+class _SelectSoft(torch.autograd.Function):
+    """SelectC.forward with soft = True (editnet.py:419-420): sel = sum_t alpha_t M_t, differentiable in both."""
+
+    @staticmethod
+    def forward(ctx, Mem, alpha):
+        Mem, alpha = _c(Mem), _c(alpha)
+        ctx.save_for_backward(Mem, alpha)
+        return select_soft_nograd(Mem, alpha)
+
+    @staticmethod
+    def backward(ctx, dsel):
+        Mem, alpha = ctx.saved_tensors
+        lib = _lib.load()
+        B, T, D = Mem.shape
+        dM = torch.empty_like(Mem)
+        dalpha = torch.empty_like(alpha)
+        check(lib.set_select_soft_bwd_f32(ptr(_c(dsel)), ptr(Mem), ptr(alpha), ptr(dM), ptr(dalpha), B, T, D,
+                                          stream_of(Mem.device)), "set_select_soft_bwd_f32")
+        return dM, dalpha
+
+
+def select_soft_nograd(Mem, alpha):
+    lib = _lib.load()
+    B, T, D = Mem.shape
+    sel = torch.empty(B, D, dtype=torch.float32, device=Mem.device)
+    check(lib.set_select_soft_f32(ptr(Mem), ptr(alpha), ptr(sel), B, T, D, stream_of(Mem.device)), "set_select_soft_f32")
+    return sel
+
+
+def select_soft(Mem, alpha):
+    return _SelectSoft.apply(Mem, alpha)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -498,6 +498,35 @@ __global__ void __launch_bounds__(512) attention_pair_bwd_k(const AttBwdArgs PV,
     if ((int)blockIdx.x < M) attention_bwd_wide_body<false, SRC>(blockIdx.x, PV, SV);
     else attention_bwd_wide_body<true, SRC>(blockIdx.x - M, PC, SCp);
 }
+// soft selection (editnet.py:419-420 with soft = True): the weighted sum over the T memory rows, terms added in index order
+__global__ void __launch_bounds__(256) select_soft_k(const float* Mem, const float* alpha, float* sel, int T, int D) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int d = tid * 4; d < D; d += 1024) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < T; ++t) acc += ldb4(Mem + ((long long)b * T + t) * D + d) * alpha[(long long)b * T + t];
+        stb4(sel + (long long)b * D + d, acc);
+    }
+}
+__global__ void __launch_bounds__(256) select_soft_bwd_k(const float* dsel, const float* Mem, const float* alpha, float* dM,
+                                                         float* dalpha, int T, int D) {
+    __shared__ float s_red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int t = 0; t < T; ++t) {
+        const float a = alpha[(long long)b * T + t];
+        float dot = 0.f;
+        for (int d = tid * 4; d < D; d += 1024) {
+            const f32x4 g = ldb4(dsel + (long long)b * D + d);
+            const f32x4 m = ldb4(Mem + ((long long)b * T + t) * D + d);
+            dot += g[0] * m[0] + g[1] * m[1] + g[2] * m[2] + g[3] * m[3];
+            stb4(dM + ((long long)b * T + t) * D + d, g * a);
+        }
+        dot = wsum(dot);
+        __syncthreads();                                   // (s_red of the previous row has been read)
+        if (lane == 0) s_red[wave] = dot;
+        __syncthreads();
+        if (tid == 0) dalpha[(long long)b * T + t] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    }
+}
 template <bool SRC>
 __global__ void __launch_bounds__(256) select_bwd_k(const float* dsel, const float* Mem, const float* alpha, float* dM,
                                                     float* dalpha, int T, int D, int acc_dm, const SrcList S) {
@@ -943,6 +972,25 @@ int set_select_bwd_acc_f32(const float* dsel, const float* Mem, const float* alp
 int set_select_bwd_f32(const float* dsel, const float* Mem, const float* alpha, float* dM, float* dalpha, int M, int T,
                        int D, void* stream) {
     return set_select_bwd_acc_f32(dsel, Mem, alpha, dM, dalpha, M, T, D, 0, stream);
+}
+
+// SelectC.forward with soft = True (editnet.py:419-420): the attention weights themselves — sel = sum_t alpha_t M_t — and its
+// backward: dM[b, t] = alpha[b, t] dsel[b], dalpha[b, t] = <dsel[b], M[b, t]>.  One workgroup per row.
+int set_select_soft_f32(const float* Mem, const float* alpha, float* sel, int M, int T, int D, void* stream) {
+    if (!Mem || !alpha || !sel || M <= 0 || T <= 0 || D <= 0) return SET_ERR_ARG;
+    if (D & 3) return SET_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(select_soft_k, dim3(M), dim3(256), 0, (hipStream_t)stream, Mem, alpha, sel, T, D);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
+}
+
+int set_select_soft_bwd_f32(const float* dsel, const float* Mem, const float* alpha, float* dM, float* dalpha, int M, int T,
+                            int D, void* stream) {
+    if (!dsel || !Mem || !alpha || !dM || !dalpha || M <= 0 || T <= 0 || D <= 0) return SET_ERR_ARG;
+    if (D & 3) return SET_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(select_soft_bwd_k, dim3(M), dim3(256), 0, (hipStream_t)stream, dsel, Mem, alpha, dM, dalpha, T, D);
+    SET_LAUNCH_CHECK();
+    return SET_OK;
 }
 
 int set_gemm_f32(const float* A, long long lda, int a_kminor, const float* B, long long ldb, int b_kminor, float* C,

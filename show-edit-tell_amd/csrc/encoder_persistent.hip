@@ -23,6 +23,10 @@
 // B <= 128 instantiation takes a wave slot per SIMD alone); the host side serialises instances of this kernel across
 // streams with an event chain (at most one runs at a time in this process), other kernels sharing the chip always finish on
 // their own, and every spin is bounded (a timeout raises the status word instead of hanging the queue).
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
+#include <cstdio>
 #include <mutex>
 #include "set_common.h"
 #include "grid_barrier.h"
@@ -248,11 +252,38 @@ static unsigned* g_penc_fault_dev[64] = {};
 static bool g_penc_disabled[64] = {};
 static int g_penc_capacity[64][9] = {};          // resident workgroups the device admits per kernel instantiation (0 = not asked yet)
 
+// ---- one owner PROCESS per device.  A persistent grid needs all of its workgroups resident at once; the mutex + event chain
+// above order the launches of one process, but two processes sharing a GPU (several ranks on one device, a second job) can
+// each get half a grid resident and wait for the rest until the 1-s time-out poisons both.  The first process that launches a
+// persistent kernel on a device takes an advisory lock on a per-device file (named after the PCI bus id, so ordinals remapped by
+// HIP_VISIBLE_DEVICES agree) and keeps it until it exits (the kernel releases it even when the process dies); every other
+// process gets SET_ERR_UNSUPPORTED from the guard — the per-step kernels, no fault, nothing disabled — and asks again at its
+// next call, so it takes over once the owner is gone.  SET_PERSISTENT_IPC_LOCK=0 switches the check off (exclusive devices);
+// a lock directory that cannot be written is treated the same way.
+static int g_penc_lock_fd[64];                   // 0 = not asked yet, > 0 = owner (open descriptor + 1), -1 = no locking
+static bool penc_process_owns(int dev) {
+    static const int on = env_int("SET_PERSISTENT_IPC_LOCK", 1);
+    if (!on || g_penc_lock_fd[dev] == -1) return true;
+    if (g_penc_lock_fd[dev] > 0) return true;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, dev) != hipSuccess) { (void)hipGetLastError(); snprintf(bus, sizeof(bus), "ord%d", dev); }
+    for (char* c = bus; *c; ++c) if (*c == ':' || *c == '/' || *c == '.') *c = '_';
+    const char* dir = getenv("SET_PERSISTENT_LOCK_DIR");
+    char path[256];
+    snprintf(path, sizeof(path), "%s/set_hip_persistent_%s.lock", dir && *dir ? dir : "/tmp", bus);
+    const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+    if (fd < 0) { g_penc_lock_fd[dev] = -1; return true; }
+    if (flock(fd, LOCK_EX | LOCK_NB) != 0) { close(fd); return false; }       // another process owns the device's persistent launches
+    g_penc_lock_fd[dev] = fd + 1;
+    return true;
+}
+
 PersistentGuard::PersistentGuard() : rc(SET_OK), dev(0), fault(nullptr), locked(false) {
     if (hipGetDevice(&dev) != hipSuccess) { rc = SET_ERR_HIP; return; }
     dev &= 63;
     g_penc_mutex.lock();
     locked = true;
+    if (!penc_process_owns(dev)) { rc = SET_ERR_UNSUPPORTED; return; }
     if (!g_penc_fault_host[dev]) {
         void* hp = nullptr; void* dp = nullptr;
         if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess) { rc = SET_ERR_HIP; return; }
@@ -311,9 +342,15 @@ int PersistentGuard::set_lds(const void* kernel, int bytes, bool (&done)[64]) {
     return SET_OK;
 }
 int PersistentGuard::test_stall() const { static const int v = env_int("SET_PENC_TEST_STALL", 0); return v; }
+// persistent launches are not to be tried on the current device: a barrier timed out earlier in this process, or another
+// process owns them (penc_process_owns; asked again at every call, so a device whose owner exited is taken over).  Callers ask
+// BEFORE they prepare anything for a persistent launch (hoisted products, the beam entry point's prologue).
 bool persistent_disabled() {
     int dev = 0;
-    return hipGetDevice(&dev) == hipSuccess && g_penc_disabled[dev & 63];
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    dev &= 63;
+    std::lock_guard<std::mutex> lk(g_penc_mutex);
+    return g_penc_disabled[dev] || !penc_process_owns(dev);
 }
 
 size_t persistent_encoder_bar_bytes() { return sizeof(unsigned) * (GBAR_WORDS + GBAR_STRIDE); }

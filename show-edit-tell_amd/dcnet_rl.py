@@ -35,21 +35,26 @@ class DAE(_DAE_XE):
             if limits.dtype != torch.int32 or not limits.is_cuda or limits.numel() != B:
                 raise _lib.SetError("row_limits must be an int32 device tensor with one entry per row")
             limits = limits.contiguous()
-        lib.set_decode_row_limits(ptr(limits) if limits is not None else None)
         seq = torch.empty(B, max_len, dtype=torch.long, device=dev)
         seq_logp = torch.empty(B, max_len, dtype=torch.float32, device=dev)
-        if sample_rl:        # multinomial sampling, eval mode, no gradients: fused device loop, Philox epilogue
-            from . import rng
-            seed = rng.next_seed()
-            check(lib.set_dcnet_sample(C.byref(w), C.byref(dims), ptr(prev), ptr(plen), int(word_map['<start>']),
-                                       int(word_map['<end>']), max_len, seed, rng.offset(rng.SITE_ROLLOUT), ptr(seq),
-                                       ptr(seq_logp), ptr(ws),
-                                       ws.numel(), stream_of(dev)), "set_dcnet_sample")
+        # (thread-local library state, set for the duration of this enqueue only — see editnet_rl.DecoderC.forward)
+        lib.set_decode_row_limits(ptr(limits) if limits is not None else None)
+        try:
+            if sample_rl:        # multinomial sampling, eval mode, no gradients: fused device loop, Philox epilogue
+                from . import rng
+                seed = rng.next_seed()
+                check(lib.set_dcnet_sample(C.byref(w), C.byref(dims), ptr(prev), ptr(plen), int(word_map['<start>']),
+                                           int(word_map['<end>']), max_len, seed, rng.offset(rng.SITE_ROLLOUT), ptr(seq),
+                                           ptr(seq_logp), ptr(ws),
+                                           ws.numel(), stream_of(dev)), "set_dcnet_sample")
+                return seq, seq_logp
+            check(lib.set_dcnet_greedy(C.byref(w), C.byref(dims), ptr(prev), ptr(plen), int(word_map['<start>']),
+                                       int(word_map['<end>']), max_len, ptr(seq), ptr(seq_logp), ptr(ws), ws.numel(),
+                                       stream_of(dev)), "set_dcnet_greedy")
             return seq, seq_logp
-        check(lib.set_dcnet_greedy(C.byref(w), C.byref(dims), ptr(prev), ptr(plen), int(word_map['<start>']),
-                                   int(word_map['<end>']), max_len, ptr(seq), ptr(seq_logp), ptr(ws), ws.numel(),
-                                   stream_of(dev)), "set_dcnet_greedy")
-        return seq, seq_logp
+        finally:
+            if limits is not None:
+                lib.set_decode_row_limits(None)
 
 
 def _dae_rollout(self, word_map, encoded_previous_captions, previous_cap_length, sample_max, sample_rl):

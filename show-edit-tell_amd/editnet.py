@@ -277,15 +277,20 @@ class CaptionAttentionC(nn.Module):
 
 
 class SelectC(nn.Module):
-    """SCMA hard selection, reference editnet.py:383-421 (soft=False path)."""
+    """SCMA selection, reference editnet.py:383-421: hard (soft=False, the only mode the reference's loops use) keeps the
+    arg-max row with the straight-through weight; soft=True is the plain weighted sum over the memory rows (:419-420)."""
 
     def __init__(self, prev_caption_dim, decoder_dim):
         super().__init__()
 
     def forward(self, previous_encoded_m, sim_weights, soft=False):
-        if soft:
-            raise NotImplementedError("soft selection is never used by the reference (soft=False always)")
         _require_cuda(previous_encoded_m, "encoder memory")
+        if soft:
+            from . import autograd_ops as A
+            Mem, alpha = _f32c(previous_encoded_m), _f32c(sim_weights)
+            if _wants_grad(self, previous_encoded_m, sim_weights):
+                return A.select_soft(Mem, alpha)
+            return A.select_soft_nograd(Mem, alpha)
         if _wants_grad(self, previous_encoded_m, sim_weights):
             from . import autograd_ops as A
             return A.select(_f32c(previous_encoded_m), _f32c(sim_weights))
@@ -323,16 +328,22 @@ class VisualAttentionC(nn.Module):
         if self.training or _wants_grad(self, decoder_hidden):
             # editnet.py:441-446 as written: region embedding (+ its Dropout(0.5) in train mode) recomputed per call
             from . import autograd_ops as A
-            if self.adaptive:
-                raise NotImplementedError("direct differentiable calls of the adaptive VisualAttentionC go through "
-                                          "DecoderC.forward (editnet_adaptive.py:438-457)")
             from . import rng
             X = _f32c(image_features)
             fe = A.philox_dropout(A.linear(X, self.att_embed[0].weight, self.att_embed[0].bias, _lib.ACT_RELU),
                                   self.att_embed[2].p, rng.next_seed(), rng.offset(rng.SITE_REGION), self.training)
+            rmask = None
+            if self.adaptive:
+                # editnet_adaptive.py:440-449: att_embed runs over the packed valid regions only — the first att_len[b] =
+                # #(nonzero feature rows) regions of a sample; padded rows of the embedding stay zero — and the attention
+                # mask is re-derived from the (dropped-out) embedding's row sums
+                valid = (X.sum(2) != 0)
+                keep = torch.arange(X.shape[1], device=X.device)[None, :] < valid.sum(1, keepdim=True)
+                fe = fe * keep[:, :, None].to(fe.dtype)
+                rmask = (fe.detach().sum(2) != 0).float()
             att1 = A.linear(fe, self.features_att.weight, self.features_att.bias)
             return A.visual_attention_from_att1(X, att1, _f32c(decoder_hidden), self.decoder_att.weight,
-                                                self.decoder_att.bias, self.full_att.weight, self.full_att.bias)
+                                                self.decoder_att.bias, self.full_att.weight, self.full_att.bias, rmask)
         lib = _lib.load()
         X, h1 = _f32c(image_features), _f32c(decoder_hidden)
         M, R, F = X.shape

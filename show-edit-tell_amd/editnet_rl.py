@@ -46,7 +46,19 @@ class DecoderC(_DecoderXE):
             if limits.dtype != torch.int32 or not limits.is_cuda or limits.numel() != image_features.shape[0]:
                 raise _lib.SetError("row_limits must be an int32 device tensor with one entry per row")
             limits = limits.contiguous()
+        # the limit pointer is thread-local state of the library that every greedy pick of this host thread reads: it is set
+        # for the duration of THIS enqueue only (it used to stay set — a later caller with another B, or after the
+        # tensor was freed, would have read it)
         lib.set_decode_row_limits(_lib.ptr(limits) if limits is not None else None)
+        try:
+            return self._decode_nograd(lib, word_map, encoded_previous_captions, previous_cap_length, image_features,
+                                       sample_rl, image_mean)
+        finally:
+            if limits is not None:
+                lib.set_decode_row_limits(None)
+
+    def _decode_nograd(self, lib, word_map, encoded_previous_captions, previous_cap_length, image_features, sample_rl,
+                       image_mean):
         dev = image_features.device
         X = _f32c(image_features)
         prev = _i64c(encoded_previous_captions)

@@ -242,8 +242,8 @@ def _beam_search_editnet_persistent(decoder, image_features, previous_caption, p
     rc = lib.set_editnet_beam_persistent(C.byref(w), C.byref(dims), ptr(X), None, ptr(prev), ptr(plen), int(word_map['<start>']),
                                          int(word_map['<end>']), picks, base + o_hp, base, base + o_bs, base + o_bw, base + o_res,
                                          ptr(ws), ws.numel(), stream_of(dev))
-    if rc == 2:                                                    # SET_ERR_UNSUPPORTED: nothing was touched
-        return None
+    if rc == 2:                                                    # SET_ERR_UNSUPPORTED: no output was touched (set_hip.h: answered
+        return None                                                # before the prologue except on a device too small for the grid)
     check(rc, "set_editnet_beam_persistent")
     host = buf.cpu().numpy()
     hw = host[:n_hw].view("int64").reshape(picks, 4)

@@ -40,11 +40,79 @@ class _PinnedRing:
     keeps its slot until it is released — late releases just add the slot to the current free list, never a second token for a
     slot that is already free).  Plain `for batch in reader:` loops release the previous batch's slot when the next one is
     asked for; a DevicePrefetcher (which keeps several batches in flight and releases each after its copy) switches that off
-    through `manual_release`."""
-    manual_release = False
+    through `manual_release_next()`, which holds for the ONE iteration started next (a later plain loop over the same reader
+    releases per batch again).  An abandoned iteration (`break`) stops AND JOINS its producer before the generator returns, so
+    no worker of an old iteration can still be filling a slot that the next iteration hands to its own producer."""
 
     def _ring_init(self):
         self._slots, self._free, self._lent, self._ring_lock = None, None, set(), threading.Lock()
+        self._manual_next = False
+
+    def manual_release_next(self):
+        """the iteration started by the next iter(reader) leaves every slot lent until release(slot) is called for it"""
+        self._manual_next = True
+
+    def _take_manual(self):
+        manual, self._manual_next = self._manual_next, False
+        return manual
+
+    def _iterate(self, work, fill, view, manual):
+        """producer thread: for (bi, item) in enumerate(work): take a free slot, fill(slot, item) -> n rows, queue it;
+        consumer (this generator): view(bi, slot, n) -> HostBatch."""
+        ready = queue.Queue(maxsize=self.depth)
+        stop = threading.Event()
+
+        def producer():
+            try:
+                with ThreadPoolExecutor(self.workers) as pool:
+                    for bi, item in enumerate(work):
+                        slot = None
+                        while slot is None and not stop.is_set():
+                            try:
+                                slot = self._free.get(timeout=0.1)
+                            except queue.Empty:
+                                pass
+                        if stop.is_set():
+                            return
+                        n = fill(pool, slot, item)
+                        while not stop.is_set():
+                            try:
+                                ready.put((bi, slot, n), timeout=0.1)
+                                break
+                            except queue.Full:
+                                pass
+                ready.put(None)
+            except BaseException as e:            # surface reader errors in the consumer
+                ready.put(e)
+
+        th = threading.Thread(target=producer, daemon=True, name="set-reader-producer")
+        th.start()
+        prev = None
+        try:
+            while True:
+                item = ready.get()
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                bi, slot, n = item
+                batch = view(bi, slot, n)
+                batch.slot, batch.owner = slot, self
+                if not manual and prev is not None:
+                    self.release(prev)                   # plain iteration: the previous batch's slot goes back
+                self._lend(slot)
+                prev = slot
+                yield batch
+        finally:
+            stop.set()
+            while th.is_alive():                         # the old producer (and its pool) is gone before anyone iterates again
+                try:
+                    ready.get_nowait()
+                except queue.Empty:
+                    pass
+                th.join(timeout=0.05)
+            if not manual and prev is not None:
+                self.release(prev)
 
     def _ring_ensure(self, make_slot):
         if self._slots is None:
@@ -108,52 +176,18 @@ class AdaptiveFeatureReader(_PinnedRing):
 
     def __iter__(self):
         self._alloc()
-        ready = queue.Queue(maxsize=self.depth)
-        stop = threading.Event()
 
-        def producer():
-            try:
-                with ThreadPoolExecutor(self.workers) as pool:
-                    for bi, ids in enumerate(self.id_batches):
-                        slot = None
-                        while slot is None and not stop.is_set():
-                            try:
-                                slot = self._free.get(timeout=0.1)
-                            except queue.Empty:
-                                pass
-                        if stop.is_set():
-                            return
-                        img, mean = self._slots[slot]
-                        img_np, mean_np = img.numpy(), mean.numpy()
-                        list(pool.map(lambda a: self._load_one(img_np, mean_np, *a), enumerate(ids)))
-                        ready.put((bi, slot, len(ids)))
-                ready.put(None)
-            except BaseException as e:            # surface reader errors in the consumer
-                ready.put(e)
+        def fill(pool, slot, ids):
+            img, mean = self._slots[slot]
+            img_np, mean_np = img.numpy(), mean.numpy()
+            list(pool.map(lambda a: self._load_one(img_np, mean_np, *a), enumerate(ids)))
+            return len(ids)
 
-        th = threading.Thread(target=producer, daemon=True)
-        th.start()
-        prev = None
-        try:
-            while True:
-                item = ready.get()
-                if item is None:
-                    return
-                if isinstance(item, BaseException):
-                    raise item
-                bi, slot, n = item
-                img, mean = self._slots[slot]
-                batch = HostBatch((img[:n], mean[:n]) + tuple(self.extras[bi] if self.extras is not None else ()))
-                batch.slot, batch.owner = slot, self
-                if not self.manual_release and prev is not None:
-                    self.release(prev)                   # plain iteration: the previous batch's slot goes back
-                self._lend(slot)
-                prev = slot
-                yield batch
-        finally:
-            stop.set()
-            if not self.manual_release and prev is not None:
-                self.release(prev)
+        def view(bi, slot, n):
+            img, mean = self._slots[slot]
+            return HostBatch((img[:n], mean[:n]) + tuple(self.extras[bi] if self.extras is not None else ()))
+
+        return self._iterate(self.id_batches, fill, view, self._take_manual())
 
 
 class FixedFeatureReader(_PinnedRing):
@@ -236,50 +270,16 @@ class FixedFeatureReader(_PinnedRing):
 
     def __iter__(self):
         self._alloc()
-        ready = queue.Queue(maxsize=self.depth)
-        stop = threading.Event()
 
-        def producer():
-            try:
-                with ThreadPoolExecutor(self.workers) as pool:
-                    for bi, refs in enumerate(self.ref_batches):
-                        slot = None
-                        while slot is None and not stop.is_set():
-                            try:
-                                slot = self._free.get(timeout=0.1)
-                            except queue.Empty:
-                                pass
-                        if stop.is_set():
-                            return
-                        img_np = self._slots[slot].numpy()
-                        list(pool.map(lambda a: self._load_one(img_np, *a), enumerate(refs)))
-                        ready.put((bi, slot, len(refs)))
-                ready.put(None)
-            except BaseException as e:
-                ready.put(e)
+        def fill(pool, slot, refs):
+            img_np = self._slots[slot].numpy()
+            list(pool.map(lambda a: self._load_one(img_np, *a), enumerate(refs)))
+            return len(refs)
 
-        th = threading.Thread(target=producer, daemon=True)
-        th.start()
-        prev = None
-        try:
-            while True:
-                item = ready.get()
-                if item is None:
-                    return
-                if isinstance(item, BaseException):
-                    raise item
-                bi, slot, n = item
-                batch = HostBatch((self._slots[slot][:n],) + tuple(self.extras[bi] if self.extras is not None else ()))
-                batch.slot, batch.owner = slot, self
-                if not self.manual_release and prev is not None:
-                    self.release(prev)                   # plain iteration: the previous batch's slot goes back
-                self._lend(slot)
-                prev = slot
-                yield batch
-        finally:
-            stop.set()
-            if not self.manual_release and prev is not None:
-                self.release(prev)
+        def view(bi, slot, n):
+            return HostBatch((self._slots[slot][:n],) + tuple(self.extras[bi] if self.extras is not None else ()))
+
+        return self._iterate(self.ref_batches, fill, view, self._take_manual())
 
 
 class HostBatch(tuple):
@@ -301,6 +301,8 @@ class DevicePrefetcher:
         prologue of batch i+1 then runs underneath the timestep loop of batch i, and the `decoder(...)` call for batch i+1
         finds it done.  What a caller that issues one decode after the other (the reference's train() / evaluate()) gains."""
         self.begin_ahead = begin_ahead
+        if isinstance(iterable, _PinnedRing):
+            iterable.manual_release_next()       # several batches in flight here: each slot is returned after ITS copy
         self.it = iter(iterable)
         self.device = torch.device(device)
         # `streams` side streams, used round-robin per staged batch (1 = the copy stream alone).  With
@@ -319,8 +321,6 @@ class DevicePrefetcher:
         ring = getattr(iterable, "depth", None)
         if isinstance(ring, int) and ring >= 1:
             self.depth = max(1, min(self.depth, ring - 1))
-        if isinstance(iterable, _PinnedRing):
-            iterable.manual_release = True       # several batches in flight here: each slot is returned after ITS copy
         self.queue = []
         self.record_timing = record_timing
         self.timeline = []

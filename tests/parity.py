@@ -185,3 +185,24 @@ def check_two_paths_rows(seq_a, logp_a, seq_b, logp_b, margins, tol=2e-5, margin
         if n:
             assert float(np.abs(logp_a[b, :n] - logp_b[b, :n]).max()) < tol
     return int(amb.sum())
+
+
+def check_sampled_paths_rows(seq_a, logp_a, seq_b, logp_b, draw_margin, tol=2e-5, margin_min=1e-4):
+    """Two implementations of the same SAMPLED rollout (same Philox stream): `draw_margin` (S,B) is the distance of every
+    draw's target from the nearest CDF boundary along trajectory a (oracle/philox_np.categorical_draw, relative to the
+    total mass; +inf behind a row's end).  Scores that differ by summation order (<= 2e-5) move a boundary by less than
+    `margin_min`, so a row whose draws all keep that distance must be bit-identical in both paths with log-probs within
+    `tol`; a row with a closer draw must agree up to that step.  Returns the number of such close-draw rows."""
+    S = draw_margin.shape[0]
+    close = (draw_margin < margin_min).any(0)
+    ok = ~close
+    assert np.array_equal(seq_a[ok], seq_b[ok]), "sampled ids differ on rows whose draws all clear the CDF boundaries"
+    if ok.any():
+        e = float(np.abs(logp_a[ok] - logp_b[ok]).max())
+        assert e < tol, "log-probs of the two sampled paths differ by %.3e" % e
+    for b in np.nonzero(close)[0]:
+        n = min(int(np.argmax(draw_margin[:, b] < margin_min)), S)
+        assert np.array_equal(seq_a[b, :n], seq_b[b, :n]), "close-draw row %d differs before its close draw at step %d" % (b, n)
+        if n:
+            assert float(np.abs(logp_a[b, :n] - logp_b[b, :n]).max()) < tol
+    return int(close.sum())

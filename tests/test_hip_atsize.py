@@ -92,7 +92,7 @@ def test_scst_rollout_b64_x5_logprobs_vs_oracle():
     """BASELINE.json configs[4] shape: 64 images x 5 sampled rollouts = 320 rows in ONE rollout (train.scst_train_step's
     layout), full dimensions, eval-mode dropout so the oracle can follow: every stored log-prob equals the numpy oracle's
     log-softmax at the drawn word when the oracle is fed the same words; reproducible per seed; rows of one image differ"""
-    from oracle import cases, editnet_np as EN
+    from oracle import cases, editnet_np as EN, philox_np as PH
     from show_edit_tell_amd import rng, synth
     from show_edit_tell_amd.train import _repeater
     d, xe, rl = editnet_modules("editnet_full_b128")
@@ -106,12 +106,6 @@ def test_scst_rollout_b64_x5_logprobs_vs_oracle():
     with rng.dropout_seed(0x5C57_0000_0064_0005), torch.no_grad():
         seq2, logp2 = rl(wm, rep(to_dev(prev)), rep(to_dev(plen)), rep(to_dev(X)), sample_max=False, sample_rl=True)
     seq, logp = _np(seq), _np(logp)
-    # the fused no-grad loop draws from the same Philox stream; its scores differ in the last bits (token-table folding), so
-    # a draw that falls within ~1e-6 of a CDF boundary may pick the neighbouring word and the row diverges from there:
-    # nearly all of the 320 rows must agree, and where they do the log-probs agree too
-    same = (seq == _np(seq2)).all(1)
-    assert same.mean() > 0.9, same.mean()
-    assert np.abs(logp[same] - _np(logp2)[same]).max() < 2e-5
     B = n_img * n_s
     assert seq.shape == (B, 18) and (logp <= 0).all()
     per_image = seq.reshape(n_s, n_img, 18)
@@ -122,8 +116,18 @@ def test_scst_rollout_b64_x5_logprobs_vs_oracle():
     words = np.full((B,), wm["<start>"], np.int64)
     live = np.ones(B, bool)
     checked = 0
+    draw_margin = np.full((18, B), np.inf)
+    seed, off = 0x5C57_0000_0064_0005, PH.site_offset(PH.SITE_ROLLOUT)
     for t in range(18):
-        lg = EN.step(S, words, B).astype(np.float64)
+        lg32 = EN.step(S, words, B)
+        # the draw itself: the device's word is the oracle's inverse-CDF draw of counter (row, t, offset) wherever the target
+        # clears the CDF boundaries (the loop rewrites <end> to 0, editnet_rl.py:531)
+        ids_o, mg = PH.categorical_draw(lg32, seed, off, t)
+        ids_o = np.where(ids_o == wm["<end>"], 0, ids_o)
+        clear = live & (mg > 1e-5)
+        assert np.array_equal(seq[clear, t], ids_o[clear]), "sampled words differ from the oracle's draws at step %d" % t
+        draw_margin[t, live] = mg[live]
+        lg = lg32.astype(np.float64)
         m = lg.max(1, keepdims=True)
         lsm = lg - (m + np.log(np.exp(lg - m).sum(1, keepdims=True)))
         w = seq[:, t]
@@ -139,3 +143,8 @@ def test_scst_rollout_b64_x5_logprobs_vs_oracle():
         if not live.any():
             break
     assert checked > B * 10
+    # the fused no-grad loop draws from the same Philox stream; its scores differ in the last bits (token-table folding):
+    # every row whose draws all keep >= 1e-4 of the total mass from a CDF boundary must be identical in both routes, a row
+    # with a closer draw must agree up to that draw (tests/parity.py) — and such rows are a handful of the 320
+    n_close = parity.check_sampled_paths_rows(seq, logp, _np(seq2), _np(logp2), draw_margin)
+    assert n_close <= 8, n_close

@@ -234,6 +234,64 @@ def test_direct_submodule_calls_are_differentiable_and_train_mode_works():
     assert torch.isfinite(Ht).all()
 
 
+def test_select_soft_matches_reference_branch():
+    """SelectC.forward(soft=True) (/root/reference/editnet.py:419-420) — the branch the reference's loops never take but
+    a drop-in must still compute: output (no-grad kernel and autograd route) and both input gradients against the
+    reference's own class (tests/golden/boundary_ops.npz, oracle/make_boundary_golden.py)."""
+    from oracle.make_boundary_golden import boundary_inputs
+    g = parity.load("boundary_ops")
+    d, xe, rl = editnet_modules("editnet_small")
+    prev, plen = to_dev(d["prev"]), to_dev(d["plen"])
+    with torch.no_grad():
+        _, M, _, _ = xe.caption_encoder(prev, plen)
+    p = boundary_inputs(d, M.shape[1])
+    alpha = to_dev(p["alpha"])
+    with torch.no_grad():
+        sel0 = xe.select(M, alpha, soft=True)
+    parity.assert_close(_np(sel0), g["soft_sel"], 1e-5, "soft selection (no-grad)")
+    Mg, ag = M.clone().requires_grad_(True), alpha.clone().requires_grad_(True)
+    sel = xe.select(Mg, ag, soft=True)
+    assert sel.requires_grad and torch.equal(sel.detach(), sel0)
+    sel.backward(to_dev(p["dsel"]))
+    parity.assert_close(_np(Mg.grad), g["soft_dM"], 1e-5, "soft selection dM")
+    parity.assert_close(_np(ag.grad), g["soft_dalpha"], 2e-5, "soft selection dalpha")
+    # the hard branch is untouched: same call without the flag still takes the arg-max row
+    with torch.no_grad():
+        hard = xe.select(M, alpha)
+    j = alpha.argmax(1)
+    assert torch.allclose(hard, M[torch.arange(M.shape[0]), j], atol=1e-6)
+
+
+def test_adaptive_visual_attention_direct_call_is_differentiable():
+    """A differentiable DIRECT call of the adaptive VisualAttentionC (/root/reference/adaptive_features/
+    editnet_adaptive.py:438-457) — formerly NotImplementedError: context, d/d(decoder_hidden) and every parameter
+    gradient of the sub-module against the reference's autograd (eval mode, ragged region counts)."""
+    from oracle.make_boundary_golden import boundary_inputs
+    g = parity.load("boundary_ops")
+    d, xe = adaptive_module("editnet_adaptive_small")
+    va = xe.visual_attention
+    X = to_dev(d["X"])
+    p = boundary_inputs(d, 1)
+    with torch.no_grad():
+        ctx0 = va(X, to_dev(d["probe"]["h1"]))
+    parity.assert_close(_np(ctx0), g["ada_ctx"], 2e-5, "adaptive visual context (no-grad)")
+    h1 = to_dev(d["probe"]["h1"]).requires_grad_(True)
+    va.zero_grad()
+    ctx = va(X, h1)
+    assert ctx.requires_grad
+    parity.assert_close(_np(ctx), g["ada_ctx"], 2e-5, "adaptive visual context (autograd route)")
+    ctx.backward(to_dev(p["dctx"]))
+    parity.assert_close(_np(h1.grad), g["ada_dh1"], 5e-5, "d context / d decoder_hidden")
+    for k, q in va.named_parameters():
+        want = g["ada_grad." + k]
+        tol = 1e-4 * max(1.0, float(np.abs(want).max()))
+        parity.assert_close(_np(q.grad), want, tol, "grad " + k)
+    va.train()                                                 # dropout site active: finite, and padded regions stay masked
+    v1 = va(X, h1.detach())
+    assert torch.isfinite(v1).all()
+    va.eval()
+
+
 def test_out_of_range_token_ids_are_clamped_with_and_without_token_table():
     """ADVICE: the table gathers must clamp ids exactly like the embedding gather does, so behaviour does not depend
     on whether the token table is active (no out-of-bounds device read)."""
@@ -325,7 +383,7 @@ print("OK", mode)
 
 @pytest.mark.parametrize("mode,env", [("stall", {"SET_PENC_TEST_STALL": "1", "SET_PENC_TIMEOUT_US": "20000"}),
                                       ("capacity", {"SET_PENC_TEST_CAPACITY": "100"})])
-def test_persistent_encoder_failure_is_loud(mode, env):
+def test_persistent_encoder_failure_is_loud(mode, env, tmp_path):
     """The persistent caption encoder can fail in two ways and neither may be silent (csrc/encoder_persistent.hip):
     * `capacity`: the device does not admit the whole grid at once (occupancy query x CU count < workgroups; forced here
       with a test hook) -> the launch is refused up front and the per-step kernels run: results equal the golden;
@@ -335,9 +393,67 @@ def test_persistent_encoder_failure_is_loud(mode, env):
     import subprocess, sys, os
     e = dict(os.environ)
     e.update(env)
+    e["SET_PERSISTENT_LOCK_DIR"] = str(tmp_path)       # this pytest process owns the device's persistent launches; the child gets its own lock
     r = subprocess.run([sys.executable, "-c", _FAULT_SCRIPT, mode], env=e, capture_output=True, text=True, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and ("OK " + mode) in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+_TWO_PROC_SCRIPT = r"""
+import json, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.getcwd(), "tests")); sys.path.insert(0, os.getcwd())
+import parity
+from hip_adapter import editnet_modules, to_dev
+from show_edit_tell_amd import _lib
+rank, rdv = int(sys.argv[1]), sys.argv[2]
+d, xe, rl = editnet_modules("editnet_full_b4")
+g = parity.load("editnet_full_b4")
+args = (d["wm"], to_dev(d["prev"]), to_dev(d["plen"]), to_dev(d["X"]), True, False)
+lib = _lib.load()
+with torch.no_grad():
+    if rank == 1:                                  # rank 0 warms up first: it is the process that takes the device's lock
+        while not os.path.exists(os.path.join(rdv, "ready0")): time.sleep(0.01)
+    for _ in range(3):                             # (the third call runs with the token table: persistent launch if allowed)
+        rl(*args)
+    torch.cuda.synchronize()
+    open(os.path.join(rdv, "ready%d" % rank), "w").close()
+    while not (os.path.exists(os.path.join(rdv, "ready0")) and os.path.exists(os.path.join(rdv, "ready1"))): time.sleep(0.005)
+    lib.set_profile_enable(1)
+    worst = 0.0
+    for i in range(60):                            # both processes decode at the same time on the one device
+        t0 = time.perf_counter()
+        seq, logp = rl(*args)
+        torch.cuda.synchronize()
+        worst = max(worst, time.perf_counter() - t0)
+        if i % 10 == 0:
+            parity.check_greedy(seq.cpu().numpy(), logp.cpu().numpy(), g)
+    tags = sorted(set(r["tag"] for r in _lib.profile_report()))
+    lib.set_profile_enable(0)
+print("RESULT " + json.dumps(dict(rank=rank, worst_s=worst, persistent=any(t.startswith("persistent") for t in tags), tags=tags)))
+"""
+
+
+def test_two_processes_on_one_device_never_interleave_persistent_grids(tmp_path):
+    """the persistent launches (every workgroup must be resident) were guarded per PROCESS only — two
+    processes sharing a GPU could each get half a grid resident and sit in the 1-s time-out.  Now the first process owns the
+    device's persistent launches (advisory lock, csrc/encoder_persistent.hip penc_process_owns); the other one is answered
+    SET_ERR_UNSUPPORTED and runs the per-step kernels.  Two processes decode concurrently on cuda:0: both match the
+    reference's golden, exactly one of them ran persistent kernels, nobody waited anywhere near the time-out, no fault."""
+    import json, subprocess, sys, os
+    e = dict(os.environ)
+    e["SET_PERSISTENT_LOCK_DIR"] = str(tmp_path)        # (a lock an earlier test process of this run still holds is not ours)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = [subprocess.Popen([sys.executable, "-c", _TWO_PROC_SCRIPT, str(r), str(tmp_path)], env=e, cwd=root,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in (0, 1)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    res = []
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so[-2000:] + se[-3000:]
+        res.append(json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][-1][7:]))
+    res.sort(key=lambda r: r["rank"])
+    assert res[0]["persistent"] and not res[1]["persistent"], res
+    assert max(r["worst_s"] for r in res) < 0.5, res       # a time-out is a 1-s stall followed by SetError
 
 
 def test_begin_ahead_pipelined_decode_is_bit_identical():

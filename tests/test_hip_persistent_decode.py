@@ -313,13 +313,14 @@ print("OK", mode)
 
 @pytest.mark.parametrize("mode,env", [("stall", {"SET_PENC_TEST_STALL": "1", "SET_PENC_TIMEOUT_US": "20000", "SET_ENC_PERSISTENT": "0"}),
                                       ("capacity", {"SET_PENC_TEST_CAPACITY": "100"})])
-def test_dcnet_persistent_decode_failure_is_loud(mode, env):
+def test_dcnet_persistent_decode_failure_is_loud(mode, env, tmp_path):
     """Same two failure modes as the persistent encoder (tests/test_hip_boundary.py): a grid that is not admitted whole is
     refused up front (per-step loop, golden parity); a workgroup that never publishes makes every bounded poll time out, the
     kernel overwrites seq_logp with NaN, the NEXT call raises SetError(SET_ERR_FAULT) once and the library keeps to the
     per-step kernels afterwards."""
     e = dict(os.environ)
     e.update(env)
+    e["SET_PERSISTENT_LOCK_DIR"] = str(tmp_path)       # this pytest process owns the device's persistent launches; the child gets its own lock
     r = subprocess.run([sys.executable, "-c", _FAULT_SCRIPT, mode], env=e, capture_output=True, text=True, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and ("OK " + mode) in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

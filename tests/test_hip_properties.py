@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 
+import parity
 from hip_adapter import editnet_modules, to_dev
 
 pytestmark = pytest.mark.gpu
@@ -29,7 +30,11 @@ def test_determinism_and_stream_independence(setup):
     a = _greedy(rl, d["wm"], prev, plen, X)           # from the 2nd call on the folded token table is used
     b = _greedy(rl, d["wm"], prev, plen, X)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), "two runs must be bit-identical"
-    assert np.abs(first[1] - a[1]).max() < 1e-4 and (first[0] == a[0]).all(1).mean() > 0.95
+    # first call vs token-table call: judged row by row with the REFERENCE's per-step top-1/top-2 margins of this very case
+    # (tests/golden/editnet_full_b128.npz): rows without a near-tie are bit-identical, a near-tie row agrees up to that step
+    margins = parity.load("editnet_full_b128")["greedy_margin"]
+    n_amb = parity.check_two_paths_rows(first[0], first[1], a[0], a[1], margins, tol=1e-4)
+    assert n_amb <= 6, n_amb
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
@@ -76,9 +81,9 @@ def test_sub_batch_consistency(setup):
     d, xe, rl, X, prev, plen = setup
     a = _greedy(rl, d["wm"], prev, plen, X)
     b = _greedy(rl, d["wm"], prev[:32].contiguous(), plen[:32].contiguous(), X[:32].contiguous())
-    same = (a[0][:32] == b[0]).all(1)
-    assert same.mean() >= 0.9
-    assert np.abs(a[1][:32][same] - b[1][same]).max() < 1e-4
+    margins = parity.load("editnet_full_b128")["greedy_margin"][:, :32]
+    n_amb = parity.check_two_paths_rows(a[0][:32], a[1][:32], b[0], b[1], margins, tol=1e-4)
+    assert n_amb <= 3, n_amb
 
 
 def test_xe_rows_beyond_decode_length_are_zero_and_prefix_consistent(setup):

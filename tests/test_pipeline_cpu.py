@@ -180,10 +180,15 @@ def test_fixed_reader_ring_is_allocated_once_and_survives_stale_and_missing_rele
     assert [t.data_ptr() for t in reader._slots] == slots, "the ring is allocated once"
     assert all(torch.equal(a, b) for a, b in zip(seen, again))
     # manual release (what DevicePrefetcher does): break early holding one batch, start a new epoch, release late
-    reader.manual_release = True
+    reader.manual_release_next()
     it = iter(reader)
     held = next(it)
     it.close()
+    # close() stops AND joins the old producer: no thread of the abandoned iteration can still be filling a slot
+    # when the next iteration's producer starts taking slots from the rebuilt free list
+    import threading
+    assert sum(1 for t in threading.enumerate() if t.name.startswith("set-reader")) == 0
+    reader.manual_release_next()
     it2 = iter(reader)
     first = next(it2)
     assert held.slot in reader._lent and first.slot != held.slot
@@ -196,6 +201,9 @@ def test_fixed_reader_ring_is_allocated_once_and_survives_stale_and_missing_rele
         reader.release(b.slot)
     assert len(rest) == len(batches) - 1
     assert reader._free.qsize() + len(reader._lent) == reader.depth
+    # the manual mode held for those iterations only: a plain loop over the same reader releases per batch again and runs
+    # through more batches than the ring has slots (the flag used to stick to the reader)
+    assert len([b[0].clone() for b in reader]) == len(batches)
     with pytest.raises(KeyError):
         pipeline.FixedFeatureReader({"t": ds["tp"]}, [[("v", 0)]], pin=False)
     with pytest.raises(IndexError):
