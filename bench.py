@@ -615,6 +615,16 @@ def train_leg(args, dec, wm, X, caps, clen, prev, plen, dev, dist, rank, world, 
                              "contractions finish (train.FlatGradBuckets / BucketedAllReduce)")
     del opt, xe
     torch.cuda.empty_cache()
+    if world == 1 and not args.no_secondary:
+        # the exchange step on a ONE-rank RCCL group (tools/rccl_one_rank.py), in a child process with a timeout: what the
+        # collectives cost before any byte crosses xGMI — the baseline for an N > 1 run's allreduce_exposed_ms / allreduce_ms
+        try:
+            r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "rccl_one_rank.py"),
+                                "--steps", str(K)], capture_output=True, text=True, timeout=300)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            out["one_rank_rccl"] = json.loads(lines[-1]) if lines else {"error": (r.stderr or r.stdout)[-300:]}
+        except Exception as e:
+            out["one_rank_rccl"] = {"error": repr(e)[:300]}
     return out
 
 

@@ -70,12 +70,13 @@ def uniforms(n, seed, offset):
     return (w[:, 0] >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
 
 
-def categorical_draw(logits, seed, offset, t=0):
+def categorical_draw(logits, seed, offset, t=0, with_alt=False):
     """the sampling epilogue's draw (csrc/epilogue.hip `sample_pick_k`) for every row of `logits` (B, V): inverse CDF of
     softmax(logits) over the kernel's fixed enumeration of the vocabulary (thread tid of 256 owns the words
     (tid + 256 q) * 4 + e, q = 0.., e = 0..3, in that order), uniform of counter (row, t, offset).  Returns (ids (B,),
     margin (B,)): margin = distance of the target from the nearest CDF boundary, relative to the total mass — draws with
-    a margin below ~1e-5 may legitimately differ between the fp32 device scan and this fp64 one."""
+    a margin below ~1e-5 may legitimately differ between the fp32 device scan and this fp64 one.  with_alt: also return
+    alt (B,) = the word on the other side of that nearest boundary — the only word such a draw can legitimately become."""
     B, V = logits.shape
     nq = -(-V // 1024)
     order = np.array([(tid + 256 * q) * 4 + e for tid in range(256) for q in range(nq) for e in range(4)])
@@ -85,11 +86,13 @@ def categorical_draw(logits, seed, offset, t=0):
     cdf = np.cumsum(pe, 1)
     u = sample_uniform(seed, offset, np.arange(B), t).astype(np.float64)
     target = u * cdf[:, -1]
-    ids, margin = np.zeros(B, np.int64), np.zeros(B)
+    ids, margin, alt = np.zeros(B, np.int64), np.zeros(B), np.zeros(B, np.int64)
     for b in range(B):
         j = int(np.searchsorted(cdf[b], target[b], side="right"))
         j = min(j, len(order) - 1)
         ids[b] = order[j]
         lo = cdf[b, j - 1] if j else 0.0
         margin[b] = min(target[b] - lo, cdf[b, j] - target[b]) / cdf[b, -1]
-    return ids, margin
+        below = (target[b] - lo) < (cdf[b, j] - target[b])
+        alt[b] = order[max(j - 1, 0)] if below else order[min(j + 1, len(order) - 1)]
+    return (ids, margin, alt) if with_alt else (ids, margin)

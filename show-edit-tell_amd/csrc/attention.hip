@@ -280,7 +280,7 @@ int caption_attention(const float* att1_c, Slabs att2_c, const float* dec_bias, 
     P.H = H; P.Mem = Mem; P.ctx = ctx; P.sel = sel; P.alpha_out = alpha_out; P.T = T; P.Dh = Dh; P.A = A;
     P.att2_out = att2_out;
     static const int v2 = env_int("SET_ATT_V2", 1);
-    static const int v2_maxm = env_int("SET_ATT_V2_MAXM", 32);
+    static const int v2_maxm = env_int("SET_ATT_V2_MAXM", 64);
     if (v2 && M <= v2_maxm && Dh <= 1024) {  // 512 threads per row, all H rows requested before the scoring phase (see v2 below)
         hipLaunchKernelGGL(caption_attention_v2_k, dim3(M), dim3(512), 0, s, P, g_row_gate);
         SET_LAUNCH_CHECK();
@@ -718,11 +718,12 @@ int step_attention(const float* att1, Slabs att2, const float* v_dec_bias, const
     ProfScope ps("step_attention", s, 0.0,
                  4.0 * M * ((double)R * A * fsn + (double)R * F + F + (double)T * A + cap_rows));
     // v2 (512 threads per row, every streamed operand requested before the scoring phase) when the columns fit its layout
-    // Default: up to SET_ATT_V2_MAXM rows (32).  Measured at B = 128 (round 3): 26.4 -> 24.3 us per launch single stream, but a
-    // 512-thread / 236-register workgroup leaves no room for another batch's kernels on its CU: 6.75 k -> 6.41 k with 7
-    // batches in flight; at B = 4 26.3 -> 21.5 us and nothing else is there to displace.
+    // Default: up to SET_ATT_V2_MAXM rows (64; 32 until round 6).  Measured at B = 128 (round 3): 26.4 -> 24.3 us per launch single
+    // stream, but a 512-thread / 236-register workgroup leaves no room for another batch's kernels on its CU: 6.75 k -> 6.41 k
+    // with 7 batches in flight; at B = 4 26.3 -> 21.5 us and nothing else is there to displace.  Round 6, 33..64 rows (one
+    // decode at a time is the case there): 23.1 -> 21.2 us per launch, B = 48 / 64 greedy decode 2.72 / 2.79 -> 2.66 / 2.75 ms.
     static const int v2 = env_int("SET_ATT_V2", 1);
-    static const int v2_maxm = env_int("SET_ATT_V2_MAXM", 32);
+    static const int v2_maxm = env_int("SET_ATT_V2_MAXM", 64);
     if (v2 && M <= v2_maxm && F <= 2048 && Dh <= 1024) {
         V.fcols = F; V.fsn = 1;
         hipLaunchKernelGGL(step_attention_v2_k, dim3(2 * M), dim3(512), 0, s, V, C, M, g_row_gate);

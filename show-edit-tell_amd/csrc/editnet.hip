@@ -389,9 +389,11 @@ static int step_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const 
                            d->adaptive ? ws.rmask : nullptr, ws.attend_img, ws.alpha, R, F, ws.att1_c, slabs_of(b[0]),
                            w->ca_dec_b, w->ca_full_w, w->ca_full_b, ws.mask, ws.H, ws.Mem, ws.ctx_cap, ws.sel,
                            ws.alpha_c, T, D, A, bt, st, &hoist));
-    // small batches (measured: up to 64 rows): the 32-row tiles leave the fused E kernel with <= 64 workgroups; the
-    // grouped GEMM (split-K over the whole chip) + pointwise is faster there
-    static const int fused_min_rows = env_int("SET_FUSED_MIN_ROWS", 65);
+    // from 17 rows the fused E kernel (32-row tiles, the copy gate as its epilogue: 12 us whatever the row count — its
+    // serial k-loop bounds it).  Until round 6 it started at 65 rows ("<= 64 workgroups"): re-measured on the 8-wave kernel
+    // of round 5, grouped GEMM + pointwise is 17 + 6.5 us at 32 rows: B = 24 / 32 / 48 / 64 greedy decode 2.19 / 2.28 / 2.75 /
+    // 2.81 -> 2.16 / 2.25 / 2.72 / 2.79 ms.  Up to 16 rows the gemv class + pointwise stays (SET_FUSED_MIN_ROWS).
+    static const int fused_min_rows = env_int("SET_FUSED_MIN_ROWS", 17);
     const bool fused = fusedk && bt >= fused_min_rows;
     // ---- D
     GemmProb dd = slab_prob(ws.sD0, bt, 4 * D, B);

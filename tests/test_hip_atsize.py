@@ -116,17 +116,18 @@ def test_scst_rollout_b64_x5_logprobs_vs_oracle():
     words = np.full((B,), wm["<start>"], np.int64)
     live = np.ones(B, bool)
     checked = 0
-    draw_margin = np.full((18, B), np.inf)
+    draw_margin, draw_alt = np.full((18, B), np.inf), np.zeros((18, B), np.int64)
     seed, off = 0x5C57_0000_0064_0005, PH.site_offset(PH.SITE_ROLLOUT)
     for t in range(18):
         lg32 = EN.step(S, words, B)
         # the draw itself: the device's word is the oracle's inverse-CDF draw of counter (row, t, offset) wherever the target
         # clears the CDF boundaries (the loop rewrites <end> to 0, editnet_rl.py:531)
-        ids_o, mg = PH.categorical_draw(lg32, seed, off, t)
+        ids_o, mg, alt = PH.categorical_draw(lg32, seed, off, t, with_alt=True)
         ids_o = np.where(ids_o == wm["<end>"], 0, ids_o)
         clear = live & (mg > 1e-5)
         assert np.array_equal(seq[clear, t], ids_o[clear]), "sampled words differ from the oracle's draws at step %d" % t
         draw_margin[t, live] = mg[live]
+        draw_alt[t] = np.where(alt == wm["<end>"], 0, alt)
         lg = lg32.astype(np.float64)
         m = lg.max(1, keepdims=True)
         lsm = lg - (m + np.log(np.exp(lg - m).sum(1, keepdims=True)))
@@ -143,8 +144,8 @@ def test_scst_rollout_b64_x5_logprobs_vs_oracle():
         if not live.any():
             break
     assert checked > B * 10
-    # the fused no-grad loop draws from the same Philox stream; its scores differ in the last bits (token-table folding):
-    # every row whose draws all keep >= 1e-4 of the total mass from a CDF boundary must be identical in both routes, a row
-    # with a closer draw must agree up to that draw (tests/parity.py) — and such rows are a handful of the 320
-    n_close = parity.check_sampled_paths_rows(seq, logp, _np(seq2), _np(logp2), draw_margin)
-    assert n_close <= 8, n_close
+    # the fused no-grad loop draws from the same Philox stream; its scores differ in the last bits (token-table folding).  A
+    # row may differ between the two routes only where the oracle shows its draw within 1e-5 of the mass from a CDF boundary,
+    # and then by the neighbouring word (tests/parity.py check_sampled_paths_rows) — a handful of the 320 rows at most
+    n_diff = parity.check_sampled_paths_rows(seq, logp, _np(seq2), _np(logp2), draw_margin, draw_alt)
+    assert n_diff <= 16, n_diff

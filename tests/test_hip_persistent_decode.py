@@ -324,3 +324,44 @@ def test_dcnet_persistent_decode_failure_is_loud(mode, env, tmp_path):
     r = subprocess.run([sys.executable, "-c", _FAULT_SCRIPT, mode], env=e, capture_output=True, text=True, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and ("OK " + mode) in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_request_coalescer_serves_concurrent_small_requests_on_one_persistent_launch():
+    """show_edit_tell_amd/serving.py: four callers with a 4-row request each, submitted from four
+    threads; the coalescer runs them as shared decodes of <= 16 rows (the persistent launch) and every caller gets the rows a
+    decode of its request alone produces — ids bit-identical (the persistent kernel's per-row arithmetic does not depend on the
+    row count), log-probs within 2e-5 — including requests whose previous captions have different padded lengths."""
+    import threading
+    from show_edit_tell_amd import serving
+    d, xe, rl = editnet_modules("editnet_full_b128")
+    wm = d["wm"]
+    X, prev, plen = to_dev(d["X"]), to_dev(d["prev"]), to_dev(d["plen"])
+    reqs = []
+    for i in range(6):
+        lo = 4 * i
+        p = prev[lo:lo + 4]
+        if i % 2:                                            # a shorter padded length: the coalescer pads it back with <pad>
+            tmax = int(plen[lo:lo + 4].max())
+            p = p[:, :max(tmax, 2)].contiguous()
+        reqs.append((p.contiguous(), plen[lo:lo + 4].contiguous(), X[lo:lo + 4].contiguous()))
+    with torch.no_grad():
+        for _ in range(3):
+            rl(wm, *reqs[0], True, False)                    # token table
+        alone = [tuple(t.clone() for t in rl(wm, *r, True, False)) for r in reqs]
+    torch.cuda.synchronize()
+    outs = {}
+    with serving.RequestCoalescer(lambda p, l, x: rl(wm, p, l, x, True, False), max_rows=16, window_s=0.01) as co:
+        def caller(i):
+            f = co.submit(*reqs[i])
+            seq, logp = f.result(timeout=120)
+            torch.cuda.synchronize()
+            outs[i] = (seq.clone(), logp.clone())
+        ths = [threading.Thread(target=caller, args=(i,)) for i in range(6)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert co.requests == 6 and co.batches < 6, (co.requests, co.batches)
+    for i in range(6):
+        assert torch.equal(outs[i][0], alone[i][0]), i
+        assert float((outs[i][1] - alone[i][1]).abs().max()) < 2e-5

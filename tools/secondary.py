@@ -233,6 +233,20 @@ def beam(dev, images=128, k=3):
         else:
             os.environ["SET_DEC_PERSISTENT"] = old
     same = sum(int(a[0] == b[0]) for a, b in zip(out_one, out_steps))
+    # the reference's PUBLISHED protocol (eval_full.py:88-237, README.md:105-108): the EditNet + DCNet ensemble, one image per
+    # call — and DCNet alone (dcnet.py:405-541).  Both run the NI = 1 case of the per-step batched search (a .cpu() per pick);
+    # only EditNet's own search has a persistent launch
+    dae_short = _dcnet(dc.DAE, dev, wm, end_boost=5.5).eval()
+
+    def per_image_fn(fn):
+        for i in range(2):
+            fn(i)
+        t, out = _timed(lambda: [fn(i) for i in range(16)], 2, 1)
+        return t / 16, out
+    t_ens, out_ens = per_image_fn(lambda i: evaluate.beam_search_ensemble(dec, dae, X[i:i + 1], prev[i:i + 1], plen[i:i + 1], wm, k))
+    t_ens_short, out_ens_short = per_image_fn(lambda i: evaluate.beam_search_ensemble(dec_short, dae_short, X[i:i + 1], prev[i:i + 1], plen[i:i + 1], wm, k))
+    t_dc, _ = per_image_fn(lambda i: evaluate.beam_search_dcnet(dae, prev[i:i + 1], plen[i:i + 1], wm, k))
+    t_dc_short, _ = per_image_fn(lambda i: evaluate.beam_search_dcnet(dae_short, prev[i:i + 1], plen[i:i + 1], wm, k))
     return {"workload": "beam search k=%d over %d images at once (editnet.py:595-718, eval_full.py:88-218)" % (k, images),
             "editnet_ms": round(1e3 * t_e, 2), "ensemble_ms": round(1e3 * t_x, 2),
             "editnet_one_image_per_call_ms": round(1e3 * t_one, 3), "editnet_one_image_per_call_per_step_kernels_ms": round(1e3 * t_one_steps, 3),
@@ -243,6 +257,11 @@ def beam(dev, images=128, k=3):
             "editnet_one_image_per_call_ending_captions_per_step_kernels_ms": round(1e3 * t_short_steps, 3),
             "ending_captions_mean_len": round(float(np.mean([len(o[0]) for o in out_short])), 2),
             "ending_captions_searches_at_step_limit": "%d of 16" % sum(int(np.isnan(o[1])) for o in out_short),
+            "ensemble_one_image_per_call_ms": round(1e3 * t_ens, 3), "ensemble_one_image_per_call_ending_captions_ms": round(1e3 * t_ens_short, 3),
+            "ensemble_one_image_per_call_mean_len": round(float(np.mean([len(o[0]) for o in out_ens])), 2),
+            "ensemble_ending_captions_mean_len": round(float(np.mean([len(o[0]) for o in out_ens_short])), 2),
+            "dcnet_one_image_per_call_ms": round(1e3 * t_dc, 3), "dcnet_one_image_per_call_ending_captions_ms": round(1e3 * t_dc_short, 3),
+            "one_image_per_call_paths": "editnet: persistent launch (k <= 4); ensemble, dcnet: per-step kernels, NI = 1 of the batched search",
             "images_per_sec_editnet": round(images / t_e, 1), "mean_caption_len": round(float(np.mean([len(s) for s in seqs])), 2)}
 
 
@@ -361,6 +380,27 @@ def concurrent_small_requests(dev, callers=4, rows=4, rounds=30):
             os.environ["SET_DEC_PERSISTENT"] = old
     if callers * rows <= 16:
         out["coalesced_one_persistent_call_requests_per_sec"] = round(run(lambda: dec(wm, allp, alll, allx, True, False)), 1)
+        # the same through the package's helper (show_edit_tell_amd/serving.py): `callers` threads submit their request and
+        # wait for their rows; the coalescer's worker batches what is waiting
+        import threading
+        from show_edit_tell_amd import serving
+        with serving.RequestCoalescer(lambda p, l, x: dec(wm, p, l, x, True, False), max_rows=16, window_s=0.0005) as co:
+            def caller(i, n):
+                for _ in range(n):
+                    co.submit(*reqs[i]).result()
+                torch.cuda.synchronize()
+
+            def burst(n):
+                ths = [threading.Thread(target=caller, args=(i, n)) for i in range(callers)]
+                for t_ in ths:
+                    t_.start()
+                for t_ in ths:
+                    t_.join()
+            burst(4)
+            t = time.perf_counter()
+            burst(rounds)
+            out["request_coalescer_requests_per_sec"] = round(callers * rounds / (time.perf_counter() - t), 1)
+            out["request_coalescer_requests_per_decode"] = round(co.requests / max(co.batches, 1), 2)
     out["note"] = ("persistent launches of one process run one after the other (grid_barrier.h PersistentGuard); a server that has "
                    "several small requests at hand coalesces them into one call of up to 16 rows")
     return out
