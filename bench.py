@@ -518,9 +518,48 @@ def main():
         line["secondary"] = secondary.all_secondary(dev)
     if not args.no_cpu_baseline and n_gpus == 1:
         line["cpu_baseline"] = cpu_baseline()
+    if not args.no_secondary and n_gpus == 1 and os.environ.get("SET_LIB_VARIANT") != "exp":
+        line["experimental"] = experimental_leg(args, line)
     print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def experimental_leg(args, line):
+    """NEVER `value`, `dtype` or `roofline`: the same decode with the grouped GEMM's >= 65-row launches on the bf16 matrix pipe
+    — every fp32 operand split exactly into three bf16 values while a k-tile is staged, six of the nine partial products
+    accumulated in fp32 (csrc/experimental/gemm_variants.inc gemm_nt_split_bf16; error vs fp64 = the fp32 kernel's).  It lives
+    in the EXPERIMENTAL build of the library (build.py --exp -> csrc/libset_hip_exp.so), loaded only by a child process with
+    SET_LIB_VARIANT=exp; the shipped library does not contain it.  What the fp32-MFMA wall costs the headline."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = os.path.join(here, "show-edit-tell_amd", "csrc", "libset_hip_exp.so")
+    if not os.path.exists(lib):
+        return {"skipped": "experimental library not built (python -m show_edit_tell_amd.build --exp)"}
+    out = {"what": "emulated-fp32 GEMM on bf16 MFMA (3-way exact split, 6 products, fp32 accumulate), SET_GEMM_SPLIT=1 on the "
+                   "experimental library variant; same metric, same workload, child process",
+           "fp32_value_this_run": line.get("value")}
+    try:
+        env = dict(os.environ, SET_LIB_VARIANT="exp", SET_GEMM_SPLIT="1")
+        cmd = [sys.executable, os.path.join(here, "bench.py"), "--no-cpu-baseline", "--no-train", "--no-secondary", "--repeat", "2",
+               "--steps", str(max(args.steps, 60)), "--warmup", str(args.warmup)]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        d = json.loads(lines[-1])
+        out.update(value=d["value"], single_stream_decode_steps_per_sec=d.get("single_stream_decode_steps_per_sec"),
+                   batches_in_flight_per_gpu=d.get("batches_in_flight_per_gpu"),
+                   gemm_us_per_launch={k: v["us_per_launch"] for k, v in d.get("kernels", {}).items() if "gemm_nt" in k},
+                   ratio_to_fp32=round(d["value"] / line["value"], 3) if line.get("value") else None)
+        # accuracy: max |error| against fp64 over the decode step's three launch shapes, both kernels
+        errs = {}
+        for mode in ("0", "1"):
+            r2 = subprocess.run([sys.executable, os.path.join(here, "tools", "gemm_microbench.py"), "128", "4096", "3072", "128", "10000",
+                                 "1024", "128", "4096", "2048"], env=dict(env, SET_GEMM_SPLIT=mode, ITERS="5"), capture_output=True,
+                                text=True, timeout=240)
+            errs["fp32_mfma" if mode == "0" else "bf16_split"] = [float(ln.split("maxerr")[1]) for ln in r2.stdout.splitlines() if "maxerr" in ln]
+        out["max_abs_err_vs_fp64_K3072_K1024_K2048"] = errs
+    except Exception as e:
+        out["error"] = repr(e)[:300]
+    return out
 
 
 def train_leg(args, dec, wm, X, caps, clen, prev, plen, dev, dist, rank, world, barrier, max_over_ranks):

@@ -10,7 +10,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libset_hip.so")
+# SET_LIB_VARIANT=exp: the experimental build of the same sources (build.py LIB_EXP; bench.py's `experimental` leg and the
+# split-precision parity test run in child processes with it).  Anything else: the shipped library.
+LIB_PATH = os.path.join(_HERE, "csrc", "libset_hip_exp.so" if os.environ.get("SET_LIB_VARIANT") == "exp" else "libset_hip.so")
 
 SET_OK = 0
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3

@@ -110,14 +110,20 @@ def test_device_prefetcher_roundtrip(setup):
 
 
 def test_split_precision_gemm_keeps_parity():
-    """The opt-in bf16x3 split-precision GEMM (SET_GEMM_SPLIT=1, csrc/gemm_f32.hip) must be fp32-grade: rerun the
-    golden parity tests of the full-size model (greedy tokens bit-exact, logits within 1e-4) and the fp64 linear
-    check with the switch on.  The switch is read once per process, hence the child process."""
+    """The EXPERIMENTAL bf16-split emulated-fp32 GEMM (SET_GEMM_SPLIT=1 on the experimental library variant,
+    csrc/experimental/gemm_variants.inc; the shipped library does not contain it) must be fp32-grade: rerun the golden
+    parity tests of the full-size model (greedy tokens bit-exact, logits within 1e-4) and the fp64 linear check with the
+    switch on.  Library variant and switch are read once per process, hence the child process."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, SET_GEMM_SPLIT="1")
+    from show_edit_tell_amd import build
+    build.build(variant="exp")
+    env = dict(os.environ, SET_GEMM_SPLIT="1", SET_LIB_VARIANT="exp")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    which = subprocess.run([sys.executable, "-c", "from show_edit_tell_amd import _lib; print(_lib.LIB_PATH)"], env=env, cwd=root,
+                           capture_output=True, text=True, timeout=300)
+    assert which.stdout.strip().endswith("libset_hip_exp.so"), which.stdout + which.stderr
     cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
            os.path.join(root, "tests", "test_hip_editnet.py"), os.path.join(root, "tests", "test_hip_ops.py"),
            "-k", "full_b128 or full_b4 or v9490 or linear_shapes or token_table"]
@@ -131,11 +137,16 @@ def test_split_precision_gemm_keeps_parity():
 def test_gemm_kernel_variants_keep_parity(env_extra):
     """Opt-in / fallback variants of the grouped GEMM (csrc/gemm_f32.hip): the 8-wave workgroup with an intra-workgroup
     K split (SET_GEMM_KGROUPS=2) and the scalar epilogue (SET_GEMM_VEC_EPILOGUE=0) must pass the same golden parity
-    tests as the default kernel.  The switches are read once per process, hence the child process."""
+    tests as the default kernel.  The switches are read once per process, hence the child process.  (The 8-wave kernel lives
+    in the experimental library variant only: SET_LIB_VARIANT=exp.)"""
     import os
     import subprocess
     import sys
     env = dict(os.environ, **env_extra)
+    if "SET_GEMM_KGROUPS" in env_extra:
+        from show_edit_tell_amd import build
+        build.build(variant="exp")
+        env["SET_LIB_VARIANT"] = "exp"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
            os.path.join(root, "tests", "test_hip_editnet.py"), os.path.join(root, "tests", "test_hip_ops.py"),
