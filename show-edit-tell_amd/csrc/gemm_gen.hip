@@ -354,13 +354,9 @@ __global__ void __launch_bounds__(256) gemm_gen_f32(const GenLaunch L) {
 #include "gemm_gen_epilogue.inc"
 }
 
-// The hand-written k-loop of the 128x64 class (round 5, `gemm_gen_asm<A_KMAJ>`): built, BIT-IDENTICAL to gemm_gen_f32, and not
-// faster (x2h weight gradient 122.7 vs 122.2 TFLOP/s: once the predicated loads were gone — HWB above — the compiler-scheduled
-// loop runs at the clock-limited rate inside a round of tiles; what is left is tile quantisation).  It lives in
-// experimental/gemm_gen_asm_kernel.inc, compiled only with -DSET_EXPERIMENTAL_GEMMS (SET_GEMM_GEN_ASM=1 selects it there).
-#ifdef SET_EXPERIMENTAL_GEMMS
-#include "experimental/gemm_gen_asm_kernel.inc"
-#endif
+// (A hand-written k-loop of the 128x64 class was built in round 5 — bit-identical to gemm_gen_f32 and not faster: x2h weight
+// gradient 122.7 vs 122.2 TFLOP/s; once the predicated loads were gone — HWB above — the compiler-scheduled loop runs at the
+// clock-limited rate inside a round of tiles, what is left is tile quantisation.  EXPERIMENTS.md 5.2; removed in round 6.)
 
 // out[m, n] (+)= sum over slabs, slab 0 first; one launch serves every split task of a group
 __global__ void __launch_bounds__(256) slab_reduce_k(const GenLaunch L) {
@@ -565,21 +561,7 @@ int gemm_gen_group(const SetGemmDesc* d, int n, int a_kminor, int b_kminor, void
         const char* name = a_kminor ? (b_kminor ? "gemm_gen_f32<tn>" : "gemm_gen_f32<tt>")
                                     : (b_kminor ? "gemm_gen_f32<nn>" : "gemm_gen_f32<nt>");
         ProfScope ps(name, s, flops, bytes);
-        // the hand-written k-loop: 128x64 tiles, B k-minor (dX, dW), operands addressable by a 31-bit offset, and with a
-        // k-major A a contraction length that fills its last k-tile (SET_GEMM_GEN_ASM=0: the compiler-scheduled kernel)
-        bool use_asm = false;
-#ifdef SET_EXPERIMENTAL_GEMMS
-        static const int asm_on = env_int("SET_GEMM_GEN_ASM", 0);
-        use_asm = asm_on && hwb && bm == 128 && b_kminor && counters_used == 0;
-        if (use_asm && !a_kminor)
-            for (int i = 0; i < n; ++i) if (L.t[i].K & 31) use_asm = false;
-        if (use_asm) {
-            if (a_kminor) hipLaunchKernelGGL(gemm_gen_asm<false>, dim3((unsigned)wg), dim3(256), 0, s, L);
-            else hipLaunchKernelGGL(gemm_gen_asm<true>, dim3((unsigned)wg), dim3(256), 0, s, L);
-        }
-#endif
-        if (use_asm) {
-        } else if (counters_used > 0) {
+        if (counters_used > 0) {
             if (bm == 128) launch_gen<128, 64, true, false>(L, !a_kminor, !b_kminor, (unsigned)wg, s);
             else launch_gen<64, 64, true, false>(L, !a_kminor, !b_kminor, (unsigned)wg, s);
         } else if (hwb) {
