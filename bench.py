@@ -58,7 +58,7 @@ PEAK_HBM_GBS = 8000.0
 TRAIN_TFLOP_PER_STEP = 1.23             # contractions of one B=128 XE training step as executed
 SURVEY_GFLOP_PER_TIMESTEP = 16.88       # SURVEY.md 8d, B = 128, eval mode, loop invariants hoisted
 EXECUTED_GFLOP_PER_DECODE = 281.0       # contractions one B = 128 greedy decode executes here (token table active), DESIGN.md 3
-PMC_FILES = ("r05_pmc_bench_traffic.json", "r04_pmc_bench_traffic.json", "r03_pmc_bench_traffic.json", "r02_pmc_bench_traffic.json", "r01_pmc_bench_traffic.json")
+PMC_FILES = ("r06_pmc_bench_traffic.json", "r05_pmc_bench_traffic.json", "r04_pmc_bench_traffic.json", "r03_pmc_bench_traffic.json", "r02_pmc_bench_traffic.json", "r01_pmc_bench_traffic.json")
 
 
 def pmc_traffic():
