@@ -139,7 +139,7 @@ __device__ __forceinline__ void pd_mma(f32x4& acc, const f32x4 (&w)[KB], const f
     }
 }
 
-// ---- EditNet: arguments shared by decode_persistent_editnet.hip (<= 8 rows) and decode_persistent_wide.hip (<= 16 rows)
+// ---- EditNet: arguments of decode_persistent_wide.hip (1 .. 16 rows; greedy, teacher-forced and beam mode)
 constexpr int PDEC_RREG = 36;      // image regions whose hoisted x2h products a thread keeps in registers
 
 struct PDecEditArgs {

@@ -1,6 +1,6 @@
 // Persistent free-running decode for small batches (B <= 8): the whole greedy loop of DCNet (dcnet_rl.py:286-346) as ONE
 // launch of D / 4 workgroups that exchange activations through flag-in-data words instead of six launches per timestep.
-// (EditNet's twin: decode_persistent_editnet.hip.)
+// (EditNet's twin: decode_persistent_wide.hip.)
 //
 // At B = 4 a timestep of the per-step path is six dependent launches of 10-25 us that stream 123 MB of weights between
 // them: every launch pays a boundary, a start-up and a tail, and the pointwise kernels between the GEMV launches run at the

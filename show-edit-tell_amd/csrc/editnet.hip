@@ -46,7 +46,7 @@ struct EditNetWs {
     float *enc_h, *enc_c, *xg, *emb_seq, *fe, *s_enc, *s_aff, *s_pre;
     int* enc_order;                   // [perm (B) | nactive (T)] of the length-ordered encoder
     char* enc_bar;                    // barrier words of the persistent encoder
-    float* pd_pv;                     // persistent small-batch decode (decode_persistent_editnet.hip): X x2h[:, 2D:]^T (B, R, 4D) ...
+    float* pd_pv;                     // persistent small-batch decode (decode_persistent_wide.hip): X x2h[:, 2D:]^T (B, R, 4D) ...
     char* pd_x;                       // ... and its exchange region
     size_t bytes;
 };
@@ -267,7 +267,7 @@ static int begin_impl(const SetEditNetWeights* w, const SetEditNetDims* d, const
         SET_TRY(gemm_group(p, 4, st, "gemm:pro cap projections"));
     }
     {
-        // small batches (persistent decode, decode_persistent_editnet.hip): the region half of copy_lstm.x2h is linear in the
+        // small batches (persistent decode, decode_persistent_wide.hip): the region half of copy_lstm.x2h is linear in the
         // visual attention weights — Pv = X x2h[:, 2D:]^T (B, R, 4D) rides the att_embed launch (same operand X)
         GemmProb p[2];
         p[0] = direct_prob(ws.fe, D, B * R, D, w->va_emb_b, SET_ACT_RELU);                // editnet.py:441
@@ -541,7 +541,7 @@ static int rollout(const SetEditNetWeights* w, const SetEditNetDims* d, const fl
     // Row gate (set_common.h): every kernel of timestep t returns at once when alive[t - 1] == 0 — the reference's `break`
     // (editnet_rl.py:546) in TIME, not only in the outputs (SET_LOOP_GATE=0: as before, outputs only).
     static const int loop_gate = env_int("SET_LOOP_GATE", 1);
-    // small batches, greedy: the whole loop as ONE persistent launch (decode_persistent_editnet.hip).  copy_lstm.x2h's region
+    // small batches, greedy: the whole loop as ONE persistent launch (decode_persistent_wide.hip).  copy_lstm.x2h's region
     // columns are linear in the visual attention weights: Pv = X x2h[:, 2D:]^T is computed here once per decode
     if (!sample && !emb_needed && !g_row_limit && editnet_persistent_ok(d, max_len)) {
         if (begun) {     // the prologue ran in an earlier call (begin_ahead), possibly under other switches: Pv is not taken on trust
@@ -655,7 +655,7 @@ int set_editnet_xe_forward(const SetEditNetWeights* w, const SetEditNetDims* d, 
     // fc(h2_t) and the phase-A products of t+1 (over the rows still in the batch then) ride one launch, as in the
     // free-running loop
     const bool emb_needed = !(w->tok_table && (d->D % 64 == 0) && env_int("SET_NO_FUSED", 0) == 0);
-    // small batches: the teacher-forced loop as ONE persistent launch too (decode_persistent_editnet.hip)
+    // small batches: the teacher-forced loop as ONE persistent launch too (decode_persistent_wide.hip)
     if (!emb_needed && editnet_persistent_ok(d, maxT)) {
         const PDecTeacher teach{caps, caps_stride, predictions, host_decode_lengths};
         const int rc = editnet_persistent_greedy(w, d, W.pre1, W.att1, W.att1_c, W.mask, W.cap_proj, W.mem_proj, W.Mem, W.pd_pv,

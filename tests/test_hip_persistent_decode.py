@@ -183,7 +183,7 @@ def test_dcnet_persistent_xe_forward_matches_golden_and_per_step():
 
 @pytest.mark.parametrize("name", ["editnet_full_b4", "editnet_full_v9490"])
 def test_editnet_persistent_decode_matches_golden_and_per_step(name):
-    """EditNet greedy at full dimensions (csrc/decode_persistent_editnet.hip): B = 4 (one row per wave, its attention rows
+    """EditNet greedy at full dimensions (csrc/decode_persistent_wide.hip): B = 4 (one row per wave, its attention rows
     resident in registers) and the B = 5 / V = 9490 fixture (two rows on one wave, streamed attention rows, a vocabulary that is
     no multiple of the 256 workgroups): the persistent launch equals the reference's golden and the per-step loop (ids
     bit-identical, log-probs within 1e-5)."""

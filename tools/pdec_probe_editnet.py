@@ -1,4 +1,4 @@
-"""Persistent small-batch EditNet decode (csrc/decode_persistent_editnet.hip) against the per-step loop.  GPU box."""
+"""Persistent small-batch EditNet decode (csrc/decode_persistent_wide.hip) against the per-step loop.  GPU box."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.getcwd(), "tests")); sys.path.insert(0, os.getcwd())
 import numpy as np, torch
