@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(256 * KG) gemm_nt_f32(const int ntasks, const 
 //
 // Same tile, same LDS image (XOR-swizzled 128-byte rows), same K permutation, same MFMA order per accumulator — the
 // results are BIT-IDENTICAL to the default kernel — and the same task descriptors, split-K slabs and epilogue.  What the
-// hand-written loop controls and the compiler-scheduled one does not (EXPERIMENTS.md 4.2):
+// hand-written loop controls and the compiler-scheduled one does not (EXPERIMENTS_r1-r4.md 4.2):
 //   * the waits: a register stage is waited for with `s_waitcnt vmcnt(4)` — exactly "all but the four requests of the
 //     younger stage" — so the prefetch distance is two k-tiles in EVERY round (the compiler's placement merges request
 //     queues at the loop head and waits for vmcnt(0) in every second round: one k-tile);
@@ -530,7 +530,7 @@ __global__ void __launch_bounds__(256) gemm_nt_f32_asm(const int ntasks, const i
 #undef ASM_HALF_ROUND
 
 // ---------------------------------------------------------------------------------------------
-// Variants that were built, measured and LOST (EXPERIMENTS_r1-r3.md 3.1b, 4.1): the weights-to-registers kernel, the LDS-DMA
+// Variants that were built, measured and LOST (EXPERIMENTS_r1-r4.md 3.1b, 4.1): the weights-to-registers kernel, the LDS-DMA
 // kernel and the bf16x3 split-precision kernel live in experimental/gemm_variants.inc and are compiled only with
 // -DSET_EXPERIMENTAL_GEMMS (tools/ubench builds; SET_HIPCC_FLAGS=-DSET_EXPERIMENTAL_GEMMS python -m show_edit_tell_amd.build --force).
 // The shipped library does not contain them; their environment switches are ignored there.

@@ -52,6 +52,11 @@ def test_workspace_queries_and_validation(lib):
     # null pointers are rejected before any HIP call
     assert lib.set_editnet_begin(None, C.byref(d), None, None, None, None, None, 0, None) == 1
     assert lib.set_linear_f32(None, 0, None, 0, None, None, 0, 1, 1, 32, 0, None, 0, None) == 1
+    # round 6: the soft selection entry points validate before any HIP call too (SET_ERR_ARG = 1, SET_ERR_UNSUPPORTED = 2)
+    assert lib.set_select_soft_f32(None, None, None, 4, 9, 64, None) == 1
+    assert lib.set_select_soft_bwd_f32(None, None, None, None, None, 4, 9, 64, None) == 1
+    one = C.c_void_p(16)                      # (never dereferenced: D % 4 != 0 is refused first)
+    assert lib.set_select_soft_f32(one, one, one, 4, 9, 66, None) == 2
 
 
 def test_modules_fail_loudly_on_cpu():
