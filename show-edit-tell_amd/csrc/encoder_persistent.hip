@@ -271,7 +271,8 @@ static bool penc_process_owns(int dev) {
     const char* dir = getenv("SET_PERSISTENT_LOCK_DIR");
     char path[256];
     snprintf(path, sizeof(path), "%s/set_hip_persistent_%s.lock", dir && *dir ? dir : "/tmp", bus);
-    const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+    int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+    if (fd < 0) fd = open(path, O_RDONLY | O_CLOEXEC);        // another user's lock file (created 0644 under the usual umask): flock needs no write access
     if (fd < 0) { g_penc_lock_fd[dev] = -1; return true; }
     if (flock(fd, LOCK_EX | LOCK_NB) != 0) { close(fd); return false; }       // another process owns the device's persistent launches
     g_penc_lock_fd[dev] = fd + 1;
