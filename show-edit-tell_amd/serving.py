@@ -63,10 +63,12 @@ def plan_batches(row_counts, max_rows):
     return out
 
 
-def pad_and_cat(requests):
+def pad_and_cat(requests, t_multiple=1):
     """requests: [(prev (n_i, T_i) int64, plen (n_i,) or (n_i, 1), *rest)] -> (prev (N, Tmax) zero-padded, plen (N,), *rest
-    concatenated along dim 0), and the row offsets."""
+    concatenated along dim 0), and the row offsets.  Tmax is rounded up to a multiple of `t_multiple` (fewer distinct
+    workspace shapes behind the decoder; the persistent launch wants an even caption length)."""
     tmax = max(r[0].shape[1] for r in requests)
+    tmax = -(-tmax // t_multiple) * t_multiple
     prevs = []
     for r in requests:
         p = r[0]
@@ -83,11 +85,14 @@ def pad_and_cat(requests):
 
 
 class RequestCoalescer:
-    def __init__(self, decode_fn, max_rows=16, window_s=0.0, device=None):
+    def __init__(self, decode_fn, max_rows=16, window_s=0.0, device=None, t_multiple=2):
         """decode_fn(prev, plen, *rest) -> tuple of tensors whose dim 0 is the batch (e.g. (seq, seq_logp)); called under
         torch.no_grad() on the worker's own stream.  window_s: how long the worker waits for more requests once it holds
-        one (0 = take what is waiting right now: adds no latency to a lone request)."""
+        one (0 = take what is waiting right now: adds no latency to a lone request).  t_multiple: previous captions are
+        padded with <pad> to a multiple of this length (2: the persistent launch takes even lengths only; a larger value
+        bounds the number of distinct workspace shapes a long-running server accumulates)."""
         self.decode_fn, self.max_rows, self.window_s = decode_fn, int(max_rows), float(window_s)
+        self.t_multiple = max(1, int(t_multiple))
         self.device = device
         self._q, self._cv, self._stop = [], threading.Condition(), False
         self.batches, self.requests = 0, 0            # counters: how many decodes served how many requests
@@ -154,10 +159,10 @@ class RequestCoalescer:
                     for _, ev, _ in batch:
                         if ev is not None:
                             stream.wait_event(ev)
-                    if len(reqs) == 1:
+                    if len(reqs) == 1 and reqs[0][0].shape[1] % self.t_multiple == 0:
                         args, offs = (reqs[0][0], reqs[0][1].reshape(-1)) + tuple(reqs[0][2:]), [0, reqs[0][0].shape[0]]
                     else:
-                        args, offs = pad_and_cat(reqs)
+                        args, offs = pad_and_cat(reqs, self.t_multiple)
                     outs = self.decode_fn(*args)
                     outs = tuple(outs) if isinstance(outs, (tuple, list)) else (outs,)
                     done = None

@@ -23,6 +23,10 @@ def test_pad_and_cat_pads_with_zero_columns():
     assert prev.shape == (5, 7) and offs == [0, 2, 5]
     assert (prev[:2, :5] == 1).all() and (prev[:2, 5:] == 0).all() and (prev[2:] == 2).all()
     assert plen.tolist() == [5, 3, 7, 7, 1] and x[:2].eq(1).all() and x[2:].eq(2).all()
+    (prev4, _, _), _ = serving.pad_and_cat([a, b], t_multiple=4)        # rounded up: 7 -> 8 columns, the extra one is <pad>
+    assert prev4.shape == (5, 8) and (prev4[:, 7] == 0).all() and torch.equal(prev4[:, :7], prev)
+    (prev1, _, _), _ = serving.pad_and_cat([a], t_multiple=2)           # a lone request with an odd length is padded too
+    assert prev1.shape == (2, 6)
 
 
 def test_coalescer_hands_every_caller_its_rows():
